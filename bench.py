@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: G+D train-step throughput, real 192x192x3 crops per second, batch 8 per GPU
+(BASELINE.json metric; config 1/2: n_layers_G=6, n_layers_D=4, BN, padding_mode=local, fp32).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = reference train.py:122-171 with disc_iters=1: D(real) fwd+bwd, G fwd of 8 images x 3x3
+patches of 128^2, D(fake) fwd+bwd, Adam(D), D(fake) fwd, bwd through D and G, Adam(G).  Inputs
+(real crops, latents) are synthetic and resident in HBM before the timed region.  With N > 1 every
+rank runs batch 8 (weak scaling): BatchNorm statistics are summed over ranks and each model's flat
+gradient is all-reduced once per step over RCCL, i.e. the single-process semantics at batch 8N.
+
+Prints ONE JSON line on rank 0; see DESIGN.md section "Measurement" for the roofline numerator
+(855.5 GF of necessary conv MACs x2 per step of batch 8) and the cpu_baseline definition.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+NECESSARY_GF_PER_STEP = 855.5      # SURVEY.md section 8d, config 1, batch 8 / 8 images
+FP32_MFMA_PEAK_TF = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU @ 2.4 GHz
+FLAGS = ["--n_layers_G", "6", "--n_layers_D", "4", "--type_norm", "BN", "--padding_mode", "local",
+         "--outer_padding", "replicate", "--num_images", "8", "--batch_size", "8", "--leak_G", "0.02",
+         "--spec_norm_D", "--smooth", "--random_crop", "192", "--seed", "1234"]
+
+
+def gpu_leg(a):
+    import torch.distributed as dist
+    from infinite_texture_gans_amd import ops, utils as U
+    from infinite_texture_gans_amd.engine import Trainer
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    group = None
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+        group = dist.group.WORLD
+    args = U.prepare_parser().parse_args(FLAGS)
+    args.beta1 = float(args.beta1)
+    torch.manual_seed(args.seed)               # identical initial weights on every rank
+    netG, netD = U.prepare_models(args, dev)
+    netG.train(), netD.train()
+    tr = Trainer(netG, netD, args, dev, dist_group=group)
+    g = torch.Generator().manual_seed(args.seed + 1 + rank)
+    n_in = a.steps + a.warmup + 2
+    reals = [(torch.rand(args.batch_size, 3, 192, 192, generator=g) * 2 - 1).to(dev) for _ in range(2)]
+    zs = [torch.randn(args.num_images, args.z_dim, 14, 14, generator=g).to(dev) for _ in range(n_in)]
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        tr.step(reals[i % 2], zs[i])
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        losses = tr.step(reals[i % 2], zs[a.warmup + i])
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+    losses = [float(v) for v in losses]
+
+    # ---- per-kernel launch durations (HIP events on the launching stream), one extra step
+    roof = None
+    if rank == 0:
+        ops.PROFILE = []
+        tr.step(reals[0], zs[-1])
+        torch.cuda.synchronize()
+        agg = {}
+        for tag, launches, flops, e0, e1 in ops.PROFILE:
+            d = agg.setdefault(tag, [0, 0.0, 0.0])
+            d[0] += launches
+            d[1] += flops
+            d[2] += e0.elapsed_time(e1) * 1e-3
+        ops.PROFILE = None
+        tag, (nl, fl, sec) = max(agg.items(), key=lambda kv: kv[1][2])
+        ach = fl / sec / 1e12
+        roof = {"bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TF,
+                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                "launches_per_step": nl, "avg_launch_us": round(sec / nl * 1e6, 1),
+                "flops_per_launch": round(fl / nl / 1e9, 3),
+                "conv_time_share": {k: round(v[2] / sum(x[2] for x in agg.values()), 3) for k, v in agg.items()},
+                "step_necessary_gflop": NECESSARY_GF_PER_STEP,
+                "step_frac_of_mfma_peak": round(NECESSARY_GF_PER_STEP * 1e9 / (dt / a.steps) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
+    if world > 1:
+        dist.barrier()
+    return rank, world, dt, args, losses, roof
+
+
+def cpu_leg():
+    """The oracle (CPU restatement of the reference path) timed on the host cores: one full train
+    step at the same config with the vectorised LocalPadder ('port')."""
+    from oracle import nets, step as ostep
+    from oracle.nets import GCfg, DCfg
+    from infinite_texture_gans_amd import utils as U
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    args = U.prepare_parser().parse_args(FLAGS)
+    torch.manual_seed(1234)
+    netG, netD = U.prepare_models(args, "cpu")          # parameter containers only (no forward on CPU)
+    gsd = ostep.as_leaf_params({k: v.clone() for k, v in netG.state_dict().items()})
+    dsd = ostep.as_leaf_params({k: v.clone() for k, v in netD.state_dict().items()})
+    gcfg = GCfg(z_dim=128, G_ch=52, base_res=4, n_layers_G=6, attention=False, leak=0.02, type_norm="BN")
+    dcfg = DCfg(img_ch=3, base_ch=64, n_layers_D=4, SN=True)
+    optD = ostep.Adam([dsd[k] for k in ostep.trainable(dsd)])
+    optG = ostep.Adam([gsd[k] for k in ostep.trainable(gsd)])
+    g = torch.Generator().manual_seed(7)
+    real = torch.rand(8, 3, 192, 192, generator=g) * 2 - 1
+    z = torch.randn(8, 128, 14, 14, generator=g)
+    t0 = time.perf_counter()
+    ostep.train_step(gsd, dsd, gcfg, dcfg, optG, optD, real, z, None, smooth=True)
+    dt = time.perf_counter() - t0
+    return {"value": round(8.0 / dt, 4), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 full G+D train step, batch 8 / 8 images (72 G-patches), vectorised LocalPadder, "
+                      "torch-CPU fp32, no warm-up (%.1f s)" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                     "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (a.gpus, a.gpus))
+    rank, world, dt, args, losses, roof = gpu_leg(a)
+    if rank != 0:
+        return
+    ms = dt / a.steps * 1e3
+    out = {"metric": "G+D train-step real 192x192x3 crops/sec (batch 8 per GPU)", "value": round(args.batch_size * world * a.steps / dt, 3),
+           "unit": "crops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "config 1/2: 241.jpg-shaped 192x192 crops, n_layers_G=6 n_layers_D=4, BN, "
+                                  "padding_mode=local (replicate), G_ch=52 D_ch=64, 3x3 patch grid of 128^2, "
+                                  "spec_norm_D, smooth, batch 8 + 8 generated images per GPU",
+                      "global_batch": args.batch_size * world, "g_patches_per_sec": round(72 * world * a.steps / dt, 1),
+                      "parallelism": "dp%d (sync-BN + flat grad all-reduce)" % world, "last_losses": losses},
+           "roofline": roof}
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_leg()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

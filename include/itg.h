@@ -1,0 +1,211 @@
+/* itg.h - C ABI of libitg_hip.so, the MI355X (gfx950) kernels behind the
+ * patch-by-patch texture-GAN train step / patch-grid inference.
+ *
+ * The reference (ai4netzero/Infinite_Texture_GANs) has no native layer: its hot
+ * path is torch ops called from Python.  Each entry point
+ * below names the reference call site(s) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller, fp32 unless noted,
+ *     16-byte aligned; nothing is allocated inside the library (workspaces are
+ *     passed in); all work is enqueued asynchronously on `stream` (a
+ *     hipStream_t passed as void*); no global state; re-entrant per stream.
+ *   - return value: 0 on success, negative itg_status on a rejected call (bad
+ *     shape, misaligned pointer, launch failure).  Nothing throws.
+ *   - activations are "patch-grid NHWC" tensors (itg_tensor): n images, each a
+ *     gh x gw grid of ph x pw patches, channels innermost, `ld` floats per pixel
+ *     (ld >= c, ld % 4 == 0, channels c..ld-1 are ZERO).  Memory order is
+ *     [n][gr][gc][y][x][ld]; a plain NHWC image is gh = gw = 1.  The reference's
+ *     patch batch (N*gh*gw, C, P, P) with p = n*gh*gw + r*gw + c (utils.py:604-607)
+ *     is exactly this order, so "merged image" coordinates (Y, X) address patch
+ *     (Y / ph, X / pw) at (Y % ph, X % pw) with no copy.
+ *   - weights stay in the reference's OIHW layout at the boundary (state_dict
+ *     compatible); packed forms are produced by itg_pack_* into caller buffers.
+ */
+#ifndef ITG_H
+#define ITG_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  ITG_OK = 0,
+  ITG_ERR_ARG = -1,      /* inconsistent shapes / unsupported geometry */
+  ITG_ERR_ALIGN = -2,    /* pointer or ld not 16-byte / 4-float aligned */
+  ITG_ERR_LAUNCH = -3,   /* hip launch error */
+  ITG_ERR_WORKSPACE = -4 /* workspace too small */
+} itg_status;
+
+typedef struct {
+  void* ptr;
+  int32_t n, gh, gw, ph, pw, c, ld;
+} itg_tensor;
+
+enum { ITG_PAD_ZERO = 0, ITG_PAD_REPLICATE = 1 };
+enum { ITG_ACT_NONE = 0, ITG_ACT_LRELU = 1, ITG_ACT_TANH = 2 };
+
+typedef struct {
+  int32_t kh, kw, stride, pad;
+  int32_t pad_mode; /* ITG_PAD_*: how reads outside the merged image resolve */
+} itg_conv_geom;
+
+int itg_version(void);
+
+/* ---- weight packing ------------------------------------------------------------
+ * OIHW master weights (nn.Conv2d.weight, reference models/layers.py:178-200) ->
+ * K-contiguous packed forms.  `scale` points to one device float multiplied into
+ * every element (1/sigma for spectral norm, layers.py:180), or NULL.
+ *   fwd   : [co_pad][kh][kw][ci_ld]           co_pad = round_up(co, 16)
+ *   dgrad : stride 1: [ci_pad][kh][kw][co_ld] taps flipped;
+ *           stride 2: 4 parity classes x [ci_pad][kh/2][kw/2][co_ld]
+ * Sizes in floats are returned by the *_size helpers (host side, no launch).     */
+int64_t itg_pack_fwd_size(int co, int ci_ld, int kh, int kw);
+int64_t itg_pack_dgrad_size(int ci, int co_ld, int kh, int kw, int stride);
+int itg_pack_fwd(const float* w_oihw, const float* scale, float* out, int co, int ci, int ci_ld,
+                 int kh, int kw, void* stream);
+int itg_pack_dgrad(const float* w_oihw, const float* scale, float* out, int co, int ci, int co_ld,
+                   int kh, int kw, int stride, void* stream);
+
+/* ---- convolution (implicit GEMM on v_mfma_f32_16x16x4_f32) ----------------------
+ * Replaces nn.Conv2d forward/backward at reference models/layers.py:25-34 (3x3 under
+ * local padding: the 1-px halo of LocalPadder, layers.py:145-173, is read straight
+ * from the neighbouring patches / clamped at the image border, never materialised),
+ * layers.py:196-200 (1x1 shortcut) and layers.py:190-194 (4x4 discriminator convs).
+ *   out = act( conv(in, w) + bias [+ residual] )
+ * in/out are patch-grid tensors; the conv runs in merged-image coordinates.
+ * act: ITG_ACT_* with slope for LRELU (slope 0 = ReLU).  bias may be NULL (length
+ * out.ld, zero-padded); residual (same layout as out) may have ptr == NULL.        */
+int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bias,
+                   const itg_tensor* residual, const itg_tensor* out, const itg_conv_geom* g,
+                   int act, float slope, void* stream);
+
+/* dX of the same conv: `dy` has the conv's output shape, `dx` its input shape.
+ * With ITG_PAD_REPLICATE the gradient of the replicated border folds back onto the
+ * edge pixels (the autograd of F.pad(..., 'replicate') at layers.py:82).           */
+int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const itg_tensor* dx,
+                     const itg_conv_geom* g, void* stream);
+
+/* dW (OIHW, accumulated into dw when accumulate != 0) and optional db (length co).
+ * workspace: itg_conv2d_wgrad_workspace() floats (split-K slabs + fp64 bias scratch). */
+int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g);
+int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw_oihw, float* db,
+                     const itg_conv_geom* g, int accumulate, float* workspace, int64_t workspace_floats,
+                     void* stream);
+
+/* ---- LocalPadder as a standalone operator -----------------------------------------
+ * reference models/layers.py:145-173 + utils.py:577-613,658-742 (training branch /
+ * first sub-image): x (n*gh*gw patches of p x p) -> y (patches of (p+2) x (p+2)),
+ * NCHW fp32 exactly as the reference module takes and returns them.  bwd is the
+ * scatter-add of halo gradients (autograd of merge + F.pad + crop).
+ * `merged` != 0: x is the already merged, pre-padded latent (n, c, gh*p+2, gw*p+2),
+ * only cropped (generator `start`, layers.py:152-155).                              */
+int itg_local_pad_fwd(const float* x, float* y, int n, int c, int gh, int gw, int p, int pad_mode,
+                      int merged, void* stream);
+int itg_local_pad_bwd(const float* dy, float* dx, int n, int c, int gh, int gw, int p, int pad_mode,
+                      int merged, void* stream);
+/* same operator on patch-grid NHWC tensors (out.ph == in.ph + 2) */
+int itg_local_pad_nhwc_fwd(const itg_tensor* x, const itg_tensor* y, int pad_mode, void* stream);
+
+/* eval-mode streaming variant (layers.py:84-143): left column / top row carried from
+ * earlier sub-images; left/top may be NULL (then outer padding on that side).
+ * left: (n, gh*p, ld) column; top: (n, gw*p+2, ld) row incl. its two corner pixels.   */
+int itg_local_pad_stream_fwd(const itg_tensor* x, const float* left, const float* top,
+                             const itg_tensor* y, int pad_mode, void* stream);
+
+/* ---- layout conversion at the NCHW boundary -------------------------------------------- */
+int itg_nchw_to_grid(const float* src, const itg_tensor* dst, int merged_src, void* stream);
+int itg_grid_to_nchw(const itg_tensor* src, float* dst, int merged_dst, void* stream);
+
+/* ---- BatchNorm2d (reference models/layers.py:279-280, generators.py:78; torch
+ * semantics: biased batch variance, eps, momentum running stats with unbiased var) ------
+ * stats: per-channel (sum, sumsq) in fp64 over all pixels of x -> sums[2*ld] (must be
+ *        zeroed by the caller; several ranks may all-reduce it before finalize).
+ * finalize: mean/rstd -> alpha = gamma*rstd, beta' = beta - mean*alpha (fp32, length
+ *        ld each, written to ab[0..ld) and ab[ld..2ld)), saves mean/rstd, updates
+ *        running stats (count = total pixels incl. other ranks; count_scale multiplies
+ *        the count used for the unbiased factor only, 4 when stats were taken before
+ *        a nearest x2 upsample).  gamma/beta NULL = affine-free (SSM's inner BN).
+ * apply: y = act(alpha*x + beta') with optional nearest x2 upsample (y.ph == 2*x.ph).
+ * bwd_reduce / bwd_apply: the autograd of apply∘finalize∘stats w.r.t. x, gamma, beta,
+ *        act derivative taken on the recomputed pre-activation.                          */
+int itg_bn_stats(const itg_tensor* x, double* sums, void* stream);
+int itg_bn_finalize(const double* sums, double count, double count_scale, const float* gamma,
+                    const float* beta, float eps, float momentum, float* running_mean,
+                    float* running_var, int64_t* num_batches_tracked, float* mean_rstd, float* ab,
+                    int c, int ld, int training, void* stream);
+int itg_bn_apply(const itg_tensor* x, const float* ab, const itg_tensor* y, int act, float slope,
+                 void* stream);
+int itg_bn_bwd_reduce(const itg_tensor* x, const itg_tensor* dy, const float* ab, const float* mean_rstd,
+                      int act, float slope, double* sums, void* stream);
+int itg_bn_bwd_apply(const itg_tensor* x, const itg_tensor* dy, const float* ab, const float* mean_rstd,
+                     const float* gamma, const double* sums, double count, int act, float slope,
+                     const itg_tensor* dx, float* dgamma, float* dbeta, void* stream);
+
+/* ---- SSM modulation (reference models/layers.py:228-234): out = (1+gamma)*xhat + beta,
+ * gamma/beta the two halves of `emb` (channels [0,c) and [c,2c)), then optional act ---- */
+int itg_ssm_modulate_fwd(const itg_tensor* x, const float* mean_rstd, const itg_tensor* emb,
+                         const itg_tensor* y, int act, float slope, void* stream);
+int itg_ssm_modulate_bwd(const itg_tensor* x, const float* mean_rstd, const itg_tensor* emb,
+                         const itg_tensor* dy, int act, float slope, const itg_tensor* dxhat,
+                         const itg_tensor* demb, void* stream);
+
+/* ---- pointwise ------------------------------------------------------------------------
+ * act fwd/bwd: nn.LeakyReLU / nn.ReLU / nn.Tanh (layers.py:289-292, generators.py:121,
+ * discriminators.py:188); bwd takes the forward OUTPUT.  upsample: nn.Upsample(x2,
+ * nearest) (generators.py:52) and its 2x2-sum backward.  axpby: out = a*x + b*y.       */
+int itg_act_fwd(const itg_tensor* x, const itg_tensor* y, int act, float slope, void* stream);
+int itg_act_bwd(const itg_tensor* out, const itg_tensor* dout, const itg_tensor* dx, int act, float slope,
+                void* stream);
+int itg_upsample2x_fwd(const itg_tensor* x, const itg_tensor* y, void* stream);
+int itg_upsample2x_bwd(const itg_tensor* dy, const itg_tensor* dx, void* stream);
+int itg_add(const itg_tensor* a, const itg_tensor* b, const itg_tensor* out, void* stream);
+/* flat helpers: out = a*(a_dev?*a_dev:1)*x + b*y over n floats (attention gate gamma*o + x at
+ * layers.py:258, EMA of buffers at train.py:176-180); dot: *out(fp64, zeroed by the call) = <x,y> */
+int itg_axpby(const float* x, const float* y, float* out, float a, const float* a_dev, float b, int64_t n,
+              void* stream);
+int itg_dot(const float* x, const float* y, int64_t n, double* out, void* stream);
+int itg_colsum(const itg_tensor* x, float* out /*c*/, double* acc /*ld scratch*/, void* stream); /* bias grad */
+
+/* ---- attention (reference models/layers.py:246-258), one workgroup per patch -----------
+ * beta_save: 2 * NB * HW * (HW/4) floats; fwd stores the softmax in the first half, bwd uses
+ * the second half as scratch for dS.                                                       */
+int itg_attention_fwd(const itg_tensor* theta, const itg_tensor* phi_pooled, const itg_tensor* g_pooled,
+                      const itg_tensor* o_mid, float* beta_save, void* stream);
+int itg_attention_bwd(const itg_tensor* theta, const itg_tensor* phi_pooled, const itg_tensor* g_pooled,
+                      float* beta_save, const itg_tensor* d_o_mid, const itg_tensor* d_theta,
+                      const itg_tensor* d_phi_pooled, const itg_tensor* d_g_pooled, void* stream);
+int itg_maxpool2_fwd(const itg_tensor* x, const itg_tensor* y, void* stream);
+int itg_maxpool2_bwd(const itg_tensor* x, const itg_tensor* y, const itg_tensor* dy, const itg_tensor* dx,
+                     void* stream);
+
+/* ---- losses (train.py:81,131-132,148-149,164-165): mean BCE-with-logits against a
+ * constant target; grad = (sigmoid(x)-t)/count * upstream.  Hinge is a build-side extra
+ * (the reference never reads --loss, utils.py:85): mode 0 = D real relu(1-x),
+ * 1 = D fake relu(1+x), 2 = G  -x.  loss_out: one device float (must be zeroed).         */
+int itg_bce_logits_fwd(const float* logits, int64_t count, float target, float* loss_out, void* stream);
+int itg_bce_logits_bwd(const float* logits, int64_t count, float target, const float* upstream,
+                       float* dlogits, void* stream);
+int itg_hinge_fwd(const float* logits, int64_t count, int mode, float* loss_out, void* stream);
+int itg_hinge_bwd(const float* logits, int64_t count, int mode, const float* upstream, float* dlogits,
+                  void* stream);
+
+/* ---- spectral norm (torch.nn.utils.spectral_norm as used at layers.py:190-194): one
+ * power iteration in place on u (rows) and v (cols), sigma = u^T W v, inv_sigma out ------ */
+int itg_spectral_norm_power_iter(const float* w, float* u, float* v, int rows, int cols, int do_iter,
+                                 float eps, float* sigma_out, float* inv_sigma_out, float* workspace,
+                                 void* stream);
+/* dW_orig = (G - <G, W/sigma> u v^T) / sigma  */
+int itg_spectral_norm_bwd(const float* g_w, const float* w_orig, const float* u, const float* v,
+                          const float* inv_sigma, int rows, int cols, float* d_w_orig, float* workspace,
+                          void* stream);
+
+/* ---- optimiser (train.py:57-58,153,169,176-180): Adam over a flat parameter buffer with
+ * optional fused EMA (ema = decay*ema + (1-decay)*p); step >= 1 ----------------------------- */
+int itg_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, int64_t count, float lr,
+                      float beta1, float beta2, float eps, int step, float ema_decay, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,114 @@
+"""ctypes binding of libitg_hip.so (the C ABI declared in include/itg.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``csrc/build.sh``; there is
+NO fallback: if it is missing, or a call is rejected, the product raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libitg_hip.so")
+
+PAD_ZERO, PAD_REPLICATE = 0, 1
+ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
+
+
+class Tensor(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("n", C.c_int32), ("gh", C.c_int32), ("gw", C.c_int32),
+                ("ph", C.c_int32), ("pw", C.c_int32), ("c", C.c_int32), ("ld", C.c_int32)]
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("pad_mode", C.c_int32)]
+
+
+_P = C.c_void_p
+_TP = C.POINTER(Tensor)
+_GP = C.POINTER(ConvGeom)
+_i, _f, _d, _l = C.c_int, C.c_float, C.c_double, C.c_int64
+
+# name -> (restype, argtypes); mirrors include/itg.h one to one
+SIGNATURES = {
+    "itg_version": (_i, []),
+    "itg_pack_fwd_size": (_l, [_i, _i, _i, _i]),
+    "itg_pack_dgrad_size": (_l, [_i, _i, _i, _i, _i]),
+    "itg_pack_fwd": (_i, [_P, _P, _P, _i, _i, _i, _i, _i, _P]),
+    "itg_pack_dgrad": (_i, [_P, _P, _P, _i, _i, _i, _i, _i, _i, _P]),
+    "itg_conv2d_fwd": (_i, [_TP, _P, _P, _TP, _TP, _GP, _i, _f, _P]),
+    "itg_conv2d_dgrad": (_i, [_TP, _P, _TP, _GP, _P]),
+    "itg_conv2d_wgrad_workspace": (_l, [_TP, _TP, _GP]),
+    "itg_conv2d_wgrad": (_i, [_TP, _TP, _P, _P, _GP, _i, _P, _l, _P]),
+    "itg_local_pad_fwd": (_i, [_P, _P, _i, _i, _i, _i, _i, _i, _i, _P]),
+    "itg_local_pad_bwd": (_i, [_P, _P, _i, _i, _i, _i, _i, _i, _i, _P]),
+    "itg_local_pad_nhwc_fwd": (_i, [_TP, _TP, _i, _P]),
+    "itg_local_pad_stream_fwd": (_i, [_TP, _P, _P, _TP, _i, _P]),
+    "itg_nchw_to_grid": (_i, [_P, _TP, _i, _P]),
+    "itg_grid_to_nchw": (_i, [_TP, _P, _i, _P]),
+    "itg_bn_stats": (_i, [_TP, _P, _P]),
+    "itg_bn_finalize": (_i, [_P, _d, _d, _P, _P, _f, _f, _P, _P, _P, _P, _P, _i, _i, _i, _P]),
+    "itg_bn_apply": (_i, [_TP, _P, _TP, _i, _f, _P]),
+    "itg_bn_bwd_reduce": (_i, [_TP, _TP, _P, _P, _i, _f, _P, _P]),
+    "itg_bn_bwd_apply": (_i, [_TP, _TP, _P, _P, _P, _P, _d, _i, _f, _TP, _P, _P, _P]),
+    "itg_ssm_modulate_fwd": (_i, [_TP, _P, _TP, _TP, _i, _f, _P]),
+    "itg_ssm_modulate_bwd": (_i, [_TP, _P, _TP, _TP, _i, _f, _TP, _TP, _P]),
+    "itg_act_fwd": (_i, [_TP, _TP, _i, _f, _P]),
+    "itg_act_bwd": (_i, [_TP, _TP, _TP, _i, _f, _P]),
+    "itg_upsample2x_fwd": (_i, [_TP, _TP, _P]),
+    "itg_upsample2x_bwd": (_i, [_TP, _TP, _P]),
+    "itg_add": (_i, [_TP, _TP, _TP, _P]),
+    "itg_colsum": (_i, [_TP, _P, _P, _P]),
+    "itg_axpby": (_i, [_P, _P, _P, _f, _P, _f, _l, _P]),
+    "itg_dot": (_i, [_P, _P, _l, _P, _P]),
+    "itg_attention_fwd": (_i, [_TP, _TP, _TP, _TP, _P, _P]),
+    "itg_attention_bwd": (_i, [_TP, _TP, _TP, _P, _TP, _TP, _TP, _TP, _P]),
+    "itg_maxpool2_fwd": (_i, [_TP, _TP, _P]),
+    "itg_maxpool2_bwd": (_i, [_TP, _TP, _TP, _TP, _P]),
+    "itg_bce_logits_fwd": (_i, [_P, _l, _f, _P, _P]),
+    "itg_bce_logits_bwd": (_i, [_P, _l, _f, _P, _P, _P]),
+    "itg_hinge_fwd": (_i, [_P, _l, _i, _P, _P]),
+    "itg_hinge_bwd": (_i, [_P, _l, _i, _P, _P, _P]),
+    "itg_spectral_norm_power_iter": (_i, [_P, _P, _P, _i, _i, _i, _f, _P, _P, _P, _P]),
+    "itg_spectral_norm_bwd": (_i, [_P, _P, _P, _P, _P, _i, _i, _P, _P, _P]),
+    "itg_adam_ema_step": (_i, [_P, _P, _P, _P, _P, _l, _f, _f, _f, _f, _i, _f, _P]),
+}
+
+_ERR = {-1: "ITG_ERR_ARG (inconsistent shapes / unsupported geometry)",
+        -2: "ITG_ERR_ALIGN (pointer or ld misaligned)",
+        -3: "ITG_ERR_LAUNCH (HIP launch failed)",
+        -4: "ITG_ERR_WORKSPACE (workspace too small)"}
+
+_lib = None
+
+
+class ItgError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ItgError(
+            "libitg_hip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the ABI and the header drift apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise ItgError("%s failed: %s" % (name, _ERR.get(rc, rc)))
+
+
+def fn(name):
+    return getattr(load(), name)

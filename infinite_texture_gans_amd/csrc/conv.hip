@@ -1,0 +1,699 @@
+// Implicit-GEMM convolution on v_mfma_f32_16x16x4_f32 for gfx950 (MI355X).
+//
+//   conv_nt_kernel : forward and input-gradient.  C[co][pixel] = sum_k W[co][k] * P[pixel][k],
+//                    k = (tap, ci) with ci innermost; both operands K-contiguous, staged
+//                    global -> registers -> LDS (double buffered), fragments read with
+//                    ds_read_b128 under a K permutation (lane group g holds k = 4g..4g+3,
+//                    MFMA step s consumes component s of every group).
+//   conv_tn_kernel : weight-gradient.  C[(tap,ci)][co] = sum_pixel X[pixel+tap][ci] * dY[pixel][co],
+//                    split over pixel ranges (grid.z) into fp32 slabs, reduced by
+//                    wgrad_reduce_kernel into the OIHW gradient.
+//
+// The pixel operand is gathered in merged-image coordinates from a patch-grid NHWC tensor, so
+// the LocalPadder halo (reference models/layers.py:145-173) is a neighbour-patch read and the
+// outer replicate / zero padding (layers.py:82) a clamp / predicate; nothing is materialised.
+#include "itg_common.h"
+
+namespace {
+
+constexpr int BK = 16;    // K elements per pipeline stage
+constexpr int LDK = 20;   // LDS row pitch (floats): BK + 4 keeps rows 16-B aligned
+
+struct ConvP {
+  GridT in, out, res;
+  const float* w;
+  const float* bias;
+  int ntaps, kw, cin_ld, Kpad;
+  int MT, MU, M;
+  int isy, ioy, isx, iox;
+  int osy, ooy, osx, oox;
+  int pad_mode, out_mode, act;
+  float slope;
+  int co_rows, nco_tiles;
+};
+
+__device__ __forceinline__ void decode_m(int m, int MT, int MU, int& n, int& t, int& u) {
+  int per = MT * MU;
+  n = m / per;
+  int r = m - n * per;
+  t = r / MU;
+  u = r - t * MU;
+}
+
+template <int BCO, int BPIX, int WCO, int WPIX>
+__global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
+  constexpr int FI = WCO / 16, FJ = WPIX / 16;
+  constexpr int WAVES_CO = BCO / WCO;
+  static_assert(WAVES_CO * (BPIX / WPIX) == 4, "4 waves per workgroup");
+  constexpr int PL = BPIX * 4 / 256;
+  constexpr int WL = (BCO * 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BCO + BPIX) * LDK];
+  float* Ws = smem;
+  float* Ps = smem + 2 * BCO * LDK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int co_tile = blockIdx.x % p.nco_tiles;
+  const int pix_tile = blockIdx.x / p.nco_tiles;
+  const int co0 = co_tile * BCO;
+  const int m0 = pix_tile * BPIX;
+  const int wco0 = (wave % WAVES_CO) * WCO;
+  const int wpix0 = (wave / WAVES_CO) * WPIX;
+  const int kg = tid & 3;
+
+  // ---- per-thread loader state: PL pixel rows, fixed k-group
+  int pn[PL], py[PL], px[PL];
+  bool pv[PL];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) {
+    int m = m0 + (tid >> 2) + i * 64;
+    pv[i] = m < p.M;
+    int n, t, u;
+    decode_m(pv[i] ? m : 0, p.MT, p.MU, n, t, u);
+    pn[i] = n;
+    py[i] = t * p.isy + p.ioy;
+    px[i] = u * p.isx + p.iox;
+  }
+  int cc = kg * 4, tap = 0, ky = 0, kx = 0;
+  while (cc >= p.cin_ld) {
+    cc -= p.cin_ld; ++tap;
+    if (++kx == p.kw) { kx = 0; ++ky; }
+  }
+
+  f32x4 rp[PL], rw[WL];
+  auto load_tiles = [&](int kk) {
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pv[i] && tap < p.ntaps) {
+        int iy = py[i] + ky, ix = px[i] + kx;
+        bool ok;
+        if (p.pad_mode == ITG_PAD_REPLICATE) {
+          iy = min(max(iy, 0), p.in.H - 1);
+          ix = min(max(ix, 0), p.in.W - 1);
+          ok = true;
+        } else {
+          ok = (unsigned)iy < (unsigned)p.in.H && (unsigned)ix < (unsigned)p.in.W;
+        }
+        if (ok) v = *reinterpret_cast<const f32x4*>(p.in.p + grid_off(p.in, pn[i], iy, ix) + cc);
+      }
+      rp[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      int row = (tid >> 2) + i * 64;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < BCO && co0 + row < p.co_rows)
+        v = *reinterpret_cast<const f32x4*>(p.w + (size_t)(co0 + row) * p.Kpad + kk * BK + kg * 4);
+      rw[i] = v;
+    }
+    cc += BK;
+    while (cc >= p.cin_ld) {
+      cc -= p.cin_ld; ++tap;
+      if (++kx == p.kw) { kx = 0; ++ky; }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PL; ++i)
+      *reinterpret_cast<f32x4*>(Ps + (buf * BPIX + (tid >> 2) + i * 64) * LDK + kg * 4) = rp[i];
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      int row = (tid >> 2) + i * 64;
+      if (row < BCO) *reinterpret_cast<f32x4*>(Ws + (buf * BCO + row) * LDK + kg * 4) = rw[i];
+    }
+  };
+
+  f32x4 acc[FI][FJ];
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.Kpad / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  const int frow = lane & 15, fk = (lane >> 4) * 4;
+  for (int kk = 0; kk < nk; ++kk) {
+    const int buf = kk & 1;
+    if (kk + 1 < nk) load_tiles(kk + 1);
+    f32x4 a[FI], b[FJ];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+      a[i] = *reinterpret_cast<const f32x4*>(Ws + (buf * BCO + wco0 + 16 * i + frow) * LDK + fk);
+#pragma unroll
+    for (int j = 0; j < FJ; ++j)
+      b[j] = *reinterpret_cast<const f32x4*>(Ps + (buf * BPIX + wpix0 + 16 * j + frow) * LDK + fk);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    if (kk + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds 4 consecutive output channels of one pixel per fragment
+  const int cq = (lane >> 4) * 4;
+#pragma unroll
+  for (int j = 0; j < FJ; ++j) {
+    int m = m0 + wpix0 + 16 * j + (lane & 15);
+    if (m >= p.M) continue;
+    int n, t, u;
+    decode_m(m, p.MT, p.MU, n, t, u);
+    int oy = t * p.osy + p.ooy, ox = u * p.osx + p.oox;
+    bool border = false;
+    if (p.out_mode == 1) {
+      int ty = min(max(oy, 0), p.out.H - 1), tx = min(max(ox, 0), p.out.W - 1);
+      border = (ty == 0) | (ty == p.out.H - 1) | (tx == 0) | (tx == p.out.W - 1);
+      oy = ty; ox = tx;
+    }
+    const int off = grid_off(p.out, n, oy, ox);
+    const int roff = p.res.p ? grid_off(p.res, n, oy, ox) : 0;
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+      int co = co0 + wco0 + 16 * i + cq;
+      if (co >= p.out.ld) continue;
+      f32x4 v = acc[i][j];
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (co + e < p.out.c) v[e] += p.bias[co + e];
+      }
+      if (p.res.p) {
+        f32x4 r = *reinterpret_cast<const f32x4*>(p.res.p + roff + co);
+        v += r;
+      }
+      if (p.act != ITG_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act, p.slope);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (co + e >= p.out.c) v[e] = 0.f;
+      float* dst = p.out.p + off + co;
+      if (border) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dst + e, v[e]);
+      } else {
+        *reinterpret_cast<f32x4*>(dst) = v;
+      }
+    }
+  }
+}
+
+// zero the 1-pixel frame of the merged image (targets of the fold-mode atomics)
+__global__ void zero_border_kernel(GridT g) {
+  int per = 2 * g.W + 2 * (g.H - 2 > 0 ? g.H - 2 : 0);
+  int q4 = g.ld >> 2;
+  int64_t total = (int64_t)g.n * per * q4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c4 = (int)(i % q4);
+    int64_t r = i / q4;
+    int b = (int)(r % per);
+    int n = (int)(r / per);
+    int Y, X;
+    if (b < g.W) { Y = 0; X = b; }
+    else if (b < 2 * g.W) { Y = g.H - 1; X = b - g.W; }
+    else { int k = b - 2 * g.W; Y = 1 + (k >> 1); X = (k & 1) ? g.W - 1 : 0; }
+    if (g.H == 1 && b >= g.W) continue;
+    *reinterpret_cast<f32x4*>(g.p + grid_off(g, n, Y, X) + c4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+template <int BCO, int BPIX, int WCO, int WPIX>
+int launch_nt(const ConvP& p, hipStream_t s) {
+  ConvP q = p;
+  q.nco_tiles = (p.co_rows + BCO - 1) / BCO;
+  int64_t npix = ((int64_t)p.M + BPIX - 1) / BPIX;
+  int64_t blocks = npix * q.nco_tiles;
+  if (blocks <= 0 || blocks > 0x7fffffff) return ITG_ERR_ARG;
+  hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX>), dim3((unsigned)blocks), dim3(256), 0, s, q);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int dispatch_nt(const ConvP& p, hipStream_t s) {
+  if (p.co_rows <= 16) return launch_nt<16, 256, 16, 64>(p, s);
+  if (p.co_rows <= 32) return launch_nt<32, 256, 32, 64>(p, s);
+  if (p.co_rows <= 64) return launch_nt<64, 256, 64, 64>(p, s);
+  return launch_nt<128, 128, 64, 64>(p, s);
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------- packing
+// fwd: out[co][k], k = (ky*kw+kx)*ci_ld + ci, rows co >= co zero, k >= K zero
+__global__ void pack_fwd_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out,
+                                int co, int ci, int ci_ld, int kh, int kw, int co_pad, int Kpad) {
+  int64_t total = (int64_t)co_pad * Kpad;
+  float sc = scale ? *scale : 1.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int k = (int)(i % Kpad);
+    int o = (int)(i / Kpad);
+    int tap = k / ci_ld, c = k - tap * ci_ld;
+    float v = 0.f;
+    if (o < co && tap < kh * kw && c < ci) {
+      int y = tap / kw, x = tap - y * kw;
+      v = w[(((size_t)o * ci + c) * kh + y) * kw + x] * sc;
+    }
+    out[i] = v;
+  }
+}
+
+// dgrad stride 1: out[ci][k], k = (ky'*kw+kx')*co_ld + co, W[co][ci][kh-1-ky'][kw-1-kx']
+// dgrad stride 2: class (ry,rx) major; taps (jy',jx') of the (kh/2 x kw/2) sub-kernel,
+//                 ky = ay + 2*(kh/2-1-jy'), ay = (ry+pad)&1 (same for x)
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out,
+                                  int co, int ci, int co_ld, int kh, int kw, int stride, int pad, int ci_pad,
+                                  int Kpad) {
+  int ncls = stride * stride;
+  int skh = kh / stride, skw = kw / stride;
+  int64_t total = (int64_t)ncls * ci_pad * Kpad;
+  float sc = scale ? *scale : 1.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int k = (int)(i % Kpad);
+    int64_t r = i / Kpad;
+    int c_in = (int)(r % ci_pad);
+    int cls = (int)(r / ci_pad);
+    int ry = cls / stride, rx = cls - ry * stride;
+    int tap = k / co_ld, o = k - tap * co_ld;
+    float v = 0.f;
+    if (c_in < ci && o < co && tap < skh * skw) {
+      int jy = tap / skw, jx = tap - jy * skw;
+      int ay = (ry + pad) % stride, ax = (rx + pad) % stride;
+      int y = ay + stride * (skh - 1 - jy), x = ax + stride * (skw - 1 - jx);
+      v = w[(((size_t)o * ci + c_in) * kh + y) * kw + x] * sc;
+    }
+    out[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------- wgrad (TN)
+struct WgP {
+  GridT x, dy;
+  float* slab;       // [splits][co_pad][Kpad]
+  int ntaps, kw, cin_ld, Kpad, Ktot;
+  int MT, MU, M;     // output-pixel domain of the conv
+  int stride, pad, pad_mode;
+  int co_rows, ncol_tiles, nco_tiles;
+  int chunks_per_split, nchunks;
+};
+
+constexpr int BKP = 16;  // pixels per pipeline stage
+
+template <int BCOL, int BCO, int WCOL, int WCO>
+__global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
+  constexpr int FI = WCOL / 16, FJ = WCO / 16;
+  constexpr int WAVES_COL = BCOL / WCOL;
+  static_assert(WAVES_COL * (BCO / WCO) == 4, "4 waves per workgroup");
+  constexpr int LDX = BCOL + 16, LDY = BCO + 16;
+  constexpr int XG = BCOL / 4, YG = BCO / 4;         // float4 groups per pixel row
+  constexpr int XL = (BKP * XG + 255) / 256, YL = (BKP * YG + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BKP * (LDX + LDY)];
+  float* Xs = smem;
+  float* Ys = smem + 2 * BKP * LDX;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col_tile = blockIdx.x % p.ncol_tiles;
+  const int co_tile = blockIdx.x / p.ncol_tiles;
+  const int col0 = col_tile * BCOL, co0 = co_tile * BCO;
+  const int wcol0 = (wave % WAVES_COL) * WCOL, wco0 = (wave / WAVES_COL) * WCO;
+  const int split = blockIdx.z;
+  const int chunk_begin = split * p.chunks_per_split;
+  const int chunk_end = min(p.nchunks, chunk_begin + p.chunks_per_split);
+
+  // X loads: thread -> (pixel row xr[i], column group xg[i]); the column (tap, ci) is fixed
+  int xr[XL], xcol[XL], xky[XL], xkx[XL], xci[XL];
+  bool xok[XL];
+  int xn[XL], xt[XL], xu[XL];
+#pragma unroll
+  for (int i = 0; i < XL; ++i) {
+    int idx = tid + i * 256;
+    xr[i] = idx / XG;
+    int g = idx - xr[i] * XG;
+    xcol[i] = g * 4;
+    int col = col0 + g * 4;
+    int tap = col / p.cin_ld;
+    xci[i] = col - tap * p.cin_ld;
+    xky[i] = tap / p.kw;
+    xkx[i] = tap - xky[i] * p.kw;
+    xok[i] = (xr[i] < BKP) && (col < p.Ktot);
+    int m = chunk_begin * BKP + xr[i];
+    decode_m(m < p.M ? m : 0, p.MT, p.MU, xn[i], xt[i], xu[i]);
+    if (m >= p.M) xn[i] = p.x.n;  // marks invalid
+  }
+  int yr[YL], yc[YL], yn[YL], yt[YL], yu[YL];
+  bool yok[YL];
+#pragma unroll
+  for (int i = 0; i < YL; ++i) {
+    int idx = tid + i * 256;
+    yr[i] = idx / YG;
+    int g = idx - yr[i] * YG;
+    yc[i] = g * 4;
+    yok[i] = (yr[i] < BKP) && (co0 + g * 4 < p.dy.ld);
+    int m = chunk_begin * BKP + yr[i];
+    decode_m(m < p.M ? m : 0, p.MT, p.MU, yn[i], yt[i], yu[i]);
+    if (m >= p.M) yn[i] = p.x.n;
+  }
+  auto advance = [&](int& n, int& t, int& u) {
+    u += BKP;
+    while (u >= p.MU) { u -= p.MU; if (++t == p.MT) { t = 0; ++n; } }
+  };
+
+  f32x4 rx[XL], ry[YL];
+  auto load_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (xok[i] && xn[i] < p.x.n) {
+        int iy = xt[i] * p.stride - p.pad + xky[i], ix = xu[i] * p.stride - p.pad + xkx[i];
+        bool ok;
+        if (p.pad_mode == ITG_PAD_REPLICATE) {
+          iy = min(max(iy, 0), p.x.H - 1); ix = min(max(ix, 0), p.x.W - 1); ok = true;
+        } else {
+          ok = (unsigned)iy < (unsigned)p.x.H && (unsigned)ix < (unsigned)p.x.W;
+        }
+        if (ok) v = *reinterpret_cast<const f32x4*>(p.x.p + grid_off(p.x, xn[i], iy, ix) + xci[i]);
+      }
+      rx[i] = v;
+      advance(xn[i], xt[i], xu[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < YL; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (yok[i] && yn[i] < p.x.n)
+        v = *reinterpret_cast<const f32x4*>(p.dy.p + grid_off(p.dy, yn[i], yt[i], yu[i]) + co0 + yc[i]);
+      ry[i] = v;
+      advance(yn[i], yt[i], yu[i]);
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < XL; ++i)
+      if (xr[i] < BKP) *reinterpret_cast<f32x4*>(Xs + (buf * BKP + xr[i]) * LDX + xcol[i]) = rx[i];
+#pragma unroll
+    for (int i = 0; i < YL; ++i)
+      if (yr[i] < BKP) *reinterpret_cast<f32x4*>(Ys + (buf * BKP + yr[i]) * LDY + yc[i]) = ry[i];
+  };
+
+  f32x4 acc[FI][FJ];
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = chunk_end - chunk_begin;
+  if (nk > 0) {
+    load_tiles();
+    store_tiles(0);
+    __syncthreads();
+    const int fr = lane & 15, fkk = lane >> 4;
+    for (int kk = 0; kk < nk; ++kk) {
+      const int buf = kk & 1;
+      if (kk + 1 < nk) load_tiles();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float a[FI], b[FJ];
+        const float* xrow = Xs + (buf * BKP + 4 * s + fkk) * LDX + wcol0 + fr;
+        const float* yrow = Ys + (buf * BKP + 4 * s + fkk) * LDY + wco0 + fr;
+#pragma unroll
+        for (int i = 0; i < FI; ++i) a[i] = xrow[16 * i];
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) b[j] = yrow[16 * j];
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+          for (int j = 0; j < FJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (kk + 1 < nk) store_tiles(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  // D[row = column index (4 consecutive per lane)][col = co]
+  float* slab = p.slab + (size_t)split * p.co_rows * p.Kpad;
+  const int cq = (lane >> 4) * 4;
+#pragma unroll
+  for (int j = 0; j < FJ; ++j) {
+    int co = co0 + wco0 + 16 * j + (lane & 15);
+    if (co >= p.co_rows) continue;
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+      int col = col0 + wcol0 + 16 * i + cq;
+      if (col >= p.Kpad) continue;
+      *reinterpret_cast<f32x4*>(slab + (size_t)co * p.Kpad + col) = acc[i][j];
+    }
+  }
+}
+
+// dW[co][ci][ky][kx] (+)= sum_z slab[z][co][(ky*kw+kx)*ci_ld + ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int co, int ci,
+                                    int ci_ld, int kh, int kw, int co_rows, int Kpad, int accumulate) {
+  int64_t total = (int64_t)co * ci * kh * kw;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int x = (int)(i % kw);
+    int64_t r = i / kw;
+    int y = (int)(r % kh); r /= kh;
+    int c = (int)(r % ci);
+    int o = (int)(r / ci);
+    size_t src = (size_t)o * Kpad + (size_t)(y * kw + x) * ci_ld + c;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slab[(size_t)z * co_rows * Kpad + src];
+    dw[i] = accumulate ? dw[i] + s : s;
+  }
+}
+
+template <int BCOL, int BCO, int WCOL, int WCO>
+int launch_tn(WgP p, int splits, hipStream_t s) {
+  p.ncol_tiles = (p.Kpad + BCOL - 1) / BCOL;
+  p.nco_tiles = (p.co_rows + BCO - 1) / BCO;
+  dim3 grid((unsigned)(p.ncol_tiles * p.nco_tiles), 1, (unsigned)splits);
+  hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO>), grid, dim3(256), 0, s, p);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+struct TnPlan { int bcol, bco, splits, chunks_per_split, nchunks, co_rows, Kpad; };
+
+TnPlan plan_tn(int64_t M, int co_ld, int Ktot) {
+  TnPlan t;
+  t.co_rows = round_up(co_ld, 16);
+  t.Kpad = round_up(Ktot, 16);
+  if (t.co_rows <= 16) { t.bco = 16; t.bcol = 256; }
+  else if (t.co_rows <= 32) { t.bco = 32; t.bcol = 256; }
+  else if (t.co_rows <= 64) { t.bco = 64; t.bcol = 256; }
+  else { t.bco = 128; t.bcol = 128; }
+  int tiles = ((t.Kpad + t.bcol - 1) / t.bcol) * ((t.co_rows + t.bco - 1) / t.bco);
+  t.nchunks = (int)((M + BKP - 1) / BKP);
+  int want = (1024 + tiles - 1) / tiles;            // ~4 workgroups per CU overall
+  int max_splits = (t.nchunks + 7) / 8;             // at least 8 chunks per split
+  int splits = want < max_splits ? want : max_splits;
+  if (splits < 1) splits = 1;
+  t.chunks_per_split = (t.nchunks + splits - 1) / splits;
+  t.splits = (t.nchunks + t.chunks_per_split - 1) / t.chunks_per_split;
+  return t;
+}
+
+int conv_out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+int itg_version(void) { return 100; }
+
+int64_t itg_pack_fwd_size(int co, int ci_ld, int kh, int kw) {
+  return (int64_t)round_up(co, 16) * round_up(kh * kw * ci_ld, BK);
+}
+
+int64_t itg_pack_dgrad_size(int ci, int co_ld, int kh, int kw, int stride) {
+  int taps = (kh / stride) * (kw / stride);
+  return (int64_t)stride * stride * round_up(ci, 16) * round_up(taps * co_ld, BK);
+}
+
+int itg_pack_fwd(const float* w, const float* scale, float* out, int co, int ci, int ci_ld, int kh, int kw,
+                 void* stream) {
+  if (!w || !out || co <= 0 || ci <= 0 || ci_ld < ci || (ci_ld & 3)) return ITG_ERR_ARG;
+  int co_pad = round_up(co, 16), Kpad = round_up(kh * kw * ci_ld, BK);
+  int64_t total = (int64_t)co_pad * Kpad;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, scale, out, co, ci, ci_ld,
+                     kh, kw, co_pad, Kpad);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_pack_dgrad(const float* w, const float* scale, float* out, int co, int ci, int co_ld, int kh, int kw,
+                   int stride, void* stream) {
+  if (!w || !out || co <= 0 || ci <= 0 || co_ld < co || (co_ld & 3)) return ITG_ERR_ARG;
+  if (stride != 1 && stride != 2) return ITG_ERR_ARG;
+  if (stride == 2 && ((kh & 1) || (kw & 1))) return ITG_ERR_ARG;
+  // pad enters only through parity (ry+pad)&1 for stride 2; the ABI fixes pad = 1 for stride-2 convs
+  int pad = 1;
+  int ci_pad = round_up(ci, 16);
+  int taps = (kh / stride) * (kw / stride);
+  int Kpad = round_up(taps * co_ld, BK);
+  int64_t total = (int64_t)stride * stride * ci_pad * Kpad;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, scale, out, co, ci,
+                     co_ld, kh, kw, stride, pad, ci_pad, Kpad);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bias, const itg_tensor* residual,
+                   const itg_tensor* out, const itg_conv_geom* g, int act, float slope, void* stream) {
+  int rc;
+  if ((rc = check_tensor(in)) || (rc = check_tensor(out))) return rc;
+  if (!w_packed || !g || g->kh <= 0 || g->kw <= 0 || g->stride <= 0 || g->pad < 0) return ITG_ERR_ARG;
+  ConvP p;
+  p.in = make_grid(in);
+  p.out = make_grid(out);
+  p.res = null_grid();
+  if (residual && residual->ptr) {
+    if ((rc = check_tensor(residual))) return rc;
+    if (!same_shape(residual, out)) return ITG_ERR_ARG;
+    p.res = make_grid(residual);
+  }
+  if (in->n != out->n) return ITG_ERR_ARG;
+  int Ho = conv_out_dim(p.in.H, g->kh, g->stride, g->pad), Wo = conv_out_dim(p.in.W, g->kw, g->stride, g->pad);
+  if (Ho != p.out.H || Wo != p.out.W) return ITG_ERR_ARG;
+  if (g->pad_mode == ITG_PAD_REPLICATE && g->stride != 1) return ITG_ERR_ARG;
+  p.w = w_packed; p.bias = bias;
+  p.ntaps = g->kh * g->kw; p.kw = g->kw; p.cin_ld = in->ld;
+  p.Kpad = round_up(p.ntaps * in->ld, BK);
+  p.MT = Ho; p.MU = Wo;
+  int64_t M = (int64_t)in->n * Ho * Wo;
+  if (M >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
+  p.M = (int)M;
+  p.isy = p.isx = g->stride; p.ioy = p.iox = -g->pad;
+  p.osy = p.osx = 1; p.ooy = p.oox = 0;
+  p.pad_mode = g->pad_mode; p.out_mode = 0; p.act = act; p.slope = slope;
+  p.co_rows = round_up(out->c, 16);
+  return dispatch_nt(p, (hipStream_t)stream);
+}
+
+int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const itg_tensor* dx, const itg_conv_geom* g,
+                     void* stream) {
+  int rc;
+  if ((rc = check_tensor(dy)) || (rc = check_tensor(dx))) return rc;
+  if (!w_packed_dgrad || !g) return ITG_ERR_ARG;
+  if (dy->n != dx->n) return ITG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  ConvP p;
+  p.in = make_grid(dy);
+  p.out = make_grid(dx);
+  p.res = null_grid();
+  int Ho = conv_out_dim(p.out.H, g->kh, g->stride, g->pad), Wo = conv_out_dim(p.out.W, g->kw, g->stride, g->pad);
+  if (Ho != p.in.H || Wo != p.in.W) return ITG_ERR_ARG;
+  p.bias = nullptr; p.act = ITG_ACT_NONE; p.slope = 0.f;
+  p.cin_ld = dy->ld;
+  p.co_rows = round_up(dx->c, 16);
+  p.pad_mode = ITG_PAD_ZERO;
+  if (g->stride == 1) {
+    p.w = w_packed_dgrad;
+    p.ntaps = g->kh * g->kw; p.kw = g->kw;
+    p.Kpad = round_up(p.ntaps * dy->ld, BK);
+    p.isy = p.isx = 1; p.osy = p.osx = 1;
+    if (g->pad_mode == ITG_PAD_REPLICATE && g->pad > 0) {
+      // padded domain, gradients of the replicated frame fold onto the edge pixels
+      p.MT = p.out.H + 2 * g->pad; p.MU = p.out.W + 2 * g->pad;
+      p.ioy = -(g->kh - 1); p.iox = -(g->kw - 1);
+      p.ooy = p.oox = -g->pad;
+      p.out_mode = 1;
+      GridT gx = p.out;
+      int64_t tot = (int64_t)gx.n * (2 * gx.W + 2 * gx.H) * (gx.ld >> 2);
+      int blocks = (int)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048);
+      hipLaunchKernelGGL(zero_border_kernel, dim3(blocks), dim3(256), 0, s, gx);
+      ITG_CHECK_LAUNCH();
+    } else {
+      p.MT = p.out.H; p.MU = p.out.W;
+      p.ioy = -(g->kh - 1 - g->pad); p.iox = -(g->kw - 1 - g->pad);
+      p.ooy = p.oox = 0;
+      p.out_mode = 0;
+    }
+    int64_t M = (int64_t)dx->n * p.MT * p.MU;
+    if (M >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
+    p.M = (int)M;
+    return dispatch_nt(p, s);
+  }
+  if (g->stride != 2 || g->pad != 1 || (g->kh & 1) || (g->kw & 1) || g->pad_mode != ITG_PAD_ZERO) return ITG_ERR_ARG;
+  int skh = g->kh / 2, skw = g->kw / 2;
+  p.ntaps = skh * skw; p.kw = skw;
+  p.Kpad = round_up(p.ntaps * dy->ld, BK);
+  p.isy = p.isx = 1; p.osy = p.osx = 2; p.out_mode = 0;
+  int ci_pad = round_up(dx->c, 16);
+  for (int ry = 0; ry < 2; ++ry)
+    for (int rx = 0; rx < 2; ++rx) {
+      int ay = (ry + g->pad) & 1, ax = (rx + g->pad) & 1;
+      int by = (ry + g->pad - ay) / 2, bx = (rx + g->pad - ax) / 2;
+      p.MT = (p.out.H - ry + 1) / 2; p.MU = (p.out.W - rx + 1) / 2;
+      if (p.MT <= 0 || p.MU <= 0) continue;
+      p.ioy = by - (skh - 1); p.iox = bx - (skw - 1);
+      p.ooy = ry; p.oox = rx;
+      p.w = w_packed_dgrad + (size_t)(ry * 2 + rx) * ci_pad * p.Kpad;
+      int64_t M = (int64_t)dx->n * p.MT * p.MU;
+      if (M >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
+      p.M = (int)M;
+      int r = dispatch_nt(p, s);
+      if (r) return r;
+    }
+  return ITG_OK;
+}
+
+int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g) {
+  if (!x || !dy || !g) return 0;
+  int64_t M = grid_pixels(dy);
+  TnPlan t = plan_tn(M, dy->ld, g->kh * g->kw * x->ld);
+  return (int64_t)t.splits * t.co_rows * t.Kpad + 2 * (int64_t)dy->ld;
+}
+
+int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float* db, const itg_conv_geom* g,
+                     int accumulate, float* workspace, int64_t workspace_floats, void* stream) {
+  int rc;
+  if ((rc = check_tensor(x)) || (rc = check_tensor(dy))) return rc;
+  if (!dw || !g || !workspace) return ITG_ERR_ARG;
+  if (x->n != dy->n) return ITG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  WgP p;
+  p.x = make_grid(x);
+  p.dy = make_grid(dy);
+  int Ho = conv_out_dim(p.x.H, g->kh, g->stride, g->pad), Wo = conv_out_dim(p.x.W, g->kw, g->stride, g->pad);
+  if (Ho != p.dy.H || Wo != p.dy.W) return ITG_ERR_ARG;
+  if (g->pad_mode == ITG_PAD_REPLICATE && g->stride != 1) return ITG_ERR_ARG;
+  int64_t M = (int64_t)x->n * Ho * Wo;
+  if (M >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
+  p.ntaps = g->kh * g->kw; p.kw = g->kw; p.cin_ld = x->ld;
+  p.Ktot = p.ntaps * x->ld;
+  TnPlan t = plan_tn(M, dy->ld, p.Ktot);
+  const int64_t slab_floats = (int64_t)t.splits * t.co_rows * t.Kpad;
+  if (slab_floats + 2 * (int64_t)dy->ld > workspace_floats) return ITG_ERR_WORKSPACE;
+  p.Kpad = t.Kpad; p.co_rows = t.co_rows;
+  p.slab = workspace;
+  p.MT = Ho; p.MU = Wo; p.M = (int)M;
+  p.stride = g->stride; p.pad = g->pad; p.pad_mode = g->pad_mode;
+  p.chunks_per_split = t.chunks_per_split; p.nchunks = t.nchunks;
+  if (t.bco == 16) rc = launch_tn<256, 16, 64, 16>(p, t.splits, s);
+  else if (t.bco == 32) rc = launch_tn<256, 32, 64, 32>(p, t.splits, s);
+  else if (t.bco == 64) rc = launch_tn<256, 64, 64, 64>(p, t.splits, s);
+  else rc = launch_tn<128, 128, 64, 64>(p, t.splits, s);
+  if (rc) return rc;
+  int64_t total = (int64_t)dy->c * x->c * g->kh * g->kw;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, dw, t.splits, dy->c,
+                     x->c, x->ld, g->kh, g->kw, t.co_rows, t.Kpad, accumulate);
+  ITG_CHECK_LAUNCH();
+  if (db) {
+    rc = itg_colsum(dy, db, reinterpret_cast<double*>(workspace + slab_floats), stream);
+    if (rc) return rc;
+  }
+  return ITG_OK;
+}
+
+}  // extern "C"

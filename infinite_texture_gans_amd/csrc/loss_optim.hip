@@ -1,0 +1,275 @@
+// Losses, spectral-norm power iteration and the fused Adam(+EMA) step (gfx950).
+// Reductions are per-wave __shfl_xor trees (64-wide) feeding one LDS slot per wave.
+//   BCE-with-logits : reference train.py:81,131-132,148-149,164-165 (nn.BCEWithLogitsLoss, mean)
+//   hinge           : build-side extra, absent from the reference (utils.py:85 is never read)
+//   spectral norm   : torch.nn.utils.spectral_norm as wrapped at reference models/layers.py:190-194
+//   Adam / EMA      : reference train.py:57-58,153,169,176-180
+#include "itg_common.h"
+
+namespace {
+
+__device__ __forceinline__ double block_sum_d(double v) {
+  __shared__ double part[16];
+  v = wave_sum_d(v);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) part[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  int nw = (blockDim.x + 63) >> 6;
+  for (int i = 0; i < nw; ++i) t += part[i];
+  return t;
+}
+
+__device__ __forceinline__ float bce_elem(float x, float t) {
+  return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+}
+
+// single workgroup: deterministic
+__global__ __launch_bounds__(1024) void bce_fwd_kernel(const float* __restrict__ x, int64_t n, float t,
+                                                       float* __restrict__ out) {
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += (double)bce_elem(x[i], t);
+  s = block_sum_d(s);
+  if (threadIdx.x == 0) *out = (float)(s / (double)n);
+}
+
+__global__ void bce_bwd_kernel(const float* __restrict__ x, int64_t n, float t, const float* __restrict__ up,
+                               float* __restrict__ dx) {
+  float sc = (up ? *up : 1.f) / (float)n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = x[i];
+    float sg = 1.f / (1.f + expf(-v));
+    dx[i] = (sg - t) * sc;
+  }
+}
+
+// hinge family as max(a + b*x, lo): D real (1,-1,0), D fake (1,1,0), G (0,-1,-inf)
+struct HingeC { float a, b, lo; };
+__device__ __forceinline__ HingeC hinge_consts(int mode) {
+  HingeC c;
+  c.a = mode == 2 ? 0.f : 1.f;
+  c.b = mode == 1 ? 1.f : -1.f;
+  c.lo = mode == 2 ? -INFINITY : 0.f;
+  return c;
+}
+
+__global__ __launch_bounds__(1024) void hinge_fwd_kernel(const float* __restrict__ x, int64_t n, int mode,
+                                                         float* __restrict__ out) {
+  const HingeC c = hinge_consts(mode);
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += (double)fmaxf(fmaf(c.b, x[i], c.a), c.lo);
+  s = block_sum_d(s);
+  if (threadIdx.x == 0) *out = (float)(s / (double)n);
+}
+
+__global__ void hinge_bwd_kernel(const float* __restrict__ x, int64_t n, int mode, const float* __restrict__ up,
+                                 float* __restrict__ dx) {
+  const HingeC c = hinge_consts(mode);
+  float sc = (up ? *up : 1.f) / (float)n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dx[i] = (fmaf(c.b, x[i], c.a) > c.lo) ? c.b * sc : 0.f;
+}
+
+// ---- spectral norm ------------------------------------------------------------------------
+// t[j] = sum_i W[i][j] * u[i]   (one thread per column, coalesced across columns)
+__global__ void sn_wt_u_kernel(const float* __restrict__ w, const float* __restrict__ u, float* __restrict__ t, int rows,
+                               int cols) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  double s = 0.0;
+  for (int i = 0; i < rows; ++i) s += (double)w[(size_t)i * cols + j] * (double)u[i];
+  t[j] = (float)s;
+}
+
+// dst = src / max(||src||, eps)    (single workgroup)
+__global__ __launch_bounds__(1024) void sn_normalize_kernel(const float* __restrict__ src, float* __restrict__ dst, int n,
+                                                            float eps) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)src[i] * (double)src[i];
+  s = block_sum_d(s);
+  float nrm = fmaxf((float)sqrt(s), eps);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i] / nrm;
+}
+
+// t[i] = sum_j W[i][j] * v[j]   (one wave per row)
+__global__ void sn_w_v_kernel(const float* __restrict__ w, const float* __restrict__ v, float* __restrict__ t, int rows,
+                              int cols) {
+  int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  double s = 0.0;
+  for (int j = lane; j < cols; j += 64) s += (double)w[(size_t)row * cols + j] * (double)v[j];
+  s = wave_sum_d(s);
+  if (lane == 0) t[row] = (float)s;
+}
+
+// sigma = dot(u, wv); inv = 1/sigma
+__global__ __launch_bounds__(1024) void sn_sigma_kernel(const float* __restrict__ u, const float* __restrict__ wv, int rows,
+                                                        float* __restrict__ sigma, float* __restrict__ inv) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < rows; i += blockDim.x) s += (double)u[i] * (double)wv[i];
+  s = block_sum_d(s);
+  if (threadIdx.x == 0) {
+    float sg = (float)s;
+    if (sigma) *sigma = sg;
+    if (inv) *inv = 1.f / sg;
+  }
+}
+
+__global__ void dot_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, double* __restrict__ out) {
+  double s = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    s += (double)a[i] * (double)b[i];
+  s = block_sum_d(s);
+  if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+// d_w_orig = (G - (<G,W_orig>/sigma) * u v^T) / sigma
+__global__ void sn_bwd_kernel(const float* __restrict__ g, const float* __restrict__ u, const float* __restrict__ v,
+                              const float* __restrict__ inv_sigma, const double* __restrict__ gdotw, int rows, int cols,
+                              float* __restrict__ d) {
+  float is = *inv_sigma;
+  float coef = (float)(*gdotw) * is;
+  int64_t n = (int64_t)rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+    d[i] = (g[i] - coef * u[r] * v[c]) * is;
+  }
+}
+
+// ---- Adam + EMA ------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            float* __restrict__ ema, int64_t n, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2_sqrt, float ema_decay) {
+  const float step = lr / bc1;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    float mi = b1 == 0.f ? gi : m[i] + (gi - m[i]) * (1.f - b1);
+    float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    float pi = p[i] - step * (mi / denom);
+    p[i] = pi;
+    if (ema) ema[i] = ema[i] * ema_decay + pi * (1.f - ema_decay);
+  }
+}
+
+__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ o, float a,
+                             const float* __restrict__ a_dev, float b, int64_t n) {
+  float aa = a_dev ? a * (*a_dev) : a;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    o[i] = aa * x[i] + b * y[i];
+}
+
+inline int nblocks(int64_t n, int cap = 4096) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+int itg_bce_logits_fwd(const float* logits, int64_t count, float target, float* loss_out, void* stream) {
+  if (!logits || !loss_out || count <= 0) return ITG_ERR_ARG;
+  hipLaunchKernelGGL(bce_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, count, target, loss_out);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_bce_logits_bwd(const float* logits, int64_t count, float target, const float* upstream, float* dlogits,
+                       void* stream) {
+  if (!logits || !dlogits || count <= 0) return ITG_ERR_ARG;
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(nblocks(count)), dim3(256), 0, (hipStream_t)stream, logits, count, target,
+                     upstream, dlogits);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_hinge_fwd(const float* logits, int64_t count, int mode, float* loss_out, void* stream) {
+  if (!logits || !loss_out || count <= 0 || mode < 0 || mode > 2) return ITG_ERR_ARG;
+  hipLaunchKernelGGL(hinge_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, count, mode, loss_out);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_hinge_bwd(const float* logits, int64_t count, int mode, const float* upstream, float* dlogits, void* stream) {
+  if (!logits || !dlogits || count <= 0 || mode < 0 || mode > 2) return ITG_ERR_ARG;
+  hipLaunchKernelGGL(hinge_bwd_kernel, dim3(nblocks(count)), dim3(256), 0, (hipStream_t)stream, logits, count, mode,
+                     upstream, dlogits);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+// workspace: rows + cols floats
+int itg_spectral_norm_power_iter(const float* w, float* u, float* v, int rows, int cols, int do_iter, float eps,
+                                 float* sigma_out, float* inv_sigma_out, float* workspace, void* stream) {
+  if (!w || !u || !v || rows <= 0 || cols <= 0 || !workspace) return ITG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  float* t_cols = workspace;
+  float* t_rows = workspace + cols;
+  if (do_iter) {
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, w, (const float*)u, t_cols, rows, cols);
+    ITG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, (const float*)t_cols, v, cols, eps);
+    ITG_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(sn_w_v_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, w, (const float*)v, t_rows, rows, cols);
+  ITG_CHECK_LAUNCH();
+  if (do_iter) {
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, (const float*)t_rows, u, rows, eps);
+    ITG_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(1024), 0, s, (const float*)u, (const float*)t_rows, rows, sigma_out,
+                     inv_sigma_out);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+// workspace: 2 floats (one fp64 accumulator, 8-byte aligned)
+int itg_spectral_norm_bwd(const float* g_w, const float* w_orig, const float* u, const float* v,
+                          const float* inv_sigma, int rows, int cols, float* d_w_orig, float* workspace, void* stream) {
+  if (!g_w || !w_orig || !u || !v || !inv_sigma || !d_w_orig || !workspace || (((uintptr_t)workspace) & 7))
+    return ITG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  double* acc = reinterpret_cast<double*>(workspace);
+  if (hipMemsetAsync(acc, 0, sizeof(double), s) != hipSuccess) return ITG_ERR_LAUNCH;
+  int64_t n = (int64_t)rows * cols;
+  hipLaunchKernelGGL(dot_kernel, dim3(nblocks(n, 512)), dim3(256), 0, s, g_w, w_orig, n, acc);
+  ITG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sn_bwd_kernel, dim3(nblocks(n)), dim3(256), 0, s, g_w, u, v, inv_sigma, (const double*)acc, rows,
+                     cols, d_w_orig);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_axpby(const float* x, const float* y, float* out, float a, const float* a_dev, float b, int64_t n,
+              void* stream) {
+  if (!x || !y || !out || n <= 0) return ITG_ERR_ARG;
+  hipLaunchKernelGGL(axpby_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, out, a, a_dev, b, n);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_dot(const float* x, const float* y, int64_t n, double* out, void* stream) {
+  if (!x || !y || !out || n <= 0) return ITG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, sizeof(double), s) != hipSuccess) return ITG_ERR_LAUNCH;
+  hipLaunchKernelGGL(dot_kernel, dim3(nblocks(n, 512)), dim3(256), 0, s, x, y, n, out);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, int64_t count, float lr, float beta1,
+                      float beta2, float eps, int step, float ema_decay, void* stream) {
+  if (!p || !g || !m || !v || count <= 0 || step < 1) return ITG_ERR_ARG;
+  double bc1 = 1.0 - pow((double)beta1, (double)step);
+  double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(count)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, count, lr,
+                     beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), ema_decay);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+}  // extern "C"

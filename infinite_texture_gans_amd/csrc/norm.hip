@@ -1,0 +1,434 @@
+// BatchNorm2d / SSM normalisation kernels for patch-grid NHWC tensors (gfx950).
+// Memory-bound: every kernel streams float4 (4 channels of one pixel) with a grid whose
+// total thread count is a multiple of ld/4, so a thread's channel group - and therefore its
+// alpha/beta/mean/rstd registers - is fixed for the whole sweep.  Per-channel sums are kept
+// in fp64 (thread partials -> LDS ds_add_f64 -> one global fp64 atomic per channel per
+// workgroup); the fp64 (sum, sumsq) pair is what ranks all-reduce for sync-BN.
+// Replaces nn.BatchNorm2d at reference models/layers.py:218,279-280 and generators.py:78,115,
+// and the modulation arithmetic of StochasticSpatialModulation.forward (layers.py:228-234).
+#include "itg_common.h"
+
+namespace {
+
+constexpr int MAX_LD = 2048;
+
+inline int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+// number of 256-thread workgroups: multiple of q4/gcd(256,q4), about `total/(256*per_thread)`
+inline int sweep_blocks(int64_t total_f4, int q4, int per_thread, int cap) {
+  int g0 = q4 / gcd_i(256, q4);
+  int64_t want = (total_f4 + 256LL * per_thread - 1) / (256LL * per_thread);
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  int64_t b = (want + g0 - 1) / g0 * g0;
+  return (int)b;
+}
+
+__device__ __forceinline__ void block_flush(double* lds, const double (&a)[4], const double (&b)[4], int cg, int ld,
+                                            double* gsum) {
+  // lds: [2*ld] zeroed by caller before use
+  for (int e = 0; e < 4; ++e) {
+    atomicAdd(&lds[cg * 4 + e], a[e]);
+    atomicAdd(&lds[ld + cg * 4 + e], b[e]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * ld; i += blockDim.x) atomicAdd(&gsum[i], lds[i]);
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t npix, int ld,
+                                                       double* __restrict__ sums) {
+  __shared__ double lds[2 * MAX_LD];
+  const int q4 = ld >> 2;
+  for (int i = threadIdx.x; i < 2 * ld; i += 256) lds[i] = 0.0;
+  __syncthreads();
+  const int64_t T = (int64_t)gridDim.x * 256;
+  const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int cg = (int)(gt % q4);
+  const int64_t step = T / q4;
+  double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+  for (int64_t pix = gt / q4; pix < npix; pix += step) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * ld + cg * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { double d = v[e]; s[e] += d; ss[e] += d * d; }
+  }
+  block_flush(lds, s, ss, cg, ld, sums);
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, double count_scale,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, int64_t* nbt,
+                                   float* __restrict__ mean_rstd, float* __restrict__ ab, int c, int ld, int training) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && training && nbt) *nbt += 1;
+  if (i >= ld) return;
+  float mean = 0.f, rstd = 0.f, a = 0.f, b = 0.f;
+  if (i < c) {
+    if (training) {
+      double m = sums[i] / count;
+      double var = sums[ld + i] / count - m * m;
+      if (var < 0) var = 0;
+      mean = (float)m;
+      rstd = (float)(1.0 / sqrt(var + (double)eps));
+      if (running_mean) {
+        double n = count * count_scale;
+        double unb = n > 1 ? var * n / (n - 1) : var;
+        running_mean[i] = (1.f - momentum) * running_mean[i] + momentum * mean;
+        running_var[i] = (1.f - momentum) * running_var[i] + momentum * (float)unb;
+      }
+    } else {
+      mean = running_mean[i];
+      rstd = 1.0f / sqrtf(running_var[i] + eps);
+    }
+    float g = gamma ? gamma[i] : 1.f;
+    a = g * rstd;
+    b = (beta ? beta[i] : 0.f) - mean * a;
+  }
+  mean_rstd[i] = mean; mean_rstd[ld + i] = rstd;
+  ab[i] = a; ab[ld + i] = b;
+}
+
+// y = act(alpha*x + beta); ups: y has 2x the patch extent (nearest)
+template <bool UPS>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       const float* __restrict__ ab, int64_t npix, int ld, int ph,
+                                                       int pw, int act, float slope) {
+  const int q4 = ld >> 2;
+  const int64_t T = (int64_t)gridDim.x * 256;
+  const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int cg = (int)(gt % q4);
+  const int64_t step = T / q4;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(ab + cg * 4);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(ab + ld + cg * 4);
+  for (int64_t pix = gt / q4; pix < npix; pix += step) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * ld + cg * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_apply(fmaf(v[e], a[e], b[e]), act, slope);
+    if (!UPS) {
+      *reinterpret_cast<f32x4*>(y + pix * ld + cg * 4) = v;
+    } else {
+      int64_t blk = pix / (ph * pw);
+      int r = (int)(pix - blk * ph * pw);
+      int yy = r / pw, xx = r - yy * pw;
+      float* o = y + ((blk * 2 * ph + 2 * yy) * (2 * pw) + 2 * xx) * (int64_t)ld + cg * 4;
+      *reinterpret_cast<f32x4*>(o) = v;
+      *reinterpret_cast<f32x4*>(o + ld) = v;
+      *reinterpret_cast<f32x4*>(o + (int64_t)2 * pw * ld) = v;
+      *reinterpret_cast<f32x4*>(o + (int64_t)2 * pw * ld + ld) = v;
+    }
+  }
+}
+
+template <bool UPS>
+__device__ __forceinline__ f32x4 load_dy(const float* __restrict__ dy, int64_t pix, int ld, int cg, int ph, int pw) {
+  if (!UPS) return *reinterpret_cast<const f32x4*>(dy + pix * ld + cg * 4);
+  int64_t blk = pix / (ph * pw);
+  int r = (int)(pix - blk * ph * pw);
+  int yy = r / pw, xx = r - yy * pw;
+  const float* o = dy + ((blk * 2 * ph + 2 * yy) * (2 * pw) + 2 * xx) * (int64_t)ld + cg * 4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(o);
+  v += *reinterpret_cast<const f32x4*>(o + ld);
+  v += *reinterpret_cast<const f32x4*>(o + (int64_t)2 * pw * ld);
+  v += *reinterpret_cast<const f32x4*>(o + (int64_t)2 * pw * ld + ld);
+  return v;
+}
+
+__device__ __forceinline__ float act_grad(float pre, int act, float slope) {
+  if (act == ITG_ACT_LRELU) return pre > 0.f ? 1.f : slope;
+  if (act == ITG_ACT_TANH) { float t = tanhf(pre); return 1.f - t * t; }
+  return 1.f;
+}
+
+template <bool UPS>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ ab,
+                                                            const float* __restrict__ mean_rstd, int64_t npix, int ld,
+                                                            int ph, int pw, int act, float slope,
+                                                            double* __restrict__ sums) {
+  __shared__ double lds[2 * MAX_LD];
+  const int q4 = ld >> 2;
+  for (int i = threadIdx.x; i < 2 * ld; i += 256) lds[i] = 0.0;
+  __syncthreads();
+  const int64_t T = (int64_t)gridDim.x * 256;
+  const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int cg = (int)(gt % q4);
+  const int64_t step = T / q4;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(ab + cg * 4);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(ab + ld + cg * 4);
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean_rstd + cg * 4);
+  const f32x4 rs = *reinterpret_cast<const f32x4*>(mean_rstd + ld + cg * 4);
+  double s[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0};
+  for (int64_t pix = gt / q4; pix < npix; pix += step) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * ld + cg * 4);
+    f32x4 g = load_dy<UPS>(dy, pix, ld, cg, ph, pw);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float ge = g[e] * act_grad(fmaf(v[e], a[e], b[e]), act, slope);
+      float xh = (v[e] - mu[e]) * rs[e];
+      s[e] += (double)ge;
+      sx[e] += (double)ge * (double)xh;
+    }
+  }
+  block_flush(lds, s, sx, cg, ld, sums);
+}
+
+template <bool UPS>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ ab,
+                                                           const float* __restrict__ mean_rstd,
+                                                           const double* __restrict__ sums, double inv_count,
+                                                           int64_t npix, int ld, int c, int ph, int pw, int act,
+                                                           float slope, float* __restrict__ dx,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int q4 = ld >> 2;
+  const int64_t T = (int64_t)gridDim.x * 256;
+  const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int cg = (int)(gt % q4);
+  const int64_t step = T / q4;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(ab + cg * 4);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(ab + ld + cg * 4);
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean_rstd + cg * 4);
+  const f32x4 rs = *reinterpret_cast<const f32x4*>(mean_rstd + ld + cg * 4);
+  f32x4 m1, m2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    m1[e] = (float)(sums[cg * 4 + e] * inv_count);
+    m2[e] = (float)(sums[ld + cg * 4 + e] * inv_count);
+  }
+  if (gt < ld) {
+    int i = (int)gt;
+    if (dgamma && i < c) dgamma[i] = (float)sums[ld + i];
+    if (dbeta && i < c) dbeta[i] = (float)sums[i];
+  }
+  for (int64_t pix = gt / q4; pix < npix; pix += step) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * ld + cg * 4);
+    f32x4 g = load_dy<UPS>(dy, pix, ld, cg, ph, pw);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float ge = g[e] * act_grad(fmaf(v[e], a[e], b[e]), act, slope);
+      float xh = (v[e] - mu[e]) * rs[e];
+      o[e] = a[e] * (ge - m1[e] - xh * m2[e]);
+    }
+    *reinterpret_cast<f32x4*>(dx + pix * ld + cg * 4) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t npix, int ld,
+                                                     double* __restrict__ sums) {
+  __shared__ double lds[MAX_LD];
+  const int q4 = ld >> 2;
+  for (int i = threadIdx.x; i < ld; i += 256) lds[i] = 0.0;
+  __syncthreads();
+  const int64_t T = (int64_t)gridDim.x * 256;
+  const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int cg = (int)(gt % q4);
+  const int64_t step = T / q4;
+  double s[4] = {0, 0, 0, 0};
+  for (int64_t pix = gt / q4; pix < npix; pix += step) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * ld + cg * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] += (double)v[e];
+  }
+  for (int e = 0; e < 4; ++e) atomicAdd(&lds[cg * 4 + e], s[e]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < ld; i += 256) atomicAdd(&sums[i], lds[i]);
+}
+
+// SSM modulation: y = act((1+gamma)*xhat + beta)
+__global__ void ssm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean_rstd,
+                               const float* __restrict__ emb, float* __restrict__ y, int64_t npix, int c, int ld,
+                               int ld_e, int act, float slope) {
+  int64_t total = npix * ld;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int ch = (int)(i % ld);
+    int64_t pix = i / ld;
+    float o = 0.f;
+    if (ch < c) {
+      float xh = (x[i] - mean_rstd[ch]) * mean_rstd[ld + ch];
+      float g = emb[pix * ld_e + ch], b = emb[pix * ld_e + c + ch];
+      o = act_apply(fmaf(1.f + g, xh, b), act, slope);
+    }
+    y[i] = o;
+  }
+}
+
+__global__ void ssm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mean_rstd,
+                               const float* __restrict__ emb, const float* __restrict__ dy, float* __restrict__ dxhat,
+                               float* __restrict__ demb, int64_t npix, int c, int ld, int ld_e, int act, float slope) {
+  int64_t total = npix * ld;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int ch = (int)(i % ld);
+    int64_t pix = i / ld;
+    float o = 0.f;
+    if (ch < c) {
+      float xh = (x[i] - mean_rstd[ch]) * mean_rstd[ld + ch];
+      float g = emb[pix * ld_e + ch], b = emb[pix * ld_e + c + ch];
+      float ge = dy[i] * act_grad(fmaf(1.f + g, xh, b), act, slope);
+      demb[pix * ld_e + ch] = ge * xh;
+      demb[pix * ld_e + c + ch] = ge;
+      o = ge * (1.f + g);
+    }
+    dxhat[i] = o;
+  }
+}
+
+__global__ void d2f_kernel(const double* __restrict__ s, float* __restrict__ o, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = (float)s[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int itg_bn_stats(const itg_tensor* x, double* sums, void* stream) {
+  int rc;
+  if ((rc = check_tensor(x))) return rc;
+  if (!sums || x->ld > MAX_LD) return ITG_ERR_ARG;
+  int64_t npix = grid_pixels(x);
+  int q4 = x->ld >> 2;
+  int blocks = sweep_blocks(npix * q4, q4, 8, 2048);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, npix,
+                     x->ld, sums);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_bn_finalize(const double* sums, double count, double count_scale, const float* gamma, const float* beta,
+                    float eps, float momentum, float* running_mean, float* running_var, int64_t* nbt,
+                    float* mean_rstd, float* ab, int c, int ld, int training, void* stream) {
+  if (!mean_rstd || !ab || c <= 0 || ld < c) return ITG_ERR_ARG;
+  if (training && !sums) return ITG_ERR_ARG;
+  if (!training && (!running_mean || !running_var)) return ITG_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((ld + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums, count,
+                     count_scale, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean_rstd, ab, c, ld,
+                     training);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+static int ups_mode(const itg_tensor* small, const itg_tensor* big, bool* ups) {
+  if (small->n != big->n || small->gh != big->gh || small->gw != big->gw || small->c != big->c ||
+      small->ld != big->ld)
+    return ITG_ERR_ARG;
+  if (small->ph == big->ph && small->pw == big->pw) { *ups = false; return ITG_OK; }
+  if (2 * small->ph == big->ph && 2 * small->pw == big->pw) { *ups = true; return ITG_OK; }
+  return ITG_ERR_ARG;
+}
+
+int itg_bn_apply(const itg_tensor* x, const float* ab, const itg_tensor* y, int act, float slope, void* stream) {
+  int rc;
+  if ((rc = check_tensor(x)) || (rc = check_tensor(y))) return rc;
+  bool ups;
+  if (!ab || (rc = ups_mode(x, y, &ups))) return rc ? rc : ITG_ERR_ARG;
+  int64_t npix = grid_pixels(x);
+  int q4 = x->ld >> 2;
+  int blocks = sweep_blocks(npix * q4, q4, 4, 4096);
+  if (ups)
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr,
+                       (float*)y->ptr, ab, npix, x->ld, x->ph, x->pw, act, slope);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr,
+                       (float*)y->ptr, ab, npix, x->ld, x->ph, x->pw, act, slope);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_bn_bwd_reduce(const itg_tensor* x, const itg_tensor* dy, const float* ab, const float* mean_rstd, int act,
+                      float slope, double* sums, void* stream) {
+  int rc;
+  if ((rc = check_tensor(x)) || (rc = check_tensor(dy))) return rc;
+  bool ups;
+  if (!ab || !mean_rstd || !sums || x->ld > MAX_LD) return ITG_ERR_ARG;
+  if ((rc = ups_mode(x, dy, &ups))) return rc;
+  int64_t npix = grid_pixels(x);
+  int q4 = x->ld >> 2;
+  int blocks = sweep_blocks(npix * q4, q4, 8, 2048);
+  if (ups)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)x->ptr, (const float*)dy->ptr, ab, mean_rstd, npix, x->ld, x->ph, x->pw, act,
+                       slope, sums);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)x->ptr, (const float*)dy->ptr, ab, mean_rstd, npix, x->ld, x->ph, x->pw, act,
+                       slope, sums);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_bn_bwd_apply(const itg_tensor* x, const itg_tensor* dy, const float* ab, const float* mean_rstd,
+                     const float* gamma, const double* sums, double count, int act, float slope,
+                     const itg_tensor* dx, float* dgamma, float* dbeta, void* stream) {
+  (void)gamma;
+  int rc;
+  if ((rc = check_tensor(x)) || (rc = check_tensor(dy)) || (rc = check_tensor(dx))) return rc;
+  bool ups;
+  if (!ab || !mean_rstd || !sums || count <= 0 || !same_shape(x, dx)) return ITG_ERR_ARG;
+  if ((rc = ups_mode(x, dy, &ups))) return rc;
+  int64_t npix = grid_pixels(x);
+  int q4 = x->ld >> 2;
+  int blocks = sweep_blocks(npix * q4, q4, 4, 4096);
+  if ((int64_t)blocks * 256 < x->ld) blocks = sweep_blocks((int64_t)x->ld * q4, q4, 1, 4096);
+  if (ups)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)x->ptr, (const float*)dy->ptr, ab, mean_rstd, sums, 1.0 / count, npix, x->ld,
+                       x->c, x->ph, x->pw, act, slope, (float*)dx->ptr, dgamma, dbeta);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)x->ptr, (const float*)dy->ptr, ab, mean_rstd, sums, 1.0 / count, npix, x->ld,
+                       x->c, x->ph, x->pw, act, slope, (float*)dx->ptr, dgamma, dbeta);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+// per-channel sum over all pixels -> out (fp32[ld]); acc is fp64[ld] scratch owned by the caller
+int itg_colsum(const itg_tensor* x, float* out, double* acc, void* stream) {
+  int rc;
+  if ((rc = check_tensor(x))) return rc;
+  if (!out || !acc || x->ld > MAX_LD) return ITG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int ld = x->ld;
+  if (hipMemsetAsync(acc, 0, sizeof(double) * ld, s) != hipSuccess) return ITG_ERR_LAUNCH;
+  int64_t npix = grid_pixels(x);
+  int q4 = ld >> 2;
+  int blocks = sweep_blocks(npix * q4, q4, 8, 2048);
+  hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, (const float*)x->ptr, npix, ld, acc);
+  ITG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(d2f_kernel, dim3((x->c + 127) / 128), dim3(128), 0, s, (const double*)acc, out, x->c);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_ssm_modulate_fwd(const itg_tensor* x, const float* mean_rstd, const itg_tensor* emb, const itg_tensor* y,
+                         int act, float slope, void* stream) {
+  int rc;
+  if ((rc = check_tensor(x)) || (rc = check_tensor(emb)) || (rc = check_tensor(y))) return rc;
+  if (!mean_rstd || !same_shape(x, y) || emb->c != 2 * x->c || grid_pixels(emb) != grid_pixels(x)) return ITG_ERR_ARG;
+  int64_t npix = grid_pixels(x);
+  int64_t total = npix * x->ld;
+  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(ssm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, mean_rstd,
+                     (const float*)emb->ptr, (float*)y->ptr, npix, x->c, x->ld, emb->ld, act, slope);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_ssm_modulate_bwd(const itg_tensor* x, const float* mean_rstd, const itg_tensor* emb, const itg_tensor* dy,
+                         int act, float slope, const itg_tensor* dxhat, const itg_tensor* demb, void* stream) {
+  int rc;
+  if ((rc = check_tensor(x)) || (rc = check_tensor(emb)) || (rc = check_tensor(dy)) || (rc = check_tensor(dxhat)) ||
+      (rc = check_tensor(demb)))
+    return rc;
+  if (!mean_rstd || !same_shape(x, dy) || !same_shape(x, dxhat) || !same_shape(emb, demb) || emb->c != 2 * x->c)
+    return ITG_ERR_ARG;
+  int64_t npix = grid_pixels(x);
+  int64_t total = npix * x->ld;
+  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(ssm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, mean_rstd,
+                     (const float*)emb->ptr, (const float*)dy->ptr, (float*)dxhat->ptr, (float*)demb->ptr, npix,
+                     x->c, x->ld, emb->ld, act, slope);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,483 @@
+// Memory-bound pointwise / data-movement kernels (gfx950): activations, nearest x2 upsample,
+// 2x2 max-pool, NCHW <-> patch-grid NHWC conversion, and the LocalPadder operator itself
+// (reference models/layers.py:38-173, utils.py:577-613,658-742) in its standalone forms.
+#include "itg_common.h"
+
+namespace {
+
+inline int blocks_for(int64_t total, int per_block = 256, int cap = 16384) {
+  int64_t b = (total + per_block - 1) / per_block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+#define GRID_STRIDE(i, total) \
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (total); i += (int64_t)gridDim.x * blockDim.x)
+
+__global__ void act_fwd_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int64_t n4, int act, float slope) {
+  GRID_STRIDE(i, n4) {
+    f32x4 v = x[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act, slope);
+    y[i] = v;
+  }
+}
+
+// derivative from the forward OUTPUT: lrelu: out>0 ? 1 : slope ; tanh: 1-out^2
+__global__ void act_bwd_kernel(const f32x4* __restrict__ out, const f32x4* __restrict__ dout, f32x4* __restrict__ dx,
+                               int64_t n4, int act, float slope) {
+  GRID_STRIDE(i, n4) {
+    f32x4 o = out[i], g = dout[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (act == ITG_ACT_LRELU) g[e] = o[e] > 0.f ? g[e] : g[e] * slope;
+      else if (act == ITG_ACT_TANH) g[e] = g[e] * (1.f - o[e] * o[e]);
+    }
+    dx[i] = g;
+  }
+}
+
+__global__ void add_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ o, int64_t n4) {
+  GRID_STRIDE(i, n4) o[i] = a[i] + b[i];
+}
+
+__global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t npix, int q4, int ph,
+                                    int pw) {
+  int64_t total = npix * q4;
+  const int ld = q4 * 4;
+  GRID_STRIDE(i, total) {
+    int c4 = (int)(i % q4);
+    int64_t pix = i / q4;
+    int64_t blk = pix / (ph * pw);
+    int r = (int)(pix - blk * ph * pw);
+    int yy = r / pw, xx = r - yy * pw;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * ld + c4 * 4);
+    float* o = y + ((blk * 2 * ph + 2 * yy) * (2 * pw) + 2 * xx) * (int64_t)ld + c4 * 4;
+    *reinterpret_cast<f32x4*>(o) = v;
+    *reinterpret_cast<f32x4*>(o + ld) = v;
+    *reinterpret_cast<f32x4*>(o + (int64_t)2 * pw * ld) = v;
+    *reinterpret_cast<f32x4*>(o + (int64_t)2 * pw * ld + ld) = v;
+  }
+}
+
+__global__ void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t npix, int q4, int ph,
+                                    int pw) {
+  int64_t total = npix * q4;
+  const int ld = q4 * 4;
+  GRID_STRIDE(i, total) {
+    int c4 = (int)(i % q4);
+    int64_t pix = i / q4;
+    int64_t blk = pix / (ph * pw);
+    int r = (int)(pix - blk * ph * pw);
+    int yy = r / pw, xx = r - yy * pw;
+    const float* o = dy + ((blk * 2 * ph + 2 * yy) * (2 * pw) + 2 * xx) * (int64_t)ld + c4 * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(o);
+    v += *reinterpret_cast<const f32x4*>(o + ld);
+    v += *reinterpret_cast<const f32x4*>(o + (int64_t)2 * pw * ld);
+    v += *reinterpret_cast<const f32x4*>(o + (int64_t)2 * pw * ld + ld);
+    *reinterpret_cast<f32x4*>(dx + pix * ld + c4 * 4) = v;
+  }
+}
+
+// 2x2 max pool inside each patch (y.ph = x.ph/2)
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t npix_out, int q4, int oph,
+                                   int opw) {
+  int64_t total = npix_out * q4;
+  const int ld = q4 * 4;
+  GRID_STRIDE(i, total) {
+    int c4 = (int)(i % q4);
+    int64_t pix = i / q4;
+    int64_t blk = pix / (oph * opw);
+    int r = (int)(pix - blk * oph * opw);
+    int yy = r / opw, xx = r - yy * opw;
+    const float* s = x + ((blk * 2 * oph + 2 * yy) * (2 * opw) + 2 * xx) * (int64_t)ld + c4 * 4;
+    f32x4 a = *reinterpret_cast<const f32x4*>(s);
+    f32x4 b = *reinterpret_cast<const f32x4*>(s + ld);
+    f32x4 c = *reinterpret_cast<const f32x4*>(s + (int64_t)2 * opw * ld);
+    f32x4 d = *reinterpret_cast<const f32x4*>(s + (int64_t)2 * opw * ld + ld);
+    f32x4 m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
+    *reinterpret_cast<f32x4*>(y + pix * ld + c4 * 4) = m;
+  }
+}
+
+// routes dy to the first element (row-major window order) equal to the max
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                   int64_t npix_out, int q4, int oph, int opw) {
+  int64_t total = npix_out * q4;
+  const int ld = q4 * 4;
+  GRID_STRIDE(i, total) {
+    int c4 = (int)(i % q4);
+    int64_t pix = i / q4;
+    int64_t blk = pix / (oph * opw);
+    int r = (int)(pix - blk * oph * opw);
+    int yy = r / opw, xx = r - yy * opw;
+    int64_t base = ((blk * 2 * oph + 2 * yy) * (2 * opw) + 2 * xx) * (int64_t)ld + c4 * 4;
+    int64_t o1 = ld, o2 = (int64_t)2 * opw * ld, o3 = o2 + ld;
+    f32x4 a = *reinterpret_cast<const f32x4*>(x + base);
+    f32x4 b = *reinterpret_cast<const f32x4*>(x + base + o1);
+    f32x4 c = *reinterpret_cast<const f32x4*>(x + base + o2);
+    f32x4 d = *reinterpret_cast<const f32x4*>(x + base + o3);
+    f32x4 g = *reinterpret_cast<const f32x4*>(dy + pix * ld + c4 * 4);
+    f32x4 ga, gb, gc, gd;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int k = 0; float m = a[e];
+      if (b[e] > m) { m = b[e]; k = 1; }
+      if (c[e] > m) { m = c[e]; k = 2; }
+      if (d[e] > m) { m = d[e]; k = 3; }
+      ga[e] = k == 0 ? g[e] : 0.f; gb[e] = k == 1 ? g[e] : 0.f;
+      gc[e] = k == 2 ? g[e] : 0.f; gd[e] = k == 3 ? g[e] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(dx + base) = ga;
+    *reinterpret_cast<f32x4*>(dx + base + o1) = gb;
+    *reinterpret_cast<f32x4*>(dx + base + o2) = gc;
+    *reinterpret_cast<f32x4*>(dx + base + o3) = gd;
+  }
+}
+
+// ---- NCHW <-> patch-grid NHWC -----------------------------------------------------------
+// dst-ordered: element (pix, ch) of the grid tensor
+__global__ void nchw_to_grid_kernel(const float* __restrict__ src, GridT d, int merged) {
+  int64_t total = (int64_t)d.n * d.gh * d.gw * d.ph * d.pw * d.ld;
+  GRID_STRIDE(i, total) {
+    int ch = (int)(i % d.ld);
+    int64_t pix = i / d.ld;
+    int x = (int)(pix % d.pw); pix /= d.pw;
+    int y = (int)(pix % d.ph); pix /= d.ph;
+    int gc = (int)(pix % d.gw); pix /= d.gw;
+    int gr = (int)(pix % d.gh);
+    int n = (int)(pix / d.gh);
+    float v = 0.f;
+    if (ch < d.c) {
+      int64_t s;
+      if (merged) s = (((int64_t)n * d.c + ch) * d.H + gr * d.ph + y) * d.W + gc * d.pw + x;
+      else s = (((((int64_t)n * d.gh + gr) * d.gw + gc) * d.c + ch) * d.ph + y) * d.pw + x;
+      v = src[s];
+    }
+    d.p[i] = v;
+  }
+}
+
+// dst-ordered over the NCHW tensor
+__global__ void grid_to_nchw_kernel(GridT s, float* __restrict__ dst, int merged) {
+  int64_t total = (int64_t)s.n * s.c * s.H * s.W;
+  GRID_STRIDE(i, total) {
+    int64_t r = i;
+    int n, ch, Y, X;
+    if (merged) {
+      X = (int)(r % s.W); r /= s.W;
+      Y = (int)(r % s.H); r /= s.H;
+      ch = (int)(r % s.c);
+      n = (int)(r / s.c);
+    } else {
+      int x = (int)(r % s.pw); r /= s.pw;
+      int y = (int)(r % s.ph); r /= s.ph;
+      ch = (int)(r % s.c); r /= s.c;
+      int gc = (int)(r % s.gw); r /= s.gw;
+      int gr = (int)(r % s.gh);
+      n = (int)(r / s.gh);
+      Y = gr * s.ph + y; X = gc * s.pw + x;
+    }
+    dst[i] = s.p[grid_off(s, n, Y, X) + ch];
+  }
+}
+
+// ---- LocalPadder, NCHW patches in / out (the reference module's own tensor format) -------
+// x: (n*gh*gw, c, p, p) or merged (n, c, gh*p+2, gw*p+2); y: (n*gh*gw, c, p+2, p+2)
+__global__ void local_pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int c, int gh, int gw,
+                                     int p, int pad_mode, int merged) {
+  const int q = p + 2;
+  const int H = gh * p, W = gw * p;
+  int64_t total = (int64_t)n * gh * gw * c * q * q;
+  GRID_STRIDE(i, total) {
+    int64_t r = i;
+    int j = (int)(r % q); r /= q;
+    int ii = (int)(r % q); r /= q;
+    int ch = (int)(r % c); r /= c;
+    int gc = (int)(r % gw); r /= gw;
+    int gr = (int)(r % gh);
+    int nn = (int)(r / gh);
+    float v;
+    if (merged) {
+      v = x[(((int64_t)nn * c + ch) * (H + 2) + gr * p + ii) * (W + 2) + gc * p + j];
+    } else {
+      int Y = gr * p + ii - 1, X = gc * p + j - 1;
+      bool ok = true;
+      if (pad_mode == ITG_PAD_REPLICATE) { Y = min(max(Y, 0), H - 1); X = min(max(X, 0), W - 1); }
+      else ok = (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
+      v = 0.f;
+      if (ok) {
+        int sr = Y / p, sc = X / p;
+        v = x[((((int64_t)nn * gh + sr) * gw + sc) * c + ch) * p * p + (Y - sr * p) * p + (X - sc * p)];
+      }
+    }
+    y[i] = v;
+  }
+}
+
+// windows (grid index r, in-window index i) that read padded coordinate Yp along one axis
+__device__ __forceinline__ int windows_of(int Yp, int p, int g, int* rr, int* ii, int cnt) {
+  // 0 <= Yp + 1 - r*p <= p + 1
+  int q = (Yp + 1 >= 0) ? (Yp + 1) / p : -1;
+  for (int r = q - 2; r <= q; ++r) {
+    if (r < 0 || r >= g) continue;
+    int i = Yp + 1 - r * p;
+    if (i >= 0 && i <= p + 1) { rr[cnt] = r; ii[cnt] = i; ++cnt; }
+  }
+  return cnt;
+}
+
+__device__ __forceinline__ int sources_of(int Y, int H, int p, int g, int pad_mode, int* rr, int* ii) {
+  int cnt = windows_of(Y, p, g, rr, ii, 0);
+  if (pad_mode == ITG_PAD_REPLICATE) {
+    if (Y == 0) cnt = windows_of(-1, p, g, rr, ii, cnt);
+    if (Y == H - 1) cnt = windows_of(H, p, g, rr, ii, cnt);
+  }
+  return cnt;
+}
+
+__global__ void local_pad_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int n, int c, int gh, int gw,
+                                     int p, int pad_mode, int merged) {
+  const int q = p + 2;
+  const int H = gh * p, W = gw * p;
+  if (merged) {
+    int64_t total = (int64_t)n * c * (H + 2) * (W + 2);
+    GRID_STRIDE(i, total) {
+      int64_t r = i;
+      int X = (int)(r % (W + 2)); r /= (W + 2);
+      int Y = (int)(r % (H + 2)); r /= (H + 2);
+      int ch = (int)(r % c);
+      int nn = (int)(r / c);
+      int ry[4], iy[4], rx[4], ix[4];
+      int cy = windows_of(Y - 1, p, gh, ry, iy, 0), cx = windows_of(X - 1, p, gw, rx, ix, 0);
+      float s = 0.f;
+      for (int a = 0; a < cy; ++a)
+        for (int b = 0; b < cx; ++b)
+          s += dy[(((((int64_t)nn * gh + ry[a]) * gw + rx[b]) * c + ch) * q + iy[a]) * q + ix[b]];
+      dx[i] = s;
+    }
+    return;
+  }
+  int64_t total = (int64_t)n * gh * gw * c * p * p;
+  GRID_STRIDE(i, total) {
+    int64_t r = i;
+    int x = (int)(r % p); r /= p;
+    int y = (int)(r % p); r /= p;
+    int ch = (int)(r % c); r /= c;
+    int gc = (int)(r % gw); r /= gw;
+    int gr = (int)(r % gh);
+    int nn = (int)(r / gh);
+    int Y = gr * p + y, X = gc * p + x;
+    int ry[6], iy[6], rx[6], ix[6];
+    int cy = sources_of(Y, H, p, gh, pad_mode, ry, iy), cx = sources_of(X, W, p, gw, pad_mode, rx, ix);
+    float s = 0.f;
+    for (int a = 0; a < cy; ++a)
+      for (int b = 0; b < cx; ++b)
+        s += dy[(((((int64_t)nn * gh + ry[a]) * gw + rx[b]) * c + ch) * q + iy[a]) * q + ix[b]];
+    dx[i] = s;
+  }
+}
+
+// patch-grid NHWC -> patch-grid NHWC with a 1-px halo; left/top carried halos optional
+__global__ void local_pad_nhwc_kernel(GridT s, GridT d, const float* __restrict__ left, const float* __restrict__ top,
+                                      int pad_mode) {
+  const int q4 = d.ld >> 2;
+  int64_t total = (int64_t)d.n * d.gh * d.gw * d.ph * d.pw * q4;
+  GRID_STRIDE(i, total) {
+    int c4 = (int)(i % q4);
+    int64_t pix = i / q4;
+    int x = (int)(pix % d.pw); pix /= d.pw;
+    int y = (int)(pix % d.ph); pix /= d.ph;
+    int gc = (int)(pix % d.gw); pix /= d.gw;
+    int gr = (int)(pix % d.gh);
+    int n = (int)(pix / d.gh);
+    int Y = gr * s.ph + y - 1, X = gc * s.pw + x - 1;   // padded coords in [-1, H], [-1, W]
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    bool done = false;
+    if (Y == -1 && top) {
+      v = *reinterpret_cast<const f32x4*>(top + ((int64_t)n * (s.W + 2) + X + 1) * s.ld + c4 * 4);
+      done = true;
+    }
+    if (!done) {
+      bool zero = false;
+      if (Y < 0 || Y >= s.H) { if (pad_mode == ITG_PAD_REPLICATE) Y = min(max(Y, 0), s.H - 1); else zero = true; }
+      if (!zero && X == -1 && left) {
+        v = *reinterpret_cast<const f32x4*>(left + ((int64_t)n * s.H + Y) * s.ld + c4 * 4);
+        done = true;
+      }
+      if (!done && !zero) {
+        if (X < 0 || X >= s.W) { if (pad_mode == ITG_PAD_REPLICATE) X = min(max(X, 0), s.W - 1); else zero = true; }
+        if (!zero) v = *reinterpret_cast<const f32x4*>(s.p + grid_off(s, n, Y, X) + c4 * 4);
+      }
+    }
+    *reinterpret_cast<f32x4*>(d.p + (i / q4) * d.ld + c4 * 4) = v;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+static int flat_check(const itg_tensor* a, const itg_tensor* b) {
+  int rc;
+  if ((rc = check_tensor(a)) || (rc = check_tensor(b))) return rc;
+  return same_shape(a, b) ? ITG_OK : ITG_ERR_ARG;
+}
+
+int itg_act_fwd(const itg_tensor* x, const itg_tensor* y, int act, float slope, void* stream) {
+  int rc = flat_check(x, y);
+  if (rc) return rc;
+  int64_t n4 = grid_pixels(x) * (x->ld >> 2);
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks_for(n4)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)x->ptr,
+                     (f32x4*)y->ptr, n4, act, slope);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_act_bwd(const itg_tensor* out, const itg_tensor* dout, const itg_tensor* dx, int act, float slope,
+                void* stream) {
+  int rc = flat_check(out, dout);
+  if (rc || (rc = flat_check(out, dx))) return rc;
+  int64_t n4 = grid_pixels(out) * (out->ld >> 2);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n4)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)out->ptr,
+                     (const f32x4*)dout->ptr, (f32x4*)dx->ptr, n4, act, slope);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_add(const itg_tensor* a, const itg_tensor* b, const itg_tensor* out, void* stream) {
+  int rc = flat_check(a, b);
+  if (rc || (rc = flat_check(a, out))) return rc;
+  int64_t n4 = grid_pixels(a) * (a->ld >> 2);
+  hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n4)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)a->ptr,
+                     (const f32x4*)b->ptr, (f32x4*)out->ptr, n4);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+static int half_check(const itg_tensor* small, const itg_tensor* big) {
+  int rc;
+  if ((rc = check_tensor(small)) || (rc = check_tensor(big))) return rc;
+  if (small->n != big->n || small->gh != big->gh || small->gw != big->gw || small->c != big->c ||
+      small->ld != big->ld || 2 * small->ph != big->ph || 2 * small->pw != big->pw)
+    return ITG_ERR_ARG;
+  return ITG_OK;
+}
+
+int itg_upsample2x_fwd(const itg_tensor* x, const itg_tensor* y, void* stream) {
+  int rc = half_check(x, y);
+  if (rc) return rc;
+  int64_t npix = grid_pixels(x);
+  int q4 = x->ld >> 2;
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(blocks_for(npix * q4)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)x->ptr, (float*)y->ptr, npix, q4, x->ph, x->pw);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_upsample2x_bwd(const itg_tensor* dy, const itg_tensor* dx, void* stream) {
+  int rc = half_check(dx, dy);
+  if (rc) return rc;
+  int64_t npix = grid_pixels(dx);
+  int q4 = dx->ld >> 2;
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(blocks_for(npix * q4)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)dy->ptr, (float*)dx->ptr, npix, q4, dx->ph, dx->pw);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_maxpool2_fwd(const itg_tensor* x, const itg_tensor* y, void* stream) {
+  int rc = half_check(y, x);
+  if (rc) return rc;
+  int64_t npix = grid_pixels(y);
+  int q4 = y->ld >> 2;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks_for(npix * q4)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)x->ptr, (float*)y->ptr, npix, q4, y->ph, y->pw);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_maxpool2_bwd(const itg_tensor* x, const itg_tensor* y, const itg_tensor* dy, const itg_tensor* dx,
+                     void* stream) {
+  (void)y;
+  int rc = half_check(dy, x);
+  if (rc || (rc = flat_check(x, dx))) return rc;
+  int64_t npix = grid_pixels(dy);
+  int q4 = dy->ld >> 2;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks_for(npix * q4)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)x->ptr, (const float*)dy->ptr, (float*)dx->ptr, npix, q4, dy->ph, dy->pw);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_nchw_to_grid(const float* src, const itg_tensor* dst, int merged_src, void* stream) {
+  int rc;
+  if (!src || (rc = check_tensor(dst))) return src ? rc : ITG_ERR_ARG;
+  GridT d = make_grid(dst);
+  int64_t total = grid_pixels(dst) * dst->ld;
+  hipLaunchKernelGGL(nchw_to_grid_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, src, d,
+                     merged_src);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_grid_to_nchw(const itg_tensor* src, float* dst, int merged_dst, void* stream) {
+  int rc;
+  if (!dst || (rc = check_tensor(src))) return dst ? rc : ITG_ERR_ARG;
+  GridT s = make_grid(src);
+  int64_t total = grid_pixels(src) * src->c;
+  hipLaunchKernelGGL(grid_to_nchw_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, s, dst,
+                     merged_dst);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_local_pad_fwd(const float* x, float* y, int n, int c, int gh, int gw, int p, int pad_mode, int merged,
+                      void* stream) {
+  if (!x || !y || n <= 0 || c <= 0 || gh <= 0 || gw <= 0 || p <= 0) return ITG_ERR_ARG;
+  int64_t total = (int64_t)n * gh * gw * c * (p + 2) * (p + 2);
+  hipLaunchKernelGGL(local_pad_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, n, c, gh,
+                     gw, p, pad_mode, merged);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_local_pad_bwd(const float* dy, float* dx, int n, int c, int gh, int gw, int p, int pad_mode, int merged,
+                      void* stream) {
+  if (!dy || !dx || n <= 0 || c <= 0 || gh <= 0 || gw <= 0 || p <= 0) return ITG_ERR_ARG;
+  int64_t total = merged ? (int64_t)n * c * (gh * p + 2) * (gw * p + 2) : (int64_t)n * gh * gw * c * p * p;
+  hipLaunchKernelGGL(local_pad_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, n, c,
+                     gh, gw, p, pad_mode, merged);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+static int pad_check(const itg_tensor* x, const itg_tensor* y) {
+  int rc;
+  if ((rc = check_tensor(x)) || (rc = check_tensor(y))) return rc;
+  if (x->n != y->n || x->gh != y->gh || x->gw != y->gw || x->c != y->c || x->ld != y->ld ||
+      y->ph != x->ph + 2 || y->pw != x->pw + 2)
+    return ITG_ERR_ARG;
+  return ITG_OK;
+}
+
+int itg_local_pad_nhwc_fwd(const itg_tensor* x, const itg_tensor* y, int pad_mode, void* stream) {
+  return itg_local_pad_stream_fwd(x, nullptr, nullptr, y, pad_mode, stream);
+}
+
+int itg_local_pad_stream_fwd(const itg_tensor* x, const float* left, const float* top, const itg_tensor* y,
+                             int pad_mode, void* stream) {
+  int rc = pad_check(x, y);
+  if (rc) return rc;
+  GridT s = make_grid(x), d = make_grid(y);
+  int64_t total = grid_pixels(y) * (y->ld >> 2);
+  hipLaunchKernelGGL(local_pad_nhwc_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, s, d, left, top,
+                     pad_mode);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,154 @@
+"""Train-step engine: flat parameter/gradient buffers, the fused Adam(+EMA) step, and the
+D-step / G-step control flow of reference train.py:122-180.
+
+MI355X-first choices (vs the reference's per-tensor torch.optim.Adam and nn.DataParallel):
+  * every model's parameters are views into ONE contiguous fp32 buffer, their gradients views
+    into another: zero_grad is one memset, Adam(+EMA) one kernel launch, and the data-parallel
+    gradient exchange one RCCL all-reduce over xGMI per model (G 21 MB, D 11 MB);
+  * one process per GPU; BatchNorm statistics are summed over ranks (fp64 sum/sumsq pairs), so
+    an N-GPU step has the single-process semantics of a batch N times larger.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .models.layers import _BNParams
+
+
+class FlatParams:
+    """Re-homes a module's parameters (and .grad) into flat buffers."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters()]
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.data = torch.empty(n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        o = 0
+        for p in self.params:
+            k = p.numel()
+            self.data[o:o + k].copy_(p.data.reshape(-1))
+            p.data = self.data[o:o + k].view(p.shape)
+            p.grad = self.grad[o:o + k].view(p.shape)
+            o += k
+        self.numel = n
+
+    def zero_grad(self):
+        self.grad.zero_()
+        # autograd must keep accumulating in place into the flat buffer
+        for p, g in zip(self.params, self._grad_views()):
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
+    def _grad_views(self):
+        o = 0
+        for p in self.params:
+            k = p.numel()
+            yield self.grad[o:o + k].view(p.shape)
+            o += k
+
+
+class FlatAdam:
+    """Adam (torch.optim.Adam semantics: bias correction, eps outside the sqrt/bc2 term, no weight
+    decay) over a FlatParams, optionally maintaining an EMA copy of the parameters in the same launch."""
+
+    def __init__(self, flat, lr=2e-4, betas=(0.0, 0.999), eps=1e-8, ema=None, ema_decay=0.999):
+        self.flat, self.lr, self.betas, self.eps = flat, lr, (float(betas[0]), float(betas[1])), eps
+        self.m = torch.zeros_like(flat.data)
+        self.v = torch.zeros_like(flat.data)
+        self.ema, self.ema_decay = ema, ema_decay
+        self.t = 0
+
+    def step(self):
+        self.t += 1
+        ops.adam_ema_step(self.flat.data, self.flat.grad, self.m, self.v, self.ema, self.lr, self.betas[0],
+                          self.betas[1], self.eps, self.t, self.ema_decay)
+
+
+class Trainer:
+    """One G+D iteration of reference train.py:122-180 on the HIP kernels."""
+
+    def __init__(self, netG, netD, args, device, netG_ema=None, dist_group=None):
+        self.netG, self.netD, self.args, self.device = netG, netD, args, device
+        self.world = 1
+        self.dist = None
+        if dist_group is not None:
+            import torch.distributed as dist
+            self.dist, self.group = dist, dist_group
+            self.world = dist.get_world_size(dist_group)
+            sync = ops.SyncGroup(dist_group)
+            netG.set_sync(sync)
+            for m in netD.modules():
+                if isinstance(m, _BNParams):
+                    m.sync = sync
+        self.flatG, self.flatD = FlatParams(netG), FlatParams(netD)
+        self.netG_ema, self.flatE = netG_ema, None
+        if netG_ema is not None:
+            self.flatE = FlatParams(netG_ema)
+            self.flatE.data.copy_(self.flatG.data)
+            for (_, b), (_, e) in zip(netG.named_buffers(), netG_ema.named_buffers()):
+                e.copy_(b)
+        b1, b2 = float(args.beta1), float(args.beta2)
+        self.optD = FlatAdam(self.flatD, args.lr_D, (b1, b2))
+        self.optG = FlatAdam(self.flatG, args.lr_G, (b1, b2), ema=self.flatE.data if self.flatE else None,
+                             ema_decay=args.ema_decay)
+        self.label_t = 0.9 if args.smooth else 1.0
+        self.hinge = getattr(args, "loss", "standard") == "hinge"
+
+    # ---- loss heads
+    def _d_loss(self, logit, real):
+        if self.hinge:
+            return ops.hinge(logit, "d_real" if real else "d_fake")
+        return ops.bce_with_logits(logit, self.label_t if real else 0.0)
+
+    def _g_loss(self, logit):
+        return ops.hinge(logit, "g") if self.hinge else ops.bce_with_logits(logit, self.label_t)
+
+    def _allreduce(self, flat):
+        """Data-parallel gradient exchange: one collective per model.  Losses are per-rank means over
+        per-rank batches, so the global-batch gradient is the average over ranks."""
+        if self.world > 1:
+            self.dist.all_reduce(flat.grad, group=self.group)
+            flat.grad.mul_(1.0 / self.world)
+
+    def sample_fake(self, z, maps):
+        return self.netG.forward_grid(z, maps, "1st_row_1st_col")
+
+    def step(self, real_x, z, maps=None):
+        """real_x: (B,3,crop,crop) on the device; z/maps: latents (see utils.sample_latents_train).
+        Returns (d_loss_real, d_loss_fake, g_loss) as 0-dim device tensors (no host sync)."""
+        netG, netD = self.netG, self.netD
+        # ---------------- D step (train.py:124-154, disc_iters handled by the caller)
+        self.flatD.zero_grad()
+        d_real = self._d_loss(netD(real_x), True)
+        d_real.backward()
+        fake = self.sample_fake(z, maps)                       # GT patches, graph kept for the G step
+        fake_logit = ops.to_nchw(netD.forward_grid(fake.detach()))
+        d_fake = self._d_loss(fake_logit, False)
+        d_fake.backward()
+        self._allreduce(self.flatD)
+        self.optD.step()
+        # ---------------- G step (train.py:161-169).  D's weight gradients of this pass are never
+        # read (zeroed at the next D step), so they are not computed.
+        self.flatG.zero_grad()
+        for p in self.flatD.params:
+            p.requires_grad_(False)
+        try:
+            g_loss = self._g_loss(ops.to_nchw(netD.forward_grid(fake)))
+            g_loss.backward()
+        finally:
+            for p in self.flatD.params:
+                p.requires_grad_(True)
+        self._allreduce(self.flatG)
+        self.optG.step()                                        # + EMA of the parameters (train.py:176-180)
+        if self.netG_ema is not None:
+            self._ema_buffers()
+        return d_real.detach(), d_fake.detach(), g_loss.detach()
+
+    def _ema_buffers(self):
+        d = self.args.ema_decay
+        for (_, b), (_, e) in zip(self.netG.named_buffers(), self.netG_ema.named_buffers()):
+            if b.dtype == torch.float32:
+                ops.axpby(e, b, d, 1.0 - d, out=e)
+            else:   # int64 num_batches_tracked: float arithmetic, truncated on copy (train.py:178)
+                e.copy_(e * d + b * (1 - d))

@@ -1,0 +1,61 @@
+"""PatchDiscriminator with the reference's constructor signature and state_dict keys
+(reference models/discriminators.py:156-210) on the HIP conv kernels.  The other
+discriminator classes of the reference are dead code there (utils.py:205-207) and are
+not provided."""
+import torch.nn as nn
+
+from .. import ops
+from ..ops import GT
+from .layers import conv4x4, conv3x3, _BNParams
+
+
+class PatchDiscriminator(nn.Module):
+    """PatchGAN discriminator: conv(s2)+LReLU(0.2), n_layers_D-1 x [conv+LReLU], conv -> logit map."""
+
+    def __init__(self, img_ch=1, base_ch=64, n_layers_D=4, kw=4, SN=False, norm_layer=None):
+        super().__init__()
+        self.img_ch = img_ch
+        if kw == 4:
+            conv_fun = conv4x4
+        elif kw == 3:
+            conv_fun = conv3x3
+        else:
+            raise ValueError("kw must be 3 or 4")
+        if norm_layer not in (None, 'batch'):
+            raise NotImplementedError("norm_layer=%r: only None and 'batch' are built (instance norm is unused "
+                                      "by every reference configuration)" % (norm_layer,))
+        nf = base_ch
+        seq = [conv_fun(img_ch, base_ch, SN=SN, s=2, bias=True), nn.LeakyReLU(0.2, False)]
+        for n in range(1, n_layers_D):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            stride = 1 if n == n_layers_D - 1 else 2
+            seq.append(conv_fun(nf_prev, nf, s=stride, SN=SN, bias=True))
+            if norm_layer:
+                seq.append(_BNParams(nf, affine=True))
+            seq.append(nn.LeakyReLU(0.2, False))
+        seq.append(conv_fun(nf, 1, s=1, SN=SN, bias=True))
+        self.model = nn.Sequential(*seq)
+
+    def forward_grid(self, x):
+        """x: GT image (any patch grid).  Returns the logit map as a 1x1-grid GT."""
+        mods = list(self.model)
+        h, i = x, 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(nxt, nn.LeakyReLU):
+                h = m.run(h, act=ops.ACT_LRELU, slope=nxt.negative_slope, out_grid=(1, 1))
+                i += 2
+            elif isinstance(nxt, _BNParams):
+                h = m.run(h, out_grid=(1, 1))
+                h = nxt.run(h, act=ops.ACT_LRELU, slope=mods[i + 2].negative_slope)
+                i += 3
+            else:
+                h = m.run(h, out_grid=(1, 1))
+                i += 1
+        return h
+
+    def forward(self, x):
+        if isinstance(x, GT):
+            return self.forward_grid(x)
+        return ops.to_nchw(self.forward_grid(ops.to_grid(x, 1, 1, merged=True)), merged=True)

@@ -1,0 +1,389 @@
+"""Layer modules with the reference's names, constructor signatures and state_dict keys
+(reference models/layers.py), executing on the MI355X kernels of libitg_hip.so.
+
+Every module accepts either the reference's NCHW tensors (patch batches, converted at the
+module boundary) or the internal patch-grid NHWC form (:class:`ops.GT`), in which case the
+result stays in that form - this is how the generator keeps its whole forward/backward in
+NHWC without per-layer conversions.  There is no CPU path.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import GT
+
+
+def _pad_mode(outer_padding):
+    if outer_padding == "replicate":
+        return ops.PAD_REPLICATE
+    if outer_padding == "constant":
+        return ops.PAD_ZERO
+    raise ValueError("outer_padding must be 'replicate' or 'constant', got %r" % (outer_padding,))
+
+
+# ------------------------------------------------------------------------------- parameters
+class _ConvParams(nn.Module):
+    """Holds a conv's parameters under the reference's names: ``weight``/``bias`` or, with
+    spectral norm, ``weight_orig``/``weight_u``/``weight_v``/``bias`` (the buffers of
+    torch.nn.utils.spectral_norm as wrapped at reference models/layers.py:178-200).
+    Orthogonal init, zero bias (reference utils.py:745-750)."""
+
+    def __init__(self, ch_in, ch_out, k, SN=False, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.ch_in, self.ch_out, self.k, self.stride, self.padding, self.SN = ch_in, ch_out, k, stride, padding, SN
+        w = torch.empty(ch_out, ch_in, k, k)
+        nn.init.orthogonal_(w, gain=1)
+        if SN:
+            self.weight_orig = nn.Parameter(w)
+            u = nn.functional.normalize(torch.randn(ch_out), dim=0, eps=1e-12)
+            v = nn.functional.normalize(torch.randn(ch_in * k * k), dim=0, eps=1e-12)
+            self.register_buffer("weight_u", u)
+            self.register_buffer("weight_v", v)
+        else:
+            self.weight = nn.Parameter(w)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(ch_out))
+        else:
+            self.register_parameter("bias", None)
+
+    def weight_and_sn(self):
+        """(weight tensor, sn tuple or None); runs the power iteration in training mode."""
+        if not self.SN:
+            return self.weight, None
+        inv = ops.sn_power_iter(self.weight_orig, self.weight_u, self.weight_v, training=self.training)
+        return self.weight_orig, (inv, self.weight_u.clone(), self.weight_v.clone())
+
+    def run(self, x, pad=None, pad_mode=ops.PAD_ZERO, act=ops.ACT_NONE, slope=0.0, residual=None, out_grid=None):
+        w, sn = self.weight_and_sn()
+        return ops.conv(x, w, self.bias, self.k, self.k, self.stride, self.padding if pad is None else pad,
+                        pad_mode, act, slope, residual, sn, out_grid)
+
+    def forward(self, x):
+        """Plain conv on an NCHW image batch (zero padding), as the reference's nn.Conv2d."""
+        g = x if isinstance(x, GT) else ops.to_grid(x, 1, 1, merged=True)
+        y = self.run(g)
+        return y if isinstance(x, GT) else ops.to_nchw(y, merged=True)
+
+
+def conv3x3(ch_in, ch_out, SN=False, s=1, p=1, bias=True, padding_mode="zeros"):
+    return _ConvParams(ch_in, ch_out, 3, SN, s, p, bias)
+
+
+def conv4x4(ch_in, ch_out, SN=False, s=2, p=1, bias=True):
+    return _ConvParams(ch_in, ch_out, 4, SN, s, p, bias)
+
+
+def conv1x1(ch_in, ch_out, SN=False, s=1, p=0, bias=True):
+    return _ConvParams(ch_in, ch_out, 1, SN, s, p, bias)
+
+
+# ------------------------------------------------------------------------------- LocalPadder
+class LocalPadder(nn.Module):
+    """The local-padding operator (reference models/layers.py:38-173).
+
+    Training mode (and the first sub-image at inference): every patch receives a 1-pixel halo
+    from its 8 grid neighbours; the outer frame of the merged image is replicated or zero.
+    Eval mode streams sub-images in raster order and carries the left column / top row of the
+    previous ones.  The class-level configuration of the reference is kept
+    (:meth:`set_attributes`); a generator additionally pins a per-instance copy so that two
+    generators with different grids can coexist.
+    """
+    num_patches_h = 3
+    num_patches_w = 3
+    outer_padding = "replicate"
+    padding_size = 1
+    conv_reduction = 2
+
+    @classmethod
+    def set_attributes(cls, num_patches_h=3, num_patches_w=3, outer_padding="replicate", padding_size=1,
+                       conv_reduction=2):
+        cls.num_patches_h, cls.num_patches_w = num_patches_h, num_patches_w
+        cls.outer_padding, cls.padding_size, cls.conv_reduction = outer_padding, padding_size, conv_reduction
+
+    def __init__(self, merge_patches_into_image=True):
+        super().__init__()
+        self.merge_patches_into_image = merge_patches_into_image
+        self._cfg = None
+        self.reset_state()
+
+    def pin(self, gh, gw, outer):
+        self._cfg = (gh, gw, outer)
+
+    def cfg(self):
+        if self._cfg is not None:
+            return self._cfg
+        if self.padding_size != 1 or self.conv_reduction != 2:
+            raise ValueError("only padding_size=1 / conv_reduction=2 (3x3 convs) is meaningful")
+        return self.num_patches_h, self.num_patches_w, self.outer_padding
+
+    def reset_state(self):
+        self._v = self._v_next = None       # left column now / for the next sub-image: (n, gh*P, ld)
+        self._h = None                      # top row for this call: (n, gw*P+2, ld)
+        self._h_cur = self._h_next = None   # row buffers: current sub-image row / being assembled
+
+    def first_position(self, image_location):
+        return self.training or ("1st_row" in image_location and "1st_col" in image_location)
+
+    # ---- eval-mode state machine (reference layers.py:103-143) on patch-grid tensors
+    def _update(self, x, loc):
+        t = x.t
+        n, gh, gw, ph, pw, ld = t.shape
+        outer = self.cfg()[2]
+        if self._v_next is not None:
+            self._v = self._v_next
+        self._v_next = None if "last_col" in loc else t[:, :, gw - 2, :, pw - 1, :].reshape(n, gh * ph, ld).contiguous()
+        row = t[:, gh - 2, :, ph - 1, :, :].reshape(n, gw * pw, ld)
+        s = row if "last_col" in loc else row[:, :(gw - 1) * pw]
+        if "1st_col" in loc:
+            if "1st_row" not in loc:
+                hn = self._h_next
+                if outer == "replicate":
+                    self._h_cur = torch.cat((hn[:, :1], hn, hn[:, -1:]), 1)
+                else:
+                    z = torch.zeros_like(hn[:, :1])
+                    self._h_cur = torch.cat((z, hn, z), 1)
+            self._h_next = s.contiguous()
+        else:
+            self._h_next = torch.cat((self._h_next, s), 1)
+        if self._h_cur is not None:
+            self._h = self._h_cur[:, :gw * pw + 2].contiguous()
+            self._h_cur = None if "last_col" in loc else self._h_cur[:, (gw - 1) * pw:]
+
+    def halo_sources(self, x, image_location):
+        """Eval mode: update the carried halos from this sub-image and return (left, top) to use."""
+        self._update(x, image_location)
+        if "1st_row" in image_location and "1st_col" in image_location:
+            return None, None
+        left = None if "1st_col" in image_location else self._v
+        top = None if "1st_row" in image_location else self._h
+        return left, top
+
+    def forward(self, input, image_location="1st_row_1st_col"):
+        gh, gw, outer = self.cfg()
+        pm = _pad_mode(outer)
+        if not self.merge_patches_into_image:
+            # already merged + randomly padded latent: crop only (reference layers.py:152-155,165-170)
+            return ops.local_pad_nchw(input, gh, gw, pm, merged=True)
+        if self.training:
+            return ops.local_pad_nchw(input, gh, gw, pm, merged=False)
+        x = ops.to_grid(input, gh, gw, merged=False)
+        left, top = self.halo_sources(x, image_location)
+        return ops.to_nchw(ops.local_pad_grid(x, pm, left, top), merged=False)
+
+
+class conv2d_lp(nn.Module):
+    """3x3 convolution with local padding (reference models/layers.py:8-36)."""
+
+    def __init__(self, ch_in, ch_out, SN=False, padding_mode="zeros", merge_patches_into_image=True):
+        super().__init__()
+        self.padding_mode = padding_mode
+        if padding_mode == "local":
+            self.local_padder = LocalPadder(merge_patches_into_image)
+            self.conv = conv3x3(ch_in, ch_out, SN, 1, 0)
+        else:
+            self.conv = conv3x3(ch_in, ch_out, SN, 1, 1)
+
+    def forward_grid(self, x, image_location="1st_row_1st_col", act=ops.ACT_NONE, slope=0.0, residual=None):
+        """x: GT patches (or, for the generator's ``start`` layer, the merged latent as a 1x1-grid GT)."""
+        if self.padding_mode != "local":
+            # per-patch zero padding: every patch is an independent image
+            n, gh, gw, ph, pw, ld = x.t.shape
+            flat = GT(x.t.reshape(n * gh * gw, 1, 1, ph, pw, ld), x.c)
+            r = None if residual is None else GT(residual.t.reshape(n * gh * gw, 1, 1, ph, pw, -1), residual.c)
+            y = self.conv.run(flat, pad=1, pad_mode=ops.PAD_ZERO, act=act, slope=slope, residual=r)
+            return GT(y.t.reshape(n, gh, gw, ph, pw, -1), y.c)
+        lp = self.local_padder
+        gh, gw, outer = lp.cfg()
+        if not lp.merge_patches_into_image:
+            # valid conv over the pre-padded merged latent == crop(b+2, stride b) + valid conv per patch
+            return self.conv.run(x, pad=0, act=act, slope=slope, residual=residual, out_grid=(gh, gw))
+        if lp.training:
+            # halo + outer padding are resolved inside the conv's tile loader
+            return self.conv.run(x, pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope, residual=residual)
+        left, top = lp.halo_sources(x, image_location)
+        if left is None and top is None and "1st_row" in image_location and "1st_col" in image_location:
+            return self.conv.run(x, pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope, residual=residual)
+        xp = ops.local_pad_grid(x, _pad_mode(outer), left, top)
+        n, g1, g2, ph, pw, ld = xp.t.shape
+        flat = GT(xp.t.reshape(n * g1 * g2, 1, 1, ph, pw, ld), xp.c)
+        r = None if residual is None else GT(residual.t.reshape(n * g1 * g2, 1, 1, ph - 2, pw - 2, -1), residual.c)
+        y = self.conv.run(flat, pad=0, act=act, slope=slope, residual=r)
+        return GT(y.t.reshape(n, g1, g2, ph - 2, pw - 2, -1), y.c)
+
+    def forward(self, x, image_location="1st_row_1st_col"):
+        if isinstance(x, GT):
+            return self.forward_grid(x, image_location)
+        if self.padding_mode != "local":
+            return ops.to_nchw(self.conv.run(ops.to_grid(x, 1, 1, True), pad=1), True)
+        lp = self.local_padder
+        gh, gw, _ = lp.cfg()
+        if lp.merge_patches_into_image:
+            g = ops.to_grid(x, gh, gw, merged=False)
+        else:
+            g = ops.to_grid(x, 1, 1, merged=True)
+        return ops.to_nchw(self.forward_grid(g, image_location), merged=False)
+
+
+# ------------------------------------------------------------------------------- normalisation
+class _BNParams(nn.BatchNorm2d):
+    """nn.BatchNorm2d as a parameter/buffer container (same state_dict keys); the arithmetic
+    runs in the HIP kernels.  ``sync`` (an ops.SyncGroup) makes the statistics global."""
+    sync = None
+
+    def run(self, x, act=ops.ACT_NONE, slope=0.0, upsample=False):
+        return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked,
+                          training=self.training, eps=self.eps, momentum=self.momentum, act=act, slope=slope,
+                          upsample=upsample, sync=self.sync)
+
+    def forward(self, x):
+        if isinstance(x, GT):
+            return self.run(x)
+        return ops.to_nchw(self.run(ops.to_grid(x, 1, 1, True)), True)
+
+
+class StochasticSpatialModulation(nn.Module):
+    """(1+gamma)*BN(x)+beta with [gamma,beta] = embed(ReLU(mlp_shared(map))).
+    reference models/layers.py:203-234."""
+
+    def __init__(self, in_channel, map_dim, SN=False, padding_mode="zeros"):
+        super().__init__()
+        self.in_channel = in_channel
+        self.out_channels = in_channel * 2
+        self.p = 1 if padding_mode == "zeros" else 0
+        self.bn = _BNParams(in_channel, affine=False)
+        self.mlp_shared = nn.Sequential(conv3x3(map_dim, 128, SN=SN, p=self.p), nn.ReLU())
+        self.embed = conv3x3(128, self.out_channels, bias=True, SN=SN, p=self.p)
+        w = self.embed.weight_orig if SN else self.embed.weight
+        with torch.no_grad():      # the reference's (odd) init: re-orthogonalise dim-1 slice, zero the rest
+            nn.init.orthogonal_(w.data[:, :in_channel], gain=1)
+            w.data[:, in_channel:].zero_()
+
+    def run(self, x, maps, act=ops.ACT_NONE, slope=0.0):
+        """x: GT (n,gh,gw,r,r); maps: NCHW (n*gh*gw, map_dim, r+4, r+4) or an equivalent 1x1-grid GT."""
+        m = maps if isinstance(maps, GT) else ops.to_grid(maps.float(), 1, 1, merged=True)
+        a = self.mlp_shared[0].run(m, pad=self.p, act=ops.ACT_LRELU, slope=0.0)
+        e = self.embed.run(a, pad=self.p)
+        n, gh, gw, ph, pw, _ = x.t.shape
+        if e.t.shape[3] != ph or e.t.shape[4] != pw or e.t.shape[0] != n * gh * gw:
+            raise ValueError("modulation map does not match the activation: %r vs %r" % (e, x))
+        e = GT(e.t.reshape(n, gh, gw, ph, pw, -1), e.c)
+        bn = self.bn
+        return ops.ssm_modulate(x, e, bn.running_mean, bn.running_var, bn.num_batches_tracked, training=bn.training,
+                                eps=bn.eps, momentum=bn.momentum, act=act, slope=slope, sync=bn.sync)
+
+    def forward(self, inputs, maps):
+        if isinstance(inputs, GT):
+            return self.run(inputs, maps)
+        g = ops.to_grid(inputs, 1, 1, merged=True)
+        g = GT(g.t.reshape(1, g.t.shape[0], 1, *g.t.shape[3:]), g.c)   # patches as a (nb x 1) grid
+        y = self.run(g, maps)
+        return ops.to_nchw(GT(y.t.reshape(y.t.shape[1], 1, 1, *y.t.shape[3:]), y.c), True)
+
+
+class Attention(nn.Module):
+    """SAGAN-style self-attention inside each patch (reference models/layers.py:236-258)."""
+
+    def __init__(self, channels, SN=False):
+        super().__init__()
+        self.channels = channels
+        self.theta = conv1x1(channels, channels // 8, SN=SN)
+        self.phi = conv1x1(channels, channels // 8, SN=SN)
+        self.g = conv1x1(channels, channels // 2, SN=SN)
+        self.o = conv1x1(channels // 2, channels, SN=SN)
+        self.gamma = nn.Parameter(torch.tensor(0.0), requires_grad=True)
+
+    def run(self, x):
+        theta = self.theta.run(x)
+        phi = ops.maxpool2(self.phi.run(x))
+        g = ops.maxpool2(self.g.run(x))
+        mid = ops.attention_core(theta, phi, g)
+        o = self.o.run(mid)
+        # gamma*o + x: the scalar gate is applied with a tensor op on the NHWC buffer (pad lanes stay 0)
+        return GT(_ScaleAdd.apply(o.t, x.t, self.gamma), x.c)
+
+    def forward(self, inputs):
+        if isinstance(inputs, GT):
+            return self.run(inputs)
+        nb = inputs.shape[0]
+        g = ops.to_grid(inputs, nb, 1, merged=False)
+        return ops.to_nchw(self.run(g), merged=False)
+
+
+class _ScaleAdd(torch.autograd.Function):
+    """gamma*o + x (reference layers.py:258); gamma is a 0-dim parameter read on the device."""
+
+    @staticmethod
+    def forward(ctx, o, x, gamma):
+        ctx.save_for_backward(o, gamma)
+        return ops.axpby(o, x, 1.0, 1.0, a_dev=gamma)
+
+    @staticmethod
+    def backward(ctx, g):
+        o, gamma = ctx.saved_tensors
+        g = g.contiguous()
+        return ops.axpby(g, g, 1.0, 0.0, a_dev=gamma), g, ops.dot(g, o).to(torch.float32).reshape(())
+
+
+# ------------------------------------------------------------------------------- residual block
+class ResBlockGenerator(nn.Module):
+    """norm -> act -> conv2d_lp -> norm -> act -> conv2d_lp (+ 1x1 shortcut iff in != out).
+    reference models/layers.py:260-322."""
+
+    def __init__(self, generator, in_channels, out_channels, hidden_channels=None, padding_mode="zeros"):
+        super().__init__()
+        hidden_channels = out_channels if hidden_channels is None else hidden_channels
+        self.learnable_sc = in_channels != out_channels
+        self.type_norm = generator.type_norm
+        self.leak = generator.leak
+        self.map_dim = generator.map_dim
+        self.SN = generator.SN
+        self.conv1 = conv2d_lp(in_channels, hidden_channels, self.SN, padding_mode)
+        self.conv2 = conv2d_lp(hidden_channels, out_channels, self.SN, padding_mode)
+        if self.learnable_sc:
+            self.conv3 = conv1x1(in_channels, out_channels, SN=self.SN)
+        if self.type_norm == "BN":
+            self.bn1 = _BNParams(in_channels)
+            self.bn2 = _BNParams(hidden_channels)
+        elif self.type_norm == "SSM":
+            self.bn1 = StochasticSpatialModulation(in_channels, self.map_dim, self.SN, padding_mode)
+            self.bn2 = StochasticSpatialModulation(hidden_channels, self.map_dim, self.SN, padding_mode)
+            if self.learnable_sc:
+                self.bn3 = StochasticSpatialModulation(in_channels, self.map_dim, self.SN, padding_mode)
+        else:
+            raise ValueError("type_norm must be 'BN' or 'SSM', got %r" % (self.type_norm,))
+        # nn.LeakyReLU(leak) if leak > 0 else nn.ReLU(): both are ACT_LRELU with slope = leak
+        self.activation = nn.LeakyReLU(self.leak) if self.leak > 0 else nn.ReLU()
+
+    def forward_grid(self, x, map=None, image_location="1st_row_1st_col", upsample_input=False):
+        """x: GT.  ``upsample_input``: x is the block input BEFORE the generator's nearest x2
+        upsample; the upsample is then folded into bn1 (BN mode) and moved behind the 1x1 shortcut."""
+        A, s = ops.ACT_LRELU, float(self.leak)
+        if self.type_norm == "SSM":
+            if upsample_input:
+                x = ops.upsample2x(x)
+                upsample_input = False
+            out = self.bn1.run(x, map, act=A, slope=s)
+        else:
+            out = self.bn1.run(x, act=A, slope=s, upsample=upsample_input)
+        out = self.conv1.forward_grid(out, image_location)
+        if self.type_norm == "SSM":
+            out = self.bn2.run(out, map, act=A, slope=s)
+        else:
+            out = self.bn2.run(out, act=A, slope=s)
+        if self.learnable_sc:
+            sc = x
+            if self.type_norm == "SSM":
+                sc = self.bn3.run(sc, map)
+            sc = self.conv3.run(sc)
+            if upsample_input:
+                sc = ops.upsample2x(sc)
+        else:
+            sc = ops.upsample2x(x) if upsample_input else x
+        return self.conv2.forward_grid(out, image_location, residual=sc)
+
+    def forward(self, x, map=None, image_location="1st_row_1st_col"):
+        if isinstance(x, GT):
+            return self.forward_grid(x, map, image_location)
+        gh, gw, _ = self.conv1.local_padder.cfg() if self.conv1.padding_mode == "local" else (x.shape[0], 1, None)
+        g = ops.to_grid(x, gh, gw, merged=False)
+        return ops.to_nchw(self.forward_grid(g, map, image_location), merged=False)

@@ -1,0 +1,657 @@
+"""torch.autograd bindings over the C ABI (include/itg.h).
+
+PyTorch supplies device memory, the stream and the autograd tape; every piece of arithmetic
+on the hot path is a call into libitg_hip.so.  Activations travel as *patch-grid NHWC*
+tensors: a contiguous fp32 CUDA tensor of shape (n, gh, gw, ph, pw, ld) plus the logical
+channel count ``c`` (ld = c rounded up to 4, pad channels are zero) - see :class:`GT`.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import Tensor as _T, ConvGeom as _G, PAD_ZERO, PAD_REPLICATE, ACT_NONE, ACT_LRELU, ACT_TANH  # noqa: F401
+
+
+def ld_for(c):
+    return (int(c) + 3) // 4 * 4
+
+
+# Optional launch profiler (bench.py): a list that receives (kernel_tag, n_launches, flops, ev0, ev1)
+# per convolution call, with HIP events recorded on the launching stream.  None = off.
+PROFILE = None
+
+
+def _nt_tag(rows):
+    r = (int(rows) + 15) // 16 * 16
+    return "conv_nt<%s>" % ("16,256" if r <= 16 else "32,256" if r <= 32 else "64,256" if r <= 64 else "128,128")
+
+
+class _Prof:
+    def __init__(self, tag, launches, flops):
+        self.rec = PROFILE is not None
+        if self.rec:
+            self.item = [tag, launches, flops, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+
+    def __enter__(self):
+        if self.rec:
+            self.item[3].record()
+
+    def __exit__(self, *a):
+        if self.rec:
+            self.item[4].record()
+            PROFILE.append(tuple(self.item))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _desc(t, c):
+    n, gh, gw, ph, pw, ld = t.shape
+    return _T(t.data_ptr(), n, gh, gw, ph, pw, int(c), ld)
+
+
+def _null_desc():
+    return _T(None, 1, 1, 1, 1, 1, 1, 4)
+
+
+def _req_cuda(t, what):
+    if not t.is_cuda:
+        raise _lib.ItgError("%s must live on the GPU: this build has no CPU path" % what)
+    if t.dtype != torch.float32:
+        raise _lib.ItgError("%s must be float32 (the reference path is fp32 end to end)" % what)
+
+
+class GT:
+    """Patch-grid NHWC activation: ``t`` is (n, gh, gw, ph, pw, ld), ``c`` logical channels."""
+    __slots__ = ("t", "c")
+
+    def __init__(self, t, c):
+        self.t, self.c = t, int(c)
+
+    n = property(lambda s: s.t.shape[0])
+    gh = property(lambda s: s.t.shape[1])
+    gw = property(lambda s: s.t.shape[2])
+    ph = property(lambda s: s.t.shape[3])
+    pw = property(lambda s: s.t.shape[4])
+    ld = property(lambda s: s.t.shape[5])
+
+    def detach(self):
+        return GT(self.t.detach(), self.c)
+
+    def __repr__(self):
+        return "GT(n=%d grid=%dx%d patch=%dx%d c=%d ld=%d)" % (self.n, self.gh, self.gw, self.ph, self.pw, self.c, self.ld)
+
+
+# ------------------------------------------------------------------------------- layout
+class _ToGrid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gh, gw, merged):
+        _req_cuda(x, "input")
+        x = x.contiguous()
+        if merged:
+            n, c, H, W = x.shape
+            ph, pw = H // gh, W // gw
+            if ph * gh != H or pw * gw != W:
+                raise _lib.ItgError("image %dx%d does not divide into a %dx%d grid" % (H, W, gh, gw))
+        else:
+            nb, c, ph, pw = x.shape
+            n = nb // (gh * gw)
+            if n * gh * gw != nb:
+                raise _lib.ItgError("patch batch %d is not a multiple of the %dx%d grid" % (nb, gh, gw))
+        out = torch.empty((n, gh, gw, ph, pw, ld_for(c)), device=x.device, dtype=torch.float32)
+        d = _desc(out, c)
+        _lib.call("itg_nchw_to_grid", _ptr(x), C.byref(d), int(merged), _stream())
+        ctx.meta = (tuple(x.shape), c, merged)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, c, merged = ctx.meta
+        g = g.contiguous()
+        out = torch.empty(shape, device=g.device, dtype=torch.float32)
+        d = _desc(g, c)
+        _lib.call("itg_grid_to_nchw", C.byref(d), _ptr(out), int(merged), _stream())
+        return out, None, None, None
+
+
+class _ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, c, merged):
+        t = t.contiguous()
+        n, gh, gw, ph, pw, ld = t.shape
+        shape = (n, c, gh * ph, gw * pw) if merged else (n * gh * gw, c, ph, pw)
+        out = torch.empty(shape, device=t.device, dtype=torch.float32)
+        d = _desc(t, c)
+        _lib.call("itg_grid_to_nchw", C.byref(d), _ptr(out), int(merged), _stream())
+        ctx.meta = (tuple(t.shape), c, merged)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, c, merged = ctx.meta
+        g = g.contiguous()
+        out = torch.empty(shape, device=g.device, dtype=torch.float32)
+        d = _desc(out, c)
+        _lib.call("itg_nchw_to_grid", _ptr(g), C.byref(d), int(merged), _stream())
+        return out, None, None
+
+
+def to_grid(x, gh=1, gw=1, merged=True):
+    """NCHW tensor -> GT.  merged: x is (n, c, gh*ph, gw*pw); else a patch batch (n*gh*gw, c, ph, pw)."""
+    return GT(_ToGrid.apply(x, gh, gw, merged), x.shape[1])
+
+
+def to_nchw(g, merged=True):
+    return _ToNCHW.apply(g.t, g.c, merged)
+
+
+# ------------------------------------------------------------------------------- spectral norm
+def sn_power_iter(w_orig, u, v, training=True, eps=1e-12):
+    """One power iteration in place on (u, v) (training) and 1/sigma as a 1-element tensor.
+    torch.nn.utils.spectral_norm semantics as used at reference models/layers.py:190-194."""
+    rows = w_orig.shape[0]
+    cols = w_orig.numel() // rows
+    ws = torch.empty(rows + cols + 2, device=w_orig.device, dtype=torch.float32)
+    inv = ws[rows + cols:rows + cols + 1]
+    with torch.no_grad():
+        _lib.call("itg_spectral_norm_power_iter", _ptr(w_orig), _ptr(u), _ptr(v), rows, cols, int(training),
+                  float(eps), None, _ptr(inv), _ptr(ws), _stream())
+    return inv
+
+
+# ------------------------------------------------------------------------------- convolution
+class _Conv(torch.autograd.Function):
+    """out = act(conv(x, w*scale) + bias [+ residual]) on patch-grid tensors (merged-image
+    coordinates).  ``sn`` = (inv_sigma, u, v) makes ``w`` the spectral-norm ``weight_orig``."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, sn, c_in, geom, act, slope, out_grid):
+        kh, kw, stride, pad, pad_mode = geom
+        n, gh, gw, ph, pw, ld = x.shape
+        co, ci = w.shape[0], w.shape[1]
+        if ci != c_in or w.shape[2] != kh or w.shape[3] != kw:
+            raise _lib.ItgError("weight %s does not match conv geometry (c_in=%d, k=%dx%d)" % (tuple(w.shape), c_in, kh, kw))
+        H, W = gh * ph, gw * pw
+        Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+        ogh, ogw = out_grid
+        if Ho % ogh or Wo % ogw:
+            raise _lib.ItgError("conv output %dx%d does not divide into a %dx%d grid" % (Ho, Wo, ogh, ogw))
+        x = x.contiguous()
+        st = _stream()
+        inv_sigma = sn[0] if sn is not None else None
+        wp = torch.empty(_lib.fn("itg_pack_fwd_size")(co, ld, kh, kw), device=x.device, dtype=torch.float32)
+        _lib.call("itg_pack_fwd", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, ld, kh, kw, st)
+        out = torch.empty((n, ogh, ogw, Ho // ogh, Wo // ogw, ld_for(co)), device=x.device, dtype=torch.float32)
+        dx_, do_ = _desc(x, c_in), _desc(out, co)
+        dr_ = _desc(residual, co) if residual is not None else _null_desc()
+        g = _G(kh, kw, stride, pad, pad_mode)
+        with _Prof(_nt_tag(co), 1, 2.0 * n * Ho * Wo * co * ci * kh * kw):
+            _lib.call("itg_conv2d_fwd", C.byref(dx_), _ptr(wp), _ptr(bias), C.byref(dr_), C.byref(do_), C.byref(g),
+                      act, float(slope), st)
+        ctx.geom, ctx.act, ctx.slope, ctx.c_in, ctx.co = geom, act, slope, c_in, co
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        ctx.sn = sn
+        ctx.save_for_backward(x, w, out if act != ACT_NONE else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, out = ctx.saved_tensors
+        kh, kw, stride, pad, pad_mode = ctx.geom
+        co, ci = ctx.co, ctx.c_in
+        st = _stream()
+        dout = dout.contiguous()
+        if ctx.act != ACT_NONE:
+            dy = torch.empty_like(dout)
+            a, b, c_ = _desc(out, co), _desc(dout, co), _desc(dy, co)
+            _lib.call("itg_act_bwd", C.byref(a), C.byref(b), C.byref(c_), ctx.act, float(ctx.slope), st)
+        else:
+            dy = dout
+        g = _G(kh, kw, stride, pad, pad_mode)
+        ddy = _desc(dy, co)
+        inv_sigma = ctx.sn[0] if ctx.sn is not None else None
+        gx = gw_ = gb = None
+        if ctx.needs_input_grad[0]:
+            wp = torch.empty(_lib.fn("itg_pack_dgrad_size")(ci, dy.shape[5], kh, kw, stride), device=x.device,
+                             dtype=torch.float32)
+            _lib.call("itg_pack_dgrad", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, dy.shape[5], kh, kw, stride, st)
+            gx = torch.empty_like(x)
+            ddx = _desc(gx, ci)
+            npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
+            with _Prof(_nt_tag(ci), stride * stride, 2.0 * npix_out * co * ci * kh * kw):
+                _lib.call("itg_conv2d_dgrad", C.byref(ddy), _ptr(wp), C.byref(ddx), C.byref(g), st)
+        need_w = ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if need_w or need_b:
+            dxd = _desc(x, ci)
+            nws = _lib.fn("itg_conv2d_wgrad_workspace")(C.byref(dxd), C.byref(ddy), C.byref(g))
+            ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+            gw_ = torch.empty_like(w)
+            gb = torch.empty(co, device=x.device, dtype=torch.float32) if need_b else None
+            npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
+            with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1, 2.0 * npix_out * co * ci * kh * kw):
+                _lib.call("itg_conv2d_wgrad", C.byref(dxd), C.byref(ddy), _ptr(gw_), _ptr(gb), C.byref(g), 0,
+                          _ptr(ws), nws, st)
+            if ctx.sn is not None:
+                _, u, v = ctx.sn
+                rows, cols = co, w.numel() // co
+                d_orig = torch.empty_like(w)
+                ws2 = torch.empty(2, device=x.device, dtype=torch.float64)
+                _lib.call("itg_spectral_norm_bwd", _ptr(gw_), _ptr(w), _ptr(u), _ptr(v), _ptr(inv_sigma), rows, cols,
+                          _ptr(d_orig), _ptr(ws2), st)
+                gw_ = d_orig
+            if not need_w:
+                gw_ = None
+        gres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
+        return gx, gw_, gb, gres, None, None, None, None, None, None
+
+
+def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, residual=None,
+         sn=None, out_grid=None):
+    """x: GT.  Returns GT with ``out_grid`` (default: the input grid)."""
+    og = out_grid if out_grid is not None else (x.gh, x.gw)
+    r = residual.t if residual is not None else None
+    t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode), act, slope, og)
+    return GT(t, w.shape[0])
+
+
+# ------------------------------------------------------------------------------- batch norm (+act, +upsample)
+class SyncGroup:
+    """Optional process group over which BatchNorm statistics are summed (sync-BN)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+
+    def all_reduce(self, t):
+        self.dist.all_reduce(t, group=self.group)
+
+
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, c, training, eps, momentum, act, slope, ups, sync):
+        x = x.contiguous()
+        n, gh, gw, ph, pw, ld = x.shape
+        dev = x.device
+        st = _stream()
+        dx_ = _desc(x, c)
+        count = float(x.numel() // ld)
+        sums = None
+        if training:
+            sums = torch.zeros(2 * ld, device=dev, dtype=torch.float64)
+            _lib.call("itg_bn_stats", C.byref(dx_), _ptr(sums), st)
+            if sync is not None and sync.world > 1:
+                sync.all_reduce(sums)
+                count *= sync.world
+        stat = torch.empty(4 * ld, device=dev, dtype=torch.float32)
+        mean_rstd, ab = stat[:2 * ld], stat[2 * ld:]
+        _lib.call("itg_bn_finalize", _ptr(sums), count, 4.0 if ups else 1.0, _ptr(gamma), _ptr(beta), float(eps),
+                  float(momentum), _ptr(rm), _ptr(rv), _ptr(nbt), _ptr(mean_rstd), _ptr(ab), c, ld, int(training), st)
+        s = 2 if ups else 1
+        y = torch.empty((n, gh, gw, ph * s, pw * s, ld), device=dev, dtype=torch.float32)
+        dy_ = _desc(y, c)
+        _lib.call("itg_bn_apply", C.byref(dx_), _ptr(ab), C.byref(dy_), act, float(slope), st)
+        ctx.meta = (c, act, slope, count, sync, training, gamma is not None)
+        ctx.save_for_backward(x, stat)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stat = ctx.saved_tensors
+        c, act, slope, count, sync, training, affine = ctx.meta
+        if not training:
+            raise _lib.ItgError("BatchNorm backward is only implemented for training-mode statistics")
+        ld = x.shape[5]
+        mean_rstd, ab = stat[:2 * ld], stat[2 * ld:]
+        dy = dy.contiguous()
+        st = _stream()
+        dx_, ddy_ = _desc(x, c), _desc(dy, c)
+        sums = torch.zeros(2 * ld, device=x.device, dtype=torch.float64)
+        _lib.call("itg_bn_bwd_reduce", C.byref(dx_), C.byref(ddy_), _ptr(ab), _ptr(mean_rstd), act, float(slope),
+                  _ptr(sums), st)
+        dgb = torch.empty(2 * c, device=x.device, dtype=torch.float32) if affine else None
+        if sync is not None and sync.world > 1:
+            # dgamma/dbeta are the LOCAL sums (the gradient all-reduce adds the ranks up later);
+            # the dx formula needs the GLOBAL ones.
+            local = sums.clone()
+            sync.all_reduce(sums)
+        else:
+            local = sums
+        gx = torch.empty_like(x)
+        dgx = _desc(gx, c)
+        _lib.call("itg_bn_bwd_apply", C.byref(dx_), C.byref(ddy_), _ptr(ab), _ptr(mean_rstd), None, _ptr(sums),
+                  count, act, float(slope), C.byref(dgx), None, None, st)
+        dg = db = None
+        if affine:
+            dg = local[ld:ld + c].to(torch.float32)
+            db = local[:c].to(torch.float32)
+        return gx, dg, db, None, None, None, None, None, None, None, None, None, None, None
+
+
+def bn_act(x, gamma, beta, rm, rv, nbt, training=True, eps=1e-5, momentum=0.1, act=ACT_NONE, slope=0.0,
+           upsample=False, sync=None):
+    """y = act(BatchNorm(x)) [nearest-upsampled x2 when ``upsample``]: statistics are taken on x
+    (identical to those of the upsampled tensor), the unbiased running_var uses the x4 count."""
+    t = _BNAct.apply(x.t, gamma, beta, rm, rv, nbt, x.c, training, eps, momentum, act, slope, upsample, sync)
+    return GT(t, x.c)
+
+
+def bn_stats_only(x, rm, rv, nbt, training=True, eps=1e-5, momentum=0.1, sync=None):
+    """Affine-free BN statistics for SSM: returns mean_rstd (2*ld) and updates running stats."""
+    t = x.t.contiguous()
+    ld = t.shape[5]
+    st = _stream()
+    dx_ = _desc(t, x.c)
+    count = float(t.numel() // ld)
+    sums = None
+    if training:
+        sums = torch.zeros(2 * ld, device=t.device, dtype=torch.float64)
+        _lib.call("itg_bn_stats", C.byref(dx_), _ptr(sums), st)
+        if sync is not None and sync.world > 1:
+            sync.all_reduce(sums)
+            count *= sync.world
+    stat = torch.empty(4 * ld, device=t.device, dtype=torch.float32)
+    _lib.call("itg_bn_finalize", _ptr(sums), count, 1.0, None, None, float(eps), float(momentum), _ptr(rm), _ptr(rv),
+              _ptr(nbt), _ptr(stat[:2 * ld]), _ptr(stat[2 * ld:]), x.c, ld, int(training), st)
+    return stat, count
+
+
+# ------------------------------------------------------------------------------- SSM modulation
+class _SSM(torch.autograd.Function):
+    """y = act((1+gamma)*xhat + beta), xhat = affine-free BN(x), [gamma,beta] = emb halves.
+    reference models/layers.py:228-234."""
+
+    @staticmethod
+    def forward(ctx, x, emb, rm, rv, nbt, c, training, eps, momentum, act, slope, sync):
+        x, emb = x.contiguous(), emb.contiguous()
+        stat, count = bn_stats_only(GT(x, c), rm, rv, nbt, training, eps, momentum, sync)
+        ld = x.shape[5]
+        y = torch.empty_like(x)
+        a, e, o = _desc(x, c), _desc(emb, 2 * c), _desc(y, c)
+        _lib.call("itg_ssm_modulate_fwd", C.byref(a), _ptr(stat[:2 * ld]), C.byref(e), C.byref(o), act, float(slope),
+                  _stream())
+        ctx.meta = (c, act, slope, count, sync, training)
+        ctx.save_for_backward(x, emb, stat)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, emb, stat = ctx.saved_tensors
+        c, act, slope, count, sync, training = ctx.meta
+        ld = x.shape[5]
+        st = _stream()
+        dy = dy.contiguous()
+        dxhat = torch.empty_like(x)
+        demb = torch.zeros_like(emb)
+        a, e, g = _desc(x, c), _desc(emb, 2 * c), _desc(dy, c)
+        h, de = _desc(dxhat, c), _desc(demb, 2 * c)
+        mean_rstd = stat[:2 * ld]
+        _lib.call("itg_ssm_modulate_bwd", C.byref(a), _ptr(mean_rstd), C.byref(e), C.byref(g), act, float(slope),
+                  C.byref(h), C.byref(de), st)
+        if not training:
+            raise _lib.ItgError("SSM backward is only implemented for training-mode statistics")
+        # affine-free BN backward on dxhat: alpha = rstd, beta' = -mean*rstd are stat[2ld:]
+        ab = stat[2 * ld:]
+        sums = torch.zeros(2 * ld, device=x.device, dtype=torch.float64)
+        _lib.call("itg_bn_bwd_reduce", C.byref(a), C.byref(h), _ptr(ab), _ptr(mean_rstd), ACT_NONE, 0.0, _ptr(sums), st)
+        if sync is not None and sync.world > 1:
+            sync.all_reduce(sums)
+        gx = torch.empty_like(x)
+        dgx = _desc(gx, c)
+        _lib.call("itg_bn_bwd_apply", C.byref(a), C.byref(h), _ptr(ab), _ptr(mean_rstd), None, _ptr(sums), count,
+                  ACT_NONE, 0.0, C.byref(dgx), None, None, st)
+        return gx, demb, None, None, None, None, None, None, None, None, None, None
+
+
+def ssm_modulate(x, emb, rm, rv, nbt, training=True, eps=1e-5, momentum=0.1, act=ACT_NONE, slope=0.0, sync=None):
+    t = _SSM.apply(x.t, emb.t, rm, rv, nbt, x.c, training, eps, momentum, act, slope, sync)
+    return GT(t, x.c)
+
+
+# ------------------------------------------------------------------------------- pointwise
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c, act, slope):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        a, b = _desc(x, c), _desc(y, c)
+        _lib.call("itg_act_fwd", C.byref(a), C.byref(b), act, float(slope), _stream())
+        ctx.meta = (c, act, slope)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        c, act, slope = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        a, b, d = _desc(y, c), _desc(dy, c), _desc(dx, c)
+        _lib.call("itg_act_bwd", C.byref(a), C.byref(b), C.byref(d), act, float(slope), _stream())
+        return dx, None, None, None
+
+
+def act(x, kind, slope=0.0):
+    return GT(_Act.apply(x.t, x.c, kind, slope), x.c)
+
+
+class _Up(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c):
+        x = x.contiguous()
+        n, gh, gw, ph, pw, ld = x.shape
+        y = torch.empty((n, gh, gw, 2 * ph, 2 * pw, ld), device=x.device, dtype=torch.float32)
+        a, b = _desc(x, c), _desc(y, c)
+        _lib.call("itg_upsample2x_fwd", C.byref(a), C.byref(b), _stream())
+        ctx.c = c
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        n, gh, gw, ph, pw, ld = dy.shape
+        dx = torch.empty((n, gh, gw, ph // 2, pw // 2, ld), device=dy.device, dtype=torch.float32)
+        a, b = _desc(dy, ctx.c), _desc(dx, ctx.c)
+        _lib.call("itg_upsample2x_bwd", C.byref(a), C.byref(b), _stream())
+        return dx, None
+
+
+def upsample2x(x):
+    return GT(_Up.apply(x.t, x.c), x.c)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, c):
+        a, b = a.contiguous(), b.contiguous()
+        o = torch.empty_like(a)
+        da, db, do = _desc(a, c), _desc(b, c), _desc(o, c)
+        _lib.call("itg_add", C.byref(da), C.byref(db), C.byref(do), _stream())
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g, None
+
+
+def add(a, b):
+    return GT(_Add.apply(a.t, b.t, a.c), a.c)
+
+
+class _Pool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c):
+        x = x.contiguous()
+        n, gh, gw, ph, pw, ld = x.shape
+        y = torch.empty((n, gh, gw, ph // 2, pw // 2, ld), device=x.device, dtype=torch.float32)
+        a, b = _desc(x, c), _desc(y, c)
+        _lib.call("itg_maxpool2_fwd", C.byref(a), C.byref(b), _stream())
+        ctx.c = c
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        a, b, g, d = _desc(x, ctx.c), _desc(y, ctx.c), _desc(dy, ctx.c), _desc(dx, ctx.c)
+        _lib.call("itg_maxpool2_bwd", C.byref(a), C.byref(b), C.byref(g), C.byref(d), _stream())
+        return dx, None
+
+
+def maxpool2(x):
+    return GT(_Pool.apply(x.t, x.c), x.c)
+
+
+# ------------------------------------------------------------------------------- attention core
+class _Att(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, theta, phi, g, c8, c2):
+        theta, phi, g = theta.contiguous(), phi.contiguous(), g.contiguous()
+        n, gh, gw, ph, pw, _ = theta.shape
+        nb, hw, j = n * gh * gw, ph * pw, phi.shape[3] * phi.shape[4]
+        o = torch.empty((n, gh, gw, ph, pw, g.shape[5]), device=theta.device, dtype=torch.float32)
+        beta = torch.empty(2 * nb * hw * j, device=theta.device, dtype=torch.float32)
+        a, b, c_, d = _desc(theta, c8), _desc(phi, c8), _desc(g, c2), _desc(o, c2)
+        _lib.call("itg_attention_fwd", C.byref(a), C.byref(b), C.byref(c_), C.byref(d), _ptr(beta), _stream())
+        ctx.meta = (c8, c2)
+        ctx.save_for_backward(theta, phi, g, beta)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        theta, phi, g, beta = ctx.saved_tensors
+        c8, c2 = ctx.meta
+        do = do.contiguous()
+        dth, dph, dg = torch.empty_like(theta), torch.empty_like(phi), torch.empty_like(g)
+        a, b, c_, d = _desc(theta, c8), _desc(phi, c8), _desc(g, c2), _desc(do, c2)
+        e, f, h = _desc(dth, c8), _desc(dph, c8), _desc(dg, c2)
+        _lib.call("itg_attention_bwd", C.byref(a), C.byref(b), C.byref(c_), _ptr(beta), C.byref(d), C.byref(e),
+                  C.byref(f), C.byref(h), _stream())
+        return dth, dph, dg, None, None
+
+
+def attention_core(theta, phi_pooled, g_pooled):
+    t = _Att.apply(theta.t, phi_pooled.t, g_pooled.t, theta.c, g_pooled.c)
+    return GT(t, g_pooled.c)
+
+
+# ------------------------------------------------------------------------------- LocalPadder (NCHW API form)
+class _LocalPad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gh, gw, pad_mode, merged):
+        _req_cuda(x, "LocalPadder input")
+        x = x.contiguous()
+        if merged:
+            n, c = x.shape[0], x.shape[1]
+            p = x.shape[3] // gw
+        else:
+            n, c, p = x.shape[0] // (gh * gw), x.shape[1], x.shape[3]
+        y = torch.empty((n * gh * gw, c, p + 2, p + 2), device=x.device, dtype=torch.float32)
+        _lib.call("itg_local_pad_fwd", _ptr(x), _ptr(y), n, c, gh, gw, p, pad_mode, int(merged), _stream())
+        ctx.meta = (tuple(x.shape), n, c, gh, gw, p, pad_mode, merged)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, n, c, gh, gw, p, pad_mode, merged = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty(shape, device=dy.device, dtype=torch.float32)
+        _lib.call("itg_local_pad_bwd", _ptr(dy), _ptr(dx), n, c, gh, gw, p, pad_mode, int(merged), _stream())
+        return dx, None, None, None, None
+
+
+def local_pad_nchw(x, gh, gw, pad_mode=PAD_REPLICATE, merged=False):
+    return _LocalPad.apply(x, gh, gw, pad_mode, merged)
+
+
+def local_pad_grid(x, pad_mode=PAD_REPLICATE, left=None, top=None):
+    """Inference-side halo gather on GT tensors with optional carried left column / top row."""
+    t = x.t.contiguous()
+    n, gh, gw, ph, pw, ld = t.shape
+    y = torch.empty((n, gh, gw, ph + 2, pw + 2, ld), device=t.device, dtype=torch.float32)
+    a, b = _desc(t, x.c), _desc(y, x.c)
+    _lib.call("itg_local_pad_stream_fwd", C.byref(a), _ptr(left), _ptr(top), C.byref(b), pad_mode, _stream())
+    return GT(y, x.c)
+
+
+# ------------------------------------------------------------------------------- losses
+class _BCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        _req_cuda(logits, "logits")
+        logits = logits.contiguous()
+        out = torch.empty((), device=logits.device, dtype=torch.float32)
+        _lib.call("itg_bce_logits_fwd", _ptr(logits), logits.numel(), float(target), _ptr(out), _stream())
+        ctx.target = float(target)
+        ctx.save_for_backward(logits)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (logits,) = ctx.saved_tensors
+        g = g.contiguous()
+        d = torch.empty_like(logits)
+        _lib.call("itg_bce_logits_bwd", _ptr(logits), logits.numel(), ctx.target, _ptr(g), _ptr(d), _stream())
+        return d, None
+
+
+def bce_with_logits(logits, target):
+    """Mean BCE-with-logits against a constant target (reference train.py:81,131-132)."""
+    return _BCE.apply(logits, target)
+
+
+class _Hinge(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, mode):
+        _req_cuda(logits, "logits")
+        logits = logits.contiguous()
+        out = torch.empty((), device=logits.device, dtype=torch.float32)
+        _lib.call("itg_hinge_fwd", _ptr(logits), logits.numel(), int(mode), _ptr(out), _stream())
+        ctx.mode = int(mode)
+        ctx.save_for_backward(logits)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (logits,) = ctx.saved_tensors
+        d = torch.empty_like(logits)
+        _lib.call("itg_hinge_bwd", _ptr(logits), logits.numel(), ctx.mode, _ptr(g.contiguous()), _ptr(d), _stream())
+        return d, None
+
+
+def hinge(logits, mode):
+    """mode: 'd_real' | 'd_fake' | 'g' (build-side extra; not in the reference)."""
+    return _Hinge.apply(logits, {"d_real": 0, "d_fake": 1, "g": 2}[mode])
+
+
+# ------------------------------------------------------------------------------- flat helpers
+def axpby(x, y, a, b, a_dev=None, out=None):
+    """out = a*(a_dev)*x + b*y over flat fp32 buffers."""
+    x, y = x.contiguous(), y.contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("itg_axpby", _ptr(x), _ptr(y), _ptr(out), float(a), _ptr(a_dev), float(b), x.numel(), _stream())
+    return out
+
+
+def dot(x, y):
+    """<x, y> accumulated in fp64 -> 1-element fp64 tensor."""
+    out = torch.empty(1, device=x.device, dtype=torch.float64)
+    _lib.call("itg_dot", _ptr(x.contiguous()), _ptr(y.contiguous()), x.numel(), _ptr(out), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------- optimiser
+def adam_ema_step(p, g, m, v, ema, lr, beta1, beta2, eps, step, ema_decay=0.999):
+    """Fused Adam (+EMA) over flat fp32 buffers, in place."""
+    _lib.call("itg_adam_ema_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ema), p.numel(), float(lr), float(beta1),
+              float(beta2), float(eps), int(step), float(ema_decay), _stream())

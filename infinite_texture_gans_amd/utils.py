@@ -1,0 +1,335 @@
+"""Host-side helpers with the reference's names and call signatures (reference utils.py):
+flag parser, device/seed/model preparation, patch merge/crop, latent builders and the
+patch-by-patch samplers (training and inference tiling)."""
+import argparse
+import math
+import os
+import random
+import time
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .models.generators import ResidualPatchGenerator
+from .models.discriminators import PatchDiscriminator
+
+# (flag, type | 'flag', default, help) - same names, types and defaults as reference utils.py:15-132.
+# argparse prefix abbreviation is kept on (README's `--type_norm BN` resolves to --type_norm_G).
+_FLAGS = [
+    ("data", str, "single_image", "type of data"),
+    ("data_path", str, "datasets/241.jpg", "data path"),
+    ("data_ext", str, "jpg", "data extension txt, png"),
+    ("center_crop", int, None, "center cropping"),
+    ("random_crop", int, None, "random cropping"),
+    ("resize_h", int, None, "resize for h"),
+    ("resize_w", int, None, "resize for w"),
+    ("sampling", int, 8000, "randomly sample --sampling instances from the training data if not None"),
+    ("D_model", str, "patch_GAN", "discriminator model (only patch_GAN is built)"),
+    ("attention", "flag", False, "use attention in the generator"),
+    ("img_ch", int, 3, "number of image channels"),
+    ("G_ch", int, 52, "base channel multiplier of the generator"),
+    ("D_ch", int, 64, "base channel multiplier of the discriminator"),
+    ("leak_G", float, 0, "LeakyReLU slope of the generator, 0 = ReLU"),
+    ("leak_D", float, 0, "unused by patch_GAN (slope is 0.2)"),
+    ("z_dim", int, 128, "channels of the latent input"),
+    ("map_dim", int, 1, "channels of the SSM modulation maps"),
+    ("spec_norm_D", "flag", False, "spectral normalisation in the discriminator"),
+    ("spec_norm_G", "flag", False, "spectral normalisation in the generator"),
+    ("n_layers_D", int, 4, "number of discriminator layers"),
+    ("n_layers_G", int, 6, "number of generator layers (4, 5 or 6)"),
+    ("norm_layer_D", str, None, "normalisation layer in the discriminator (None | batch)"),
+    ("base_res", int, 4, "base resolution of G"),
+    ("padding_mode", str, "zeros", "padding used in G: zeros or local"),
+    ("type_norm_G", str, "BN", "normalisation used in G: BN or SSM"),
+    ("lr_G", float, 2e-4, "generator learning rate"),
+    ("lr_D", float, 2e-4, "discriminator learning rate"),
+    ("beta1", float, 0, "Adam beta1"),
+    ("beta2", float, 0.999, "Adam beta2"),
+    ("batch_size", int, 64, "discriminator batch size (real crops per step)"),
+    ("loss", str, "standard", "standard (BCE, what the reference always uses) | hinge (build-side extra)"),
+    ("disc_iters", int, 1, "discriminator updates per generator update"),
+    ("epochs", int, 1, "number of epochs"),
+    ("saving_rate", int, 30, "save checkpoints every N epochs"),
+    ("ema", "flag", False, "keep an EMA copy of G"),
+    ("ema_decay", float, 0.999, "EMA decay rate"),
+    ("decay_lr", str, None, "learning-rate decay: exp | step"),
+    ("seed", int, None, "fixed seed (None = random)"),
+    ("smooth", "flag", False, "one-sided label smoothing (0.9)"),
+    ("num_images", int, 8, "images generated per step"),
+    ("num_patches_width", int, 3, "patches along the width of an image"),
+    ("num_patches_height", int, 3, "patches along the height of an image"),
+    ("outer_padding", str, "replicate", "outer padding of the patch grid: replicate | constant"),
+    ("padding_size", int, 1, "padding size of local padding"),
+    ("conv_reduction", int, 2, "spatial reduction of the convolution"),
+    ("num_gpus", int, 1, "number of GPUs (ranks are launched with torch.distributed.run)"),
+    ("dev_num", int, 0, "GPU index when a single GPU is used"),
+    ("num_workers", int, 0, "data loader workers"),
+    ("fname", str, "models_cp", "folder for checkpoints"),
+]
+
+
+def prepare_parser():
+    parser = argparse.ArgumentParser()
+    for name, typ, default, hlp in _FLAGS:
+        if typ == "flag":
+            parser.add_argument("--" + name, action="store_true", default=default, help=hlp)
+        else:
+            parser.add_argument("--" + name, type=typ, default=default, help=hlp)
+    parser.add_argument("--gpu_list", nargs="+", default=None, type=int, help="kept for CLI compatibility")
+    return parser
+
+
+def prepare_device(args):
+    """One process drives one GPU.  LOCAL_RANK (torch.distributed.run) wins over --dev_num."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("no GPU visible: this build runs on MI355X only (there is no CPU path)")
+    idx = int(os.environ.get("LOCAL_RANK", args.dev_num))
+    print("Device: ", idx)
+    torch.cuda.set_device(idx)
+    return torch.device("cuda", idx)
+
+
+def prepare_seed(args):
+    seed = random.randint(1, 10000) if args.seed is None else args.seed
+    print("Random Seed: ", seed)
+    return seed
+
+
+def prepare_models(args, device="cpu"):
+    netG = ResidualPatchGenerator(
+        z_dim=args.z_dim, G_ch=args.G_ch, base_res=args.base_res, n_layers_G=args.n_layers_G,
+        attention=args.attention, img_ch=args.img_ch, leak=args.leak_G, SN=args.spec_norm_G,
+        type_norm=args.type_norm_G, map_dim=args.map_dim, padding_mode=args.padding_mode,
+        outer_padding=args.outer_padding, num_patches_h=args.num_patches_height,
+        num_patches_w=args.num_patches_width, padding_size=args.padding_size,
+        conv_reduction=args.conv_reduction).to(device)
+    if args.D_model != "patch_GAN":
+        raise NotImplementedError("only --D_model patch_GAN exists on the reference's own path (utils.py:205-207)")
+    netD = PatchDiscriminator(img_ch=args.img_ch, base_ch=args.D_ch, n_layers_D=args.n_layers_D, kw=4,
+                              SN=args.spec_norm_D, norm_layer=args.norm_layer_D).to(device)
+    return netG, netD
+
+
+def prepare_filename(args):
+    filename = str(args.epochs) + "_"
+    if args.fname is not None:
+        os.makedirs(args.fname, exist_ok=True)
+        filename = args.fname + "/" + filename
+    return filename
+
+
+def elapsed_time(start_time):
+    return time.time() - start_time
+
+
+def init_weight(m):
+    """Kept for API compatibility; modules of this build initialise themselves (orthogonal
+    conv weights, zero biases - reference utils.py:745-762)."""
+    return m
+
+
+# ------------------------------------------------------------------------------- merge / crop
+def merge_patches_into_image(patches, num_rows=3, num_cols=3, device="cpu"):
+    """(B, C, ph, pw) patches, image-major then row then column -> (B/(rows*cols), C, rows*ph, cols*pw).
+    reference utils.py:577-613.  GPU tensors go through the HIP layout kernels."""
+    if patches.is_cuda:
+        return ops.to_nchw(ops.to_grid(patches, num_rows, num_cols, merged=False), merged=True)
+    b, c, ph, pw = patches.shape
+    n = b // (num_rows * num_cols)
+    return patches.reshape(n, num_rows, num_cols, c, ph, pw).permute(0, 3, 1, 4, 2, 5).reshape(
+        n, c, num_rows * ph, num_cols * pw)
+
+
+def crop_images(img, cropping_size_h=256, cropping_size_w=256, stride=256, device="cpu"):
+    """Sliding-window crops (window h x w, one stride for both axes), row-major per image, images
+    outermost.  reference utils.py:658-742.  Pure data movement (host-side latents in the samplers)."""
+    n, c, h, w = img.shape
+    if h < cropping_size_h or w < cropping_size_w:
+        return img.new_zeros((0,))
+    u = img.unfold(2, cropping_size_h, stride).unfold(3, cropping_size_w, stride)
+    nh, nw = u.shape[2], u.shape[3]
+    return u.permute(0, 2, 3, 1, 4, 5).reshape(n * nh * nw, c, cropping_size_h, cropping_size_w).contiguous()
+
+
+def crop_image(img, cropping_size_h=256, cropping_size_w=256, stride=256, device="cpu"):
+    return crop_images(img.unsqueeze(0), cropping_size_h, cropping_size_w, stride, device)
+
+
+# ------------------------------------------------------------------------------- latents
+def build_z(num_images=1, z_dim=128, base_res=4, num_patches_height=3, num_patches_width=3,
+            total_num_patches_height=3, total_num_patches_width=3, device="cpu"):
+    """Full-grid latent cut into overlapping sub-image latents.  reference utils.py:221-234."""
+    z_full = torch.randn(num_images, z_dim, total_num_patches_height * base_res + 2,
+                         total_num_patches_width * base_res + 2).to(device)
+    return crop_images(z_full, num_patches_height * base_res + 2, num_patches_width * base_res + 2,
+                       (num_patches_width - 1) * base_res, device=device)
+
+
+def build_maps(num_images=1, map_dim=1, n_layers_G=4, base_res=4, num_patches_height=3, num_patches_width=3,
+               total_num_patches_height=3, total_num_patches_width=3, device="cpu"):
+    """Per-layer full-grid SSM maps cut into overlapping sub-image maps.  reference utils.py:237-256."""
+    out = []
+    for i in range(n_layers_G):
+        r = (2 ** i) * base_res
+        full = torch.randn(num_images, map_dim, total_num_patches_height * r + 4,
+                           total_num_patches_width * r + 4).to(device)
+        out.append(crop_images(full, num_patches_height * r + 4, num_patches_width * r + 4,
+                               (num_patches_width - 1) * r, device=device))
+    return out
+
+
+def _unwrap(netG):
+    return netG.module if hasattr(netG, "module") else netG
+
+
+def sample_latents_train(netG, z_dim=128, base_res=4, map_dim=1, num_images=1, num_patches_height=3,
+                         num_patches_width=3, device="cpu"):
+    """z then SSM maps 0..nl-1, drawn on the CPU generator and moved to ``device``
+    (the reference's RNG order, utils.py:503-519)."""
+    g = _unwrap(netG)
+    z = torch.randn(num_images, z_dim, num_patches_height * base_res + 2, num_patches_width * base_res + 2).to(device)
+    maps = [None] * g.n_layers_G
+    if g.type_norm == "SSM":
+        maps = []
+        for i in range(g.n_layers_G):
+            r = (2 ** i) * base_res
+            m = torch.randn(num_images, map_dim, num_patches_height * r + 4, num_patches_width * r + 4).to(device)
+            maps.append(crop_images(m, r + 4, r + 4, r, device=device))
+    return z, maps
+
+
+def sample_from_gen_PatchByPatch_train(netG, z_dim=128, base_res=4, map_dim=1, num_images=1, num_patches_height=3,
+                                       num_patches_width=3, device="cpu"):
+    """Generate ``num_images`` images patch by patch (training).  reference utils.py:475-527."""
+    z, maps = sample_latents_train(netG, z_dim, base_res, map_dim, num_images, num_patches_height,
+                                   num_patches_width, device)
+    g = netG.forward_grid(z, maps, "1st_row_1st_col") if hasattr(netG, "forward_grid") else None
+    if g is None:
+        return merge_patches_into_image(netG(z, maps, image_location="1st_row_1st_col"), num_patches_height,
+                                        num_patches_width, device)
+    return ops.to_nchw(g, merged=True)
+
+
+def sample_from_gen(netG, z_dim=128, base_res=4, map_dim=1, num_images=1, tiles=False, device="cpu"):
+    """Non-local baseline sampler (padding_mode='zeros').  reference utils.py:530-575 (without tiling)."""
+    g = _unwrap(netG)
+    z = torch.randn(num_images, z_dim, base_res, base_res).to(device)
+    maps = [None] * g.n_layers_G
+    if g.type_norm == "SSM":
+        maps = [torch.randn(num_images, map_dim, (2 ** i) * base_res, (2 ** i) * base_res).to(device)
+                for i in range(g.n_layers_G)]
+    if tiles:
+        raise NotImplementedError("--tiles (Real-ESRGAN style tiling, reference utils.py:401-470) is outside the "
+                                  "local-padding hot path")
+    return netG(z, maps)
+
+
+# ------------------------------------------------------------------------------- inference tiling
+def _location(ih, iw, steps_h, steps_w):
+    """image_location strings of reference utils.py:321-337."""
+    if steps_h == 1:
+        s = "1st_row_last_row"
+    elif ih == 0:
+        s = "1st_row"
+    elif ih == steps_h - 1:
+        s = "last_row"
+    else:
+        s = "inter_row"
+    if steps_w == 1:
+        return s + "_1st_col_last_col"
+    if iw == 0:
+        return s + "_1st_col"
+    if iw == steps_w - 1:
+        return s + "_last_col"
+    return s + "_inter_col"
+
+
+def tiling_plan(n_layers_G, base_res, num_patches_height, num_patches_width, out_h, out_w):
+    """(steps_h, steps_w, T_h, T_w, P) of reference utils.py:294-303."""
+    p = (2 ** (n_layers_G - 1)) * base_res
+    steps_h = math.ceil((out_h / p - 1) / (num_patches_height - 1))
+    steps_w = math.ceil((out_w / p - 1) / (num_patches_width - 1))
+    if steps_h < 1 or steps_w < 1:
+        raise ValueError("output %dx%d must exceed one generator patch (%d px)" % (out_h, out_w, p))
+    return steps_h, steps_w, steps_h * (num_patches_height - 1) + 1, steps_w * (num_patches_width - 1) + 1, p
+
+
+def sample_from_gen_PatchByPatch_test(netG, z_dim=128, base_res=4, map_dim=1, num_images=1, num_patches_height=3,
+                                      num_patches_width=3, device="cpu", output_resolution_height=384,
+                                      output_resolution_width=384, z_full=None, maps_full=None,
+                                      one_shot=None):
+    """Generate one large image (reference utils.py:258-397).
+
+    Default (``one_shot=None``): generators without attention run ONE forward over the whole
+    T_h x T_w patch grid - bit-equivalent to the reference's streamed schedule and
+    free of its 2.1x recomputation; generators with attention stream 3x3 sub-images in raster order
+    with carried halos exactly as the reference does.  ``one_shot=False`` forces streaming.
+    ``z_full`` / ``maps_full`` inject pre-built full-grid latents (tests); otherwise they are drawn
+    in the reference's RNG order: z first, then maps 0..nl-1.
+    """
+    g = _unwrap(netG)
+    nph, npw = num_patches_height, num_patches_width
+    steps_h, steps_w, t_h, t_w, p = tiling_plan(g.n_layers_G, base_res, nph, npw, output_resolution_height,
+                                                output_resolution_width)
+    ssm = g.type_norm == "SSM"
+    if z_full is None:
+        z_full = torch.randn(num_images, z_dim, t_h * base_res + 2, t_w * base_res + 2)
+        maps_full = [torch.randn(num_images, map_dim, t_h * (2 ** i) * base_res + 4, t_w * (2 ** i) * base_res + 4)
+                     for i in range(g.n_layers_G)] if ssm else None
+    if one_shot is None:
+        one_shot = not g.attention
+    with torch.no_grad():
+        if one_shot:
+            return _generate_one_shot(g, z_full, maps_full, t_h, t_w, base_res, device)[
+                :, :, :output_resolution_height, :output_resolution_width]
+        return _generate_streamed(g, z_full, maps_full, steps_h, steps_w, p, base_res, nph, npw, device)[
+            :, :, :output_resolution_height, :output_resolution_width]
+
+
+def _generate_one_shot(g, z_full, maps_full, t_h, t_w, base_res, device):
+    saved = (g.num_patches_h, g.num_patches_w)
+    from .models.layers import LocalPadder
+    pads = [m for m in g.modules() if isinstance(m, LocalPadder)]
+    try:
+        g.num_patches_h, g.num_patches_w = t_h, t_w
+        for m in pads:
+            m.pin(t_h, t_w, g.outer_padding)
+            m.reset_state()
+        maps = None
+        if maps_full is not None:
+            maps = [crop_images(maps_full[i].to(device), (2 ** i) * base_res + 4, (2 ** i) * base_res + 4,
+                                (2 ** i) * base_res) for i in range(g.n_layers_G)]
+        out = g.forward_grid(z_full.to(device), maps, "1st_row_1st_col_last_row_last_col")
+        return ops.to_nchw(out, merged=True).cpu()
+    finally:
+        g.num_patches_h, g.num_patches_w = saved
+        for m in pads:
+            m.pin(saved[0], saved[1], g.outer_padding)
+            m.reset_state()
+
+
+def _generate_streamed(g, z_full, maps_full, steps_h, steps_w, p, base_res, nph, npw, device):
+    g.reset_stream_state()
+    z_sub = crop_images(z_full, nph * base_res + 2, npw * base_res + 2, (npw - 1) * base_res)
+    m_sub = None
+    if maps_full is not None:
+        m_sub = [crop_images(maps_full[i], nph * (2 ** i) * base_res + 4, npw * (2 ** i) * base_res + 4,
+                             (npw - 1) * (2 ** i) * base_res) for i in range(g.n_layers_G)]
+    rows, k = [], 0
+    for ih in range(steps_h):
+        row = []
+        for iw in range(steps_w):
+            loc = _location(ih, iw, steps_h, steps_w)
+            maps = None
+            if m_sub is not None:
+                maps = [crop_images(m_sub[i][[k]].to(device), (2 ** i) * base_res + 4, (2 ** i) * base_res + 4,
+                                    (2 ** i) * base_res) for i in range(g.n_layers_G)]
+            img = ops.to_nchw(g.forward_grid(z_sub[[k]].to(device), maps, loc), merged=True).cpu()
+            hh = img.shape[-2] if ih == steps_h - 1 else p * (nph - 1)
+            ww = img.shape[-1] if iw == steps_w - 1 else p * (npw - 1)
+            row.append(img[:, :, :hh, :ww])
+            k += 1
+        rows.append(torch.cat(row, -1))
+    g.reset_stream_state()
+    return torch.cat(rows, -2)

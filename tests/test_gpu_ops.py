@@ -1,0 +1,262 @@
+"""GPU parity, op level: every C-ABI kernel family against the CPU oracle (torch-CPU primitives
++ oracle.patches) on the same seeded inputs.  fp32 tolerances are written at each check."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import load, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+cuda = torch.device("cuda")
+
+
+def _ops():
+    from infinite_texture_gans_amd import ops
+    return ops
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------- LocalPadder (bit exact)
+def test_local_pad_matches_reference_golden_bit_exact():
+    ops = _ops()
+    fx = load("patch_ops")
+    for i in range(5):
+        gh, gw, p, rep = [int(v) for v in fx["lp%d_cfg" % i]]
+        pm = ops.PAD_REPLICATE if rep else ops.PAD_ZERO
+        x = torch.from_numpy(fx["lp%d_x" % i]).to(cuda).requires_grad_(True)
+        y = ops.local_pad_nchw(x, gh, gw, pm)
+        assert torch.equal(y.detach().cpu(), torch.from_numpy(fx["lp%d_y" % i]))
+        (dx,) = torch.autograd.grad(y, x, torch.from_numpy(fx["lp%d_dy" % i]).to(cuda))
+        assert rel_l2(dx.cpu(), fx["lp%d_dx" % i]) < 1e-6      # sums of <= 9 terms, order may differ
+        from infinite_texture_gans_amd import utils as U
+        assert torch.equal(U.merge_patches_into_image(x.detach(), gh, gw).cpu(), torch.from_numpy(fx["lp%d_merged" % i]))
+    z = torch.from_numpy(fx["start_z"]).to(cuda)
+    assert torch.equal(ops.local_pad_nchw(z, 3, 3, ops.PAD_REPLICATE, merged=True).cpu(), torch.from_numpy(fx["start_y"]))
+
+
+def test_local_pad_grid_matches_nchw_and_edge_sizes():
+    ops = _ops()
+    from oracle import patches as P
+    for (n, c, gh, gw, p, outer) in [(1, 5, 1, 1, 1, "replicate"), (2, 13, 3, 2, 1, "constant"), (1, 7, 2, 5, 6, "replicate")]:
+        x = torch.randn(n * gh * gw, c, p, p, generator=_gen(p))
+        want = P.local_pad(x, gh, gw, outer)
+        pm = ops.PAD_REPLICATE if outer == "replicate" else ops.PAD_ZERO
+        got = ops.local_pad_nchw(x.to(cuda), gh, gw, pm)
+        assert torch.equal(got.cpu(), want)
+        g = ops.local_pad_grid(ops.to_grid(x.to(cuda), gh, gw, merged=False), pm)
+        assert torch.equal(ops.to_nchw(g, merged=False).cpu(), want)
+        # backward of the NCHW operator incl. p = 1 (every pixel is a border pixel)
+        xr = x.clone().requires_grad_(True)
+        dy = torch.randn(want.shape, generator=_gen(3))
+        (dref,) = torch.autograd.grad(P.local_pad(xr, gh, gw, outer), xr, dy)
+        xg = x.to(cuda).requires_grad_(True)
+        (dgot,) = torch.autograd.grad(ops.local_pad_nchw(xg, gh, gw, pm), xg, dy.to(cuda))
+        assert rel_l2(dgot.cpu(), dref) < 1e-6
+
+
+# ------------------------------------------------------------------------------- convolution
+CONV_CASES = [
+    # name, n, (gh,gw), P, cin, cout, k, stride, pad, mode
+    ("lp3x3_rep_13_26", 2, (3, 3), 4, 13, 26, 3, 1, 1, "replicate"),
+    ("lp3x3_zero_26_13", 1, (2, 3), 8, 26, 13, 3, 1, 1, "constant"),
+    ("lp3x3_rep_52_104", 1, (3, 3), 8, 52, 104, 3, 1, 1, "replicate"),
+    ("lp3x3_rep_p1", 1, (4, 3), 1, 8, 8, 3, 1, 1, "replicate"),
+    ("d4x4_s2_3_8", 2, (1, 1), 24, 3, 8, 4, 2, 1, "zeros"),
+    ("d4x4_s2_16_32_odd", 1, (1, 1), 23, 16, 32, 4, 2, 1, "zeros"),
+    ("d4x4_s1_8_1", 2, (1, 1), 12, 8, 1, 4, 1, 1, "zeros"),
+    ("d4x4_s2_64_128", 1, (1, 1), 48, 64, 128, 4, 2, 1, "zeros"),
+    ("d4x4_s1_128_160", 1, (1, 1), 20, 128, 160, 4, 1, 1, "zeros"),
+    ("c1x1_26_13", 2, (3, 3), 4, 26, 13, 1, 1, 0, "zeros"),
+    ("fake_grid_into_D", 2, (3, 3), 8, 3, 8, 4, 2, 1, "zeros"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(case):
+    ops = _ops()
+    from oracle import patches as P
+    name, n, (gh, gw), p, cin, cout, k, stride, pad, mode = case
+    g = _gen(hash(name) % 1000)
+    x = torch.randn(n * gh * gw, cin, p, p, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    # ---- oracle: merge -> pad per mode -> conv (== LocalPadder + valid conv per patch for 3x3)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    m = P.merge(xr, gh, gw)
+    if mode == "replicate":
+        yr = F.conv2d(F.pad(m, (pad,) * 4, mode="replicate"), wr, br, stride=stride)
+    else:
+        yr = F.conv2d(m, wr, br, stride=stride, padding=pad)
+    yr = F.leaky_relu(yr, 0.2)
+    dy = torch.randn(yr.shape, generator=g)
+    dxr, dwr, dbr = torch.autograd.grad(yr, (xr, wr, br), dy)
+    # ---- HIP
+    xg, wg, bg = (t.to(cuda).requires_grad_(True) for t in (x, w, b))
+    gx = ops.to_grid(xg, gh, gw, merged=False)
+    pm = ops.PAD_REPLICATE if mode == "replicate" else ops.PAD_ZERO
+    out_grid = (gh, gw) if stride == 1 and k != 4 else (1, 1)
+    yg = ops.to_nchw(ops.conv(gx, wg, bg, k, k, stride, pad, pm, ops.ACT_LRELU, 0.2, out_grid=out_grid), merged=True)
+    assert yg.shape == yr.shape
+    assert rel_l2(yg.detach().cpu(), yr.detach()) < 2e-6
+    dxg, dwg, dbg = torch.autograd.grad(yg, (xg, wg, bg), dy.to(cuda))
+    assert rel_l2(dxg.cpu(), dxr) < 5e-6
+    assert rel_l2(dwg.cpu(), dwr) < 5e-6
+    assert rel_l2(dbg.cpu(), dbr) < 5e-6
+
+
+def test_conv_start_layer_valid_on_merged_latent_and_residual_tanh():
+    ops = _ops()
+    from oracle import patches as P
+    g = _gen(5)
+    z = torch.randn(2, 16, 3 * 4 + 2, 3 * 4 + 2, generator=g)
+    w = torch.randn(24, 16, 3, 3, generator=g) / 12
+    b = torch.randn(24, generator=g) * 0.1
+    want = F.conv2d(P.local_pad(z, 3, 3, merged_input=True), w, b)          # (18, 24, 4, 4)
+    got = ops.conv(ops.to_grid(z.to(cuda), 1, 1, True), w.to(cuda), b.to(cuda), 3, 3, 1, 0, out_grid=(3, 3))
+    assert rel_l2(ops.to_nchw(got, merged=False).cpu(), want) < 2e-6
+    # residual + tanh epilogue
+    r = torch.randn(want.shape, generator=g)
+    rg = ops.to_grid(r.to(cuda), 3, 3, merged=False)
+    got2 = ops.conv(ops.to_grid(z.to(cuda), 1, 1, True), w.to(cuda), b.to(cuda), 3, 3, 1, 0, act=ops.ACT_TANH,
+                    residual=rg, out_grid=(3, 3))
+    assert rel_l2(ops.to_nchw(got2, merged=False).cpu(), torch.tanh(want + r)) < 2e-6
+
+
+# ------------------------------------------------------------------------------- BatchNorm (+act, +upsample)
+@pytest.mark.parametrize("c,ups", [(13, False), (26, True), (104, False), (416, True)])
+def test_bn_act_train_fwd_bwd_running_stats(c, ups):
+    ops = _ops()
+    g = _gen(c)
+    x = torch.randn(6, c, 5, 5, generator=g) * 1.5 + 0.3
+    gamma = 1 + 0.1 * torch.randn(c, generator=g)
+    beta = 0.1 * torch.randn(c, generator=g)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if ups else xr
+    rmr, rvr = rm.clone(), rv.clone()
+    yr = F.leaky_relu(F.batch_norm(xin, rmr, rvr, gr, br, True, 0.1, 1e-5), 0.02)
+    dy = torch.randn(yr.shape, generator=g)
+    dxr, dgr, dbr = torch.autograd.grad(yr, (xr, gr, br), dy)
+    xg, gg, bg = (t.to(cuda).requires_grad_(True) for t in (x, gamma, beta))
+    rmg, rvg, nbt = rm.to(cuda), rv.to(cuda), torch.zeros((), dtype=torch.int64, device=cuda)
+    y = ops.bn_act(ops.to_grid(xg, 6, 1, merged=False), gg, bg, rmg, rvg, nbt, True, 1e-5, 0.1, ops.ACT_LRELU, 0.02, ups)
+    yg = ops.to_nchw(y, merged=False)
+    assert rel_l2(yg.detach().cpu(), yr.detach()) < 2e-6
+    assert rel_l2(rmg.cpu(), rmr) < 1e-6 and rel_l2(rvg.cpu(), rvr) < 1e-6 and int(nbt) == 1
+    dxg, dgg, dbg = torch.autograd.grad(yg, (xg, gg, bg), dy.to(cuda))
+    assert rel_l2(dxg.cpu(), dxr) < 1e-5
+    assert rel_l2(dgg.cpu(), dgr) < 1e-5 and rel_l2(dbg.cpu(), dbr) < 1e-5
+
+
+def test_bn_eval_uses_running_stats():
+    ops = _ops()
+    g = _gen(1)
+    x = torch.randn(4, 13, 6, 6, generator=g)
+    rm, rv = 0.1 * torch.randn(13, generator=g), 1 + 0.2 * torch.rand(13, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(13, generator=g), 0.1 * torch.randn(13, generator=g)
+    want = F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-5)
+    y = ops.bn_act(ops.to_grid(x.to(cuda), 4, 1, False), gamma.to(cuda), beta.to(cuda), rm.to(cuda), rv.to(cuda),
+                   torch.zeros((), dtype=torch.int64, device=cuda), training=False)
+    assert rel_l2(ops.to_nchw(y, False).cpu(), want) < 2e-6
+
+
+# ------------------------------------------------------------------------------- pointwise
+def test_pointwise_ops():
+    ops = _ops()
+    g = _gen(2)
+    x = torch.randn(4, 13, 8, 8, generator=g)
+    xr = x.clone().requires_grad_(True)
+    xg = x.to(cuda).requires_grad_(True)
+    gx = ops.to_grid(xg, 4, 1, False)
+    for name, ref, got in [
+        ("up", F.interpolate(xr, scale_factor=2, mode="nearest"), ops.upsample2x(gx)),
+        ("pool", F.max_pool2d(xr, [2, 2]), ops.maxpool2(gx)),
+        ("lrelu", F.leaky_relu(xr, 0.2), ops.act(gx, ops.ACT_LRELU, 0.2)),
+        ("relu", F.relu(xr), ops.act(gx, ops.ACT_LRELU, 0.0)),
+        ("tanh", torch.tanh(xr), ops.act(gx, ops.ACT_TANH)),
+        ("add", xr + xr, ops.add(gx, gx)),
+    ]:
+        gn = ops.to_nchw(got, False)
+        assert rel_l2(gn.detach().cpu(), ref.detach()) < 1e-6, name
+        dy = torch.randn(ref.shape, generator=_gen(3))
+        (dr,) = torch.autograd.grad(ref, xr, dy, retain_graph=True)
+        (dg,) = torch.autograd.grad(gn, xg, dy.to(cuda), retain_graph=True)
+        assert rel_l2(dg.cpu(), dr) < 1e-6, name
+
+
+# ------------------------------------------------------------------------------- losses
+def test_bce_and_hinge():
+    ops = _ops()
+    from oracle import step
+    g = _gen(4)
+    x = torch.randn(8, 1, 22, 22, generator=g) * 3
+    for t in (0.0, 0.9, 1.0):
+        xr = x.clone().requires_grad_(True)
+        lr = step.bce_logits(xr, t)
+        (dr,) = torch.autograd.grad(lr, xr)
+        xg = x.to(cuda).requires_grad_(True)
+        lg = ops.bce_with_logits(xg, t)
+        (dg,) = torch.autograd.grad(lg, xg)
+        assert abs(float(lg) - float(lr)) < 1e-6 * max(1.0, abs(float(lr)))
+        assert rel_l2(dg.cpu(), dr) < 1e-6
+    xr = x.clone().requires_grad_(True)
+    xg = x.to(cuda).requires_grad_(True)
+    for mode, ref in [("d_real", F.relu(1 - xr).mean()), ("d_fake", F.relu(1 + xr).mean()), ("g", -xr.mean())]:
+        lg = ops.hinge(xg, mode)
+        assert abs(float(lg) - float(ref)) < 1e-6
+        (dr,) = torch.autograd.grad(ref, xr)
+        (dg,) = torch.autograd.grad(lg, xg)
+        assert rel_l2(dg.cpu(), dr) < 1e-6
+
+
+# ------------------------------------------------------------------------------- spectral norm
+def test_spectral_norm_iteration_and_backward():
+    ops = _ops()
+    from oracle import nets
+    g = _gen(6)
+    w = torch.randn(32, 16, 4, 4, generator=g)
+    u = F.normalize(torch.randn(32, generator=g), dim=0)
+    v = F.normalize(torch.randn(256, generator=g), dim=0)
+    sd = {"c.weight_orig": w.clone().requires_grad_(True), "c.weight_u": u.clone(), "c.weight_v": v.clone()}
+    weff = nets.sn_weight(sd, "c", training=True)
+    gup = torch.randn(w.shape, generator=g)
+    (dref,) = torch.autograd.grad(weff, sd["c.weight_orig"], gup)
+    wg, ug, vg = w.to(cuda), u.to(cuda), v.to(cuda)
+    inv = ops.sn_power_iter(wg, ug, vg, training=True)
+    assert rel_l2(ug.cpu(), sd["c.weight_u"]) < 1e-6 and rel_l2(vg.cpu(), sd["c.weight_v"]) < 1e-6
+    assert rel_l2((wg * inv).cpu(), weff.detach()) < 1e-6
+    from infinite_texture_gans_amd import _lib
+    import ctypes as C
+    d = torch.empty_like(wg)
+    ws = torch.empty(2, device=cuda, dtype=torch.float64)
+    _lib.call("itg_spectral_norm_bwd", C.c_void_p(gup.to(cuda).data_ptr()), C.c_void_p(wg.data_ptr()),
+              C.c_void_p(ug.data_ptr()), C.c_void_p(vg.data_ptr()), C.c_void_p(inv.data_ptr()), 32, 256,
+              C.c_void_p(d.data_ptr()), C.c_void_p(ws.data_ptr()), None)
+    torch.cuda.synchronize()
+    assert rel_l2(d.cpu(), dref) < 1e-5
+
+
+# ------------------------------------------------------------------------------- Adam + EMA
+def test_adam_ema_matches_oracle_adam():
+    ops = _ops()
+    from oracle import step
+    g = _gen(7)
+    p0 = torch.randn(1000, generator=g)
+    pr = p0.clone().requires_grad_(True)
+    opt = step.Adam([pr], lr=2e-4, betas=(0.0, 0.999))
+    pg, m, v = p0.to(cuda), torch.zeros(1000, device=cuda), torch.zeros(1000, device=cuda)
+    ema = pg.clone()
+    er = p0.clone()
+    for t in range(1, 4):
+        gr = torch.randn(1000, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        er = er * 0.999 + pr.detach() * 0.001
+        ops.adam_ema_step(pg, gr.to(cuda), m, v, ema, 2e-4, 0.0, 0.999, 1e-8, t, 0.999)
+    assert rel_l2(pg.cpu(), pr.detach()) < 1e-6
+    assert rel_l2(ema.cpu(), er) < 1e-6
