@@ -104,13 +104,26 @@ def gpu_leg(a):
     return rank, world, dt, args, losses, roof
 
 
+def host_cores():
+    """Cores this process may actually use: cgroup quota, else affinity mask, capped at the 16-core
+    share a one-GPU box grants (oversubscribing the host's 256 hardware threads is 10x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("ITG_CPU_THREADS", 16))))
+
+
 def cpu_leg():
     """The oracle (CPU restatement of the reference path) timed on the host cores: one full train
     step at the same config with the vectorised LocalPadder ('port')."""
     from oracle import nets, step as ostep
     from oracle.nets import GCfg, DCfg
     from infinite_texture_gans_amd import utils as U
-    ncores = os.cpu_count() or 1
+    ncores = host_cores()
     torch.set_num_threads(ncores)
     args = U.prepare_parser().parse_args(FLAGS)
     torch.manual_seed(1234)

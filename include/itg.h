@@ -76,15 +76,19 @@ int itg_pack_dgrad(const float* w_oihw, const float* scale, float* out, int co, 
  * in/out are patch-grid tensors; the conv runs in merged-image coordinates.
  * act: ITG_ACT_* with slope for LRELU (slope 0 = ReLU).  bias may be NULL (length
  * out.ld, zero-padded); residual (same layout as out) may have ptr == NULL.        */
+/* workspace (floats) for the split-K path taken when the grid would under-fill the 256 CUs;
+ * 0 when the call does not split.  The same sizes are re-derived inside the launch.            */
+int64_t itg_conv2d_fwd_workspace(const itg_tensor* in, const itg_tensor* out, const itg_conv_geom* g);
+int64_t itg_conv2d_dgrad_workspace(const itg_tensor* dy, const itg_tensor* dx, const itg_conv_geom* g);
 int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bias,
                    const itg_tensor* residual, const itg_tensor* out, const itg_conv_geom* g,
-                   int act, float slope, void* stream);
+                   int act, float slope, float* workspace, int64_t workspace_floats, void* stream);
 
 /* dX of the same conv: `dy` has the conv's output shape, `dx` its input shape.
  * With ITG_PAD_REPLICATE the gradient of the replicated border folds back onto the
  * edge pixels (the autograd of F.pad(..., 'replicate') at layers.py:82).           */
 int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const itg_tensor* dx,
-                     const itg_conv_geom* g, void* stream);
+                     const itg_conv_geom* g, float* workspace, int64_t workspace_floats, void* stream);
 
 /* dW (OIHW, accumulated into dw when accumulate != 0) and optional db (length co).
  * workspace: itg_conv2d_wgrad_workspace() floats (split-K slabs + fp64 bias scratch). */
@@ -191,7 +195,8 @@ int itg_hinge_bwd(const float* logits, int64_t count, int mode, const float* ups
                   void* stream);
 
 /* ---- spectral norm (torch.nn.utils.spectral_norm as used at layers.py:190-194): one
- * power iteration in place on u (rows) and v (cols), sigma = u^T W v, inv_sigma out ------ */
+ * power iteration in place on u (rows) and v (cols), sigma = u^T W v, inv_sigma out;
+ * workspace: 8*cols + rows floats ----------------------------------------------------------- */
 int itg_spectral_norm_power_iter(const float* w, float* u, float* v, int rows, int cols, int do_iter,
                                  float eps, float* sigma_out, float* inv_sigma_out, float* workspace,
                                  void* stream);

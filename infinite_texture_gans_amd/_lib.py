@@ -35,8 +35,10 @@ SIGNATURES = {
     "itg_pack_dgrad_size": (_l, [_i, _i, _i, _i, _i]),
     "itg_pack_fwd": (_i, [_P, _P, _P, _i, _i, _i, _i, _i, _P]),
     "itg_pack_dgrad": (_i, [_P, _P, _P, _i, _i, _i, _i, _i, _i, _P]),
-    "itg_conv2d_fwd": (_i, [_TP, _P, _P, _TP, _TP, _GP, _i, _f, _P]),
-    "itg_conv2d_dgrad": (_i, [_TP, _P, _TP, _GP, _P]),
+    "itg_conv2d_fwd_workspace": (_l, [_TP, _TP, _GP]),
+    "itg_conv2d_dgrad_workspace": (_l, [_TP, _TP, _GP]),
+    "itg_conv2d_fwd": (_i, [_TP, _P, _P, _TP, _TP, _GP, _i, _f, _P, _l, _P]),
+    "itg_conv2d_dgrad": (_i, [_TP, _P, _TP, _GP, _P, _l, _P]),
     "itg_conv2d_wgrad_workspace": (_l, [_TP, _TP, _GP]),
     "itg_conv2d_wgrad": (_i, [_TP, _TP, _P, _P, _GP, _i, _P, _l, _P]),
     "itg_local_pad_fwd": (_i, [_P, _P, _i, _i, _i, _i, _i, _i, _i, _P]),

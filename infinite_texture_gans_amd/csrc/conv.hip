@@ -30,6 +30,8 @@ struct ConvP {
   int pad_mode, out_mode, act;
   float slope;
   int co_rows, nco_tiles;
+  float* partial;      // split-K slabs [ksplit][M][co_rows] (ksplit > 1)
+  int ksplit, kchunks; // K chunks (of BK) per split
 };
 
 __device__ __forceinline__ void decode_m(int m, int MT, int MU, int& n, int& t, int& u) {
@@ -75,11 +77,12 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
     py[i] = t * p.isy + p.ioy;
     px[i] = u * p.isx + p.iox;
   }
-  int cc = kg * 4, tap = 0, ky = 0, kx = 0;
-  while (cc >= p.cin_ld) {
-    cc -= p.cin_ld; ++tap;
-    if (++kx == p.kw) { kx = 0; ++ky; }
-  }
+  const int nk_total = p.Kpad / BK;
+  const int kk0 = blockIdx.z * p.kchunks;
+  const int kk1 = min(nk_total, kk0 + p.kchunks);
+  int tap = (kk0 * BK + kg * 4) / p.cin_ld;
+  int cc = kk0 * BK + kg * 4 - tap * p.cin_ld;
+  int ky = tap / p.kw, kx = tap - ky * p.kw;
 
   f32x4 rp[PL], rw[WL];
   auto load_tiles = [&](int kk) {
@@ -131,14 +134,13 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
 #pragma unroll
     for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.Kpad / BK;
-  load_tiles(0);
+  load_tiles(kk0);
   store_tiles(0);
   __syncthreads();
   const int frow = lane & 15, fk = (lane >> 4) * 4;
-  for (int kk = 0; kk < nk; ++kk) {
-    const int buf = kk & 1;
-    if (kk + 1 < nk) load_tiles(kk + 1);
+  for (int kk = kk0; kk < kk1; ++kk) {
+    const int buf = (kk - kk0) & 1;
+    if (kk + 1 < kk1) load_tiles(kk + 1);
     f32x4 a[FI], b[FJ];
 #pragma unroll
     for (int i = 0; i < FI; ++i)
@@ -153,12 +155,26 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
 #pragma unroll
         for (int j = 0; j < FJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-    if (kk + 1 < nk) store_tiles(buf ^ 1);
+    if (kk + 1 < kk1) store_tiles(buf ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue: lane holds 4 consecutive output channels of one pixel per fragment
   const int cq = (lane >> 4) * 4;
+  if (p.ksplit > 1) {
+    float* slab = p.partial + (size_t)blockIdx.z * p.M * p.co_rows;
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) {
+      int m = m0 + wpix0 + 16 * j + (lane & 15);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < FI; ++i) {
+        int co = co0 + wco0 + 16 * i + cq;
+        if (co < p.co_rows) *reinterpret_cast<f32x4*>(slab + (size_t)m * p.co_rows + co) = acc[i][j];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < FJ; ++j) {
     int m = m0 + wpix0 + 16 * j + (lane & 15);
@@ -225,6 +241,92 @@ __global__ void zero_border_kernel(GridT g) {
   }
 }
 
+// split-K second stage: out = act(sum_z partial[z] + bias [+ residual]) with the same output mapping
+__global__ void splitk_epilogue_kernel(ConvP p) {
+  const int q4 = p.out.ld >> 2;
+  int64_t total = (int64_t)p.M * q4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c4 = (int)(i % q4);
+    int m = (int)(i / q4);
+    int co = c4 * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < p.ksplit; ++z)
+      v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)z * p.M + m) * p.co_rows + co);
+    int n, t, u;
+    decode_m(m, p.MT, p.MU, n, t, u);
+    int oy = t * p.osy + p.ooy, ox = u * p.osx + p.oox;
+    bool border = false;
+    if (p.out_mode == 1) {
+      int ty = min(max(oy, 0), p.out.H - 1), tx = min(max(ox, 0), p.out.W - 1);
+      border = (ty == 0) | (ty == p.out.H - 1) | (tx == 0) | (tx == p.out.W - 1);
+      oy = ty; ox = tx;
+    }
+    const int off = grid_off(p.out, n, oy, ox);
+    if (p.bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (co + e < p.out.c) v[e] += p.bias[co + e];
+    }
+    if (p.res.p) v += *reinterpret_cast<const f32x4*>(p.res.p + grid_off(p.res, n, oy, ox) + co);
+    if (p.act != ITG_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act, p.slope);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (co + e >= p.out.c) v[e] = 0.f;
+    float* dst = p.out.p + off + co;
+    if (border) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(dst + e, v[e]);
+    } else {
+      *reinterpret_cast<f32x4*>(dst) = v;
+    }
+  }
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Tile / split-K plan.  The chip has 256 CUs; every workgroup is 4 waves (one per SIMD), so a CU's
+// time is (#workgroups it runs) x (work of one), and equal-sized workgroups quantise badly when
+// their count is a small non-multiple of 256.  Pick the pixel-tile width that minimises
+// ceil(blocks / 256) * tile work, then split K when the grid still under-fills the chip.
+struct NtPlan { int bco, bpix, ksplit, kchunks; int64_t ws_floats; };
+
+NtPlan plan_nt(int64_t M, int co_rows, int Kpad) {
+  NtPlan pl;
+  const int cands_big[3] = {256, 128, 64};
+  if (co_rows <= 16) pl.bco = 16;
+  else if (co_rows <= 32) pl.bco = 32;
+  else if (co_rows <= 64) pl.bco = 64;
+  else pl.bco = 128;
+  const int nco = (co_rows + pl.bco - 1) / pl.bco;
+  double best = 1e30;
+  pl.bpix = 128;
+  for (int ci = 0; ci < 3; ++ci) {
+    int bp = cands_big[ci];
+    if (pl.bco == 128 && bp == 256) continue;              // 128x256 is not instantiated
+    int64_t blocks = ((M + bp - 1) / bp) * nco;
+    double waves = (double)((blocks + 255) / 256);
+    double pen = bp >= 256 ? 1.0 : (bp == 128 ? (pl.bco == 128 ? 1.0 : 1.04) : (pl.bco == 128 ? 1.08 : 1.12));
+    double cost = waves * bp * pen;
+    if (cost < best) { best = cost; pl.bpix = bp; }
+  }
+  const int nk = Kpad / BK;
+  int64_t blocks = ((M + pl.bpix - 1) / pl.bpix) * nco;
+  pl.ksplit = 1;
+  if (blocks < 512 && nk >= 32) {
+    int want = (int)((768 + blocks - 1) / blocks);
+    int maxs = nk / 16;
+    pl.ksplit = want < maxs ? want : maxs;
+    if (pl.ksplit < 1) pl.ksplit = 1;
+  }
+  pl.kchunks = (nk + pl.ksplit - 1) / pl.ksplit;
+  pl.ksplit = (nk + pl.kchunks - 1) / pl.kchunks;
+  pl.ws_floats = pl.ksplit > 1 ? (int64_t)pl.ksplit * M * co_rows : 0;
+  return pl;
+}
+
 template <int BCO, int BPIX, int WCO, int WPIX>
 int launch_nt(const ConvP& p, hipStream_t s) {
   ConvP q = p;
@@ -232,19 +334,37 @@ int launch_nt(const ConvP& p, hipStream_t s) {
   int64_t npix = ((int64_t)p.M + BPIX - 1) / BPIX;
   int64_t blocks = npix * q.nco_tiles;
   if (blocks <= 0 || blocks > 0x7fffffff) return ITG_ERR_ARG;
-  hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX>), dim3((unsigned)blocks), dim3(256), 0, s, q);
+  hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX>), dim3((unsigned)blocks, 1, (unsigned)p.ksplit), dim3(256),
+                     0, s, q);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }
 
-int dispatch_nt(const ConvP& p, hipStream_t s) {
-  if (p.co_rows <= 16) return launch_nt<16, 256, 16, 64>(p, s);
-  if (p.co_rows <= 32) return launch_nt<32, 256, 32, 64>(p, s);
-  if (p.co_rows <= 64) return launch_nt<64, 256, 64, 64>(p, s);
-  return launch_nt<128, 128, 64, 64>(p, s);
+int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s) {
+  NtPlan pl = plan_nt(p.M, p.co_rows, p.Kpad);
+  if (pl.ws_floats > workspace_floats || (pl.ws_floats && !workspace)) return ITG_ERR_WORKSPACE;
+  p.ksplit = pl.ksplit; p.kchunks = pl.kchunks; p.partial = workspace;
+  int rc;
+  if (pl.bco == 16) {
+    rc = pl.bpix == 256 ? launch_nt<16, 256, 16, 64>(p, s) : pl.bpix == 128 ? launch_nt<16, 128, 16, 32>(p, s)
+                                                                             : launch_nt<16, 64, 16, 16>(p, s);
+  } else if (pl.bco == 32) {
+    rc = pl.bpix == 256 ? launch_nt<32, 256, 32, 64>(p, s) : pl.bpix == 128 ? launch_nt<32, 128, 32, 32>(p, s)
+                                                                             : launch_nt<32, 64, 32, 16>(p, s);
+  } else if (pl.bco == 64) {
+    rc = pl.bpix == 256 ? launch_nt<64, 256, 64, 64>(p, s) : pl.bpix == 128 ? launch_nt<64, 128, 64, 32>(p, s)
+                                                                             : launch_nt<64, 64, 32, 32>(p, s);
+  } else {
+    rc = pl.bpix == 128 ? launch_nt<128, 128, 64, 64>(p, s) : launch_nt<128, 64, 64, 32>(p, s);
+  }
+  if (rc || pl.ksplit == 1) return rc;
+  int64_t total = (int64_t)p.M * (p.out.ld >> 2);
+  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, p);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
 }
 
-inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // ------------------------------------------------------------------------------- packing
 // fwd: out[co][k], k = (ky*kw+kx)*ci_ld + ci, rows co >= co zero, k >= K zero
@@ -454,17 +574,34 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
 // dW[co][ci][ky][kx] (+)= sum_z slab[z][co][(ky*kw+kx)*ci_ld + ci]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int co, int ci,
                                     int ci_ld, int kh, int kw, int co_rows, int Kpad, int accumulate) {
-  int64_t total = (int64_t)co * ci * kh * kw;
+  // one thread per (o, c): slab reads are coalesced along c, each thread writes kh*kw contiguous floats
+  const int taps = kh * kw;
+  int64_t total = (int64_t)co * ci;
+  const size_t zstride = (size_t)co_rows * Kpad;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int x = (int)(i % kw);
-    int64_t r = i / kw;
-    int y = (int)(r % kh); r /= kh;
-    int c = (int)(r % ci);
-    int o = (int)(r / ci);
-    size_t src = (size_t)o * Kpad + (size_t)(y * kw + x) * ci_ld + c;
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += slab[(size_t)z * co_rows * Kpad + src];
-    dw[i] = accumulate ? dw[i] + s : s;
+    int c = (int)(i % ci);
+    int o = (int)(i / ci);
+    const float* src = slab + (size_t)o * Kpad + c;
+    float* dst = dw + i * taps;
+    for (int t = 0; t < taps; ++t) {
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z) s += src[(size_t)z * zstride + (size_t)t * ci_ld];
+      dst[t] = accumulate ? dst[t] + s : s;
+    }
+  }
+}
+
+// out[zo][e] = sum over the zo-th group of `group` slabs
+__global__ void slab_group_reduce_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, int64_t e4, int splits,
+                                         int group, int ngroups) {
+  int64_t total = e4 * ngroups;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t e = i % e4;
+    int zo = (int)(i / e4);
+    int z1 = min(splits, (zo + 1) * group);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int z = zo * group; z < z1; ++z) v += in[(size_t)z * e4 + e];
+    out[i] = v;
   }
 }
 
@@ -478,7 +615,8 @@ int launch_tn(WgP p, int splits, hipStream_t s) {
   return ITG_OK;
 }
 
-struct TnPlan { int bcol, bco, splits, chunks_per_split, nchunks, co_rows, Kpad; };
+constexpr int RED_GROUP = 16;   // slabs summed per thread in either reduce stage
+struct TnPlan { int bcol, bco, splits, chunks_per_split, nchunks, co_rows, Kpad, ngroups; int64_t slab_floats, ws_floats; };
 
 TnPlan plan_tn(int64_t M, int co_ld, int Ktot) {
   TnPlan t;
@@ -496,6 +634,9 @@ TnPlan plan_tn(int64_t M, int co_ld, int Ktot) {
   if (splits < 1) splits = 1;
   t.chunks_per_split = (t.nchunks + splits - 1) / splits;
   t.splits = (t.nchunks + t.chunks_per_split - 1) / t.chunks_per_split;
+  t.slab_floats = (int64_t)t.splits * t.co_rows * t.Kpad;
+  t.ngroups = t.splits > RED_GROUP ? (t.splits + RED_GROUP - 1) / RED_GROUP : 0;
+  t.ws_floats = t.slab_floats + (int64_t)t.ngroups * t.co_rows * t.Kpad;
   return t;
 }
 
@@ -547,8 +688,34 @@ int itg_pack_dgrad(const float* w, const float* scale, float* out, int co, int c
   return ITG_OK;
 }
 
+int64_t itg_conv2d_fwd_workspace(const itg_tensor* in, const itg_tensor* out, const itg_conv_geom* g) {
+  if (!in || !out || !g) return 0;
+  return plan_nt(grid_pixels(out), round_up(out->c, 16), round_up(g->kh * g->kw * in->ld, BK)).ws_floats;
+}
+
+int64_t itg_conv2d_dgrad_workspace(const itg_tensor* dy, const itg_tensor* dx, const itg_conv_geom* g) {
+  if (!dy || !dx || !g) return 0;
+  int co_rows = round_up(dx->c, 16);
+  int64_t H = (int64_t)dx->gh * dx->ph, W = (int64_t)dx->gw * dx->pw;
+  if (g->stride == 1) {
+    int e = (g->pad_mode == ITG_PAD_REPLICATE) ? 2 * g->pad : 0;
+    return plan_nt((int64_t)dx->n * (H + e) * (W + e), co_rows, round_up(g->kh * g->kw * dy->ld, BK)).ws_floats;
+  }
+  int Kpad = round_up((g->kh / 2) * (g->kw / 2) * dy->ld, BK);
+  int64_t best = 0;
+  for (int ry = 0; ry < 2; ++ry)
+    for (int rx = 0; rx < 2; ++rx) {
+      int64_t M = (int64_t)dx->n * ((H - ry + 1) / 2) * ((W - rx + 1) / 2);
+      if (M <= 0) continue;
+      int64_t w = plan_nt(M, co_rows, Kpad).ws_floats;
+      if (w > best) best = w;
+    }
+  return best;
+}
+
 int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bias, const itg_tensor* residual,
-                   const itg_tensor* out, const itg_conv_geom* g, int act, float slope, void* stream) {
+                   const itg_tensor* out, const itg_conv_geom* g, int act, float slope, float* workspace,
+                   int64_t workspace_floats, void* stream) {
   int rc;
   if ((rc = check_tensor(in)) || (rc = check_tensor(out))) return rc;
   if (!w_packed || !g || g->kh <= 0 || g->kw <= 0 || g->stride <= 0 || g->pad < 0) return ITG_ERR_ARG;
@@ -576,11 +743,11 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   p.osy = p.osx = 1; p.ooy = p.oox = 0;
   p.pad_mode = g->pad_mode; p.out_mode = 0; p.act = act; p.slope = slope;
   p.co_rows = round_up(out->c, 16);
-  return dispatch_nt(p, (hipStream_t)stream);
+  return dispatch_nt(p, workspace, workspace_floats, (hipStream_t)stream);
 }
 
 int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const itg_tensor* dx, const itg_conv_geom* g,
-                     void* stream) {
+                     float* workspace, int64_t workspace_floats, void* stream) {
   int rc;
   if ((rc = check_tensor(dy)) || (rc = check_tensor(dx))) return rc;
   if (!w_packed_dgrad || !g) return ITG_ERR_ARG;
@@ -621,7 +788,7 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const it
     int64_t M = (int64_t)dx->n * p.MT * p.MU;
     if (M >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
     p.M = (int)M;
-    return dispatch_nt(p, s);
+    return dispatch_nt(p, workspace, workspace_floats, s);
   }
   if (g->stride != 2 || g->pad != 1 || (g->kh & 1) || (g->kw & 1) || g->pad_mode != ITG_PAD_ZERO) return ITG_ERR_ARG;
   int skh = g->kh / 2, skw = g->kw / 2;
@@ -641,7 +808,7 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const it
       int64_t M = (int64_t)dx->n * p.MT * p.MU;
       if (M >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
       p.M = (int)M;
-      int r = dispatch_nt(p, s);
+      int r = dispatch_nt(p, workspace, workspace_floats, s);
       if (r) return r;
     }
   return ITG_OK;
@@ -651,7 +818,7 @@ int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, co
   if (!x || !dy || !g) return 0;
   int64_t M = grid_pixels(dy);
   TnPlan t = plan_tn(M, dy->ld, g->kh * g->kw * x->ld);
-  return (int64_t)t.splits * t.co_rows * t.Kpad + 2 * (int64_t)dy->ld;
+  return t.ws_floats + 2 * (int64_t)dy->ld;
 }
 
 int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float* db, const itg_conv_geom* g,
@@ -672,8 +839,7 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
   p.ntaps = g->kh * g->kw; p.kw = g->kw; p.cin_ld = x->ld;
   p.Ktot = p.ntaps * x->ld;
   TnPlan t = plan_tn(M, dy->ld, p.Ktot);
-  const int64_t slab_floats = (int64_t)t.splits * t.co_rows * t.Kpad;
-  if (slab_floats + 2 * (int64_t)dy->ld > workspace_floats) return ITG_ERR_WORKSPACE;
+  if (t.ws_floats + 2 * (int64_t)dy->ld > workspace_floats) return ITG_ERR_WORKSPACE;
   p.Kpad = t.Kpad; p.co_rows = t.co_rows;
   p.slab = workspace;
   p.MT = Ho; p.MU = Wo; p.M = (int)M;
@@ -684,13 +850,25 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
   else if (t.bco == 64) rc = launch_tn<256, 64, 64, 64>(p, t.splits, s);
   else rc = launch_tn<128, 128, 64, 64>(p, t.splits, s);
   if (rc) return rc;
-  int64_t total = (int64_t)dy->c * x->c * g->kh * g->kw;
+  const float* red_src = workspace;
+  int red_n = t.splits;
+  if (t.ngroups > 0) {
+    int64_t e4 = (int64_t)t.co_rows * t.Kpad / 4;
+    float* stage = workspace + t.slab_floats;
+    int64_t tot4 = e4 * t.ngroups;
+    int b2 = (int)((tot4 + 255) / 256 < 8192 ? (tot4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(slab_group_reduce_kernel, dim3(b2), dim3(256), 0, s, (const f32x4*)workspace, (f32x4*)stage, e4,
+                       t.splits, RED_GROUP, t.ngroups);
+    ITG_CHECK_LAUNCH();
+    red_src = stage; red_n = t.ngroups;
+  }
+  int64_t total = (int64_t)dy->c * x->c;
   int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, dw, t.splits, dy->c,
-                     x->c, x->ld, g->kh, g->kw, t.co_rows, t.Kpad, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, red_src, dw, red_n, dy->c, x->c, x->ld, g->kh,
+                     g->kw, t.co_rows, t.Kpad, accumulate);
   ITG_CHECK_LAUNCH();
   if (db) {
-    rc = itg_colsum(dy, db, reinterpret_cast<double*>(workspace + slab_floats), stream);
+    rc = itg_colsum(dy, db, reinterpret_cast<double*>(workspace + t.ws_floats), stream);
     if (rc) return rc;
   }
   return ITG_OK;

@@ -73,23 +73,38 @@ __global__ void hinge_bwd_kernel(const float* __restrict__ x, int64_t n, int mod
 
 // ---- spectral norm ------------------------------------------------------------------------
 // t[j] = sum_i W[i][j] * u[i]   (one thread per column, coalesced across columns)
-__global__ void sn_wt_u_kernel(const float* __restrict__ w, const float* __restrict__ u, float* __restrict__ t, int rows,
-                               int cols) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= cols) return;
+// (64 columns x 4 row lanes per workgroup, blockIdx.y = one of SN_RS row slices; partial sums per slice)
+constexpr int SN_RS = 8;
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ w, const float* __restrict__ u,
+                                                      float* __restrict__ part, int rows, int cols) {
+  __shared__ double red[4][64];
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int per = (rows + SN_RS - 1) / SN_RS;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
   double s = 0.0;
-  for (int i = 0; i < rows; ++i) s += (double)w[(size_t)i * cols + j] * (double)u[i];
-  t[j] = (float)s;
+  if (j < cols)
+    for (int i = r0 + rl; i < r1; i += 4) s += (double)w[(size_t)i * cols + j] * (double)u[i];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && j < cols)
+    part[(size_t)blockIdx.y * cols + j] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
+                                                  red[3][threadIdx.x]);
 }
 
-// dst = src / max(||src||, eps)    (single workgroup)
+// dst = src / max(||src||, eps), src = sum of `nparts` partial vectors    (single workgroup)
 __global__ __launch_bounds__(1024) void sn_normalize_kernel(const float* __restrict__ src, float* __restrict__ dst, int n,
-                                                            float eps) {
+                                                            int nparts, float eps) {
   double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)src[i] * (double)src[i];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float v = 0.f;
+    for (int p = 0; p < nparts; ++p) v += src[(size_t)p * n + i];
+    dst[i] = v;
+    s += (double)v * (double)v;
+  }
   s = block_sum_d(s);
   float nrm = fmaxf((float)sqrt(s), eps);
-  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i] / nrm;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = dst[i] / nrm;
 }
 
 // t[i] = sum_j W[i][j] * v[j]   (one wave per row)
@@ -202,23 +217,24 @@ int itg_hinge_bwd(const float* logits, int64_t count, int mode, const float* ups
   return ITG_OK;
 }
 
-// workspace: rows + cols floats
+// workspace: 8*cols + rows floats
 int itg_spectral_norm_power_iter(const float* w, float* u, float* v, int rows, int cols, int do_iter, float eps,
                                  float* sigma_out, float* inv_sigma_out, float* workspace, void* stream) {
   if (!w || !u || !v || rows <= 0 || cols <= 0 || !workspace) return ITG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   float* t_cols = workspace;
-  float* t_rows = workspace + cols;
+  float* t_rows = workspace + (size_t)SN_RS * cols;
   if (do_iter) {
-    hipLaunchKernelGGL(sn_wt_u_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, w, (const float*)u, t_cols, rows, cols);
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3((cols + 63) / 64, SN_RS), dim3(256), 0, s, w, (const float*)u, t_cols, rows,
+                       cols);
     ITG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, (const float*)t_cols, v, cols, eps);
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, (const float*)t_cols, v, cols, SN_RS, eps);
     ITG_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(sn_w_v_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, w, (const float*)v, t_rows, rows, cols);
   ITG_CHECK_LAUNCH();
   if (do_iter) {
-    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, (const float*)t_rows, u, rows, eps);
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, (const float*)t_rows, u, rows, 1, eps);
     ITG_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(1024), 0, s, (const float*)u, (const float*)t_rows, rows, sigma_out,

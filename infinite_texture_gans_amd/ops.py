@@ -157,8 +157,8 @@ def sn_power_iter(w_orig, u, v, training=True, eps=1e-12):
     torch.nn.utils.spectral_norm semantics as used at reference models/layers.py:190-194."""
     rows = w_orig.shape[0]
     cols = w_orig.numel() // rows
-    ws = torch.empty(rows + cols + 2, device=w_orig.device, dtype=torch.float32)
-    inv = ws[rows + cols:rows + cols + 1]
+    ws = torch.empty(rows + 8 * cols + 2, device=w_orig.device, dtype=torch.float32)
+    inv = ws[rows + 8 * cols:rows + 8 * cols + 1]
     with torch.no_grad():
         _lib.call("itg_spectral_norm_power_iter", _ptr(w_orig), _ptr(u), _ptr(v), rows, cols, int(training),
                   float(eps), None, _ptr(inv), _ptr(ws), _stream())
@@ -191,9 +191,11 @@ class _Conv(torch.autograd.Function):
         dx_, do_ = _desc(x, c_in), _desc(out, co)
         dr_ = _desc(residual, co) if residual is not None else _null_desc()
         g = _G(kh, kw, stride, pad, pad_mode)
+        nws = _lib.fn("itg_conv2d_fwd_workspace")(C.byref(dx_), C.byref(do_), C.byref(g))
+        ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
         with _Prof(_nt_tag(co), 1, 2.0 * n * Ho * Wo * co * ci * kh * kw):
             _lib.call("itg_conv2d_fwd", C.byref(dx_), _ptr(wp), _ptr(bias), C.byref(dr_), C.byref(do_), C.byref(g),
-                      act, float(slope), st)
+                      act, float(slope), _ptr(ws), nws, st)
         ctx.geom, ctx.act, ctx.slope, ctx.c_in, ctx.co = geom, act, slope, c_in, co
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.sn = sn
@@ -224,8 +226,10 @@ class _Conv(torch.autograd.Function):
             gx = torch.empty_like(x)
             ddx = _desc(gx, ci)
             npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
+            nws = _lib.fn("itg_conv2d_dgrad_workspace")(C.byref(ddy), C.byref(ddx), C.byref(g))
+            ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
             with _Prof(_nt_tag(ci), stride * stride, 2.0 * npix_out * co * ci * kh * kw):
-                _lib.call("itg_conv2d_dgrad", C.byref(ddy), _ptr(wp), C.byref(ddx), C.byref(g), st)
+                _lib.call("itg_conv2d_dgrad", C.byref(ddy), _ptr(wp), C.byref(ddx), C.byref(g), _ptr(ws), nws, st)
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if need_w or need_b:

@@ -73,6 +73,9 @@ CONV_CASES = [
     ("d4x4_s1_128_160", 1, (1, 1), 20, 128, 160, 4, 1, 1, "zeros"),
     ("c1x1_26_13", 2, (3, 3), 4, 26, 13, 1, 1, 0, "zeros"),
     ("fake_grid_into_D", 2, (3, 3), 8, 3, 8, 4, 2, 1, "zeros"),
+    ("lp3x3_rep_128_64_splitk", 1, (3, 3), 4, 128, 64, 3, 1, 1, "replicate"),      # small M, long K: split-K + fold
+    ("lp3x3_rep_8_8_manysplits", 2, (3, 3), 32, 8, 8, 3, 1, 1, "replicate"),       # wgrad two-stage slab reduce
+    ("d4x4_s2_32_48_mid", 2, (1, 1), 40, 32, 48, 4, 2, 1, "zeros"),
 ]
 
 

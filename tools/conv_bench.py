@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Per-shape microbenchmark of the conv kernels (fwd / dgrad / wgrad) at the config-1 layer shapes.
+Usage (GPU box):  python tools/conv_bench.py [filter]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from infinite_texture_gans_amd import ops, _lib  # noqa: E402
+
+dev = torch.device("cuda")
+# name, n, grid, P(in patch), cin, cout, k, stride, pad, mode
+SHAPES = [
+    ("D0 fake 3->64 s2", 8, (3, 3), 128, 3, 64, 4, 2, 1, "zero"),
+    ("D1 fake 64->128 s2", 8, (1, 1), 192, 64, 128, 4, 2, 1, "zero"),
+    ("D2 fake 128->256 s2", 8, (1, 1), 96, 128, 256, 4, 2, 1, "zero"),
+    ("D3 fake 256->512 s1", 8, (1, 1), 48, 256, 512, 4, 1, 1, "zero"),
+    ("D4 fake 512->1 s1", 8, (1, 1), 47, 512, 1, 4, 1, 1, "zero"),
+    ("D1 real 64->128 s2", 8, (1, 1), 96, 64, 128, 4, 2, 1, "zero"),
+    ("D2 real 128->256 s2", 8, (1, 1), 48, 128, 256, 4, 2, 1, "zero"),
+    ("D3 real 256->512 s1", 8, (1, 1), 24, 256, 512, 4, 1, 1, "zero"),
+    ("G b1 416->416 P4", 8, (3, 3), 4, 416, 416, 3, 1, 1, "rep"),
+    ("G b2c1 416->208 P8", 8, (3, 3), 8, 416, 208, 3, 1, 1, "rep"),
+    ("G b3c1 208->104 P16", 8, (3, 3), 16, 208, 104, 3, 1, 1, "rep"),
+    ("G b4c1 104->52 P32", 8, (3, 3), 32, 104, 52, 3, 1, 1, "rep"),
+    ("G b5c1 52->26 P64", 8, (3, 3), 64, 52, 26, 3, 1, 1, "rep"),
+    ("G b6c1 26->13 P128", 8, (3, 3), 128, 26, 13, 3, 1, 1, "rep"),
+    ("G b6c2 13->13 P128", 8, (3, 3), 128, 13, 13, 3, 1, 1, "rep"),
+    ("G final 13->3 P128", 8, (3, 3), 128, 13, 3, 3, 1, 1, "rep"),
+]
+
+
+def timeit(fn, iters=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    flt = sys.argv[1] if len(sys.argv) > 1 else ""
+    tot = [0.0, 0.0, 0.0]
+    for name, n, (gh, gw), p, ci, co, k, s, pad, mode in SHAPES:
+        if flt and flt not in name:
+            continue
+        x = torch.randn(n, gh, gw, p, p, ops.ld_for(ci), device=dev)
+        x[..., ci:] = 0
+        w = torch.randn(co, ci, k, k, device=dev) / (ci * k * k) ** 0.5
+        b = torch.zeros(co, device=dev)
+        pm = ops.PAD_REPLICATE if mode == "rep" else ops.PAD_ZERO
+        og = (gh, gw) if k == 3 else (1, 1)
+        gx = ops.GT(x.requires_grad_(True), ci)
+        wq = w.requires_grad_(True)
+        y = ops.conv(gx, wq, b, k, k, s, pad, pm, out_grid=og)
+        npix = y.t.numel() // y.t.shape[-1]
+        flops = 2.0 * npix * co * ci * k * k
+        dy = torch.randn_like(y.t)
+        t_f = timeit(lambda: ops.conv(ops.GT(x.detach(), ci), w.detach(), b, k, k, s, pad, pm, out_grid=og))
+        # dgrad only / wgrad only through autograd with selective requires_grad
+        xg = x.detach().requires_grad_(True)
+        yd = ops.conv(ops.GT(xg, ci), w.detach(), None, k, k, s, pad, pm, out_grid=og)
+        t_d = timeit(lambda: torch.autograd.grad(yd.t, xg, dy, retain_graph=True))
+        wg = w.detach().requires_grad_(True)
+        yw = ops.conv(ops.GT(x.detach(), ci), wg, None, k, k, s, pad, pm, out_grid=og)
+        t_w = timeit(lambda: torch.autograd.grad(yw.t, wg, dy, retain_graph=True))
+        tot[0] += t_f; tot[1] += t_d; tot[2] += t_w
+        print("%-24s %7.2f GF | fwd %7.1f us %6.1f TF | dgrad %7.1f us %6.1f TF | wgrad %7.1f us %6.1f TF" % (
+            name, flops / 1e9, t_f * 1e6, flops / t_f / 1e12, t_d * 1e6, flops / t_d / 1e12, t_w * 1e6,
+            flops / t_w / 1e12), flush=True)
+    print("sum fwd %.2f ms dgrad %.2f ms wgrad %.2f ms" % tuple(t * 1e3 for t in tot))
+
+
+if __name__ == "__main__":
+    main()
