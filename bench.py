@@ -63,12 +63,20 @@ def gpu_leg(a):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        tr.step(reals[i % 2], zs[i])
+    # One iteration is ~600 kernel launches: on one GPU it is recorded once into a hipGraph (after the
+    # warm-up iterations) and replayed; multi-GPU runs stay eager unless ITG_GRAPH=1 (RCCL inside capture).
+    use_graph = os.environ.get("ITG_GRAPH", "1" if world == 1 else "0") == "1"
+    if use_graph:
+        tr.capture(reals[0], zs[0], warmup=max(1, a.warmup))
+        step = tr.step_graphed
+    else:
+        for i in range(a.warmup):
+            tr.step(reals[i % 2], zs[i])
+        step = tr.step
     sync()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        losses = tr.step(reals[i % 2], zs[a.warmup + i])
+        losses = step(reals[i % 2], zs[a.warmup + i])
     sync()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -168,7 +176,8 @@ def main():
                                   "padding_mode=local (replicate), G_ch=52 D_ch=64, 3x3 patch grid of 128^2, "
                                   "spec_norm_D, smooth, batch 8 + 8 generated images per GPU",
                       "global_batch": args.batch_size * world, "g_patches_per_sec": round(72 * world * a.steps / dt, 1),
-                      "parallelism": "dp%d (sync-BN + flat grad all-reduce)" % world, "last_losses": losses},
+                      "parallelism": "dp%d (sync-BN + flat grad all-reduce)" % world, "last_losses": losses,
+                      "launch": "hipGraph replay" if os.environ.get("ITG_GRAPH", "1" if world == 1 else "0") == "1" else "eager"},
            "roofline": roof}
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_leg()

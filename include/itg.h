@@ -206,9 +206,11 @@ int itg_spectral_norm_bwd(const float* g_w, const float* w_orig, const float* u,
                           void* stream);
 
 /* ---- optimiser (train.py:57-58,153,169,176-180): Adam over a flat parameter buffer with
- * optional fused EMA (ema = decay*ema + (1-decay)*p); step >= 1 ----------------------------- */
+ * optional fused EMA (ema = decay*ema + (1-decay)*p); step >= 1, read from *step_dev (device int32)
+ * when given so that a captured hipGraph replays with the right bias correction ---------------- */
 int itg_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, int64_t count, float lr,
-                      float beta1, float beta2, float eps, int step, float ema_decay, void* stream);
+                      float beta1, float beta2, float eps, int step, const int32_t* step_dev, float ema_decay,
+                      void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,7 @@
 // The pixel operand is gathered in merged-image coordinates from a patch-grid NHWC tensor, so
 // the LocalPadder halo (reference models/layers.py:145-173) is a neighbour-patch read and the
 // outer replicate / zero padding (layers.py:82) a clamp / predicate; nothing is materialised.
+#include <cstdlib>
 #include "itg_common.h"
 
 namespace {
@@ -42,16 +43,19 @@ __device__ __forceinline__ void decode_m(int m, int MT, int MU, int& n, int& t, 
   u = r - t * MU;
 }
 
-template <int BCO, int BPIX, int WCO, int WPIX>
+template <int BCO, int BPIX, int WCO, int WPIX, int TBK>
 __global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
   constexpr int FI = WCO / 16, FJ = WPIX / 16;
   constexpr int WAVES_CO = BCO / WCO;
   static_assert(WAVES_CO * (BPIX / WPIX) == 4, "4 waves per workgroup");
-  constexpr int PL = BPIX * 4 / 256;
-  constexpr int WL = (BCO * 4 + 255) / 256;
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BCO + BPIX) * LDK];
+  constexpr int LDT = TBK + 4;               // LDS row pitch (floats), rows stay 16-B aligned
+  constexpr int KG = TBK / 4;                // float4 groups per tile row
+  constexpr int RPP = 256 / KG;              // tile rows covered per load pass
+  constexpr int PL = BPIX / RPP;
+  constexpr int WL = (BCO + RPP - 1) / RPP;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BCO + BPIX) * LDT];
   float* Ws = smem;
-  float* Ps = smem + 2 * BCO * LDK;
+  float* Ps = smem + 2 * BCO * LDT;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -62,14 +66,15 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
   const int m0 = pix_tile * BPIX;
   const int wco0 = (wave % WAVES_CO) * WCO;
   const int wpix0 = (wave / WAVES_CO) * WPIX;
-  const int kg = tid & 3;
+  const int kg = tid % KG;
+  const int lrow = tid / KG;
 
   // ---- per-thread loader state: PL pixel rows, fixed k-group
   int pn[PL], py[PL], px[PL];
   bool pv[PL];
 #pragma unroll
   for (int i = 0; i < PL; ++i) {
-    int m = m0 + (tid >> 2) + i * 64;
+    int m = m0 + lrow + i * RPP;
     pv[i] = m < p.M;
     int n, t, u;
     decode_m(pv[i] ? m : 0, p.MT, p.MU, n, t, u);
@@ -77,11 +82,11 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
     py[i] = t * p.isy + p.ioy;
     px[i] = u * p.isx + p.iox;
   }
-  const int nk_total = p.Kpad / BK;
+  const int nk_total = (p.Kpad + TBK - 1) / TBK;
   const int kk0 = blockIdx.z * p.kchunks;
   const int kk1 = min(nk_total, kk0 + p.kchunks);
-  int tap = (kk0 * BK + kg * 4) / p.cin_ld;
-  int cc = kk0 * BK + kg * 4 - tap * p.cin_ld;
+  int tap = (kk0 * TBK + kg * 4) / p.cin_ld;
+  int cc = kk0 * TBK + kg * 4 - tap * p.cin_ld;
   int ky = tap / p.kw, kx = tap - ky * p.kw;
 
   f32x4 rp[PL], rw[WL];
@@ -103,15 +108,16 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
       }
       rp[i] = v;
     }
+    const int kw0 = kk * TBK + kg * 4;
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
-      int row = (tid >> 2) + i * 64;
+      int row = lrow + i * RPP;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < BCO && co0 + row < p.co_rows)
-        v = *reinterpret_cast<const f32x4*>(p.w + (size_t)(co0 + row) * p.Kpad + kk * BK + kg * 4);
+      if (row < BCO && co0 + row < p.co_rows && kw0 < p.Kpad)
+        v = *reinterpret_cast<const f32x4*>(p.w + (size_t)(co0 + row) * p.Kpad + kw0);
       rw[i] = v;
     }
-    cc += BK;
+    cc += TBK;
     while (cc >= p.cin_ld) {
       cc -= p.cin_ld; ++tap;
       if (++kx == p.kw) { kx = 0; ++ky; }
@@ -120,11 +126,11 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
   auto store_tiles = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < PL; ++i)
-      *reinterpret_cast<f32x4*>(Ps + (buf * BPIX + (tid >> 2) + i * 64) * LDK + kg * 4) = rp[i];
+      *reinterpret_cast<f32x4*>(Ps + (buf * BPIX + lrow + i * RPP) * LDT + kg * 4) = rp[i];
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
-      int row = (tid >> 2) + i * 64;
-      if (row < BCO) *reinterpret_cast<f32x4*>(Ws + (buf * BCO + row) * LDK + kg * 4) = rw[i];
+      int row = lrow + i * RPP;
+      if (row < BCO) *reinterpret_cast<f32x4*>(Ws + (buf * BCO + row) * LDT + kg * 4) = rw[i];
     }
   };
 
@@ -141,20 +147,23 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
   for (int kk = kk0; kk < kk1; ++kk) {
     const int buf = (kk - kk0) & 1;
     if (kk + 1 < kk1) load_tiles(kk + 1);
-    f32x4 a[FI], b[FJ];
 #pragma unroll
-    for (int i = 0; i < FI; ++i)
-      a[i] = *reinterpret_cast<const f32x4*>(Ws + (buf * BCO + wco0 + 16 * i + frow) * LDK + fk);
-#pragma unroll
-    for (int j = 0; j < FJ; ++j)
-      b[j] = *reinterpret_cast<const f32x4*>(Ps + (buf * BPIX + wpix0 + 16 * j + frow) * LDK + fk);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int c16 = 0; c16 < TBK; c16 += 16) {
+      f32x4 a[FI], b[FJ];
 #pragma unroll
       for (int i = 0; i < FI; ++i)
+        a[i] = *reinterpret_cast<const f32x4*>(Ws + (buf * BCO + wco0 + 16 * i + frow) * LDT + c16 + fk);
 #pragma unroll
-        for (int j = 0; j < FJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < FJ; ++j)
+        b[j] = *reinterpret_cast<const f32x4*>(Ps + (buf * BPIX + wpix0 + 16 * j + frow) * LDT + c16 + fk);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+          for (int j = 0; j < FJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
     if (kk + 1 < kk1) store_tiles(buf ^ 1);
     __syncthreads();
   }
@@ -291,10 +300,17 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // time is (#workgroups it runs) x (work of one), and equal-sized workgroups quantise badly when
 // their count is a small non-multiple of 256.  Pick the pixel-tile width that minimises
 // ceil(blocks / 256) * tile work, then split K when the grid still under-fills the chip.
-struct NtPlan { int bco, bpix, ksplit, kchunks; int64_t ws_floats; };
+struct NtPlan { int bco, bpix, tbk, ksplit, kchunks; int64_t ws_floats; };
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
 
 NtPlan plan_nt(int64_t M, int co_rows, int Kpad) {
   NtPlan pl;
+  static const int force_bk = env_int("ITG_NT_BK", 0);   // tuning override: 16 | 32
+  pl.tbk = force_bk ? force_bk : 16;   // BK=32 halves the barriers but costs occupancy (LDS): measured 3-8 % slower
   const int cands_big[3] = {256, 128, 64};
   if (co_rows <= 16) pl.bco = 16;
   else if (co_rows <= 32) pl.bco = 32;
@@ -312,12 +328,12 @@ NtPlan plan_nt(int64_t M, int co_rows, int Kpad) {
     double cost = waves * bp * pen;
     if (cost < best) { best = cost; pl.bpix = bp; }
   }
-  const int nk = Kpad / BK;
+  const int nk = (Kpad + pl.tbk - 1) / pl.tbk;
   int64_t blocks = ((M + pl.bpix - 1) / pl.bpix) * nco;
   pl.ksplit = 1;
-  if (blocks < 512 && nk >= 32) {
+  if (blocks < 512 && nk * pl.tbk >= 512) {
     int want = (int)((768 + blocks - 1) / blocks);
-    int maxs = nk / 16;
+    int maxs = nk * pl.tbk / 256;
     pl.ksplit = want < maxs ? want : maxs;
     if (pl.ksplit < 1) pl.ksplit = 1;
   }
@@ -328,14 +344,17 @@ NtPlan plan_nt(int64_t M, int co_rows, int Kpad) {
 }
 
 template <int BCO, int BPIX, int WCO, int WPIX>
-int launch_nt(const ConvP& p, hipStream_t s) {
+int launch_nt(const ConvP& p, int tbk, hipStream_t s) {
   ConvP q = p;
   q.nco_tiles = (p.co_rows + BCO - 1) / BCO;
   int64_t npix = ((int64_t)p.M + BPIX - 1) / BPIX;
   int64_t blocks = npix * q.nco_tiles;
   if (blocks <= 0 || blocks > 0x7fffffff) return ITG_ERR_ARG;
-  hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX>), dim3((unsigned)blocks, 1, (unsigned)p.ksplit), dim3(256),
-                     0, s, q);
+  dim3 grid((unsigned)blocks, 1, (unsigned)p.ksplit);
+  if (tbk == 32)
+    hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 32>), grid, dim3(256), 0, s, q);
+  else
+    hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16>), grid, dim3(256), 0, s, q);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }
@@ -344,18 +363,19 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
   NtPlan pl = plan_nt(p.M, p.co_rows, p.Kpad);
   if (pl.ws_floats > workspace_floats || (pl.ws_floats && !workspace)) return ITG_ERR_WORKSPACE;
   p.ksplit = pl.ksplit; p.kchunks = pl.kchunks; p.partial = workspace;
+  const int k = pl.tbk;
   int rc;
   if (pl.bco == 16) {
-    rc = pl.bpix == 256 ? launch_nt<16, 256, 16, 64>(p, s) : pl.bpix == 128 ? launch_nt<16, 128, 16, 32>(p, s)
-                                                                             : launch_nt<16, 64, 16, 16>(p, s);
+    rc = pl.bpix == 256 ? launch_nt<16, 256, 16, 64>(p, k, s) : pl.bpix == 128 ? launch_nt<16, 128, 16, 32>(p, k, s)
+                                                                                : launch_nt<16, 64, 16, 16>(p, k, s);
   } else if (pl.bco == 32) {
-    rc = pl.bpix == 256 ? launch_nt<32, 256, 32, 64>(p, s) : pl.bpix == 128 ? launch_nt<32, 128, 32, 32>(p, s)
-                                                                             : launch_nt<32, 64, 32, 16>(p, s);
+    rc = pl.bpix == 256 ? launch_nt<32, 256, 32, 64>(p, k, s) : pl.bpix == 128 ? launch_nt<32, 128, 32, 32>(p, k, s)
+                                                                                : launch_nt<32, 64, 32, 16>(p, k, s);
   } else if (pl.bco == 64) {
-    rc = pl.bpix == 256 ? launch_nt<64, 256, 64, 64>(p, s) : pl.bpix == 128 ? launch_nt<64, 128, 64, 32>(p, s)
-                                                                             : launch_nt<64, 64, 32, 32>(p, s);
+    rc = pl.bpix == 256 ? launch_nt<64, 256, 64, 64>(p, k, s) : pl.bpix == 128 ? launch_nt<64, 128, 64, 32>(p, k, s)
+                                                                                : launch_nt<64, 64, 32, 32>(p, k, s);
   } else {
-    rc = pl.bpix == 128 ? launch_nt<128, 128, 64, 64>(p, s) : launch_nt<128, 64, 64, 32>(p, s);
+    rc = pl.bpix == 128 ? launch_nt<128, 128, 64, 64>(p, k, s) : launch_nt<128, 64, 64, 32>(p, k, s);
   }
   if (rc || pl.ksplit == 1) return rc;
   int64_t total = (int64_t)p.M * (p.out.ld >> 2);
@@ -572,23 +592,29 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
 }
 
 // dW[co][ci][ky][kx] (+)= sum_z slab[z][co][(ky*kw+kx)*ci_ld + ci]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int co, int ci,
-                                    int ci_ld, int kh, int kw, int co_rows, int Kpad, int accumulate) {
-  // one thread per (o, c): slab reads are coalesced along c, each thread writes kh*kw contiguous floats
+// One workgroup per (o, 64-channel chunk): slab reads are coalesced along ci, the (ci, tap) tile is
+// transposed through LDS so that the OIHW store is one contiguous run of 64*taps floats.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits,
+                                                           int co, int ci, int ci_ld, int kh, int kw, int co_rows,
+                                                           int Kpad, int accumulate) {
+  __shared__ float tile[64 * 49];
   const int taps = kh * kw;
-  int64_t total = (int64_t)co * ci;
+  const int nchunk = (ci + 63) / 64;
+  const int o = blockIdx.x / nchunk;
+  const int c0 = (blockIdx.x - o * nchunk) * 64;
+  const int cn = min(64, ci - c0);
   const size_t zstride = (size_t)co_rows * Kpad;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int c = (int)(i % ci);
-    int o = (int)(i / ci);
-    const float* src = slab + (size_t)o * Kpad + c;
-    float* dst = dw + i * taps;
-    for (int t = 0; t < taps; ++t) {
-      float s = 0.f;
-      for (int z = 0; z < splits; ++z) s += src[(size_t)z * zstride + (size_t)t * ci_ld];
-      dst[t] = accumulate ? dst[t] + s : s;
-    }
+  const float* src = slab + (size_t)o * Kpad + c0;
+  for (int idx = threadIdx.x; idx < 64 * taps; idx += 256) {
+    int c = idx & 63, t = idx >> 6;
+    float s = 0.f;
+    if (c < cn)
+      for (int z = 0; z < splits; ++z) s += src[(size_t)z * zstride + (size_t)t * ci_ld + c];
+    tile[c * taps + t] = s;
   }
+  __syncthreads();
+  float* dst = dw + ((size_t)o * ci + c0) * taps;
+  for (int idx = threadIdx.x; idx < cn * taps; idx += 256) dst[idx] = accumulate ? dst[idx] + tile[idx] : tile[idx];
 }
 
 // out[zo][e] = sum over the zo-th group of `group` slabs
@@ -862,8 +888,8 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
     ITG_CHECK_LAUNCH();
     red_src = stage; red_n = t.ngroups;
   }
-  int64_t total = (int64_t)dy->c * x->c;
-  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (g->kh * g->kw > 49) return ITG_ERR_ARG;
+  int blocks = dy->c * ((x->c + 63) / 64);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, red_src, dw, red_n, dy->c, x->c, x->ld, g->kh,
                      g->kw, t.co_rows, t.Kpad, accumulate);
   ITG_CHECK_LAUNCH();

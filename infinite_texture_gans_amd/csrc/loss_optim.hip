@@ -155,8 +155,12 @@ __global__ void sn_bwd_kernel(const float* __restrict__ g, const float* __restri
 
 // ---- Adam + EMA ------------------------------------------------------------------------------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            float* __restrict__ ema, int64_t n, float lr, float b1, float b2, float eps, float bc1,
-                            float bc2_sqrt, float ema_decay) {
+                            float* __restrict__ ema, int64_t n, float lr, float b1, float b2, float eps, int step_host,
+                            const int* __restrict__ step_dev, float ema_decay) {
+  // step count from device memory when given (stays correct under hipGraph replay)
+  const int t = step_dev ? *step_dev : step_host;
+  const float bc1 = (float)(1.0 - pow((double)b1, (double)t));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)t));
   const float step = lr / bc1;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float gi = g[i];
@@ -278,12 +282,10 @@ int itg_dot(const float* x, const float* y, int64_t n, double* out, void* stream
 }
 
 int itg_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, int64_t count, float lr, float beta1,
-                      float beta2, float eps, int step, float ema_decay, void* stream) {
-  if (!p || !g || !m || !v || count <= 0 || step < 1) return ITG_ERR_ARG;
-  double bc1 = 1.0 - pow((double)beta1, (double)step);
-  double bc2 = 1.0 - pow((double)beta2, (double)step);
+                      float beta2, float eps, int step, const int32_t* step_dev, float ema_decay, void* stream) {
+  if (!p || !g || !m || !v || count <= 0 || (!step_dev && step < 1)) return ITG_ERR_ARG;
   hipLaunchKernelGGL(adam_kernel, dim3(nblocks(count)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, count, lr,
-                     beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), ema_decay);
+                     beta1, beta2, eps, step, (const int*)step_dev, ema_decay);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .dist import SyncGroup, average_flat_gradient
 from .models.layers import _BNParams
 
 
@@ -58,11 +59,13 @@ class FlatAdam:
         self.v = torch.zeros_like(flat.data)
         self.ema, self.ema_decay = ema, ema_decay
         self.t = 0
+        self.t_dev = torch.zeros((), device=flat.data.device, dtype=torch.int32)   # graph-replay-safe step count
 
     def step(self):
         self.t += 1
+        self.t_dev.add_(1)
         ops.adam_ema_step(self.flat.data, self.flat.grad, self.m, self.v, self.ema, self.lr, self.betas[0],
-                          self.betas[1], self.eps, self.t, self.ema_decay)
+                          self.betas[1], self.eps, self.t, self.ema_decay, step_dev=self.t_dev)
 
 
 class Trainer:
@@ -71,12 +74,10 @@ class Trainer:
     def __init__(self, netG, netD, args, device, netG_ema=None, dist_group=None):
         self.netG, self.netD, self.args, self.device = netG, netD, args, device
         self.world = 1
-        self.dist = None
+        self.sync = None
         if dist_group is not None:
-            import torch.distributed as dist
-            self.dist, self.group = dist, dist_group
-            self.world = dist.get_world_size(dist_group)
-            sync = ops.SyncGroup(dist_group)
+            self.sync = sync = SyncGroup(dist_group)
+            self.world = sync.world
             netG.set_sync(sync)
             for m in netD.modules():
                 if isinstance(m, _BNParams):
@@ -107,9 +108,7 @@ class Trainer:
     def _allreduce(self, flat):
         """Data-parallel gradient exchange: one collective per model.  Losses are per-rank means over
         per-rank batches, so the global-batch gradient is the average over ranks."""
-        if self.world > 1:
-            self.dist.all_reduce(flat.grad, group=self.group)
-            flat.grad.mul_(1.0 / self.world)
+        average_flat_gradient(flat.grad, self.sync)
 
     def sample_fake(self, z, maps):
         return self.netG.forward_grid(z, maps, "1st_row_1st_col")
@@ -144,6 +143,38 @@ class Trainer:
         if self.netG_ema is not None:
             self._ema_buffers()
         return d_real.detach(), d_fake.detach(), g_loss.detach()
+
+    # ---- hipGraph: the whole iteration (~600 launches) as one graph replay
+    def capture(self, real_x, z, maps=None, warmup=2):
+        """Record one iteration into a hipGraph.  ``warmup`` ordinary (training!) iterations run first on a
+        side stream so that every lazily created buffer exists; inputs are copied into static buffers on
+        each :meth:`step_graphed`.  Everything the step needs is stream-ordered device work: weights, Adam
+        state and step counters, BN/SN buffers all live in device memory, nothing is read back."""
+        self._g_real, self._g_z = real_x.clone(), z.clone()
+        self._g_maps = None if maps is None or maps[0] is None else [m.clone() for m in maps]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step(self._g_real, self._g_z, self._g_maps)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._g_out = self.step(self._g_real, self._g_z, self._g_maps)
+        self.optD.t -= 1      # capture only records: undo the host-side counters of the recorded call
+        self.optG.t -= 1
+        return self
+
+    def step_graphed(self, real_x, z, maps=None):
+        self._g_real.copy_(real_x, non_blocking=True)
+        self._g_z.copy_(z, non_blocking=True)
+        if self._g_maps is not None:
+            for d, s_ in zip(self._g_maps, maps):
+                d.copy_(s_, non_blocking=True)
+        self.graph.replay()
+        self.optD.t += 1
+        self.optG.t += 1
+        return self._g_out
 
     def _ema_buffers(self):
         d = self.args.ema_decay

@@ -266,16 +266,7 @@ def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=AC
 
 
 # ------------------------------------------------------------------------------- batch norm (+act, +upsample)
-class SyncGroup:
-    """Optional process group over which BatchNorm statistics are summed (sync-BN)."""
-
-    def __init__(self, group=None):
-        import torch.distributed as dist
-        self.dist, self.group = dist, group
-        self.world = dist.get_world_size(group)
-
-    def all_reduce(self, t):
-        self.dist.all_reduce(t, group=self.group)
+from .dist import SyncGroup  # noqa: E402,F401  (sync-BN statistics exchange)
 
 
 class _BNAct(torch.autograd.Function):
@@ -293,7 +284,7 @@ class _BNAct(torch.autograd.Function):
             _lib.call("itg_bn_stats", C.byref(dx_), _ptr(sums), st)
             if sync is not None and sync.world > 1:
                 sync.all_reduce(sums)
-                count *= sync.world
+                count = sync.global_count(count)
         stat = torch.empty(4 * ld, device=dev, dtype=torch.float32)
         mean_rstd, ab = stat[:2 * ld], stat[2 * ld:]
         _lib.call("itg_bn_finalize", _ptr(sums), count, 4.0 if ups else 1.0, _ptr(gamma), _ptr(beta), float(eps),
@@ -360,7 +351,7 @@ def bn_stats_only(x, rm, rv, nbt, training=True, eps=1e-5, momentum=0.1, sync=No
         _lib.call("itg_bn_stats", C.byref(dx_), _ptr(sums), st)
         if sync is not None and sync.world > 1:
             sync.all_reduce(sums)
-            count *= sync.world
+            count = sync.global_count(count)
     stat = torch.empty(4 * ld, device=t.device, dtype=torch.float32)
     _lib.call("itg_bn_finalize", _ptr(sums), count, 1.0, None, None, float(eps), float(momentum), _ptr(rm), _ptr(rv),
               _ptr(nbt), _ptr(stat[:2 * ld]), _ptr(stat[2 * ld:]), x.c, ld, int(training), st)
@@ -655,7 +646,8 @@ def dot(x, y):
 
 
 # ------------------------------------------------------------------------------- optimiser
-def adam_ema_step(p, g, m, v, ema, lr, beta1, beta2, eps, step, ema_decay=0.999):
-    """Fused Adam (+EMA) over flat fp32 buffers, in place."""
+def adam_ema_step(p, g, m, v, ema, lr, beta1, beta2, eps, step, ema_decay=0.999, step_dev=None):
+    """Fused Adam (+EMA) over flat fp32 buffers, in place.  ``step_dev``: int32 device scalar holding the
+    step count (graph-replay safe); else the host integer ``step``."""
     _lib.call("itg_adam_ema_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ema), p.numel(), float(lr), float(beta1),
-              float(beta2), float(eps), int(step), float(ema_decay), _stream())
+              float(beta2), float(eps), int(step), _ptr(step_dev), float(ema_decay), _stream())

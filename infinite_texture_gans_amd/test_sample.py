@@ -1,0 +1,69 @@
+"""Inference CLI with the reference's flags (reference test_sample.py): load a checkpoint written by
+either this build or the reference (optional DataParallel 'module.' prefix), generate one image of
+arbitrary size patch by patch, write it with PIL."""
+import argparse
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import utils as U
+from .models import generators
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('--output_resolution_height', type=int, default=384, help='output_resolution_height')
+    p.add_argument('--output_resolution_width', type=int, default=384, help='output_resolution_width')
+    p.add_argument('--output_name', type=str, default='241_generated.jpg', help='name of the generated image')
+    p.add_argument('--model_path', type=str, default='results/241_lp_bn_outerpadRepl/300__ema.pth',
+                   help='path of the generator network')
+    p.add_argument('--tiles', default=False, action='store_true', help='use tiling of the input')
+    return p
+
+
+def load_G(state_dict_G, netG):
+    sd = OrderedDict((k.replace('module.', ''), v) for k, v in state_dict_G.items())
+    netG.load_state_dict(sd)
+    return netG.eval()
+
+
+def save_image(img, path):
+    """img: (1, C, H, W) in [0, 1]."""
+    from PIL import Image
+    a = (img[0].clamp(0, 1) * 255 + 0.5).to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+    Image.fromarray(a[:, :, 0] if a.shape[2] == 1 else a).save(path)
+
+
+def main(argv=None):
+    a = build_parser().parse_args(argv)
+    if not torch.cuda.is_available():
+        raise RuntimeError("no GPU visible: this build runs on MI355X only")
+    device = torch.device("cuda:0")
+    folder = os.path.dirname(a.model_path)
+    ckpt = torch.load(a.model_path, map_location='cpu', weights_only=False)   # args is a pickled Namespace
+    args = ckpt['args']
+    netG = generators.ResidualPatchGenerator(
+        z_dim=args.z_dim, G_ch=args.G_ch, base_res=args.base_res, n_layers_G=args.n_layers_G,
+        attention=args.attention, img_ch=args.img_ch, leak=args.leak_G, SN=False, type_norm=args.type_norm_G,
+        map_dim=1, padding_mode=args.padding_mode, outer_padding=args.outer_padding, num_patches_h=3,
+        num_patches_w=3, padding_size=1, conv_reduction=2)
+    netG = load_G(ckpt['netG_state_dict'], netG).to(device)
+    print(args)
+    with torch.no_grad():
+        if args.padding_mode == 'local':
+            img = U.sample_from_gen_PatchByPatch_test(
+                netG, z_dim=args.z_dim, num_images=1, output_resolution_height=a.output_resolution_height,
+                output_resolution_width=a.output_resolution_width, device=device).cpu()
+        else:
+            scale = 2 ** (netG.n_layers_G - 1)
+            img = U.sample_from_gen(netG, z_dim=args.z_dim, base_res=a.output_resolution_height // scale,
+                                    num_images=1, tiles=a.tiles, device=device).cpu()
+    path = os.path.join(folder, a.output_name)
+    print('The image is saved as:', path)
+    save_image(img * 0.5 + 0.5, path)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,94 @@
+"""Training CLI with the reference's flags and control flow (reference train.py), one process per GPU.
+
+    python train.py --data_path datasets/241.jpg --random_crop 192 --padding_mode local --type_norm BN ...
+    python -m torch.distributed.run --nproc-per-node 8 train.py ...        # data parallel over RCCL
+"""
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from . import utils as U
+from .data import SingleImageCrops
+from .engine import Trainer
+
+
+def train(args):
+    device = U.prepare_device(args)
+    seed = U.prepare_seed(args)
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+        group = dist.group.WORLD
+    random.seed(seed), torch.manual_seed(seed), np.random.seed(seed)
+    args.beta1, args.beta2 = float(args.beta1), float(args.beta2)    # the reference's int default breaks torch>=2
+    if rank == 0:
+        print(args)
+    if args.data != "single_image":
+        raise NotImplementedError("--data %s: only single_image is on the hot path" % args.data)
+    data = SingleImageCrops(args.data_path, args.data_ext, args.sampling, args.random_crop, args.center_crop,
+                            args.batch_size, device, seed=seed + 17 * rank)
+    netG, netD = U.prepare_models(args, device)          # same seed -> same initial weights on every rank
+    netG_ema = None
+    if args.ema:
+        netG_ema, _ = U.prepare_models(args, device)
+        for p in netG_ema.parameters():
+            p.requires_grad = False
+    if rank == 0:
+        print(netG), print(netD)
+        print("# Params. G: ", sum(p.numel() for p in netG.parameters()))
+        print("# Params. D: ", sum(p.numel() for p in netD.parameters()))
+    netG.train(), netD.train()
+    tr = Trainer(netG, netD, args, device, netG_ema=netG_ema, dist_group=group)
+    gammas = None
+    if args.decay_lr == "exp":
+        gammas = lambda e: 0.99 ** e                                          # noqa: E731
+    elif args.decay_lr == "step":
+        gammas = lambda e: 0.5 ** sum(e >= m for m in (40, 80, 120))          # noqa: E731
+    filename = U.prepare_filename(args)
+    start = time.time()
+    G_losses, D_losses = [], []
+    torch.manual_seed(seed + 1000 * rank)                # latents: disjoint CPU RNG stream per rank
+    print("Starting Training Loop...")
+    for epoch in range(args.epochs):
+        d_run = torch.zeros((), device=device)
+        g_run = torch.zeros((), device=device)
+        n_d = n_g = 0
+        for data_b in data:
+            real_x = data_b[0]
+            b = real_x.shape[0]
+            for _ in range(args.disc_iters):
+                z, maps = U.sample_latents_train(netG, args.z_dim, args.base_res, args.map_dim, args.num_images,
+                                                 args.num_patches_height, args.num_patches_width, device)
+                d_real, d_fake, g_loss = tr.step(real_x, z, maps)
+            d_run += d_fake * args.num_images + d_real * b
+            g_run += g_loss * args.num_images
+            n_d += b
+            n_g += args.num_images
+        if gammas is not None:
+            tr.optD.lr, tr.optG.lr = args.lr_D * gammas(epoch + 1), args.lr_G * gammas(epoch + 1)
+        d_l, g_l = float(d_run) / n_d, float(g_run) / n_g      # the only host sync of the epoch
+        if rank == 0:
+            print('[%d/%d]\tLoss_D: %.4f\tLoss_G: %.4f, elapsed_time = %.4f min'
+                  % (epoch + 1, args.epochs, d_l, g_l, U.elapsed_time(start) / 60))
+        G_losses.append(g_l), D_losses.append(d_l)
+        last = epoch + 1 == args.epochs
+        if rank == 0 and args.saving_rate is not None and ((epoch + 1) % args.saving_rate == 0 or last):
+            torch.save({'epoch': epoch + 1, 'netG_state_dict': netG.state_dict(), 'netD_state_dict': netD.state_dict(),
+                        'Gloss': G_losses, 'Dloss': D_losses, 'args': args, 'seed': seed},
+                       filename + str(epoch + 1) + ".pth")
+        if rank == 0 and last and args.ema:
+            torch.save({'netG_state_dict': netG_ema.state_dict(), 'args': args}, filename + "_ema.pth")
+
+
+def main(argv=None):
+    train(U.prepare_parser().parse_args(argv))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,77 @@
+"""CPU-side checks of the C-ABI boundary: the in-tree library loads, exports every symbol that
+include/itg.h declares, the ctypes table mirrors the header, and the host-only helpers (no kernel
+launch) behave.  No compute call is made here - there is no GPU in this tier."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "itg.h")
+
+
+def declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(itg_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from infinite_texture_gans_amd import _lib
+    return _lib
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared()
+    assert len(names) >= 40
+    so = ctypes.CDLL(lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(so, n)]
+    assert not missing, missing
+
+
+def test_ctypes_table_mirrors_header(lib):
+    assert sorted(lib.SIGNATURES) == declared()
+
+
+def test_argument_counts_match_header(lib):
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, (_, args) in lib.SIGNATURES.items():
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, src, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ("", "void") else len(params.split(","))
+        assert n == len(args), (name, n, len(args))
+
+
+def test_host_only_helpers(lib):
+    so = lib.load()
+    assert so.itg_version() >= 100
+    # packed sizes: rows rounded to 16, K rounded to 16
+    assert so.itg_pack_fwd_size(13, 28, 3, 3) == 16 * 256
+    assert so.itg_pack_dgrad_size(3, 64, 4, 4, 2) == 4 * 16 * 256
+    assert so.itg_pack_dgrad_size(26, 16, 3, 3, 1) == 32 * 144
+
+
+def test_rejected_calls_return_error_codes_not_crashes(lib):
+    so = lib.load()
+    # null / inconsistent arguments must come back as ITG_ERR_* (negative), never touch the device
+    assert so.itg_bce_logits_fwd(None, 4, ctypes.c_float(1.0), None, None) < 0
+    assert so.itg_local_pad_fwd(None, None, 1, 1, 3, 3, 4, 1, 0, None) < 0
+    t = lib.Tensor(None, 1, 1, 1, 4, 4, 3, 4)
+    assert so.itg_bn_stats(ctypes.byref(t), None, None) < 0
+    bad_ld = lib.Tensor(ctypes.c_void_p(64), 1, 1, 1, 4, 4, 3, 3)      # ld not a multiple of 4
+    assert so.itg_act_fwd(ctypes.byref(bad_ld), ctypes.byref(bad_ld), 1, ctypes.c_float(0.2), None) == -2
+
+
+def test_product_has_no_cpu_fallback_and_does_not_import_oracle():
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); import infinite_texture_gans_amd.utils, infinite_texture_gans_amd.engine; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'product imported the oracle'; "
+            "import torch; from infinite_texture_gans_amd import ops, _lib\n"
+            "try:\n    ops.to_grid(torch.zeros(1,3,4,4), 1, 1, True)\n    raise SystemExit('CPU tensor was accepted')\n"
+            "except _lib.ItgError: pass") % ROOT
+    subprocess.check_call([sys.executable, "-c", code])

@@ -192,3 +192,40 @@ def test_product_refuses_cpu_tensors():
         ops.to_grid(torch.zeros(1, 3, 4, 4), 1, 1, True)
     with pytest.raises(_lib.ItgError):
         ops.bce_with_logits(torch.zeros(4), 1.0)
+
+
+def test_graph_replay_equals_eager_step():
+    """The hipGraph-captured iteration must do exactly what the eager iteration does (incl. Adam's
+    device-side step counter and the spectral-norm power iterations)."""
+    from infinite_texture_gans_amd.engine import Trainer
+    from infinite_texture_gans_amd import utils as U
+    fx = load("train_bn_nl4_sn")
+    a = parse_flags(fx["argv"])
+    real = [torch.from_numpy(fx["real_x%d" % s]).to(cuda) for s in range(2)]
+    z = [torch.from_numpy(fx["z%d" % s]).to(cuda) for s in range(2)]
+    res = []
+    for graphed in (False, True):
+        G, D = build(a, state(fx, "G0/"), state(fx, "D0/"))
+        G.train(), D.train()
+        args = U.prepare_parser().parse_args(["--smooth"])
+        args.beta1 = 0.0
+        tr = Trainer(G, D, args, cuda)
+        if graphed:
+            tr.capture(real[0], z[0], warmup=1)            # one eager step on (real0, z0) ...
+            l = tr.step_graphed(real[1], z[1])              # ... then a replayed one on (real1, z1)
+        else:
+            tr.step(real[0], z[0])
+            l = tr.step(real[1], z[1])
+        torch.cuda.synchronize()
+        res.append(([float(v) for v in l], {k: v.clone() for k, v in G.state_dict().items()},
+                    {k: v.clone() for k, v in D.state_dict().items()}))
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-5), (res[0][0], res[1][0])
+    assert np.allclose(res[0][0], fx["loss1"], rtol=1e-4, atol=1e-6)
+    for i in (1, 2):
+        for k in res[0][i]:
+            a_, b_ = res[1][i][k].double().cpu(), res[0][i][k].double().cpu()
+            if i == 1 and k.endswith("bias") and "conv" in k and k != "final.conv.bias":
+                # zero-gradient biases (F11): Adam(beta1=0) turns summation-order noise into +-lr steps
+                assert (a_ - b_).abs().max() <= 2 * 2e-4 * 2 + 1e-7, k
+                continue
+            assert rel_l2(a_, b_) < 1e-5, k
