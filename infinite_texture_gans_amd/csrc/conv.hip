@@ -31,6 +31,7 @@ struct ConvP {
   int pad_mode, out_mode, act;
   float slope;
   int co_rows, nco_tiles;
+  unsigned in_bytes, w_bytes;   // buffer-resource extents of the pixel operand / packed weights
   float* partial;      // split-K slabs [ksplit][M][co_rows] (ksplit > 1)
   int ksplit, kchunks; // K chunks (of BK) per split
 };
@@ -69,9 +70,14 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
   const int kg = tid % KG;
   const int lrow = tid / KG;
 
-  // ---- per-thread loader state: PL pixel rows, fixed k-group
+  // ---- loader state.  Both operands are fetched with raw buffer loads: a lane's byte offset is
+  // (pixel offset + channel offset); rows that read padding / lie past M carry an offset equal to the
+  // buffer size, so the hardware range check returns zeros - no branches, no selects in the K loop.
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in.p, 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
   int pn[PL], py[PL], px[PL];
   bool pv[PL];
+  unsigned poff[PL];
 #pragma unroll
   for (int i = 0; i < PL; ++i) {
     int m = m0 + lrow + i * RPP;
@@ -82,45 +88,53 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
     py[i] = t * p.isy + p.ioy;
     px[i] = u * p.isx + p.iox;
   }
+  unsigned woff[WL];
+#pragma unroll
+  for (int i = 0; i < WL; ++i) {
+    int row = lrow + i * RPP;
+    woff[i] = (row < BCO && co0 + row < p.co_rows) ? (unsigned)(((size_t)(co0 + row) * p.Kpad + kg * 4) * 4) : p.w_bytes;
+  }
   const int nk_total = (p.Kpad + TBK - 1) / TBK;
   const int kk0 = blockIdx.z * p.kchunks;
   const int kk1 = min(nk_total, kk0 + p.kchunks);
   int tap = (kk0 * TBK + kg * 4) / p.cin_ld;
   int cc = kk0 * TBK + kg * 4 - tap * p.cin_ld;
   int ky = tap / p.kw, kx = tap - ky * p.kw;
+  auto locate = [&]() {   // pixel byte offsets of the current tap
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+      int iy = py[i] + ky, ix = px[i] + kx;
+      bool ok = pv[i] && tap < p.ntaps;
+      if (p.pad_mode == ITG_PAD_REPLICATE) {
+        iy = min(max(iy, 0), p.in.H - 1);
+        ix = min(max(ix, 0), p.in.W - 1);
+      } else {
+        ok = ok && (unsigned)iy < (unsigned)p.in.H && (unsigned)ix < (unsigned)p.in.W;
+        iy = min(max(iy, 0), p.in.H - 1);
+        ix = min(max(ix, 0), p.in.W - 1);
+      }
+      unsigned o = (unsigned)grid_off(p.in, pn[i], iy, ix) * 4u;
+      poff[i] = ok ? o : p.in_bytes;
+    }
+  };
+  locate();
 
   f32x4 rp[PL], rw[WL];
   auto load_tiles = [&](int kk) {
 #pragma unroll
-    for (int i = 0; i < PL; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pv[i] && tap < p.ntaps) {
-        int iy = py[i] + ky, ix = px[i] + kx;
-        bool ok;
-        if (p.pad_mode == ITG_PAD_REPLICATE) {
-          iy = min(max(iy, 0), p.in.H - 1);
-          ix = min(max(ix, 0), p.in.W - 1);
-          ok = true;
-        } else {
-          ok = (unsigned)iy < (unsigned)p.in.H && (unsigned)ix < (unsigned)p.in.W;
-        }
-        if (ok) v = *reinterpret_cast<const f32x4*>(p.in.p + grid_off(p.in, pn[i], iy, ix) + cc);
-      }
-      rp[i] = v;
-    }
-    const int kw0 = kk * TBK + kg * 4;
+    for (int i = 0; i < PL; ++i)
+      rp[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, poff[i] + (unsigned)cc * 4u, 0, 0));
+    const int ksoff = kk * TBK * 4;
 #pragma unroll
-    for (int i = 0; i < WL; ++i) {
-      int row = lrow + i * RPP;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < BCO && co0 + row < p.co_rows && kw0 < p.Kpad)
-        v = *reinterpret_cast<const f32x4*>(p.w + (size_t)(co0 + row) * p.Kpad + kw0);
-      rw[i] = v;
-    }
+    for (int i = 0; i < WL; ++i)
+      rw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw_, woff[i], ksoff, 0));
     cc += TBK;
-    while (cc >= p.cin_ld) {
-      cc -= p.cin_ld; ++tap;
-      if (++kx == p.kw) { kx = 0; ++ky; }
+    if (__any(cc >= p.cin_ld)) {       // wave-uniform: some lane moves on to the next filter tap
+      while (cc >= p.cin_ld) {
+        cc -= p.cin_ld; ++tap;
+        if (++kx == p.kw) { kx = 0; ++ky; }
+      }
+      locate();
     }
   };
   auto store_tiles = [&](int buf) {
@@ -363,6 +377,12 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
   NtPlan pl = plan_nt(p.M, p.co_rows, p.Kpad);
   if (pl.ws_floats > workspace_floats || (pl.ws_floats && !workspace)) return ITG_ERR_WORKSPACE;
   p.ksplit = pl.ksplit; p.kchunks = pl.kchunks; p.partial = workspace;
+  {
+    int64_t ib = (int64_t)p.in.n * p.in.gh * p.in.gw * p.in.ph * p.in.pw * p.in.ld * 4;
+    int64_t wb = (int64_t)p.co_rows * p.Kpad * 4;
+    if (ib >= 0xFFFF0000LL || wb >= 0xFFFF0000LL) return ITG_ERR_ARG;   // 32-bit buffer offsets
+    p.in_bytes = (unsigned)ib; p.w_bytes = (unsigned)wb;
+  }
   const int k = pl.tbk;
   int rc;
   if (pl.bco == 16) {
