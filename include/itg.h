@@ -142,9 +142,11 @@ int itg_bn_apply(const itg_tensor* x, const float* ab, const itg_tensor* y, int 
                  void* stream);
 int itg_bn_bwd_reduce(const itg_tensor* x, const itg_tensor* dy, const float* ab, const float* mean_rstd,
                       int act, float slope, double* sums, void* stream);
+/* sums: (possibly all-reduced) global backward sums used for dx; sums_local: this rank's own sums that
+ * become dgamma/dbeta (NULL = sums).  accumulate != 0 adds into dgamma/dbeta (gradient sinks).      */
 int itg_bn_bwd_apply(const itg_tensor* x, const itg_tensor* dy, const float* ab, const float* mean_rstd,
-                     const float* gamma, const double* sums, double count, int act, float slope,
-                     const itg_tensor* dx, float* dgamma, float* dbeta, void* stream);
+                     const double* sums_local, const double* sums, double count, int act, float slope,
+                     const itg_tensor* dx, float* dgamma, float* dbeta, int accumulate, void* stream);
 
 /* ---- SSM modulation (reference models/layers.py:228-234): out = (1+gamma)*xhat + beta,
  * gamma/beta the two halves of `emb` (channels [0,c) and [c,2c)), then optional act ---- */
@@ -202,8 +204,8 @@ int itg_spectral_norm_power_iter(const float* w, float* u, float* v, int rows, i
                                  void* stream);
 /* dW_orig = (G - <G, W/sigma> u v^T) / sigma  */
 int itg_spectral_norm_bwd(const float* g_w, const float* w_orig, const float* u, const float* v,
-                          const float* inv_sigma, int rows, int cols, float* d_w_orig, float* workspace,
-                          void* stream);
+                          const float* inv_sigma, int rows, int cols, float* d_w_orig, int accumulate,
+                          float* workspace, void* stream);
 
 /* ---- optimiser (train.py:57-58,153,169,176-180): Adam over a flat parameter buffer with
  * optional fused EMA (ema = decay*ema + (1-decay)*p); step >= 1, read from *step_dev (device int32)

@@ -51,7 +51,7 @@ SIGNATURES = {
     "itg_bn_finalize": (_i, [_P, _d, _d, _P, _P, _f, _f, _P, _P, _P, _P, _P, _i, _i, _i, _P]),
     "itg_bn_apply": (_i, [_TP, _P, _TP, _i, _f, _P]),
     "itg_bn_bwd_reduce": (_i, [_TP, _TP, _P, _P, _i, _f, _P, _P]),
-    "itg_bn_bwd_apply": (_i, [_TP, _TP, _P, _P, _P, _P, _d, _i, _f, _TP, _P, _P, _P]),
+    "itg_bn_bwd_apply": (_i, [_TP, _TP, _P, _P, _P, _P, _d, _i, _f, _TP, _P, _P, _i, _P]),
     "itg_ssm_modulate_fwd": (_i, [_TP, _P, _TP, _TP, _i, _f, _P]),
     "itg_ssm_modulate_bwd": (_i, [_TP, _P, _TP, _TP, _i, _f, _TP, _TP, _P]),
     "itg_act_fwd": (_i, [_TP, _TP, _i, _f, _P]),
@@ -71,7 +71,7 @@ SIGNATURES = {
     "itg_hinge_fwd": (_i, [_P, _l, _i, _P, _P]),
     "itg_hinge_bwd": (_i, [_P, _l, _i, _P, _P, _P]),
     "itg_spectral_norm_power_iter": (_i, [_P, _P, _P, _i, _i, _i, _f, _P, _P, _P, _P]),
-    "itg_spectral_norm_bwd": (_i, [_P, _P, _P, _P, _P, _i, _i, _P, _P, _P]),
+    "itg_spectral_norm_bwd": (_i, [_P, _P, _P, _P, _P, _i, _i, _P, _i, _P, _P]),
     "itg_adam_ema_step": (_i, [_P, _P, _P, _P, _P, _l, _f, _f, _f, _f, _i, _P, _f, _P]),
 }
 

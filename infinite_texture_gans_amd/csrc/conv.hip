@@ -457,11 +457,13 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, const float* __re
 struct WgP {
   GridT x, dy;
   float* slab;       // [splits][co_pad][Kpad]
+  float* dbslab;     // [splits][co_pad] bias-gradient partials, or null
   int ntaps, kw, cin_ld, Kpad, Ktot;
   int MT, MU, M;     // output-pixel domain of the conv
   int stride, pad, pad_mode;
   int co_rows, ncol_tiles, nco_tiles;
   int chunks_per_split, nchunks;
+  unsigned x_bytes, dy_bytes;
 };
 
 constexpr int BKP = 16;  // pixels per pipeline stage
@@ -487,7 +489,12 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
   const int chunk_begin = split * p.chunks_per_split;
   const int chunk_end = min(p.nchunks, chunk_begin + p.chunks_per_split);
 
-  // X loads: thread -> (pixel row xr[i], column group xg[i]); the column (tap, ci) is fixed
+  // X loads: thread -> (pixel row xr[i], column group); the column (tap, ci) is fixed, the pixel moves.
+  // Raw buffer loads: an offset equal to the buffer size reads zeros (padding, rows past M, columns past K).
+  // The bias gradient sum_pixel dY[pixel][co] is accumulated on the side by the col_tile 0 workgroups from
+  // the dY values they stage anyway (dbslab[split][co]).
+  const __amdgpu_buffer_rsrc_t rxr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x.p, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ryr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy.p, 0, p.dy_bytes, 0x00020000);
   int xr[XL], xcol[XL], xky[XL], xkx[XL], xci[XL];
   bool xok[XL];
   int xn[XL], xt[XL], xu[XL];
@@ -529,36 +536,35 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
   auto load_tiles = [&]() {
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (xok[i] && xn[i] < p.x.n) {
-        int iy = xt[i] * p.stride - p.pad + xky[i], ix = xu[i] * p.stride - p.pad + xkx[i];
-        bool ok;
-        if (p.pad_mode == ITG_PAD_REPLICATE) {
-          iy = min(max(iy, 0), p.x.H - 1); ix = min(max(ix, 0), p.x.W - 1); ok = true;
-        } else {
-          ok = (unsigned)iy < (unsigned)p.x.H && (unsigned)ix < (unsigned)p.x.W;
-        }
-        if (ok) v = *reinterpret_cast<const f32x4*>(p.x.p + grid_off(p.x, xn[i], iy, ix) + xci[i]);
-      }
+      const bool live = xn[i] < p.x.n;
+      int iy = xt[i] * p.stride - p.pad + xky[i], ix = xu[i] * p.stride - p.pad + xkx[i];
+      bool ok = xok[i] && live;
+      if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.x.H && (unsigned)ix < (unsigned)p.x.W;
+      iy = min(max(iy, 0), p.x.H - 1); ix = min(max(ix, 0), p.x.W - 1);
+      unsigned o = ((unsigned)grid_off(p.x, live ? xn[i] : 0, iy, ix) + (unsigned)xci[i]) * 4u;
+      f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxr, ok ? o : p.x_bytes, 0, 0));
       rx[i] = v;
       advance(xn[i], xt[i], xu[i]);
     }
 #pragma unroll
     for (int i = 0; i < YL; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (yok[i] && yn[i] < p.x.n)
-        v = *reinterpret_cast<const f32x4*>(p.dy.p + grid_off(p.dy, yn[i], yt[i], yu[i]) + co0 + yc[i]);
-      ry[i] = v;
+      const bool live = yn[i] < p.x.n;
+      unsigned o = ((unsigned)grid_off(p.dy, live ? yn[i] : 0, live ? yt[i] : 0, live ? yu[i] : 0) + (unsigned)(co0 + yc[i])) * 4u;
+      ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ryr, (yok[i] && live) ? o : p.dy_bytes, 0, 0));
       advance(yn[i], yt[i], yu[i]);
     }
   };
+  f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
+  const bool do_db = p.dbslab != nullptr && col_tile == 0;
   auto store_tiles = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < XL; ++i)
       if (xr[i] < BKP) *reinterpret_cast<f32x4*>(Xs + (buf * BKP + xr[i]) * LDX + xcol[i]) = rx[i];
 #pragma unroll
-    for (int i = 0; i < YL; ++i)
+    for (int i = 0; i < YL; ++i) {
       if (yr[i] < BKP) *reinterpret_cast<f32x4*>(Ys + (buf * BKP + yr[i]) * LDY + yc[i]) = ry[i];
+      if (do_db) dbacc += ry[i];
+    }
   };
 
   f32x4 acc[FI][FJ];
@@ -595,6 +601,20 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
       __syncthreads();
     }
   }
+  if (do_db) {   // deterministic reduction of the per-thread dY sums over the staged pixel rows
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+    red[tid] = dbacc;
+    __syncthreads();
+    constexpr int RP = (256 / YG) < 1 ? 1 : (256 / YG);      // pixel rows covered per load pass
+    if (tid < BCO && co0 + tid < p.co_rows) {
+      float sdb = 0.f;
+      if (YG <= 256) {
+        for (int r = 0; r < RP; ++r) sdb += red[r * YG + (tid >> 2)][tid & 3];
+      }
+      p.dbslab[(size_t)split * p.co_rows + co0 + tid] = sdb;
+    }
+  }
   // D[row = column index (4 consecutive per lane)][col = co]
   float* slab = p.slab + (size_t)split * p.co_rows * p.Kpad;
   const int cq = (lane >> 4) * 4;
@@ -614,9 +634,10 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
 // dW[co][ci][ky][kx] (+)= sum_z slab[z][co][(ky*kw+kx)*ci_ld + ci]
 // One workgroup per (o, 64-channel chunk): slab reads are coalesced along ci, the (ci, tap) tile is
 // transposed through LDS so that the OIHW store is one contiguous run of 64*taps floats.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits,
-                                                           int co, int ci, int ci_ld, int kh, int kw, int co_rows,
-                                                           int Kpad, int accumulate) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                           float* __restrict__ db, const float* __restrict__ dbslab,
+                                                           int dbsplits, int splits, int co, int ci, int ci_ld, int kh,
+                                                           int kw, int co_rows, int Kpad, int accumulate) {
   __shared__ float tile[64 * 49];
   const int taps = kh * kw;
   const int nchunk = (ci + 63) / 64;
@@ -625,6 +646,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const int cn = min(64, ci - c0);
   const size_t zstride = (size_t)co_rows * Kpad;
   const float* src = slab + (size_t)o * Kpad + c0;
+  if (db && c0 == 0) {      // bias gradient: sum of the per-split partials (fixed order -> deterministic)
+    __shared__ float part[256];
+    float sdb = 0.f;
+    for (int z = threadIdx.x; z < dbsplits; z += 256) sdb += dbslab[(size_t)z * co_rows + o];
+    part[threadIdx.x] = sdb;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int i = 0; i < 256; ++i) t += part[i];
+      db[o] = accumulate ? db[o] + t : t;
+    }
+    __syncthreads();
+  }
   for (int idx = threadIdx.x; idx < 64 * taps; idx += 256) {
     int c = idx & 63, t = idx >> 6;
     float s = 0.f;
@@ -864,7 +898,7 @@ int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, co
   if (!x || !dy || !g) return 0;
   int64_t M = grid_pixels(dy);
   TnPlan t = plan_tn(M, dy->ld, g->kh * g->kw * x->ld);
-  return t.ws_floats + 2 * (int64_t)dy->ld;
+  return t.ws_floats + (int64_t)t.splits * t.co_rows;
 }
 
 int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float* db, const itg_conv_geom* g,
@@ -885,12 +919,18 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
   p.ntaps = g->kh * g->kw; p.kw = g->kw; p.cin_ld = x->ld;
   p.Ktot = p.ntaps * x->ld;
   TnPlan t = plan_tn(M, dy->ld, p.Ktot);
-  if (t.ws_floats + 2 * (int64_t)dy->ld > workspace_floats) return ITG_ERR_WORKSPACE;
+  if (t.ws_floats + (int64_t)t.splits * t.co_rows > workspace_floats) return ITG_ERR_WORKSPACE;
   p.Kpad = t.Kpad; p.co_rows = t.co_rows;
   p.slab = workspace;
+  p.dbslab = db ? workspace + t.ws_floats : nullptr;       // [splits][co_rows] after the slabs
   p.MT = Ho; p.MU = Wo; p.M = (int)M;
   p.stride = g->stride; p.pad = g->pad; p.pad_mode = g->pad_mode;
   p.chunks_per_split = t.chunks_per_split; p.nchunks = t.nchunks;
+  {
+    int64_t xb = grid_pixels(x) * x->ld * 4, yb = grid_pixels(dy) * dy->ld * 4;
+    if (xb >= 0xFFFF0000LL || yb >= 0xFFFF0000LL) return ITG_ERR_ARG;
+    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
+  }
   if (t.bco == 16) rc = launch_tn<256, 16, 64, 16>(p, t.splits, s);
   else if (t.bco == 32) rc = launch_tn<256, 32, 64, 32>(p, t.splits, s);
   else if (t.bco == 64) rc = launch_tn<256, 64, 64, 64>(p, t.splits, s);
@@ -910,13 +950,9 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
   }
   if (g->kh * g->kw > 49) return ITG_ERR_ARG;
   int blocks = dy->c * ((x->c + 63) / 64);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, red_src, dw, red_n, dy->c, x->c, x->ld, g->kh,
-                     g->kw, t.co_rows, t.Kpad, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, red_src, dw, db, (const float*)p.dbslab,
+                     t.splits, red_n, dy->c, x->c, x->ld, g->kh, g->kw, t.co_rows, t.Kpad, accumulate);
   ITG_CHECK_LAUNCH();
-  if (db) {
-    rc = itg_colsum(dy, db, reinterpret_cast<double*>(workspace + t.ws_floats), stream);
-    if (rc) return rc;
-  }
   return ITG_OK;
 }
 

@@ -143,13 +143,14 @@ __global__ void dot_kernel(const float* __restrict__ a, const float* __restrict_
 // d_w_orig = (G - (<G,W_orig>/sigma) * u v^T) / sigma
 __global__ void sn_bwd_kernel(const float* __restrict__ g, const float* __restrict__ u, const float* __restrict__ v,
                               const float* __restrict__ inv_sigma, const double* __restrict__ gdotw, int rows, int cols,
-                              float* __restrict__ d) {
+                              float* __restrict__ d, int accumulate) {
   float is = *inv_sigma;
   float coef = (float)(*gdotw) * is;
   int64_t n = (int64_t)rows * cols;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
-    d[i] = (g[i] - coef * u[r] * v[c]) * is;
+    float val = (g[i] - coef * u[r] * v[c]) * is;
+    d[i] = accumulate ? d[i] + val : val;
   }
 }
 
@@ -249,7 +250,8 @@ int itg_spectral_norm_power_iter(const float* w, float* u, float* v, int rows, i
 
 // workspace: 2 floats (one fp64 accumulator, 8-byte aligned)
 int itg_spectral_norm_bwd(const float* g_w, const float* w_orig, const float* u, const float* v,
-                          const float* inv_sigma, int rows, int cols, float* d_w_orig, float* workspace, void* stream) {
+                          const float* inv_sigma, int rows, int cols, float* d_w_orig, int accumulate, float* workspace,
+                          void* stream) {
   if (!g_w || !w_orig || !u || !v || !inv_sigma || !d_w_orig || !workspace || (((uintptr_t)workspace) & 7))
     return ITG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -259,7 +261,7 @@ int itg_spectral_norm_bwd(const float* g_w, const float* w_orig, const float* u,
   hipLaunchKernelGGL(dot_kernel, dim3(nblocks(n, 512)), dim3(256), 0, s, g_w, w_orig, n, acc);
   ITG_CHECK_LAUNCH();
   hipLaunchKernelGGL(sn_bwd_kernel, dim3(nblocks(n)), dim3(256), 0, s, g_w, u, v, inv_sigma, (const double*)acc, rows,
-                     cols, d_w_orig);
+                     cols, d_w_orig, accumulate);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }

@@ -175,10 +175,12 @@ template <bool UPS>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            const float* __restrict__ ab,
                                                            const float* __restrict__ mean_rstd,
-                                                           const double* __restrict__ sums, double inv_count,
+                                                           const double* __restrict__ sums,
+                                                           const double* __restrict__ sums_local, double inv_count,
                                                            int64_t npix, int ld, int c, int ph, int pw, int act,
                                                            float slope, float* __restrict__ dx,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           int accumulate) {
   const int q4 = ld >> 2;
   const int64_t T = (int64_t)gridDim.x * 256;
   const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -196,8 +198,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
   if (gt < ld) {
     int i = (int)gt;
-    if (dgamma && i < c) dgamma[i] = (float)sums[ld + i];
-    if (dbeta && i < c) dbeta[i] = (float)sums[i];
+    if (dgamma && i < c) dgamma[i] = (accumulate ? dgamma[i] : 0.f) + (float)sums_local[ld + i];
+    if (dbeta && i < c) dbeta[i] = (accumulate ? dbeta[i] : 0.f) + (float)sums_local[i];
   }
   for (int64_t pix = gt / q4; pix < npix; pix += step) {
     f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * ld + cg * 4);
@@ -357,9 +359,9 @@ int itg_bn_bwd_reduce(const itg_tensor* x, const itg_tensor* dy, const float* ab
 }
 
 int itg_bn_bwd_apply(const itg_tensor* x, const itg_tensor* dy, const float* ab, const float* mean_rstd,
-                     const float* gamma, const double* sums, double count, int act, float slope,
-                     const itg_tensor* dx, float* dgamma, float* dbeta, void* stream) {
-  (void)gamma;
+                     const double* sums_local, const double* sums, double count, int act, float slope,
+                     const itg_tensor* dx, float* dgamma, float* dbeta, int accumulate, void* stream) {
+  if (!sums_local) sums_local = sums;
   int rc;
   if ((rc = check_tensor(x)) || (rc = check_tensor(dy)) || (rc = check_tensor(dx))) return rc;
   bool ups;
@@ -371,12 +373,12 @@ int itg_bn_bwd_apply(const itg_tensor* x, const itg_tensor* dy, const float* ab,
   if ((int64_t)blocks * 256 < x->ld) blocks = sweep_blocks((int64_t)x->ld * q4, q4, 1, 4096);
   if (ups)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)x->ptr, (const float*)dy->ptr, ab, mean_rstd, sums, 1.0 / count, npix, x->ld,
-                       x->c, x->ph, x->pw, act, slope, (float*)dx->ptr, dgamma, dbeta);
+                       (const float*)x->ptr, (const float*)dy->ptr, ab, mean_rstd, sums, sums_local, 1.0 / count,
+                       npix, x->ld, x->c, x->ph, x->pw, act, slope, (float*)dx->ptr, dgamma, dbeta, accumulate);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)x->ptr, (const float*)dy->ptr, ab, mean_rstd, sums, 1.0 / count, npix, x->ld,
-                       x->c, x->ph, x->pw, act, slope, (float*)dx->ptr, dgamma, dbeta);
+                       (const float*)x->ptr, (const float*)dy->ptr, ab, mean_rstd, sums, sums_local, 1.0 / count,
+                       npix, x->ld, x->c, x->ph, x->pw, act, slope, (float*)dx->ptr, dgamma, dbeta, accumulate);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }

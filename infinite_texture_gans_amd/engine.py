@@ -83,6 +83,11 @@ class Trainer:
                 if isinstance(m, _BNParams):
                     m.sync = sync
         self.flatG, self.flatD = FlatParams(netG), FlatParams(netD)
+        from .models.layers import _ConvParams
+        for net in (netG, netD):        # backward kernels accumulate straight into the flat .grad buffers
+            for m in net.modules():
+                if isinstance(m, (_ConvParams, _BNParams)):
+                    m.grad_sinks = True
         self.netG_ema, self.flatE = netG_ema, None
         if netG_ema is not None:
             self.flatE = FlatParams(netG_ema)

@@ -46,17 +46,28 @@ class _ConvParams(nn.Module):
         else:
             self.register_parameter("bias", None)
 
+    # Set by engine.Trainer: parameter gradients are accumulated by the backward kernels straight into
+    # the (flat) .grad buffers instead of being handed to autograd's AccumulateGrad.
+    grad_sinks = False
+
     def weight_and_sn(self):
-        """(weight tensor, sn tuple or None); runs the power iteration in training mode."""
+        """(weight tensor, sn tuple or None); runs the power iteration in training mode.  u / v are not
+        copied: they only change in the next forward, which never precedes this forward's backward."""
         if not self.SN:
             return self.weight, None
         inv = ops.sn_power_iter(self.weight_orig, self.weight_u, self.weight_v, training=self.training)
-        return self.weight_orig, (inv, self.weight_u.clone(), self.weight_v.clone())
+        return self.weight_orig, (inv, self.weight_u, self.weight_v)
+
+    def _sinks(self, w):
+        if not self.grad_sinks or not w.requires_grad or w.grad is None:
+            return None
+        b = self.bias
+        return (w.grad, b.grad if (b is not None and b.grad is not None) else None)
 
     def run(self, x, pad=None, pad_mode=ops.PAD_ZERO, act=ops.ACT_NONE, slope=0.0, residual=None, out_grid=None):
         w, sn = self.weight_and_sn()
         return ops.conv(x, w, self.bias, self.k, self.k, self.stride, self.padding if pad is None else pad,
-                        pad_mode, act, slope, residual, sn, out_grid)
+                        pad_mode, act, slope, residual, sn, out_grid, self._sinks(w))
 
     def forward(self, x):
         """Plain conv on an NCHW image batch (zero padding), as the reference's nn.Conv2d."""
@@ -229,11 +240,15 @@ class _BNParams(nn.BatchNorm2d):
     """nn.BatchNorm2d as a parameter/buffer container (same state_dict keys); the arithmetic
     runs in the HIP kernels.  ``sync`` (an ops.SyncGroup) makes the statistics global."""
     sync = None
+    grad_sinks = False
 
     def run(self, x, act=ops.ACT_NONE, slope=0.0, upsample=False):
+        sinks = None
+        if self.grad_sinks and self.weight is not None and self.weight.requires_grad and self.weight.grad is not None:
+            sinks = (self.weight.grad, self.bias.grad)
         return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked,
                           training=self.training, eps=self.eps, momentum=self.momentum, act=act, slope=slope,
-                          upsample=upsample, sync=self.sync)
+                          upsample=upsample, sync=self.sync, sinks=sinks)
 
     def forward(self, x):
         if isinstance(x, GT):

@@ -171,7 +171,7 @@ class _Conv(torch.autograd.Function):
     coordinates).  ``sn`` = (inv_sigma, u, v) makes ``w`` the spectral-norm ``weight_orig``."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, sn, c_in, geom, act, slope, out_grid):
+    def forward(ctx, x, w, bias, residual, sn, c_in, geom, act, slope, out_grid, sinks=None):
         kh, kw, stride, pad, pad_mode = geom
         n, gh, gw, ph, pw, ld = x.shape
         co, ci = w.shape[0], w.shape[1]
@@ -199,6 +199,7 @@ class _Conv(torch.autograd.Function):
         ctx.geom, ctx.act, ctx.slope, ctx.c_in, ctx.co = geom, act, slope, c_in, co
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.sn = sn
+        ctx.sinks = sinks          # (weight.grad, bias.grad) buffers to accumulate into, or None
         ctx.save_for_backward(x, w, out if act != ACT_NONE else None)
         return out
 
@@ -236,32 +237,43 @@ class _Conv(torch.autograd.Function):
             dxd = _desc(x, ci)
             nws = _lib.fn("itg_conv2d_wgrad_workspace")(C.byref(dxd), C.byref(ddy), C.byref(g))
             ws = torch.empty(nws, device=x.device, dtype=torch.float32)
-            gw_ = torch.empty_like(w)
-            gb = torch.empty(co, device=x.device, dtype=torch.float32) if need_b else None
+            wsink, bsink = ctx.sinks if ctx.sinks is not None else (None, None)
+            direct_w = wsink is not None and ctx.sn is None and need_w
+            direct_b = bsink is not None and need_b
+            fresh = torch.zeros_like if (direct_w or direct_b) else torch.empty_like   # accumulate flag is shared
+            gw_ = wsink if direct_w else fresh(w)
+            gb = bsink if direct_b else (fresh(w[:, 0, 0, 0]) if need_b else None)
             npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
             with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1, 2.0 * npix_out * co * ci * kh * kw):
-                _lib.call("itg_conv2d_wgrad", C.byref(dxd), C.byref(ddy), _ptr(gw_), _ptr(gb), C.byref(g), 0,
-                          _ptr(ws), nws, st)
-            if ctx.sn is not None:
+                # one accumulate flag covers dw and db: a sink for one of them implies sinks for both
+                _lib.call("itg_conv2d_wgrad", C.byref(dxd), C.byref(ddy), _ptr(gw_), _ptr(gb), C.byref(g),
+                          int(direct_w or direct_b), _ptr(ws), nws, st)
+            if ctx.sn is not None and need_w:
                 _, u, v = ctx.sn
                 rows, cols = co, w.numel() // co
-                d_orig = torch.empty_like(w)
+                d_orig = wsink if wsink is not None else torch.empty_like(w)
                 ws2 = torch.empty(2, device=x.device, dtype=torch.float64)
                 _lib.call("itg_spectral_norm_bwd", _ptr(gw_), _ptr(w), _ptr(u), _ptr(v), _ptr(inv_sigma), rows, cols,
-                          _ptr(d_orig), _ptr(ws2), st)
-                gw_ = d_orig
+                          _ptr(d_orig), int(wsink is not None), _ptr(ws2), st)
+                gw_ = None if wsink is not None else d_orig
+            elif direct_w:
+                gw_ = None
+            if direct_b:
+                gb = None
             if not need_w:
                 gw_ = None
         gres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
-        return gx, gw_, gb, gres, None, None, None, None, None, None
+        return gx, gw_, gb, gres, None, None, None, None, None, None, None
 
 
 def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, residual=None,
-         sn=None, out_grid=None):
-    """x: GT.  Returns GT with ``out_grid`` (default: the input grid)."""
+         sn=None, out_grid=None, sinks=None):
+    """x: GT.  Returns GT with ``out_grid`` (default: the input grid).  ``sinks`` = (weight.grad, bias.grad)
+    buffers: the backward then accumulates the parameter gradients straight into them (and reports no
+    gradient to autograd), which removes one AccumulateGrad add kernel per parameter."""
     og = out_grid if out_grid is not None else (x.gh, x.gw)
     r = residual.t if residual is not None else None
-    t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode), act, slope, og)
+    t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode), act, slope, og, sinks)
     return GT(t, w.shape[0])
 
 
@@ -271,7 +283,7 @@ from .dist import SyncGroup  # noqa: E402,F401  (sync-BN statistics exchange)
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, rm, rv, nbt, c, training, eps, momentum, act, slope, ups, sync):
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, c, training, eps, momentum, act, slope, ups, sync, sinks=None):
         x = x.contiguous()
         n, gh, gw, ph, pw, ld = x.shape
         dev = x.device
@@ -294,6 +306,7 @@ class _BNAct(torch.autograd.Function):
         dy_ = _desc(y, c)
         _lib.call("itg_bn_apply", C.byref(dx_), _ptr(ab), C.byref(dy_), act, float(slope), st)
         ctx.meta = (c, act, slope, count, sync, training, gamma is not None)
+        ctx.sinks = sinks
         ctx.save_for_backward(x, stat)
         return y
 
@@ -311,7 +324,6 @@ class _BNAct(torch.autograd.Function):
         sums = torch.zeros(2 * ld, device=x.device, dtype=torch.float64)
         _lib.call("itg_bn_bwd_reduce", C.byref(dx_), C.byref(ddy_), _ptr(ab), _ptr(mean_rstd), act, float(slope),
                   _ptr(sums), st)
-        dgb = torch.empty(2 * c, device=x.device, dtype=torch.float32) if affine else None
         if sync is not None and sync.world > 1:
             # dgamma/dbeta are the LOCAL sums (the gradient all-reduce adds the ranks up later);
             # the dx formula needs the GLOBAL ones.
@@ -321,20 +333,27 @@ class _BNAct(torch.autograd.Function):
             local = sums
         gx = torch.empty_like(x)
         dgx = _desc(gx, c)
-        _lib.call("itg_bn_bwd_apply", C.byref(dx_), C.byref(ddy_), _ptr(ab), _ptr(mean_rstd), None, _ptr(sums),
-                  count, act, float(slope), C.byref(dgx), None, None, st)
         dg = db = None
+        acc = 0
         if affine:
-            dg = local[ld:ld + c].to(torch.float32)
-            db = local[:c].to(torch.float32)
-        return gx, dg, db, None, None, None, None, None, None, None, None, None, None, None
+            if ctx.sinks is not None:
+                dg, db = ctx.sinks
+                acc = 1
+            else:
+                dg = torch.empty(c, device=x.device, dtype=torch.float32)
+                db = torch.empty(c, device=x.device, dtype=torch.float32)
+        _lib.call("itg_bn_bwd_apply", C.byref(dx_), C.byref(ddy_), _ptr(ab), _ptr(mean_rstd), _ptr(local), _ptr(sums),
+                  count, act, float(slope), C.byref(dgx), _ptr(dg), _ptr(db), acc, st)
+        if acc:
+            dg = db = None
+        return gx, dg, db, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def bn_act(x, gamma, beta, rm, rv, nbt, training=True, eps=1e-5, momentum=0.1, act=ACT_NONE, slope=0.0,
-           upsample=False, sync=None):
+           upsample=False, sync=None, sinks=None):
     """y = act(BatchNorm(x)) [nearest-upsampled x2 when ``upsample``]: statistics are taken on x
     (identical to those of the upsampled tensor), the unbiased running_var uses the x4 count."""
-    t = _BNAct.apply(x.t, gamma, beta, rm, rv, nbt, x.c, training, eps, momentum, act, slope, upsample, sync)
+    t = _BNAct.apply(x.t, gamma, beta, rm, rv, nbt, x.c, training, eps, momentum, act, slope, upsample, sync, sinks)
     return GT(t, x.c)
 
 
@@ -401,7 +420,7 @@ class _SSM(torch.autograd.Function):
         gx = torch.empty_like(x)
         dgx = _desc(gx, c)
         _lib.call("itg_bn_bwd_apply", C.byref(a), C.byref(h), _ptr(ab), _ptr(mean_rstd), None, _ptr(sums), count,
-                  ACT_NONE, 0.0, C.byref(dgx), None, None, st)
+                  ACT_NONE, 0.0, C.byref(dgx), None, None, 0, st)
         return gx, demb, None, None, None, None, None, None, None, None, None, None
 
 

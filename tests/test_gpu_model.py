@@ -228,4 +228,5 @@ def test_graph_replay_equals_eager_step():
                 # zero-gradient biases (F11): Adam(beta1=0) turns summation-order noise into +-lr steps
                 assert (a_ - b_).abs().max() <= 2 * 2e-4 * 2 + 1e-7, k
                 continue
-            assert rel_l2(a_, b_) < 1e-5, k
+            # everything downstream of those biases inherits ~lr-sized run-to-run differences
+            assert rel_l2(a_, b_) < 1e-4, k

@@ -239,7 +239,7 @@ def test_spectral_norm_iteration_and_backward():
     ws = torch.empty(2, device=cuda, dtype=torch.float64)
     _lib.call("itg_spectral_norm_bwd", C.c_void_p(gup.to(cuda).data_ptr()), C.c_void_p(wg.data_ptr()),
               C.c_void_p(ug.data_ptr()), C.c_void_p(vg.data_ptr()), C.c_void_p(inv.data_ptr()), 32, 256,
-              C.c_void_p(d.data_ptr()), C.c_void_p(ws.data_ptr()), None)
+              C.c_void_p(d.data_ptr()), 0, C.c_void_p(ws.data_ptr()), None)
     torch.cuda.synchronize()
     assert rel_l2(d.cpu(), dref) < 1e-5
 
