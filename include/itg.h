@@ -202,6 +202,11 @@ int itg_hinge_bwd(const float* logits, int64_t count, int mode, const float* ups
 int itg_spectral_norm_power_iter(const float* w, float* u, float* v, int rows, int cols, int do_iter,
                                  float eps, float* sigma_out, float* inv_sigma_out, float* workspace,
                                  void* stream);
+/* the same iteration for n <= 8 layers in 4 launches; host arrays of n device pointers / sizes,
+ * workspace[l]: 8*cols[l] + rows[l] floats, inv_sigma_out[l]: one device float                     */
+int itg_spectral_norm_power_iter_multi(int n, const float* const* w, float* const* u, float* const* v,
+                                       const int* rows, const int* cols, int do_iter, float eps,
+                                       float* const* inv_sigma_out, float* const* workspace, void* stream);
 /* dW_orig = (G - <G, W/sigma> u v^T) / sigma  */
 int itg_spectral_norm_bwd(const float* g_w, const float* w_orig, const float* u, const float* v,
                           const float* inv_sigma, int rows, int cols, float* d_w_orig, int accumulate,

@@ -71,6 +71,7 @@ SIGNATURES = {
     "itg_hinge_fwd": (_i, [_P, _l, _i, _P, _P]),
     "itg_hinge_bwd": (_i, [_P, _l, _i, _P, _P, _P]),
     "itg_spectral_norm_power_iter": (_i, [_P, _P, _P, _i, _i, _i, _f, _P, _P, _P, _P]),
+    "itg_spectral_norm_power_iter_multi": (_i, [_i, _P, _P, _P, _P, _P, _i, _f, _P, _P, _P]),
     "itg_spectral_norm_bwd": (_i, [_P, _P, _P, _P, _P, _i, _i, _P, _i, _P, _P]),
     "itg_adam_ema_step": (_i, [_P, _P, _P, _P, _P, _l, _f, _f, _f, _f, _i, _P, _f, _P]),
 }

@@ -34,6 +34,11 @@ struct ConvP {
   unsigned in_bytes, w_bytes;   // buffer-resource extents of the pixel operand / packed weights
   float* partial;      // split-K slabs [ksplit][M][co_rows] (ksplit > 1)
   int ksplit, kchunks; // K chunks (of BK) per split
+  // stride-2 input-gradient: the 4 output-parity classes run as ONE grid (blockIdx.y = class)
+  int ncls;
+  int cMT[4], cMU[4], cM[4], cioy[4], ciox[4], cooy[4], coox[4];
+  unsigned cwoff[4];   // float offset of the class's packed sub-kernel
+  unsigned cpoff[4];   // float offset of the class's split-K slabs
 };
 
 __device__ __forceinline__ void decode_m(int m, int MT, int MU, int& n, int& t, int& u) {
@@ -45,7 +50,14 @@ __device__ __forceinline__ void decode_m(int m, int MT, int MU, int& n, int& t, 
 }
 
 template <int BCO, int BPIX, int WCO, int WPIX, int TBK>
-__global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
+__global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 ? 5 : 3)) void conv_nt_kernel(const ConvP p) {
+  // per-class geometry (class 0 for ordinary launches); all wave-uniform scalars
+  const int cls = blockIdx.y;
+  const int cMT = p.cMT[cls], cMU = p.cMU[cls], cM = p.cM[cls];
+  const int cioy = p.cioy[cls], ciox = p.ciox[cls], cooy = p.cooy[cls], coox = p.coox[cls];
+  const float* const cw = p.w + p.cwoff[cls];
+  float* const cpartial = p.partial + p.cpoff[cls];
+  if ((int)(blockIdx.x / p.nco_tiles) * BPIX >= cM) return;
   constexpr int FI = WCO / 16, FJ = WPIX / 16;
   constexpr int WAVES_CO = BCO / WCO;
   static_assert(WAVES_CO * (BPIX / WPIX) == 4, "4 waves per workgroup");
@@ -74,19 +86,19 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
   // (pixel offset + channel offset); rows that read padding / lie past M carry an offset equal to the
   // buffer size, so the hardware range check returns zeros - no branches, no selects in the K loop.
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in.p, 0, p.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)cw, 0, p.w_bytes, 0x00020000);
   int pn[PL], py[PL], px[PL];
   bool pv[PL];
   unsigned poff[PL];
 #pragma unroll
   for (int i = 0; i < PL; ++i) {
     int m = m0 + lrow + i * RPP;
-    pv[i] = m < p.M;
+    pv[i] = m < cM;
     int n, t, u;
-    decode_m(pv[i] ? m : 0, p.MT, p.MU, n, t, u);
+    decode_m(pv[i] ? m : 0, cMT, cMU, n, t, u);
     pn[i] = n;
-    py[i] = t * p.isy + p.ioy;
-    px[i] = u * p.isx + p.iox;
+    py[i] = t * p.isy + cioy;
+    px[i] = u * p.isx + ciox;
   }
   unsigned woff[WL];
 #pragma unroll
@@ -185,11 +197,11 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
   // ---- epilogue: lane holds 4 consecutive output channels of one pixel per fragment
   const int cq = (lane >> 4) * 4;
   if (p.ksplit > 1) {
-    float* slab = p.partial + (size_t)blockIdx.z * p.M * p.co_rows;
+    float* slab = cpartial + (size_t)blockIdx.z * cM * p.co_rows;
 #pragma unroll
     for (int j = 0; j < FJ; ++j) {
       int m = m0 + wpix0 + 16 * j + (lane & 15);
-      if (m >= p.M) continue;
+      if (m >= cM) continue;
 #pragma unroll
       for (int i = 0; i < FI; ++i) {
         int co = co0 + wco0 + 16 * i + cq;
@@ -201,10 +213,10 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
 #pragma unroll
   for (int j = 0; j < FJ; ++j) {
     int m = m0 + wpix0 + 16 * j + (lane & 15);
-    if (m >= p.M) continue;
+    if (m >= cM) continue;
     int n, t, u;
-    decode_m(m, p.MT, p.MU, n, t, u);
-    int oy = t * p.osy + p.ooy, ox = u * p.osx + p.oox;
+    decode_m(m, cMT, cMU, n, t, u);
+    int oy = t * p.osy + cooy, ox = u * p.osx + coox;
     bool border = false;
     if (p.out_mode == 1) {
       int ty = min(max(oy, 0), p.out.H - 1), tx = min(max(ox, 0), p.out.W - 1);
@@ -321,8 +333,9 @@ int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-NtPlan plan_nt(int64_t M, int co_rows, int Kpad) {
+NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1) {
   NtPlan pl;
+  const int64_t M = M_total / ncls;      // per-class pixel count (classes are launched as one grid)
   static const int force_bk = env_int("ITG_NT_BK", 0);   // tuning override: 16 | 32
   pl.tbk = force_bk ? force_bk : 16;   // BK=32 halves the barriers but costs occupancy (LDS): measured 3-8 % slower
   const int cands_big[3] = {256, 128, 64};
@@ -336,14 +349,14 @@ NtPlan plan_nt(int64_t M, int co_rows, int Kpad) {
   for (int ci = 0; ci < 3; ++ci) {
     int bp = cands_big[ci];
     if (pl.bco == 128 && bp == 256) continue;              // 128x256 is not instantiated
-    int64_t blocks = ((M + bp - 1) / bp) * nco;
+    int64_t blocks = ((M + bp - 1) / bp) * nco * ncls;
     double waves = (double)((blocks + 255) / 256);
     double pen = bp >= 256 ? 1.0 : (bp == 128 ? (pl.bco == 128 ? 1.0 : 1.04) : (pl.bco == 128 ? 1.08 : 1.12));
     double cost = waves * bp * pen;
     if (cost < best) { best = cost; pl.bpix = bp; }
   }
   const int nk = (Kpad + pl.tbk - 1) / pl.tbk;
-  int64_t blocks = ((M + pl.bpix - 1) / pl.bpix) * nco;
+  int64_t blocks = ((M + pl.bpix - 1) / pl.bpix) * nco * ncls;
   pl.ksplit = 1;
   if (blocks < 512 && nk * pl.tbk >= 512) {
     int want = (int)((768 + blocks - 1) / blocks);
@@ -353,7 +366,7 @@ NtPlan plan_nt(int64_t M, int co_rows, int Kpad) {
   }
   pl.kchunks = (nk + pl.ksplit - 1) / pl.ksplit;
   pl.ksplit = (nk + pl.kchunks - 1) / pl.kchunks;
-  pl.ws_floats = pl.ksplit > 1 ? (int64_t)pl.ksplit * M * co_rows : 0;
+  pl.ws_floats = pl.ksplit > 1 ? (int64_t)pl.ksplit * M * co_rows * ncls : 0;
   return pl;
 }
 
@@ -364,7 +377,7 @@ int launch_nt(const ConvP& p, int tbk, hipStream_t s) {
   int64_t npix = ((int64_t)p.M + BPIX - 1) / BPIX;
   int64_t blocks = npix * q.nco_tiles;
   if (blocks <= 0 || blocks > 0x7fffffff) return ITG_ERR_ARG;
-  dim3 grid((unsigned)blocks, 1, (unsigned)p.ksplit);
+  dim3 grid((unsigned)blocks, (unsigned)(p.ncls > 1 ? p.ncls : 1), (unsigned)p.ksplit);
   if (tbk == 32)
     hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 32>), grid, dim3(256), 0, s, q);
   else
@@ -374,9 +387,16 @@ int launch_nt(const ConvP& p, int tbk, hipStream_t s) {
 }
 
 int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s) {
-  NtPlan pl = plan_nt(p.M, p.co_rows, p.Kpad);
+  const int ncls_ = p.ncls > 1 ? p.ncls : 1;
+  if (ncls_ == 1) {
+    p.cMT[0] = p.MT; p.cMU[0] = p.MU; p.cM[0] = p.M;
+    p.cioy[0] = p.ioy; p.ciox[0] = p.iox; p.cooy[0] = p.ooy; p.coox[0] = p.oox;
+    p.cwoff[0] = 0;
+  }
+  NtPlan pl = plan_nt((int64_t)p.M * ncls_, p.co_rows, p.Kpad, ncls_);
   if (pl.ws_floats > workspace_floats || (pl.ws_floats && !workspace)) return ITG_ERR_WORKSPACE;
   p.ksplit = pl.ksplit; p.kchunks = pl.kchunks; p.partial = workspace;
+  for (int c = 0; c < 4; ++c) p.cpoff[c] = (unsigned)((size_t)c * pl.ksplit * p.M * p.co_rows);
   {
     int64_t ib = (int64_t)p.in.n * p.in.gh * p.in.gw * p.in.ph * p.in.pw * p.in.ld * 4;
     int64_t wb = (int64_t)p.co_rows * p.Kpad * 4;
@@ -398,10 +418,20 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
     rc = pl.bpix == 128 ? launch_nt<128, 128, 64, 64>(p, k, s) : launch_nt<128, 64, 64, 32>(p, k, s);
   }
   if (rc || pl.ksplit == 1) return rc;
-  int64_t total = (int64_t)p.M * (p.out.ld >> 2);
-  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, p);
-  ITG_CHECK_LAUNCH();
+  const int ncls = p.ncls > 1 ? p.ncls : 1;
+  for (int c = 0; c < ncls; ++c) {
+    ConvP q = p;
+    if (p.ncls > 1) {
+      q.MT = p.cMT[c]; q.MU = p.cMU[c]; q.M = p.cM[c];
+      q.ioy = p.cioy[c]; q.iox = p.ciox[c]; q.ooy = p.cooy[c]; q.oox = p.coox[c];
+      q.partial = p.partial + p.cpoff[c];
+      if (q.M <= 0) continue;
+    }
+    int64_t total = (int64_t)q.M * (q.out.ld >> 2);
+    int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, q);
+    ITG_CHECK_LAUNCH();
+  }
   return ITG_OK;
 }
 
@@ -782,15 +812,8 @@ int64_t itg_conv2d_dgrad_workspace(const itg_tensor* dy, const itg_tensor* dx, c
     return plan_nt((int64_t)dx->n * (H + e) * (W + e), co_rows, round_up(g->kh * g->kw * dy->ld, BK)).ws_floats;
   }
   int Kpad = round_up((g->kh / 2) * (g->kw / 2) * dy->ld, BK);
-  int64_t best = 0;
-  for (int ry = 0; ry < 2; ++ry)
-    for (int rx = 0; rx < 2; ++rx) {
-      int64_t M = (int64_t)dx->n * ((H - ry + 1) / 2) * ((W - rx + 1) / 2);
-      if (M <= 0) continue;
-      int64_t w = plan_nt(M, co_rows, Kpad).ws_floats;
-      if (w > best) best = w;
-    }
-  return best;
+  int64_t Mmax = (int64_t)dx->n * ((H + 1) / 2) * ((W + 1) / 2);
+  return plan_nt(Mmax * 4, co_rows, Kpad, 4).ws_floats;
 }
 
 int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bias, const itg_tensor* residual,
@@ -800,6 +823,7 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   if ((rc = check_tensor(in)) || (rc = check_tensor(out))) return rc;
   if (!w_packed || !g || g->kh <= 0 || g->kw <= 0 || g->stride <= 0 || g->pad < 0) return ITG_ERR_ARG;
   ConvP p;
+  p.ncls = 1;
   p.in = make_grid(in);
   p.out = make_grid(out);
   p.res = null_grid();
@@ -834,6 +858,7 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const it
   if (dy->n != dx->n) return ITG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   ConvP p;
+  p.ncls = 1;
   p.in = make_grid(dy);
   p.out = make_grid(dx);
   p.res = null_grid();
@@ -876,22 +901,27 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const it
   p.Kpad = round_up(p.ntaps * dy->ld, BK);
   p.isy = p.isx = 1; p.osy = p.osx = 2; p.out_mode = 0;
   int ci_pad = round_up(dx->c, 16);
+  p.ncls = 4;
+  int Mmax = 0;
   for (int ry = 0; ry < 2; ++ry)
     for (int rx = 0; rx < 2; ++rx) {
+      const int c = ry * 2 + rx;
       int ay = (ry + g->pad) & 1, ax = (rx + g->pad) & 1;
       int by = (ry + g->pad - ay) / 2, bx = (rx + g->pad - ax) / 2;
-      p.MT = (p.out.H - ry + 1) / 2; p.MU = (p.out.W - rx + 1) / 2;
-      if (p.MT <= 0 || p.MU <= 0) continue;
-      p.ioy = by - (skh - 1); p.iox = bx - (skw - 1);
-      p.ooy = ry; p.oox = rx;
-      p.w = w_packed_dgrad + (size_t)(ry * 2 + rx) * ci_pad * p.Kpad;
-      int64_t M = (int64_t)dx->n * p.MT * p.MU;
-      if (M >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
-      p.M = (int)M;
-      int r = dispatch_nt(p, workspace, workspace_floats, s);
-      if (r) return r;
+      p.cMT[c] = (p.out.H - ry + 1) / 2; p.cMU[c] = (p.out.W - rx + 1) / 2;
+      int64_t M = (int64_t)dx->n * p.cMT[c] * p.cMU[c];
+      if (M >= ((int64_t)1 << 29)) return ITG_ERR_ARG;
+      p.cM[c] = (int)M;
+      if (p.cM[c] > Mmax) Mmax = p.cM[c];
+      p.cioy[c] = by - (skh - 1); p.ciox[c] = bx - (skw - 1);
+      p.cooy[c] = ry; p.coox[c] = rx;
+      p.cwoff[c] = (unsigned)((size_t)c * ci_pad * p.Kpad);
     }
-  return ITG_OK;
+  if (Mmax <= 0) return ITG_OK;
+  p.w = w_packed_dgrad;
+  p.M = Mmax; p.MT = p.cMT[0]; p.MU = p.cMU[0];
+  p.ioy = p.cioy[0]; p.iox = p.ciox[0]; p.ooy = 0; p.oox = 0;
+  return dispatch_nt(p, workspace, workspace_floats, s);
 }
 
 int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g) {

@@ -132,6 +132,94 @@ __global__ __launch_bounds__(1024) void sn_sigma_kernel(const float* __restrict_
   }
 }
 
+// ---- all spectrally-normalised layers of a model in 4 launches ---------------------------------
+constexpr int SN_MAXL = 8;
+struct SnBatch {
+  const float* w[SN_MAXL]; float* u[SN_MAXL]; float* v[SN_MAXL]; float* work[SN_MAXL]; float* inv[SN_MAXL];
+  int rows[SN_MAXL], cols[SN_MAXL];
+  int blk0[SN_MAXL + 1];   // prefix of per-layer workgroup counts for the flattened grids
+  int n;
+  float eps;
+};
+
+__device__ __forceinline__ int sn_find_layer(const SnBatch& b, int blk) {
+  int l = 0;
+  while (l + 1 < b.n && blk >= b.blk0[l + 1]) ++l;
+  return l;
+}
+
+// partial W^T u : blockIdx.x flattened over layers x column blocks of 64, blockIdx.y = row slice
+__global__ __launch_bounds__(256) void snb_wt_u_kernel(SnBatch b) {
+  __shared__ double red[4][64];
+  const int l = sn_find_layer(b, blockIdx.x);
+  const int rows = b.rows[l], cols = b.cols[l];
+  const float* w = b.w[l]; const float* u = b.u[l]; float* part = b.work[l];
+  const int j = (blockIdx.x - b.blk0[l]) * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int per = (rows + SN_RS - 1) / SN_RS;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  double s = 0.0;
+  if (j < cols)
+    for (int i = r0 + rl; i < r1; i += 4) s += (double)w[(size_t)i * cols + j] * (double)u[i];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && j < cols)
+    part[(size_t)blockIdx.y * cols + j] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
+                                                  red[3][threadIdx.x]);
+}
+
+// v = normalize(sum of partials) : one workgroup per layer
+__global__ __launch_bounds__(1024) void snb_norm_v_kernel(SnBatch b) {
+  const int l = blockIdx.x;
+  const int n = b.cols[l];
+  const float* src = b.work[l]; float* dst = b.v[l];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float v = 0.f;
+    for (int p = 0; p < SN_RS; ++p) v += src[(size_t)p * n + i];
+    dst[i] = v;
+    s += (double)v * (double)v;
+  }
+  s = block_sum_d(s);
+  float nrm = fmaxf((float)sqrt(s), b.eps);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = dst[i] / nrm;
+}
+
+// t = W v : one wave per row, blockIdx.x flattened over layers x ceil(rows/4)
+__global__ __launch_bounds__(256) void snb_w_v_kernel(SnBatch b) {
+  const int l = sn_find_layer(b, blockIdx.x);
+  const int rows = b.rows[l], cols = b.cols[l];
+  const float* w = b.w[l]; const float* v = b.v[l];
+  float* t = b.work[l] + (size_t)SN_RS * cols;
+  const int row = (blockIdx.x - b.blk0[l]) * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  double s = 0.0;
+  for (int j = lane; j < cols; j += 64) s += (double)w[(size_t)row * cols + j] * (double)v[j];
+  s = wave_sum_d(s);
+  if (lane == 0) t[row] = (float)s;
+}
+
+// u = normalize(t) (training), sigma = <u, t>, inv = 1/sigma : one workgroup per layer
+__global__ __launch_bounds__(1024) void snb_norm_u_sigma_kernel(SnBatch b, int do_iter) {
+  const int l = blockIdx.x;
+  const int n = b.rows[l];
+  const float* t = b.work[l] + (size_t)SN_RS * b.cols[l];
+  float* u = b.u[l];
+  if (do_iter) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)t[i] * (double)t[i];
+    s = block_sum_d(s);
+    float nrm = fmaxf((float)sqrt(s), b.eps);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) u[i] = t[i] / nrm;
+    __syncthreads();
+  }
+  double d = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) d += (double)u[i] * (double)t[i];
+  d = block_sum_d(d);
+  if (threadIdx.x == 0) *b.inv[l] = 1.f / (float)d;
+}
+
 __global__ void dot_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, double* __restrict__ out) {
   double s = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -244,6 +332,36 @@ int itg_spectral_norm_power_iter(const float* w, float* u, float* v, int rows, i
   }
   hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(1024), 0, s, (const float*)u, (const float*)t_rows, rows, sigma_out,
                      inv_sigma_out);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+// Same iteration for up to 8 layers at once (4 launches in total); host arrays of length n.
+int itg_spectral_norm_power_iter_multi(int n, const float* const* w, float* const* u, float* const* v, const int* rows,
+                                       const int* cols, int do_iter, float eps, float* const* inv_sigma_out,
+                                       float* const* workspace, void* stream) {
+  if (n <= 0 || n > SN_MAXL || !w || !u || !v || !rows || !cols || !inv_sigma_out || !workspace) return ITG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  SnBatch b;
+  b.n = n; b.eps = eps;
+  for (int l = 0; l < n; ++l) {
+    if (!w[l] || !u[l] || !v[l] || !inv_sigma_out[l] || !workspace[l] || rows[l] <= 0 || cols[l] <= 0) return ITG_ERR_ARG;
+    b.w[l] = w[l]; b.u[l] = u[l]; b.v[l] = v[l]; b.work[l] = workspace[l]; b.inv[l] = inv_sigma_out[l];
+    b.rows[l] = rows[l]; b.cols[l] = cols[l];
+  }
+  if (do_iter) {
+    b.blk0[0] = 0;
+    for (int l = 0; l < n; ++l) b.blk0[l + 1] = b.blk0[l] + (cols[l] + 63) / 64;
+    hipLaunchKernelGGL(snb_wt_u_kernel, dim3(b.blk0[n], SN_RS), dim3(256), 0, s, b);
+    ITG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(snb_norm_v_kernel, dim3(n), dim3(1024), 0, s, b);
+    ITG_CHECK_LAUNCH();
+  }
+  b.blk0[0] = 0;
+  for (int l = 0; l < n; ++l) b.blk0[l + 1] = b.blk0[l] + (rows[l] + 3) / 4;
+  hipLaunchKernelGGL(snb_w_v_kernel, dim3(b.blk0[n]), dim3(256), 0, s, b);
+  ITG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(snb_norm_u_sigma_kernel, dim3(n), dim3(1024), 0, s, b, do_iter);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }

@@ -6,7 +6,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..ops import GT
-from .layers import conv4x4, conv3x3, _BNParams
+from .layers import conv4x4, conv3x3, _BNParams, batched_power_iteration
 
 
 class PatchDiscriminator(nn.Module):
@@ -39,6 +39,7 @@ class PatchDiscriminator(nn.Module):
     def forward_grid(self, x):
         """x: GT image (any patch grid).  Returns the logit map as a 1x1-grid GT."""
         mods = list(self.model)
+        batched_power_iteration(self.model)      # every layer's spectral norm up front, 4 launches
         h, i = x, 0
         while i < len(mods):
             m = mods[i]

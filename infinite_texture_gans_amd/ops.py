@@ -165,6 +165,32 @@ def sn_power_iter(w_orig, u, v, training=True, eps=1e-12):
     return inv
 
 
+def sn_power_iter_multi(layers, training=True, eps=1e-12):
+    """Power iteration for several (w_orig, u, v) triples in 4 launches; returns the list of 1/sigma
+    tensors.  Falls back to per-layer calls above 8 layers."""
+    if len(layers) > 8:
+        return [sn_power_iter(w, u, v, training, eps) for (w, u, v) in layers]
+    n = len(layers)
+    rows = [w.shape[0] for (w, _, _) in layers]
+    cols = [w.numel() // w.shape[0] for (w, _, _) in layers]
+    dev = layers[0][0].device
+    sizes = [8 * c + r + 2 for r, c in zip(rows, cols)]
+    ws = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+    works, invs, o = [], [], 0
+    for sz in sizes:
+        works.append(ws[o:o + sz - 2])
+        invs.append(ws[o + sz - 2:o + sz - 1])
+        o += sz
+    PA = C.c_void_p * n
+    IA = C.c_int * n
+    with torch.no_grad():
+        _lib.call("itg_spectral_norm_power_iter_multi", n, PA(*[w.data_ptr() for (w, _, _) in layers]),
+                  PA(*[u.data_ptr() for (_, u, _) in layers]), PA(*[v.data_ptr() for (_, _, v) in layers]),
+                  IA(*rows), IA(*cols), int(training), float(eps), PA(*[t.data_ptr() for t in invs]),
+                  PA(*[t.data_ptr() for t in works]), _stream())
+    return invs
+
+
 # ------------------------------------------------------------------------------- convolution
 class _Conv(torch.autograd.Function):
     """out = act(conv(x, w*scale) + bias [+ residual]) on patch-grid tensors (merged-image
