@@ -338,31 +338,36 @@ NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1) {
   const int64_t M = M_total / ncls;      // per-class pixel count (classes are launched as one grid)
   static const int force_bk = env_int("ITG_NT_BK", 0);   // tuning override: 16 | 32
   pl.tbk = force_bk ? force_bk : 16;   // BK=32 halves the barriers but costs occupancy (LDS): measured 3-8 % slower
-  const int cands_big[3] = {256, 128, 64};
   if (co_rows <= 16) pl.bco = 16;
   else if (co_rows <= 32) pl.bco = 32;
   else if (co_rows <= 64) pl.bco = 64;
   else pl.bco = 128;
   const int nco = (co_rows + pl.bco - 1) / pl.bco;
-  double best = 1e30;
-  pl.bpix = 128;
+  const int nk = (Kpad + pl.tbk - 1) / pl.tbk;
+  // Joint choice of the pixel-tile width and the K split.  Efficiency model per candidate:
+  //   quantisation  (B*ks/256) / ceil(B*ks/256)      equal-sized workgroups on 256 CUs
+  //   fill          < 2 workgroups per CU leaves the MFMA pipe idle between phases
+  //   split cost    the second stage's slab round trip ~ ks * 100 / K of the kernel's own time
+  //   tile penalty  narrower tiles re-read the weight panel more often and carry more issue overhead
+  pl.bpix = 128; pl.ksplit = 1;
+  double best_eff = 0.0;
+  const int cands_big[3] = {256, 128, 64};
+  const int cand_ks[7] = {1, 2, 3, 4, 6, 8, 12};
   for (int ci = 0; ci < 3; ++ci) {
     int bp = cands_big[ci];
     if (pl.bco == 128 && bp == 256) continue;              // 128x256 is not instantiated
     int64_t blocks = ((M + bp - 1) / bp) * nco * ncls;
-    double waves = (double)((blocks + 255) / 256);
     double pen = bp >= 256 ? 1.0 : (bp == 128 ? (pl.bco == 128 ? 1.0 : 1.04) : (pl.bco == 128 ? 1.08 : 1.12));
-    double cost = waves * bp * pen;
-    if (cost < best) { best = cost; pl.bpix = bp; }
-  }
-  const int nk = (Kpad + pl.tbk - 1) / pl.tbk;
-  int64_t blocks = ((M + pl.bpix - 1) / pl.bpix) * nco * ncls;
-  pl.ksplit = 1;
-  if (blocks < 512 && nk * pl.tbk >= 512) {
-    int want = (int)((768 + blocks - 1) / blocks);
-    int maxs = nk * pl.tbk / 256;
-    pl.ksplit = want < maxs ? want : maxs;
-    if (pl.ksplit < 1) pl.ksplit = 1;
+    for (int i = 0; i < 7; ++i) {
+      int ks = cand_ks[i];
+      if (ks > 1 && nk * pl.tbk / ks < 256) break;
+      double b = (double)blocks * ks / 256.0;
+      double eff = b / (double)((int64_t)(b + 0.999999));
+      if (b < 2.0) eff *= b / 2.0;
+      if (ks > 1) eff /= 1.0 + ks * 100.0 / (double)Kpad;
+      eff /= pen;
+      if (eff > best_eff * 1.02) { best_eff = eff; pl.bpix = bp; pl.ksplit = ks; }
+    }
   }
   pl.kchunks = (nk + pl.ksplit - 1) / pl.ksplit;
   pl.ksplit = (nk + pl.kchunks - 1) / pl.kchunks;
