@@ -20,6 +20,11 @@ namespace {
 constexpr int BK = 16;    // K elements per pipeline stage
 constexpr int LDK = 20;   // LDS row pitch (floats): BK + 4 keeps rows 16-B aligned
 
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 struct ConvP {
   GridT in, out, res;
   const float* w;
@@ -32,6 +37,7 @@ struct ConvP {
   float slope;
   int co_rows, nco_tiles;
   unsigned in_bytes, w_bytes;   // buffer-resource extents of the pixel operand / packed weights
+  int use_tab;                  // per-row tap-offset table in LDS (narrow layers)
   float* partial;      // split-K slabs [ksplit][M][co_rows] (ksplit > 1)
   int ksplit, kchunks; // K chunks (of BK) per split
   // stride-2 input-gradient: the 4 output-parity classes run as ONE grid (blockIdx.y = class)
@@ -50,7 +56,7 @@ __device__ __forceinline__ void decode_m(int m, int MT, int MU, int& n, int& t, 
 }
 
 template <int BCO, int BPIX, int WCO, int WPIX, int TBK>
-__global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 ? 5 : 3)) void conv_nt_kernel(const ConvP p) {
+__global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 && (BCO + BPIX) <= 192 ? 5 : 3)) void conv_nt_kernel(const ConvP p) {
   // per-class geometry (class 0 for ordinary launches); all wave-uniform scalars
   const int cls = blockIdx.y;
   const int cMT = p.cMT[cls], cMU = p.cMU[cls], cM = p.cM[cls];
@@ -111,22 +117,36 @@ __global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 ? 5 : 3)) void 
   const int kk1 = min(nk_total, kk0 + p.kchunks);
   int tap = (kk0 * TBK + kg * 4) / p.cin_ld;
   int cc = kk0 * TBK + kg * 4 - tap * p.cin_ld;
-  int ky = tap / p.kw, kx = tap - ky * p.kw;
-  auto locate = [&]() {   // pixel byte offsets of the current tap
+  // Per-row byte offsets of EVERY filter tap, computed once (the rows of a workgroup never change) and
+  // kept in LDS: a tap change in the K loop is then one ds_read per row instead of ~35 VALU of clamp /
+  // patch-grid address arithmetic.  Slot [ntaps] holds the out-of-range marker for the K padding.
+  extern __shared__ unsigned taptab[];
+  const int TS = p.ntaps + 1;
+  const bool use_tab = p.use_tab != 0;       // narrow layers only: wide ones change tap rarely and need the LDS
+  auto tap_offset = [&](int i, int tt) -> unsigned {
+    const int tky = tt / p.kw, tkx = tt - tky * p.kw;
+    int iy = py[i] + tky, ix = px[i] + tkx;
+    bool ok = pv[i] && tt < p.ntaps;
+    if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.in.H && (unsigned)ix < (unsigned)p.in.W;
+    iy = min(max(iy, 0), p.in.H - 1);
+    ix = min(max(ix, 0), p.in.W - 1);
+    unsigned o = (unsigned)grid_off(p.in, pn[i], iy, ix) * 4u;
+    return ok ? o : p.in_bytes;
+  };
+  if (use_tab) {
+    for (int tt = kg; tt <= p.ntaps; tt += KG) {
 #pragma unroll
-    for (int i = 0; i < PL; ++i) {
-      int iy = py[i] + ky, ix = px[i] + kx;
-      bool ok = pv[i] && tap < p.ntaps;
-      if (p.pad_mode == ITG_PAD_REPLICATE) {
-        iy = min(max(iy, 0), p.in.H - 1);
-        ix = min(max(ix, 0), p.in.W - 1);
-      } else {
-        ok = ok && (unsigned)iy < (unsigned)p.in.H && (unsigned)ix < (unsigned)p.in.W;
-        iy = min(max(iy, 0), p.in.H - 1);
-        ix = min(max(ix, 0), p.in.W - 1);
-      }
-      unsigned o = (unsigned)grid_off(p.in, pn[i], iy, ix) * 4u;
-      poff[i] = ok ? o : p.in_bytes;
+      for (int i = 0; i < PL; ++i) taptab[(lrow + i * RPP) * TS + tt] = tap_offset(i, tt);
+    }
+    __syncthreads();
+  }
+  auto locate = [&]() {
+    if (use_tab) {
+#pragma unroll
+      for (int i = 0; i < PL; ++i) poff[i] = taptab[(lrow + i * RPP) * TS + min(tap, p.ntaps)];
+    } else {
+#pragma unroll
+      for (int i = 0; i < PL; ++i) poff[i] = tap_offset(i, tap);
     }
   };
   locate();
@@ -142,10 +162,7 @@ __global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 ? 5 : 3)) void 
       rw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw_, woff[i], ksoff, 0));
     cc += TBK;
     if (__any(cc >= p.cin_ld)) {       // wave-uniform: some lane moves on to the next filter tap
-      while (cc >= p.cin_ld) {
-        cc -= p.cin_ld; ++tap;
-        if (++kx == p.kw) { kx = 0; ++ky; }
-      }
+      while (cc >= p.cin_ld) { cc -= p.cin_ld; ++tap; }
       locate();
     }
   };
@@ -321,6 +338,162 @@ __global__ void splitk_epilogue_kernel(ConvP p) {
 }
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+// ------------------------------------------------------------------------------- small-channel 3x3 (LDS halo tile)
+// Stride-1 3x3 convolutions with <= 32 input and <= 32 output channels (the generator's last blocks
+// and `final`, forward and input-gradient).  The implicit-GEMM kernel above re-gathers every input
+// pixel 9 times through L2; here a workgroup stages one (8+2) x (32+2) pixel halo tile ONCE into LDS
+// (coalesced NHWC rows, raw buffer loads with hardware zero-fill / clamped replicate coordinates), keeps
+// the whole filter bank in LDS, and every wave runs its 64 pixels x 9 taps on MFMA from there.
+constexpr int TT_H = 8, TT_W = 32;
+constexpr int TT_PIX = (TT_H + 2) * (TT_W + 2);
+
+__device__ __forceinline__ void store_out(const ConvP& p, int n, int oy, int ox, int co, f32x4 v) {
+  bool border = false;
+  if (p.out_mode == 1) {
+    int ty = min(max(oy, 0), p.out.H - 1), tx = min(max(ox, 0), p.out.W - 1);
+    border = (ty == 0) | (ty == p.out.H - 1) | (tx == 0) | (tx == p.out.W - 1);
+    oy = ty; ox = tx;
+  }
+  const int off = grid_off(p.out, n, oy, ox);
+  if (p.bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (co + e < p.out.c) v[e] += p.bias[co + e];
+  }
+  if (p.res.p) v += *reinterpret_cast<const f32x4*>(p.res.p + grid_off(p.res, n, oy, ox) + co);
+  if (p.act != ITG_ACT_NONE) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act, p.slope);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (co + e >= p.out.c) v[e] = 0.f;
+  float* dst = p.out.p + off + co;
+  if (border) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(dst + e, v[e]);
+  } else {
+    *reinterpret_cast<f32x4*>(dst) = v;
+  }
+}
+
+template <int FI>
+__global__ __launch_bounds__(256) void conv_tile_kernel(const ConvP p, int tiles_x, int tiles_y, int cpt, int nch) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Xt = lds;                                   // [TT_PIX][cpt] (+ slack)
+  float* Wl = lds + TT_PIX * cpt + 16;               // [9][nch][16*FI][20]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int b = blockIdx.x;
+  const int tx_i = b % tiles_x; b /= tiles_x;
+  const int ty_i = b % tiles_y;
+  const int n = b / tiles_y;
+  const int t0 = ty_i * TT_H, u0 = tx_i * TT_W;
+  const int q4 = p.cin_ld >> 2;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in.p, 0, p.in_bytes, 0x00020000);
+  // ---- stage the halo tile
+  for (int e = tid; e < TT_PIX * q4; e += 256) {
+    int pix = e / q4, c4 = e - pix * q4;
+    int r = pix / (TT_W + 2), c = pix - r * (TT_W + 2);
+    int iy = t0 + p.ioy + r, ix = u0 + p.iox + c;
+    bool ok = true;
+    if (p.pad_mode != ITG_PAD_REPLICATE) ok = (unsigned)iy < (unsigned)p.in.H && (unsigned)ix < (unsigned)p.in.W;
+    iy = min(max(iy, 0), p.in.H - 1); ix = min(max(ix, 0), p.in.W - 1);
+    unsigned o = ((unsigned)grid_off(p.in, n, iy, ix) + (unsigned)c4 * 4u) * 4u;
+    f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? o : p.in_bytes, 0, 0));
+    *reinterpret_cast<f32x4*>(Xt + pix * cpt + c4 * 4) = v;
+  }
+  if (tid < 16) Xt[TT_PIX * cpt + tid] = 0.f;        // slack read by the last pixel's K-chunk overrun
+  // ---- filter bank: Wl[tap][chunk][co][k16], zero beyond cin_ld
+  const int co_rows = 16 * FI;
+  for (int e = tid; e < 9 * nch * co_rows * 16; e += 256) {
+    int k16 = e & 15;
+    int r = e >> 4;
+    int co = r % co_rows; r /= co_rows;
+    int c = r % nch;
+    int tap = r / nch;
+    int ci = c * 16 + k16;
+    float v = 0.f;
+    if (ci < p.cin_ld && co < p.co_rows) v = p.w[(size_t)co * p.Kpad + tap * p.cin_ld + ci];
+    Wl[((tap * nch + c) * co_rows + co) * 20 + k16] = v;
+  }
+  __syncthreads();
+  // ---- compute: wave w owns tile rows 2w, 2w+1; fragment f = (row 2w + f/2, columns 16*(f&1) ..)
+  f32x4 acc[FI][4];
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fj = lane & 15, g4 = (lane >> 4) * 4;
+  int pbase[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) pbase[f] = ((2 * wave + (f >> 1)) * (TT_W + 2) + 16 * (f & 1) + fj) * cpt + g4;
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int toff = (ky * (TT_W + 2) + kx) * cpt;
+    for (int c = 0; c < nch; ++c) {
+      f32x4 a[FI], bq[4];
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+        a[i] = *reinterpret_cast<const f32x4*>(Wl + ((tap * nch + c) * co_rows + 16 * i + fj) * 20 + g4);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const float* src = Xt + pbase[f] + toff + c * 16;
+        bq[f] = f32x4{src[0], src[1], src[2], src[3]};     // pitch is only 4-float aligned for some cin_ld
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], bq[f][s], acc[i][f], 0, 0, 0);
+    }
+  }
+  // ---- epilogue
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    int t = t0 + 2 * wave + (f >> 1), u = u0 + 16 * (f & 1) + fj;
+    if (t >= p.MT || u >= p.MU) continue;
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+      int co = 16 * i + g4;
+      if (co < p.out.ld) store_out(p, n, t * p.osy + p.ooy, u * p.osx + p.oox, co, acc[i][f]);
+    }
+  }
+}
+
+// eligibility + launch of the halo-tile kernel; returns 1 when it handled the call
+int try_conv_tile(const ConvP& p, hipStream_t s, int* rc) {
+  static const int enable = env_int("ITG_CONV_TILE", 0);   // experimental: only pays with a persistent pipeline
+  if (!enable || p.ncls > 1 || p.ntaps != 9 || p.kw != 3 || p.isy != 1 || p.isx != 1 || p.osy != 1 || p.osx != 1)
+    return 0;
+  if (p.cin_ld > 32 || p.co_rows > 32) return 0;
+  if ((int64_t)p.MT * p.MU < 64 * 64) return 0;          // tiny images: the gather kernel with split-K wins
+  ConvP q = p;
+  int64_t ib = (int64_t)p.in.n * p.in.gh * p.in.gw * p.in.ph * p.in.pw * p.in.ld * 4;
+  if (ib >= 0xFFFF0000LL) return 0;
+  q.in_bytes = (unsigned)ib;
+  const int cpt = (p.cin_ld % 16 == 0) ? p.cin_ld + 4 : p.cin_ld;
+  const int nch = (p.cin_ld + 15) / 16;
+  const int FI = p.co_rows / 16;
+  const int tiles_x = (p.MU + TT_W - 1) / TT_W, tiles_y = (p.MT + TT_H - 1) / TT_H;
+  const int64_t blocks = (int64_t)p.in.n * tiles_x * tiles_y;
+  const size_t lds = ((size_t)TT_PIX * cpt + 16 + (size_t)9 * nch * 16 * FI * 20) * sizeof(float);
+  if (blocks > 0x7fffffff || lds > 96 * 1024) return 0;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_done = true;
+  }
+  if (FI == 1)
+    hipLaunchKernelGGL(conv_tile_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, s, q, tiles_x, tiles_y, cpt, nch);
+  else
+    hipLaunchKernelGGL(conv_tile_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, s, q, tiles_x, tiles_y, cpt, nch);
+  *rc = hipGetLastError() == hipSuccess ? ITG_OK : ITG_ERR_LAUNCH;
+  return 1;
+}
+
 
 // Tile / split-K plan.  The chip has 256 CUs; every workgroup is 4 waves (one per SIMD), so a CU's
 // time is (#workgroups it runs) x (work of one), and equal-sized workgroups quantise badly when
@@ -328,16 +501,12 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // ceil(blocks / 256) * tile work, then split K when the grid still under-fills the chip.
 struct NtPlan { int bco, bpix, tbk, ksplit, kchunks; int64_t ws_floats; };
 
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
 NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1) {
   NtPlan pl;
   const int64_t M = M_total / ncls;      // per-class pixel count (classes are launched as one grid)
   static const int force_bk = env_int("ITG_NT_BK", 0);   // tuning override: 16 | 32
-  pl.tbk = force_bk ? force_bk : 16;   // BK=32 halves the barriers but costs occupancy (LDS): measured 3-8 % slower
+  (void)force_bk;
+  pl.tbk = 16;
   if (co_rows <= 16) pl.bco = 16;
   else if (co_rows <= 32) pl.bco = 32;
   else if (co_rows <= 64) pl.bco = 64;
@@ -383,15 +552,20 @@ int launch_nt(const ConvP& p, int tbk, hipStream_t s) {
   int64_t blocks = npix * q.nco_tiles;
   if (blocks <= 0 || blocks > 0x7fffffff) return ITG_ERR_ARG;
   dim3 grid((unsigned)blocks, (unsigned)(p.ncls > 1 ? p.ncls : 1), (unsigned)p.ksplit);
-  if (tbk == 32)
-    hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 32>), grid, dim3(256), 0, s, q);
-  else
-    hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16>), grid, dim3(256), 0, s, q);
+  (void)tbk;   // only the BK = 16 pipeline is instantiated (BK = 32 measured 3-8 % slower: LDS-limited occupancy)
+  size_t tab_bytes = (size_t)BPIX * (p.ntaps + 1) * sizeof(unsigned);
+  q.use_tab = (p.cin_ld < 64 && tab_bytes <= 24 * 1024) ? 1 : 0;
+  if (!q.use_tab) tab_bytes = 0;
+  hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16>), grid, dim3(256), tab_bytes, s, q);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }
 
 int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s) {
+  {
+    int rc_tile = ITG_OK;
+    if (try_conv_tile(p, s, &rc_tile)) return rc_tile;
+  }
   const int ncls_ = p.ncls > 1 ? p.ncls : 1;
   if (ncls_ == 1) {
     p.cMT[0] = p.MT; p.cMU[0] = p.MU; p.cM[0] = p.M;
