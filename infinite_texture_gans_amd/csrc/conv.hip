@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 && (BCO + BPIX)
   constexpr int FI = WCO / 16, FJ = WPIX / 16;
   constexpr int WAVES_CO = BCO / WCO;
   static_assert(WAVES_CO * (BPIX / WPIX) == 4, "4 waves per workgroup");
-  constexpr int LDT = TBK + 4;               // LDS row pitch (floats), rows stay 16-B aligned
+  constexpr int LDT = TBK + 4;               // LDS row pitch 20 floats (16-B aligned rows); pitch 24 is conflict-free but costs a workgroup of occupancy: measured slower
   constexpr int KG = TBK / 4;                // float4 groups per tile row
   constexpr int RPP = 256 / KG;              // tile rows covered per load pass
   constexpr int PL = BPIX / RPP;

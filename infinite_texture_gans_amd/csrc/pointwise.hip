@@ -187,34 +187,95 @@ __global__ void grid_to_nchw_kernel(GridT s, float* __restrict__ dst, int merged
 
 // ---- LocalPadder, NCHW patches in / out (the reference module's own tensor format) -------
 // x: (n*gh*gw, c, p, p) or merged (n, c, gh*p+2, gw*p+2); y: (n*gh*gw, c, p+2, p+2)
-__global__ void local_pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int c, int gh, int gw,
-                                     int p, int pad_mode, int merged) {
-  const int q = p + 2;
+// Small patches (p + 2 < 48): one whole (patch, channel) plane per wave iteration, lanes sweep the
+// flattened (p+2)^2 outputs with float-reciprocal index arithmetic.
+__global__ __launch_bounds__(256) void local_pad_fwd_flat_kernel(const float* __restrict__ x, float* __restrict__ y, int n,
+                                                                 int c, int gh, int gw, int p, int pad_mode, int merged) {
+  const int q = p + 2, qq = q * q;
   const int H = gh * p, W = gw * p;
-  int64_t total = (int64_t)n * gh * gw * c * q * q;
-  GRID_STRIDE(i, total) {
-    int64_t r = i;
-    int j = (int)(r % q); r /= q;
-    int ii = (int)(r % q); r /= q;
-    int ch = (int)(r % c); r /= c;
-    int gc = (int)(r % gw); r /= gw;
-    int gr = (int)(r % gh);
-    int nn = (int)(r / gh);
-    float v;
+  const float inv_q = 1.0f / (float)q, inv_p = 1.0f / (float)p;
+  const int64_t planes = (int64_t)n * gh * gw * c;
+  const int lane = threadIdx.x & 63;
+  const int pp = p * p;
+  for (int64_t plane = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); plane < planes; plane += (int64_t)gridDim.x * 4) {
+    int64_t r = plane;
+    const int ch = (int)(r % c); r /= c;
+    const int gc = (int)(r % gw); r /= gw;
+    const int gr = (int)(r % gh);
+    const int nn = (int)(r / gh);
+    float* dst = y + plane * qq;
     if (merged) {
-      v = x[(((int64_t)nn * c + ch) * (H + 2) + gr * p + ii) * (W + 2) + gc * p + j];
-    } else {
-      int Y = gr * p + ii - 1, X = gc * p + j - 1;
+      const float* src = x + (((int64_t)nn * c + ch) * (H + 2) + gr * p) * (W + 2) + gc * p;
+      for (int idx = lane; idx < qq; idx += 64) {
+        int i = fdiv_small(idx, inv_q), j = idx - i * q;
+        dst[idx] = src[(int64_t)i * (W + 2) + j];
+      }
+      continue;
+    }
+    const int64_t img = (int64_t)nn * gh * gw;
+    for (int idx = lane; idx < qq; idx += 64) {
+      int i = fdiv_small(idx, inv_q), j = idx - i * q;
+      int Y = gr * p + i - 1, X = gc * p + j - 1;
       bool ok = true;
       if (pad_mode == ITG_PAD_REPLICATE) { Y = min(max(Y, 0), H - 1); X = min(max(X, 0), W - 1); }
       else ok = (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
-      v = 0.f;
+      float v = 0.f;
       if (ok) {
-        int sr = Y / p, sc = X / p;
-        v = x[((((int64_t)nn * gh + sr) * gw + sc) * c + ch) * p * p + (Y - sr * p) * p + (X - sc * p)];
+        int sr = fdiv_small(Y, inv_p), sc = fdiv_small(X, inv_p);
+        v = x[((img + sr * gw + sc) * c + ch) * pp + (Y - sr * p) * p + (X - sc * p)];
+      }
+      dst[idx] = v;
+    }
+  }
+}
+
+// Work item = 8 output rows of one (patch, channel) plane, one wave per item: the plane's grid position
+// is wave-uniform, lanes sweep columns, so there is no per-element division at all and every read / write
+// is a contiguous run of a row.
+constexpr int LP_RB = 8;
+__global__ __launch_bounds__(256) void local_pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int c,
+                                                            int gh, int gw, int p, int pad_mode, int merged) {
+  const int q = p + 2, qq = q * q;
+  const int H = gh * p, W = gw * p;
+  const int nb = (q + LP_RB - 1) / LP_RB;
+  const int64_t items = (int64_t)n * gh * gw * c * nb;
+  const int lane = threadIdx.x & 63;
+  const int pp = p * p;
+  for (int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < items; item += (int64_t)gridDim.x * 4) {
+    const int band = (int)(item % nb);
+    int64_t plane = item / nb, r = plane;
+    const int ch = (int)(r % c); r /= c;
+    const int gc = (int)(r % gw); r /= gw;
+    const int gr = (int)(r % gh);
+    const int nn = (int)(r / gh);
+    float* dst = y + plane * qq;
+    const int i1 = min(q, (band + 1) * LP_RB);
+    if (merged) {
+      const float* src = x + (((int64_t)nn * c + ch) * (H + 2) + gr * p) * (W + 2) + gc * p;
+      for (int i = band * LP_RB; i < i1; ++i)
+        for (int j = lane; j < q; j += 64) dst[i * q + j] = src[(int64_t)i * (W + 2) + j];
+      continue;
+    }
+    const int64_t img = (int64_t)nn * gh * gw;
+    for (int i = band * LP_RB; i < i1; ++i) {
+      int Y = gr * p + i - 1;
+      bool oky = true;
+      if (pad_mode == ITG_PAD_REPLICATE) Y = min(max(Y, 0), H - 1);
+      else oky = (unsigned)Y < (unsigned)H;
+      const int Yc = min(max(Y, 0), H - 1);
+      const int sr = Yc / p;                                 // wave-uniform
+      const int64_t rowbase = ((img + (int64_t)sr * gw) * c + ch) * pp + (int64_t)(Yc - sr * p) * p;
+      for (int j = lane; j < q; j += 64) {
+        int X = gc * p + j - 1;
+        bool ok = oky;
+        if (pad_mode == ITG_PAD_REPLICATE) X = min(max(X, 0), W - 1);
+        else ok = ok && (unsigned)X < (unsigned)W;
+        const int Xc = min(max(X, 0), W - 1);
+        const int sc = (Xc >= (gc + 1) * p) ? gc + 1 : (Xc < gc * p ? gc - 1 : gc);
+        float v = x[rowbase + (int64_t)sc * c * pp + (Xc - sc * p)];
+        dst[i * q + j] = ok ? v : 0.f;
       }
     }
-    y[i] = v;
   }
 }
 
@@ -261,23 +322,39 @@ __global__ void local_pad_bwd_kernel(const float* __restrict__ dy, float* __rest
     }
     return;
   }
-  int64_t total = (int64_t)n * gh * gw * c * p * p;
-  GRID_STRIDE(i, total) {
-    int64_t r = i;
-    int x = (int)(r % p); r /= p;
-    int y = (int)(r % p); r /= p;
-    int ch = (int)(r % c); r /= c;
-    int gc = (int)(r % gw); r /= gw;
-    int gr = (int)(r % gh);
-    int nn = (int)(r / gh);
-    int Y = gr * p + y, X = gc * p + x;
-    int ry[6], iy[6], rx[6], ix[6];
-    int cy = sources_of(Y, H, p, gh, pad_mode, ry, iy), cx = sources_of(X, W, p, gw, pad_mode, rx, ix);
-    float s = 0.f;
-    for (int a = 0; a < cy; ++a)
-      for (int b = 0; b < cx; ++b)
-        s += dy[(((((int64_t)nn * gh + ry[a]) * gw + rx[b]) * c + ch) * q + iy[a]) * q + ix[b]];
-    dx[i] = s;
+  // work item = 8 rows of one (patch, channel) plane; interior pixels have exactly one reader (own window)
+  const int pp = p * p, qq = q * q;
+  const int nb = (p + LP_RB - 1) / LP_RB;
+  const int64_t items = (int64_t)n * gh * gw * c * nb;
+  const int lane = threadIdx.x & 63;
+  for (int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < items; item += (int64_t)gridDim.x * 4) {
+    const int band = (int)(item % nb);
+    int64_t plane = item / nb, r = plane;
+    const int ch = (int)(r % c); r /= c;
+    const int gc = (int)(r % gw); r /= gw;
+    const int gr = (int)(r % gh);
+    const int nn = (int)(r / gh);
+    const float* own = dy + plane * qq;
+    float* dst = dx + plane * pp;
+    const int y1 = min(p, (band + 1) * LP_RB);
+    for (int y = band * LP_RB; y < y1; ++y) {
+      const bool rowin = y >= 1 && y <= p - 2;
+      if (rowin)   // interior columns: one reader, no divergence
+        for (int x = 1 + lane; x <= p - 2; x += 64) dst[y * p + x] = own[(y + 1) * q + x + 1];
+      // patch-border pixels: whole rows 0 / p-1, else just the two edge columns (lanes 0 and 1)
+      for (int k = lane; k < (rowin ? 2 : p); k += 64) {
+        const int x = rowin ? (k == 0 ? 0 : p - 1) : k;
+        if (rowin && p == 1 && k == 1) continue;
+        int Y = gr * p + y, X = gc * p + x;
+        int ry[6], iy[6], rx[6], ix[6];
+        int cy = sources_of(Y, H, p, gh, pad_mode, ry, iy), cx = sources_of(X, W, p, gw, pad_mode, rx, ix);
+        float s = 0.f;
+        for (int a = 0; a < cy; ++a)
+          for (int b2 = 0; b2 < cx; ++b2)
+            s += dy[(((((int64_t)nn * gh + ry[a]) * gw + rx[b2]) * c + ch) * q + iy[a]) * q + ix[b2]];
+        dst[y * p + x] = s;
+      }
+    }
   }
 }
 
@@ -438,9 +515,16 @@ int itg_grid_to_nchw(const itg_tensor* src, float* dst, int merged_dst, void* st
 int itg_local_pad_fwd(const float* x, float* y, int n, int c, int gh, int gw, int p, int pad_mode, int merged,
                       void* stream) {
   if (!x || !y || n <= 0 || c <= 0 || gh <= 0 || gw <= 0 || p <= 0) return ITG_ERR_ARG;
-  int64_t total = (int64_t)n * gh * gw * c * (p + 2) * (p + 2);
-  hipLaunchKernelGGL(local_pad_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, n, c, gh,
-                     gw, p, pad_mode, merged);
+  if (p + 2 > 2000) return ITG_ERR_ARG;
+  if (p + 2 < 48) {
+    int64_t planes = (int64_t)n * gh * gw * c;
+    hipLaunchKernelGGL(local_pad_fwd_flat_kernel, dim3(blocks_for(planes, 4, 65536)), dim3(256), 0, (hipStream_t)stream, x,
+                       y, n, c, gh, gw, p, pad_mode, merged);
+  } else {
+    int64_t items = (int64_t)n * gh * gw * c * ((p + 2 + LP_RB - 1) / LP_RB);
+    hipLaunchKernelGGL(local_pad_fwd_kernel, dim3(blocks_for(items, 4, 65536)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       n, c, gh, gw, p, pad_mode, merged);
+  }
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }
@@ -448,9 +532,11 @@ int itg_local_pad_fwd(const float* x, float* y, int n, int c, int gh, int gw, in
 int itg_local_pad_bwd(const float* dy, float* dx, int n, int c, int gh, int gw, int p, int pad_mode, int merged,
                       void* stream) {
   if (!dy || !dx || n <= 0 || c <= 0 || gh <= 0 || gw <= 0 || p <= 0) return ITG_ERR_ARG;
-  int64_t total = merged ? (int64_t)n * c * (gh * p + 2) * (gw * p + 2) : (int64_t)n * gh * gw * c * p * p;
-  hipLaunchKernelGGL(local_pad_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, n, c,
-                     gh, gw, p, pad_mode, merged);
+  if (p + 2 > 2000) return ITG_ERR_ARG;
+  int64_t total = merged ? (int64_t)n * c * (gh * p + 2) * (gw * p + 2) : (int64_t)n * gh * gw * c * ((p + LP_RB - 1) / LP_RB);
+  int nb = merged ? blocks_for(total) : blocks_for(total, 4, 65536);
+  hipLaunchKernelGGL(local_pad_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, dx, n, c, gh, gw, p,
+                     pad_mode, merged);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }
