@@ -289,7 +289,7 @@ int itg_bn_stats(const itg_tensor* x, double* sums, void* stream) {
   if (!sums || x->ld > MAX_LD) return ITG_ERR_ARG;
   int64_t npix = grid_pixels(x);
   int q4 = x->ld >> 2;
-  int blocks = sweep_blocks(npix * q4, q4, 8, 2048);
+  int blocks = sweep_blocks(npix * q4, q4, 8, 512);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, npix,
                      x->ld, sums);
   ITG_CHECK_LAUNCH();
@@ -345,7 +345,7 @@ int itg_bn_bwd_reduce(const itg_tensor* x, const itg_tensor* dy, const float* ab
   if ((rc = ups_mode(x, dy, &ups))) return rc;
   int64_t npix = grid_pixels(x);
   int q4 = x->ld >> 2;
-  int blocks = sweep_blocks(npix * q4, q4, 8, 2048);
+  int blocks = sweep_blocks(npix * q4, q4, 8, 512);
   if (ups)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        (const float*)x->ptr, (const float*)dy->ptr, ab, mean_rstd, npix, x->ld, x->ph, x->pw, act,

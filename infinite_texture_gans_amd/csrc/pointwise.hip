@@ -300,6 +300,46 @@ __device__ __forceinline__ int sources_of(int Y, int H, int p, int g, int pad_mo
   return cnt;
 }
 
+// Readers of merged coordinate Y along one axis as <= 4 (window, in-window index) pairs held in
+// registers (fixed slots, fully unrolled use - runtime-indexed local arrays would live in scratch).
+struct AxisReaders { int r[4], i[4], n; };
+__device__ __forceinline__ void axis_add(AxisReaders& a, int Yp, int p, int g) {
+  const int q0 = (Yp + 1 >= 0) ? (Yp + 1) / p : -1;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int r = q0 - d, i = Yp + 1 - r * p;
+    const bool ok = r >= 0 && r < g && i >= 0 && i <= p + 1 && a.n < 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (ok && a.n == k) { a.r[k] = r; a.i[k] = i; }
+    a.n += ok ? 1 : 0;
+  }
+}
+__device__ __forceinline__ AxisReaders axis_readers(int Y, int H, int p, int g, int pad_mode) {
+  AxisReaders a;
+  a.n = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { a.r[k] = 0; a.i[k] = 0; }
+  axis_add(a, Y, p, g);
+  if (pad_mode == ITG_PAD_REPLICATE) {
+    if (Y == 0) axis_add(a, -1, p, g);
+    if (Y == H - 1) axis_add(a, H, p, g);
+  }
+  return a;
+}
+__device__ __forceinline__ float gather_readers(const float* __restrict__ dy, int64_t img_base, int ch, int c, int gh,
+                                                int gw, int p, int q, int H, int W, int Y, int X, int pad_mode) {
+  const AxisReaders ay = axis_readers(Y, H, p, gh, pad_mode), ax = axis_readers(X, W, p, gw, pad_mode);
+  float s = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (a < ay.n && b < ax.n)
+        s += dy[((((img_base + ay.r[a]) * gw + ax.r[b]) * c + ch) * q + ay.i[a]) * q + ax.i[b]];
+  return s;
+}
+
 __global__ void local_pad_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int n, int c, int gh, int gw,
                                      int p, int pad_mode, int merged) {
   const int q = p + 2;
@@ -345,14 +385,7 @@ __global__ void local_pad_bwd_kernel(const float* __restrict__ dy, float* __rest
       for (int k = lane; k < (rowin ? 2 : p); k += 64) {
         const int x = rowin ? (k == 0 ? 0 : p - 1) : k;
         if (rowin && p == 1 && k == 1) continue;
-        int Y = gr * p + y, X = gc * p + x;
-        int ry[6], iy[6], rx[6], ix[6];
-        int cy = sources_of(Y, H, p, gh, pad_mode, ry, iy), cx = sources_of(X, W, p, gw, pad_mode, rx, ix);
-        float s = 0.f;
-        for (int a = 0; a < cy; ++a)
-          for (int b2 = 0; b2 < cx; ++b2)
-            s += dy[(((((int64_t)nn * gh + ry[a]) * gw + rx[b2]) * c + ch) * q + iy[a]) * q + ix[b2]];
-        dst[y * p + x] = s;
+        dst[y * p + x] = gather_readers(dy, (int64_t)nn * gh, ch, c, gh, gw, p, q, H, W, gr * p + y, gc * p + x, pad_mode);
       }
     }
   }
