@@ -292,8 +292,22 @@ class StochasticSpatialModulation(nn.Module):
     def run(self, x, maps, act=ops.ACT_NONE, slope=0.0):
         """x: GT (n,gh,gw,r,r); maps: NCHW (n*gh*gw, map_dim, r+4, r+4) or an equivalent 1x1-grid GT."""
         m = maps if isinstance(maps, GT) else ops.to_grid(maps.float(), 1, 1, merged=True)
-        a = self.mlp_shared[0].run(m, pad=self.p, act=ops.ACT_LRELU, slope=0.0)
-        e = self.embed.run(a, pad=self.p)
+        nb = m.t.shape[0]
+        # the 128-channel hidden map is the largest tensor of the model: at inference (thousands of patches)
+        # the per-patch map convs run in chunks so that it stays below the 32-bit offset range of the kernels
+        per_patch = 128 * m.t.shape[3] * m.t.shape[4]
+        chunk = max(1, min(nb, (1 << 29) // max(1, per_patch)))
+        if chunk >= nb or torch.is_grad_enabled():
+            a = self.mlp_shared[0].run(m, pad=self.p, act=ops.ACT_LRELU, slope=0.0)
+            e = self.embed.run(a, pad=self.p)
+        else:
+            parts = []
+            for i in range(0, nb, chunk):
+                mi = GT(m.t[i:i + chunk], m.c)
+                ai = self.mlp_shared[0].run(mi, pad=self.p, act=ops.ACT_LRELU, slope=0.0)
+                parts.append(self.embed.run(ai, pad=self.p).t)
+                del ai
+            e = GT(torch.cat(parts, 0), 2 * self.in_channel)
         n, gh, gw, ph, pw, _ = x.t.shape
         if e.t.shape[3] != ph or e.t.shape[4] != pw or e.t.shape[0] != n * gh * gw:
             raise ValueError("modulation map does not match the activation: %r vs %r" % (e, x))
