@@ -92,11 +92,13 @@ def gpu_leg(a):
     losses = [float(v) for v in losses]
 
     # ---- per-kernel launch durations (HIP events on the launching stream), one extra step
+    # (every rank runs this iteration: it contains the sync-BN / gradient collectives)
     roof = None
     if rank == 0:
         ops.PROFILE = []
-        tr.step(reals[0], zs[-1])
-        torch.cuda.synchronize()
+    tr.step(reals[0], zs[-1])
+    torch.cuda.synchronize()
+    if rank == 0:
         agg = {}
         for tag, launches, flops, e0, e1 in ops.PROFILE:
             d = agg.setdefault(tag, [0, 0.0, 0.0])
