@@ -113,8 +113,10 @@ int itg_local_pad_nhwc_fwd(const itg_tensor* x, const itg_tensor* y, int pad_mod
 
 /* eval-mode streaming variant (layers.py:84-143): left column / top row carried from
  * earlier sub-images; left/top may be NULL (then outer padding on that side).
- * left: (n, gh*p, ld) column; top: (n, gw*p+2, ld) row incl. its two corner pixels.   */
-int itg_local_pad_stream_fwd(const itg_tensor* x, const float* left, const float* top,
+ * left: (n, gh*p, ld) column; top: (n, gw*p+2, ld) row incl. its two corner pixels.
+ * bottom: same shape as top - the halo row of the patch row BELOW when the patch grid is sharded
+ * by rows across GPUs (the row arrives over RCCL); NULL = outer padding.                  */
+int itg_local_pad_stream_fwd(const itg_tensor* x, const float* left, const float* top, const float* bottom,
                              const itg_tensor* y, int pad_mode, void* stream);
 
 /* ---- layout conversion at the NCHW boundary -------------------------------------------- */

@@ -393,7 +393,7 @@ __global__ void local_pad_bwd_kernel(const float* __restrict__ dy, float* __rest
 
 // patch-grid NHWC -> patch-grid NHWC with a 1-px halo; left/top carried halos optional
 __global__ void local_pad_nhwc_kernel(GridT s, GridT d, const float* __restrict__ left, const float* __restrict__ top,
-                                      int pad_mode) {
+                                      const float* __restrict__ bottom, int pad_mode) {
   const int q4 = d.ld >> 2;
   int64_t total = (int64_t)d.n * d.gh * d.gw * d.ph * d.pw * q4;
   GRID_STRIDE(i, total) {
@@ -409,6 +409,10 @@ __global__ void local_pad_nhwc_kernel(GridT s, GridT d, const float* __restrict_
     bool done = false;
     if (Y == -1 && top) {
       v = *reinterpret_cast<const f32x4*>(top + ((int64_t)n * (s.W + 2) + X + 1) * s.ld + c4 * 4);
+      done = true;
+    }
+    if (Y == s.H && bottom) {   // halo row received from the rank that owns the patch row below
+      v = *reinterpret_cast<const f32x4*>(bottom + ((int64_t)n * (s.W + 2) + X + 1) * s.ld + c4 * 4);
       done = true;
     }
     if (!done) {
@@ -584,17 +588,17 @@ static int pad_check(const itg_tensor* x, const itg_tensor* y) {
 }
 
 int itg_local_pad_nhwc_fwd(const itg_tensor* x, const itg_tensor* y, int pad_mode, void* stream) {
-  return itg_local_pad_stream_fwd(x, nullptr, nullptr, y, pad_mode, stream);
+  return itg_local_pad_stream_fwd(x, nullptr, nullptr, nullptr, y, pad_mode, stream);
 }
 
-int itg_local_pad_stream_fwd(const itg_tensor* x, const float* left, const float* top, const itg_tensor* y,
-                             int pad_mode, void* stream) {
+int itg_local_pad_stream_fwd(const itg_tensor* x, const float* left, const float* top, const float* bottom,
+                             const itg_tensor* y, int pad_mode, void* stream) {
   int rc = pad_check(x, y);
   if (rc) return rc;
   GridT s = make_grid(x), d = make_grid(y);
   int64_t total = grid_pixels(y) * (y->ld >> 2);
   hipLaunchKernelGGL(local_pad_nhwc_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, s, d, left, top,
-                     pad_mode);
+                     bottom, pad_mode);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }

@@ -58,3 +58,67 @@ def max_over_ranks(seconds, device, sync):
     if sync is not None and sync.world > 1:
         sync.dist.all_reduce(t, op=sync.dist.ReduceOp.MAX, group=sync.group)
     return float(t)
+
+
+# ------------------------------------------------------------------------------- patch-grid row sharding
+class RowHalo:
+    """Halo exchange for a patch grid sharded by patch ROWS over ranks (rank r owns a contiguous band
+    of patch rows; outer borders stay local).  Before every 3x3 conv each rank sends its first pixel
+    row up and its last pixel row down and receives the neighbours' rows: two messages of
+    n * W * ld floats per conv layer and direction, posted together (batch_isend_irecv -> one RCCL
+    group call over the two xGMI links involved).  Rows are (n, W, ld) fp32 tensors."""
+
+    def __init__(self, rank, world, group=None):
+        self.rank, self.world, self.group = rank, world, group
+
+    def band(self, total_rows):
+        """[a, b) patch rows of this rank (contiguous, as equal as possible, none empty)."""
+        if self.world > total_rows:
+            raise ValueError("cannot shard %d patch rows over %d ranks" % (total_rows, self.world))
+        base, extra = divmod(total_rows, self.world)
+        a = self.rank * base + min(self.rank, extra)
+        return a, a + base + (1 if self.rank < extra else 0)
+
+    def exchange(self, first_row, last_row):
+        """-> (top, bottom): the row above this band / below it, or None at the grid's outer border."""
+        import torch.distributed as dist
+        ops, top, bottom = [], None, None
+        if self.rank > 0:
+            top = torch.empty_like(first_row)
+            ops += [dist.P2POp(dist.isend, first_row, self.rank - 1, self.group),
+                    dist.P2POp(dist.irecv, top, self.rank - 1, self.group)]
+        if self.rank < self.world - 1:
+            bottom = torch.empty_like(last_row)
+            ops += [dist.P2POp(dist.isend, last_row, self.rank + 1, self.group),
+                    dist.P2POp(dist.irecv, bottom, self.rank + 1, self.group)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return top, bottom
+
+
+class ThreadRowHalo(RowHalo):
+    """Same protocol between Python threads of ONE process (all bands on one GPU): used to validate the
+    sharded path against the unsharded result on a single-GPU box."""
+
+    class Shared:
+        def __init__(self, world):
+            import threading
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.first = [None] * world
+            self.last = [None] * world
+
+    def __init__(self, rank, shared):
+        super().__init__(rank, shared.world)
+        self.shared = shared
+
+    def exchange(self, first_row, last_row):
+        s = self.shared
+        s.first[self.rank], s.last[self.rank] = first_row, last_row
+        torch.cuda.synchronize() if first_row.is_cuda else None
+        s.barrier.wait()
+        top = s.last[self.rank - 1].clone() if self.rank > 0 else None
+        bottom = s.first[self.rank + 1].clone() if self.rank < self.world - 1 else None
+        s.barrier.wait()
+        return top, bottom

@@ -131,6 +131,7 @@ class LocalPadder(nn.Module):
         super().__init__()
         self.merge_patches_into_image = merge_patches_into_image
         self._cfg = None
+        self.halo = None       # dist.RowHalo when the patch grid is sharded by rows across ranks
         self.reset_state()
 
     def pin(self, gh, gw, outer):
@@ -224,6 +225,8 @@ class conv2d_lp(nn.Module):
         if not lp.merge_patches_into_image:
             # valid conv over the pre-padded merged latent == crop(b+2, stride b) + valid conv per patch
             return self.conv.run(x, pad=0, act=act, slope=slope, residual=residual, out_grid=(gh, gw))
+        if lp.halo is not None:
+            return self._forward_row_sharded(x, lp, outer, act, slope, residual)
         if lp.training:
             # halo + outer padding are resolved inside the conv's tile loader
             return self.conv.run(x, pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope, residual=residual)
@@ -236,6 +239,29 @@ class conv2d_lp(nn.Module):
         r = None if residual is None else GT(residual.t.reshape(n * g1 * g2, 1, 1, ph - 2, pw - 2, -1), residual.c)
         y = self.conv.run(flat, pad=0, act=act, slope=slope, residual=r)
         return GT(y.t.reshape(n, g1, g2, ph - 2, pw - 2, -1), y.c)
+
+    def _forward_row_sharded(self, x, lp, outer, act, slope, residual):
+        """This rank owns a band of patch rows: fetch the neighbours' boundary pixel rows (RCCL send/recv),
+        build the padded patches with them (outer padding only at the true image border), valid conv."""
+        t = x.t
+        n, gh, gw, ph, pw, ld = t.shape
+        first = t[:, 0, :, 0, :, :].reshape(n, gw * pw, ld).contiguous()
+        last = t[:, gh - 1, :, ph - 1, :, :].reshape(n, gw * pw, ld).contiguous()
+        top, bottom = lp.halo.exchange(first, last)
+
+        def widen(row):     # + the two corner pixels: the columns are not sharded, so plain outer padding
+            if row is None:
+                return None
+            if outer == "replicate":
+                return torch.cat((row[:, :1], row, row[:, -1:]), 1).contiguous()
+            z = torch.zeros_like(row[:, :1])
+            return torch.cat((z, row, z), 1).contiguous()
+
+        xp = ops.local_pad_grid(x, _pad_mode(outer), top=widen(top), bottom=widen(bottom))
+        flat = GT(xp.t.reshape(n * gh * gw, 1, 1, ph + 2, pw + 2, ld), xp.c)
+        r = None if residual is None else GT(residual.t.reshape(n * gh * gw, 1, 1, ph, pw, -1), residual.c)
+        y = self.conv.run(flat, pad=0, act=act, slope=slope, residual=r)
+        return GT(y.t.reshape(n, gh, gw, ph, pw, -1), y.c)
 
     def forward(self, x, image_location="1st_row_1st_col"):
         if isinstance(x, GT):

@@ -613,13 +613,15 @@ def local_pad_nchw(x, gh, gw, pad_mode=PAD_REPLICATE, merged=False):
     return _LocalPad.apply(x, gh, gw, pad_mode, merged)
 
 
-def local_pad_grid(x, pad_mode=PAD_REPLICATE, left=None, top=None):
-    """Inference-side halo gather on GT tensors with optional carried left column / top row."""
+def local_pad_grid(x, pad_mode=PAD_REPLICATE, left=None, top=None, bottom=None):
+    """Inference-side halo gather on GT tensors with optional carried left column / top row (streaming)
+    and top / bottom halo rows received from neighbouring ranks (row-sharded patch grid)."""
     t = x.t.contiguous()
     n, gh, gw, ph, pw, ld = t.shape
     y = torch.empty((n, gh, gw, ph + 2, pw + 2, ld), device=t.device, dtype=torch.float32)
     a, b = _desc(t, x.c), _desc(y, x.c)
-    _lib.call("itg_local_pad_stream_fwd", C.byref(a), _ptr(left), _ptr(top), C.byref(b), pad_mode, _stream())
+    _lib.call("itg_local_pad_stream_fwd", C.byref(a), _ptr(left), _ptr(top), _ptr(bottom), C.byref(b), pad_mode,
+              _stream())
     return GT(y, x.c)
 
 

@@ -40,7 +40,18 @@ def main(argv=None):
     a = build_parser().parse_args(argv)
     if not torch.cuda.is_available():
         raise RuntimeError("no GPU visible: this build runs on MI355X only")
-    device = torch.device("cuda:0")
+    world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    halo = None
+    if world > 1:
+        # torch.distributed.run --nproc-per-node N test_sample.py ...: the patch grid is sharded by patch rows,
+        # one band per GPU, with a halo-row exchange (RCCL send/recv) before every 3x3 conv
+        import torch.distributed as dist
+        from .dist import RowHalo
+        dist.init_process_group("nccl", device_id=device)
+        halo = RowHalo(rank, world, dist.group.WORLD)
     folder = os.path.dirname(a.model_path)
     ckpt = torch.load(a.model_path, map_location='cpu', weights_only=False)   # args is a pickled Namespace
     args = ckpt['args']
@@ -50,9 +61,22 @@ def main(argv=None):
         map_dim=1, padding_mode=args.padding_mode, outer_padding=args.outer_padding, num_patches_h=3,
         num_patches_w=3, padding_size=1, conv_reduction=2)
     netG = load_G(ckpt['netG_state_dict'], netG).to(device)
-    print(args)
+    if rank == 0:
+        print(args)
     with torch.no_grad():
-        if args.padding_mode == 'local':
+        if args.padding_mode == 'local' and halo is not None:
+            seed = int(os.environ.get("ITG_SAMPLE_SEED", torch.seed() if world == 1 else 1234))
+            torch.manual_seed(seed)                      # every rank draws the SAME full-grid latents
+            strip = U.sample_from_gen_PatchByPatch_test(
+                netG, z_dim=args.z_dim, num_images=1, output_resolution_height=a.output_resolution_height,
+                output_resolution_width=a.output_resolution_width, device=device, halo=halo)
+            import torch.distributed as dist
+            strips = [None] * world if rank == 0 else None
+            dist.gather_object(strip, strips, dst=0)
+            if rank != 0:
+                return
+            img = torch.cat(strips, -2)
+        elif args.padding_mode == 'local':
             img = U.sample_from_gen_PatchByPatch_test(
                 netG, z_dim=args.z_dim, num_images=1, output_resolution_height=a.output_resolution_height,
                 output_resolution_width=a.output_resolution_width, device=device).cpu()

@@ -258,7 +258,7 @@ def tiling_plan(n_layers_G, base_res, num_patches_height, num_patches_width, out
 def sample_from_gen_PatchByPatch_test(netG, z_dim=128, base_res=4, map_dim=1, num_images=1, num_patches_height=3,
                                       num_patches_width=3, device="cpu", output_resolution_height=384,
                                       output_resolution_width=384, z_full=None, maps_full=None,
-                                      one_shot=None):
+                                      one_shot=None, halo=None):
     """Generate one large image (reference utils.py:258-397).
 
     Default (``one_shot=None``): generators without attention run ONE forward over the whole
@@ -280,6 +280,12 @@ def sample_from_gen_PatchByPatch_test(netG, z_dim=128, base_res=4, map_dim=1, nu
     if one_shot is None:
         one_shot = not g.attention
     with torch.no_grad():
+        if halo is not None:
+            # patch grid sharded by patch rows over halo.world ranks; returns THIS rank's strip of rows
+            if g.attention:
+                raise ValueError("row-sharded generation needs a generator without attention (SURVEY.md F7)")
+            return _generate_row_sharded(g, z_full, maps_full, t_h, t_w, base_res, device, halo, p,
+                                         output_resolution_height, output_resolution_width)
         if one_shot:
             return _generate_one_shot(g, z_full, maps_full, t_h, t_w, base_res, device)[
                 :, :, :output_resolution_height, :output_resolution_width]
@@ -307,6 +313,38 @@ def _generate_one_shot(g, z_full, maps_full, t_h, t_w, base_res, device):
         for m in pads:
             m.pin(saved[0], saved[1], g.outer_padding)
             m.reset_state()
+
+
+def _generate_row_sharded(g, z_full, maps_full, t_h, t_w, base_res, device, halo, p, out_h, out_w):
+    """One-shot generation with the T_h x T_w patch grid split by patch rows over the ranks of ``halo``
+    (dist.RowHalo): every 3x3 conv exchanges one pixel row with each neighbour.  Latents are the SAME
+    full-grid tensors on every rank (same seed); each rank cuts out its band (+ the latent's own halo)."""
+    from .models.layers import LocalPadder
+    a, b = halo.band(t_h)
+    pads = [m for m in g.modules() if isinstance(m, LocalPadder)]
+    saved = (g.num_patches_h, g.num_patches_w)
+    try:
+        g.num_patches_h, g.num_patches_w = b - a, t_w
+        for m in pads:
+            m.pin(b - a, t_w, g.outer_padding)
+            m.reset_state()
+            m.halo = halo if m.merge_patches_into_image else None
+        z_loc = z_full[:, :, a * base_res:b * base_res + 2, :].to(device)
+        maps = None
+        if maps_full is not None:
+            maps = []
+            for i in range(g.n_layers_G):
+                r = (2 ** i) * base_res
+                maps.append(crop_images(maps_full[i][:, :, a * r:b * r + 4, :].to(device), r + 4, r + 4, r))
+        strip = ops.to_nchw(g.forward_grid(z_loc, maps, "1st_row_1st_col"), merged=True).cpu()
+        lo, hi = a * p, min(b * p, out_h)
+        return strip[:, :, :max(0, hi - lo), :out_w]
+    finally:
+        g.num_patches_h, g.num_patches_w = saved
+        for m in pads:
+            m.pin(saved[0], saved[1], g.outer_padding)
+            m.reset_state()
+            m.halo = None
 
 
 def _generate_streamed(g, z_full, maps_full, steps_h, steps_w, p, base_res, nph, npw, device):

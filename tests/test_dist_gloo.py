@@ -104,3 +104,29 @@ def test_two_rank_sync_bn_and_flat_grad_allreduce_match_single_process(tmp_path)
     flat = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, ps)])
     err = float((got["flat"] - flat).norm() / flat.norm())
     assert err < 1e-5, err
+
+
+def halo_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from infinite_texture_gans_amd.dist import RowHalo
+        h = RowHalo(rank, world, dist.group.WORLD)
+        assert h.band(7) == [(0, 3), (3, 5), (5, 7)][rank]
+        first = torch.full((2, 5, 4), 10.0 * rank + 1)
+        last = torch.full((2, 5, 4), 10.0 * rank + 2)
+        top, bottom = h.exchange(first, last)
+        ok = (top is None) == (rank == 0) and (bottom is None) == (rank == world - 1)
+        if top is not None:
+            ok = ok and bool((top == 10.0 * (rank - 1) + 2).all())          # the LAST row of the band above
+        if bottom is not None:
+            ok = ok and bool((bottom == 10.0 * (rank + 1) + 1).all())       # the FIRST row of the band below
+        torch.save(ok, out + str(rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_halo_exchange_over_gloo(tmp_path):
+    out = str(tmp_path / "ok")
+    mp.spawn(halo_worker, args=(3, free_port(), out), nprocs=3, join=True)
+    assert all(torch.load(out + str(r)) for r in range(3))
