@@ -48,6 +48,7 @@ enum { ITG_ACT_NONE = 0, ITG_ACT_LRELU = 1, ITG_ACT_TANH = 2 };
 typedef struct {
   int32_t kh, kw, stride, pad;
   int32_t pad_mode; /* ITG_PAD_*: how reads outside the merged image resolve */
+  int32_t pad_h;    /* vertical padding when it differs from `pad` (row-sharded grids: 0); < 0 = same as pad */
 } itg_conv_geom;
 
 int itg_version(void);

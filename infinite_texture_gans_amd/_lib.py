@@ -20,7 +20,10 @@ class Tensor(C.Structure):
 
 class ConvGeom(C.Structure):
     _fields_ = [("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
-                ("pad_mode", C.c_int32)]
+                ("pad_mode", C.c_int32), ("pad_h", C.c_int32)]
+
+    def __init__(self, kh, kw, stride, pad, pad_mode, pad_h=-1):
+        super().__init__(kh, kw, stride, pad, pad_mode, pad_h)
 
 
 _P = C.c_void_p

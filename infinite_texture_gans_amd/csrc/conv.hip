@@ -676,7 +676,7 @@ struct WgP {
   float* dbslab;     // [splits][co_pad] bias-gradient partials, or null
   int ntaps, kw, cin_ld, Kpad, Ktot;
   int MT, MU, M;     // output-pixel domain of the conv
-  int stride, pad, pad_mode;
+  int stride, pad, pad_h, pad_mode;
   int co_rows, ncol_tiles, nco_tiles;
   int chunks_per_split, nchunks;
   unsigned x_bytes, dy_bytes;
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const bool live = xn[i] < p.x.n;
-      int iy = xt[i] * p.stride - p.pad + xky[i], ix = xu[i] * p.stride - p.pad + xkx[i];
+      int iy = xt[i] * p.stride - p.pad_h + xky[i], ix = xu[i] * p.stride - p.pad + xkx[i];
       bool ok = xok[i] && live;
       if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.x.H && (unsigned)ix < (unsigned)p.x.W;
       iy = min(max(iy, 0), p.x.H - 1); ix = min(max(ix, 0), p.x.W - 1);
@@ -937,6 +937,9 @@ TnPlan plan_tn(int64_t M, int co_ld, int Ktot) {
 }
 
 int conv_out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
+// vertical padding may differ from the horizontal one (row-sharded patch grids carry their halo rows
+// explicitly and pad only the columns): pad_h < 0 means "same as pad"
+inline int pad_v(const itg_conv_geom* g) { return g->pad_h >= 0 ? g->pad_h : g->pad; }
 
 }  // namespace
 
@@ -994,8 +997,8 @@ int64_t itg_conv2d_dgrad_workspace(const itg_tensor* dy, const itg_tensor* dx, c
   int co_rows = round_up(dx->c, 16);
   int64_t H = (int64_t)dx->gh * dx->ph, W = (int64_t)dx->gw * dx->pw;
   if (g->stride == 1) {
-    int e = (g->pad_mode == ITG_PAD_REPLICATE) ? 2 * g->pad : 0;
-    return plan_nt((int64_t)dx->n * (H + e) * (W + e), co_rows, round_up(g->kh * g->kw * dy->ld, BK)).ws_floats;
+    int eh = (g->pad_mode == ITG_PAD_REPLICATE) ? 2 * pad_v(g) : 0, ew = (g->pad_mode == ITG_PAD_REPLICATE) ? 2 * g->pad : 0;
+    return plan_nt((int64_t)dx->n * (H + eh) * (W + ew), co_rows, round_up(g->kh * g->kw * dy->ld, BK)).ws_floats;
   }
   int Kpad = round_up((g->kh / 2) * (g->kw / 2) * dy->ld, BK);
   int64_t Mmax = (int64_t)dx->n * ((H + 1) / 2) * ((W + 1) / 2);
@@ -1019,7 +1022,7 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
     p.res = make_grid(residual);
   }
   if (in->n != out->n) return ITG_ERR_ARG;
-  int Ho = conv_out_dim(p.in.H, g->kh, g->stride, g->pad), Wo = conv_out_dim(p.in.W, g->kw, g->stride, g->pad);
+  int Ho = conv_out_dim(p.in.H, g->kh, g->stride, pad_v(g)), Wo = conv_out_dim(p.in.W, g->kw, g->stride, g->pad);
   if (Ho != p.out.H || Wo != p.out.W) return ITG_ERR_ARG;
   if (g->pad_mode == ITG_PAD_REPLICATE && g->stride != 1) return ITG_ERR_ARG;
   p.w = w_packed; p.bias = bias;
@@ -1029,7 +1032,7 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   int64_t M = (int64_t)in->n * Ho * Wo;
   if (M >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
   p.M = (int)M;
-  p.isy = p.isx = g->stride; p.ioy = p.iox = -g->pad;
+  p.isy = p.isx = g->stride; p.ioy = -pad_v(g); p.iox = -g->pad;
   p.osy = p.osx = 1; p.ooy = p.oox = 0;
   p.pad_mode = g->pad_mode; p.out_mode = 0; p.act = act; p.slope = slope;
   p.co_rows = round_up(out->c, 16);
@@ -1048,7 +1051,8 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const it
   p.in = make_grid(dy);
   p.out = make_grid(dx);
   p.res = null_grid();
-  int Ho = conv_out_dim(p.out.H, g->kh, g->stride, g->pad), Wo = conv_out_dim(p.out.W, g->kw, g->stride, g->pad);
+  const int padh = pad_v(g);
+  int Ho = conv_out_dim(p.out.H, g->kh, g->stride, padh), Wo = conv_out_dim(p.out.W, g->kw, g->stride, g->pad);
   if (Ho != p.in.H || Wo != p.in.W) return ITG_ERR_ARG;
   p.bias = nullptr; p.act = ITG_ACT_NONE; p.slope = 0.f;
   p.cin_ld = dy->ld;
@@ -1059,11 +1063,11 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const it
     p.ntaps = g->kh * g->kw; p.kw = g->kw;
     p.Kpad = round_up(p.ntaps * dy->ld, BK);
     p.isy = p.isx = 1; p.osy = p.osx = 1;
-    if (g->pad_mode == ITG_PAD_REPLICATE && g->pad > 0) {
+    if (g->pad_mode == ITG_PAD_REPLICATE && (g->pad > 0 || padh > 0)) {
       // padded domain, gradients of the replicated frame fold onto the edge pixels
-      p.MT = p.out.H + 2 * g->pad; p.MU = p.out.W + 2 * g->pad;
+      p.MT = p.out.H + 2 * padh; p.MU = p.out.W + 2 * g->pad;
       p.ioy = -(g->kh - 1); p.iox = -(g->kw - 1);
-      p.ooy = p.oox = -g->pad;
+      p.ooy = -padh; p.oox = -g->pad;
       p.out_mode = 1;
       GridT gx = p.out;
       int64_t tot = (int64_t)gx.n * (2 * gx.W + 2 * gx.H) * (gx.ld >> 2);
@@ -1072,7 +1076,7 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const it
       ITG_CHECK_LAUNCH();
     } else {
       p.MT = p.out.H; p.MU = p.out.W;
-      p.ioy = -(g->kh - 1 - g->pad); p.iox = -(g->kw - 1 - g->pad);
+      p.ioy = -(g->kh - 1 - padh); p.iox = -(g->kw - 1 - g->pad);
       p.ooy = p.oox = 0;
       p.out_mode = 0;
     }
@@ -1081,7 +1085,8 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const it
     p.M = (int)M;
     return dispatch_nt(p, workspace, workspace_floats, s);
   }
-  if (g->stride != 2 || g->pad != 1 || (g->kh & 1) || (g->kw & 1) || g->pad_mode != ITG_PAD_ZERO) return ITG_ERR_ARG;
+  if (g->stride != 2 || g->pad != 1 || padh != 1 || (g->kh & 1) || (g->kw & 1) || g->pad_mode != ITG_PAD_ZERO)
+    return ITG_ERR_ARG;
   int skh = g->kh / 2, skw = g->kw / 2;
   p.ntaps = skh * skw; p.kw = skw;
   p.Kpad = round_up(p.ntaps * dy->ld, BK);
@@ -1127,7 +1132,7 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
   WgP p;
   p.x = make_grid(x);
   p.dy = make_grid(dy);
-  int Ho = conv_out_dim(p.x.H, g->kh, g->stride, g->pad), Wo = conv_out_dim(p.x.W, g->kw, g->stride, g->pad);
+  int Ho = conv_out_dim(p.x.H, g->kh, g->stride, pad_v(g)), Wo = conv_out_dim(p.x.W, g->kw, g->stride, g->pad);
   if (Ho != p.dy.H || Wo != p.dy.W) return ITG_ERR_ARG;
   if (g->pad_mode == ITG_PAD_REPLICATE && g->stride != 1) return ITG_ERR_ARG;
   int64_t M = (int64_t)x->n * Ho * Wo;
@@ -1140,7 +1145,7 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
   p.slab = workspace;
   p.dbslab = db ? workspace + t.ws_floats : nullptr;       // [splits][co_rows] after the slabs
   p.MT = Ho; p.MU = Wo; p.M = (int)M;
-  p.stride = g->stride; p.pad = g->pad; p.pad_mode = g->pad_mode;
+  p.stride = g->stride; p.pad = g->pad; p.pad_h = pad_v(g); p.pad_mode = g->pad_mode;
   p.chunks_per_split = t.chunks_per_split; p.nchunks = t.nchunks;
   {
     int64_t xb = grid_pixels(x) * x->ld * 4, yb = grid_pixels(dy) * dy->ld * 4;

@@ -42,7 +42,7 @@ class SyncGroup:
 def average_flat_gradient(flat_grad, sync):
     """ONE all-reduce of a model's flat gradient buffer, then the 1/world factor of the global mean."""
     if sync is not None and sync.world > 1:
-        sync.dist.all_reduce(flat_grad, op=sync.dist.ReduceOp.SUM, group=sync.group)
+        sync.all_reduce(flat_grad)
         flat_grad.mul_(1.0 / sync.world)
     return flat_grad
 
@@ -82,6 +82,12 @@ class RowHalo:
     def exchange(self, first_row, last_row):
         """-> (top, bottom): the row above this band / below it, or None at the grid's outer border."""
         import torch.distributed as dist
+        if first_row.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal of the protocol with several ranks on ONE GPU (gloo has no device send/recv):
+            # stage the rows through host memory.  RCCL runs take the direct path below.
+            top, bottom = self.exchange(first_row.cpu(), last_row.cpu())
+            dev = first_row.device
+            return (None if top is None else top.to(dev)), (None if bottom is None else bottom.to(dev))
         ops, top, bottom = [], None, None
         if self.rank > 0:
             top = torch.empty_like(first_row)
@@ -122,3 +128,61 @@ class ThreadRowHalo(RowHalo):
         bottom = s.first[self.rank + 1].clone() if self.rank < self.world - 1 else None
         s.barrier.wait()
         return top, bottom
+
+
+# ------------------------------------------------------------------------------- row-sharded TRAINING
+class BandComm(RowHalo):
+    """Collectives of a train step whose patch grid is sharded by rows (BASELINE config 4):
+    halo rows per conv (exchange, also used by the backward for the halo gradients), sync-BN sums and
+    flat-gradient averaging (all_reduce), and the band -> full-image gather in front of the
+    discriminator (all_gather).  Backed by torch.distributed (RCCL on GPUs, gloo on CPU)."""
+
+    def __init__(self, rank, world, group=None):
+        super().__init__(rank, world, group)
+        import torch.distributed as dist
+        self.dist = dist
+
+    def all_reduce(self, t):
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def global_count(self, local_count):
+        """Images are split evenly over ranks in front of the discriminator."""
+        return local_count * self.world
+
+    def band_sync(self, total_rows):
+        """Statistics group for layers that run on this rank's band of ``total_rows`` patch rows."""
+        a, b = self.band(total_rows)
+        return _BandSync(self, total_rows, b - a)
+
+    def all_gather(self, t):
+        """list of every rank's tensor (bands may have different heights: sizes are exchanged first)."""
+        if t.is_cuda and self.dist.get_backend(self.group) == "gloo":      # one-GPU rehearsal, see exchange()
+            return [o.to(t.device) for o in self.all_gather(t.cpu())]
+        sizes = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(self.world)]
+        self.dist.all_gather(sizes, torch.tensor([t.shape[-2]], dtype=torch.int64, device=t.device), group=self.group)
+        outs = [torch.empty(t.shape[:-2] + (int(s), t.shape[-1]), dtype=t.dtype, device=t.device) for s in sizes]
+        if all(int(s) == t.shape[-2] for s in sizes):
+            self.dist.all_gather(outs, t.contiguous(), group=self.group)
+        else:
+            for r in range(self.world):      # ragged bands: one broadcast per rank
+                if r == self.rank:
+                    outs[r].copy_(t)
+                self.dist.broadcast(outs[r], src=r, group=self.group)
+        return outs
+
+
+class _BandSync:
+    """BatchNorm statistics over all bands: sums are all-reduced, and the pixel count scales by
+    total_rows / my_rows (bands may differ in height, every pixel row is equally wide)."""
+
+    def __init__(self, comm, total_rows, my_rows):
+        self.comm, self.world, self.total, self.mine = comm, comm.world, total_rows, my_rows
+
+    def all_reduce(self, t):
+        return self.comm.all_reduce(t)
+
+    def global_count(self, local_count):
+        assert (local_count * self.total) % self.mine == 0
+        return local_count * self.total // self.mine

@@ -188,3 +188,77 @@ class Trainer:
                 ops.axpby(e, b, d, 1.0 - d, out=e)
             else:   # int64 num_batches_tracked: float arithmetic, truncated on copy (train.py:178)
                 e.copy_(e * d + b * (1 - d))
+
+
+class BandTrainer(Trainer):
+    """The same iteration with the generator's patch grid sharded by patch ROWS over ranks (one fake
+    image larger than one GPU wants to hold: BASELINE config 4).
+
+    Rank r generates a band of patch rows of EVERY fake image: each 3x3 conv exchanges one pixel row
+    with each neighbour (forward) and the halo gradients travel back the same way (backward);
+    BatchNorm statistics are summed over bands.  In front of the discriminator the bands are gathered
+    into whole images and D runs data-parallel over images (rank r scores images r*n/W..), so the
+    gradient of a band is the sum over the ranks that scored its images.  Real crops are sharded over
+    ranks as in plain data parallelism.  Results equal the single-process step on the whole batch.
+
+    ``z`` handed to :meth:`step` is the FULL merged latent, identical on all ranks (same seed)."""
+
+    def __init__(self, netG, netD, args, device, comm, netG_ema=None):
+        super().__init__(netG, netD, args, device, netG_ema=netG_ema)
+        from .models.layers import LocalPadder
+        if netG.padding_mode != 'local':
+            raise ValueError("row sharding is defined for padding_mode='local'")
+        if netG.attention or netG.type_norm != 'BN':
+            raise NotImplementedError("band training covers the BN generator without attention")
+        self.comm, self.sync, self.world = comm, comm, comm.world
+        self.total_rows = netG.num_patches_h
+        self.band = comm.band(self.total_rows)
+        netG.set_sync(comm.band_sync(self.total_rows))
+        for m in netD.modules():
+            if isinstance(m, _BNParams):
+                m.sync = comm
+        for m in netG.modules():                         # the band is one "patch" in image layout
+            if isinstance(m, LocalPadder):
+                m.pin(1, 1, netG.outer_padding)
+                m.halo = comm if m.merge_patches_into_image else None
+
+    def _mine(self, n):
+        if n % self.world:
+            raise ValueError("batch of %d images does not split evenly over %d ranks" % (n, self.world))
+        k = n // self.world
+        return slice(self.comm.rank * k, (self.comm.rank + 1) * k)
+
+    def sample_fake(self, z, maps=None):
+        """-> this rank's share of whole fake images (NCHW), differentiable w.r.t. every band."""
+        a, b = self.band
+        r = self.netG.base_res
+        band = ops.to_nchw(self.netG.forward_grid(z[:, :, a * r:b * r + 2, :].contiguous(), None, "1st_row_1st_col"),
+                           merged=True)
+        full = ops.gather_rows(band, self.comm)
+        return full[self._mine(full.shape[0])].contiguous()
+
+    def step(self, real_x, z, maps=None):
+        """real_x: this rank's shard of real crops; z: the full merged latent (same on all ranks)."""
+        netD = self.netD
+        self.flatD.zero_grad()
+        d_real = self._d_loss(netD(real_x), True)
+        d_real.backward()
+        fake = self.sample_fake(z)
+        d_fake = self._d_loss(netD(fake.detach()), False)
+        d_fake.backward()
+        self._allreduce(self.flatD)
+        self.optD.step()
+        self.flatG.zero_grad()
+        for p in self.flatD.params:
+            p.requires_grad_(False)
+        try:
+            g_loss = self._g_loss(netD(fake))
+            g_loss.backward()
+        finally:
+            for p in self.flatD.params:
+                p.requires_grad_(True)
+        self._allreduce(self.flatG)
+        self.optG.step()
+        if self.netG_ema is not None:
+            self._ema_buffers()
+        return d_real.detach(), d_fake.detach(), g_loss.detach()

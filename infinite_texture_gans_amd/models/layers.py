@@ -68,10 +68,11 @@ class _ConvParams(nn.Module):
         b = self.bias
         return (w.grad, b.grad if (b is not None and b.grad is not None) else None)
 
-    def run(self, x, pad=None, pad_mode=ops.PAD_ZERO, act=ops.ACT_NONE, slope=0.0, residual=None, out_grid=None):
+    def run(self, x, pad=None, pad_mode=ops.PAD_ZERO, act=ops.ACT_NONE, slope=0.0, residual=None, out_grid=None,
+            pad_h=-1):
         w, sn = self.weight_and_sn()
         return ops.conv(x, w, self.bias, self.k, self.k, self.stride, self.padding if pad is None else pad,
-                        pad_mode, act, slope, residual, sn, out_grid, self._sinks(w))
+                        pad_mode, act, slope, residual, sn, out_grid, self._sinks(w), pad_h)
 
     def forward(self, x):
         """Plain conv on an NCHW image batch (zero padding), as the reference's nn.Conv2d."""
@@ -226,6 +227,8 @@ class conv2d_lp(nn.Module):
             # valid conv over the pre-padded merged latent == crop(b+2, stride b) + valid conv per patch
             return self.conv.run(x, pad=0, act=act, slope=slope, residual=residual, out_grid=(gh, gw))
         if lp.halo is not None:
+            if lp.training:
+                return self._forward_band_train(x, lp, outer, act, slope, residual)
             return self._forward_row_sharded(x, lp, outer, act, slope, residual)
         if lp.training:
             # halo + outer padding are resolved inside the conv's tile loader
@@ -239,6 +242,25 @@ class conv2d_lp(nn.Module):
         r = None if residual is None else GT(residual.t.reshape(n * g1 * g2, 1, 1, ph - 2, pw - 2, -1), residual.c)
         y = self.conv.run(flat, pad=0, act=act, slope=slope, residual=r)
         return GT(y.t.reshape(n, g1, g2, ph - 2, pw - 2, -1), y.c)
+
+    def _forward_band_train(self, x, lp, outer, act, slope, residual):
+        """Training with the patch grid sharded by rows: x is this rank's band in image layout
+        (n, 1, 1, H, W, ld).  The band is extended by the neighbours' boundary rows (differentiable RCCL
+        exchange; at the image border the outer padding row) and convolved with vertical padding 0."""
+        t = x.t
+        n, g1, g2, H, W, ld = t.shape
+        if g1 != 1 or g2 != 1:
+            raise ValueError("band training expects the image layout (1x1 grid), got %r" % (x,))
+        rows = t[:, 0, 0]
+        first, last = rows[:, 0], rows[:, H - 1]
+        top, bottom = ops.halo_exchange(first, last, lp.halo)
+        if top is None:
+            top = first if outer == "replicate" else torch.zeros_like(first)
+        if bottom is None:
+            bottom = last if outer == "replicate" else torch.zeros_like(last)
+        ext = torch.cat((top.unsqueeze(1), rows, bottom.unsqueeze(1)), 1).reshape(n, 1, 1, H + 2, W, ld)
+        return self.conv.run(GT(ext, x.c), pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope,
+                             residual=residual, pad_h=0)
 
     def _forward_row_sharded(self, x, lp, outer, act, slope, residual):
         """This rank owns a band of patch rows: fetch the neighbours' boundary pixel rows (RCCL send/recv),

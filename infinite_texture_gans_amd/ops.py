@@ -198,13 +198,14 @@ class _Conv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, residual, sn, c_in, geom, act, slope, out_grid, sinks=None):
-        kh, kw, stride, pad, pad_mode = geom
+        kh, kw, stride, pad, pad_mode, pad_h = geom
+        pv = pad_h if pad_h >= 0 else pad
         n, gh, gw, ph, pw, ld = x.shape
         co, ci = w.shape[0], w.shape[1]
         if ci != c_in or w.shape[2] != kh or w.shape[3] != kw:
             raise _lib.ItgError("weight %s does not match conv geometry (c_in=%d, k=%dx%d)" % (tuple(w.shape), c_in, kh, kw))
         H, W = gh * ph, gw * pw
-        Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+        Ho, Wo = (H + 2 * pv - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
         ogh, ogw = out_grid
         if Ho % ogh or Wo % ogw:
             raise _lib.ItgError("conv output %dx%d does not divide into a %dx%d grid" % (Ho, Wo, ogh, ogw))
@@ -216,7 +217,7 @@ class _Conv(torch.autograd.Function):
         out = torch.empty((n, ogh, ogw, Ho // ogh, Wo // ogw, ld_for(co)), device=x.device, dtype=torch.float32)
         dx_, do_ = _desc(x, c_in), _desc(out, co)
         dr_ = _desc(residual, co) if residual is not None else _null_desc()
-        g = _G(kh, kw, stride, pad, pad_mode)
+        g = _G(kh, kw, stride, pad, pad_mode, pad_h)
         nws = _lib.fn("itg_conv2d_fwd_workspace")(C.byref(dx_), C.byref(do_), C.byref(g))
         ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
         with _Prof(_nt_tag(co), 1, 2.0 * n * Ho * Wo * co * ci * kh * kw):
@@ -232,7 +233,7 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x, w, out = ctx.saved_tensors
-        kh, kw, stride, pad, pad_mode = ctx.geom
+        kh, kw, stride, pad, pad_mode, pad_h = ctx.geom
         co, ci = ctx.co, ctx.c_in
         st = _stream()
         dout = dout.contiguous()
@@ -242,7 +243,7 @@ class _Conv(torch.autograd.Function):
             _lib.call("itg_act_bwd", C.byref(a), C.byref(b), C.byref(c_), ctx.act, float(ctx.slope), st)
         else:
             dy = dout
-        g = _G(kh, kw, stride, pad, pad_mode)
+        g = _G(kh, kw, stride, pad, pad_mode, pad_h)
         ddy = _desc(dy, co)
         inv_sigma = ctx.sn[0] if ctx.sn is not None else None
         gx = gw_ = gb = None
@@ -293,13 +294,13 @@ class _Conv(torch.autograd.Function):
 
 
 def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, residual=None,
-         sn=None, out_grid=None, sinks=None):
+         sn=None, out_grid=None, sinks=None, pad_h=-1):
     """x: GT.  Returns GT with ``out_grid`` (default: the input grid).  ``sinks`` = (weight.grad, bias.grad)
     buffers: the backward then accumulates the parameter gradients straight into them (and reports no
     gradient to autograd), which removes one AccumulateGrad add kernel per parameter."""
     og = out_grid if out_grid is not None else (x.gh, x.gw)
     r = residual.t if residual is not None else None
-    t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode), act, slope, og, sinks)
+    t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode, pad_h), act, slope, og, sinks)
     return GT(t, w.shape[0])
 
 
@@ -623,6 +624,58 @@ def local_pad_grid(x, pad_mode=PAD_REPLICATE, left=None, top=None, bottom=None):
     _lib.call("itg_local_pad_stream_fwd", C.byref(a), _ptr(left), _ptr(top), _ptr(bottom), C.byref(b), pad_mode,
               _stream())
     return GT(y, x.c)
+
+
+# ------------------------------------------------------------------------------- row-sharded grids (training)
+class _HaloExchange(torch.autograd.Function):
+    """(first_row, last_row) of this rank's band -> (row above, row below).  The backward is the same
+    exchange applied to the halo gradients: the gradient of the row this rank sent up comes back as
+    the upper neighbour's bottom-halo gradient, and vice versa."""
+
+    @staticmethod
+    def forward(ctx, first, last, comm):
+        ctx.comm = comm
+        top, bottom = comm.exchange(first.contiguous(), last.contiguous())
+        ctx.has = (top is not None, bottom is not None)
+        ctx.shape = tuple(first.shape)
+        return (top if top is not None else first.new_zeros(0), bottom if bottom is not None else first.new_zeros(0))
+
+    @staticmethod
+    def backward(ctx, dtop, dbottom):
+        z = lambda: torch.zeros(ctx.shape, device=dtop.device if dtop.numel() else dbottom.device, dtype=torch.float32)  # noqa: E731
+        up = dtop.contiguous() if ctx.has[0] else z()
+        down = dbottom.contiguous() if ctx.has[1] else z()
+        from_above, from_below = ctx.comm.exchange(up, down)
+        return (from_above if from_above is not None else z(), from_below if from_below is not None else z(), None)
+
+
+def halo_exchange(first, last, comm):
+    """-> (top, bottom) with None at the grid's outer border; differentiable."""
+    top, bottom = _HaloExchange.apply(first, last, comm)
+    return (top if top.numel() else None), (bottom if bottom.numel() else None)
+
+
+class _GatherRows(torch.autograd.Function):
+    """Bands (n, c, h_r, W) of all ranks -> full images (n, c, H, W) on every rank.  Backward: the
+    gradient of this rank's band summed over ranks."""
+
+    @staticmethod
+    def forward(ctx, band, comm):
+        parts = comm.all_gather(band.contiguous())
+        ctx.comm = comm
+        ctx.lo = sum(p.shape[-2] for p in parts[:comm.rank])
+        ctx.h = band.shape[-2]
+        return torch.cat(parts, -2)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        ctx.comm.all_reduce(g)
+        return g[..., ctx.lo:ctx.lo + ctx.h, :].contiguous(), None
+
+
+def gather_rows(band, comm):
+    return _GatherRows.apply(band, comm)
 
 
 # ------------------------------------------------------------------------------- losses

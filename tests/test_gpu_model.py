@@ -269,3 +269,62 @@ def test_row_sharded_generation_equals_unsharded(tag, world):
     got = torch.cat(strips, -2)
     assert got.shape == fx["image"].shape
     assert rel_l2(got, fx["image"]) < 1e-4, rel_l2(got, fx["image"])
+
+
+def _band_worker(rank, world, port, tag, out_path):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import torch.distributed as dist
+    from infinite_texture_gans_amd.engine import BandTrainer
+    from infinite_texture_gans_amd.dist import BandComm
+    from infinite_texture_gans_amd import utils as U
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fx = load("train_" + tag)
+        a = parse_flags(fx["argv"])
+        G, D = build(a, state(fx, "G0/"), state(fx, "D0/"))
+        G.train(), D.train()
+        args = U.prepare_parser().parse_args([])
+        args.smooth, args.beta1 = a["smooth"], 0.0
+        tr = BandTrainer(G, D, args, cuda, BandComm(rank, world))
+        losses = []
+        for s in range(int(fx["steps"])):
+            real = torch.from_numpy(fx["real_x%d" % s])
+            k = real.shape[0] // world
+            l = tr.step(real[rank * k:(rank + 1) * k].to(cuda), torch.from_numpy(fx["z%d" % s]).to(cuda))
+            losses.append([float(v) for v in l])
+        torch.save({"losses": losses, "G": {k: v.cpu() for k, v in G.state_dict().items()},
+                    "D": {k: v.cpu() for k, v in D.state_dict().items()}}, "%s.%d" % (out_path, rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_band_sharded_train_step_matches_reference_golden(world, tmp_path):
+    """BASELINE config 4's protocol (patch rows of every fake image sharded over ranks, halo rows
+    exchanged per conv in forward AND backward, sync-BN, D data-parallel over gathered images) must
+    reproduce the single-process reference step.  Ranks are separate processes sharing the one GPU of
+    the test box; the collectives run over gloo (RCCL refuses two ranks on one device)."""
+    import torch.multiprocessing as mp
+    tag = "bn_nl4_sn"
+    out = str(tmp_path / "band")
+    mp.spawn(_band_worker, args=(world, 29611, tag, out), nprocs=world, join=True)
+    res = [torch.load("%s.%d" % (out, r)) for r in range(world)]
+    fx = load("train_" + tag)
+    steps = int(fx["steps"])
+    for s in range(steps):
+        mean = np.mean([r["losses"][s] for r in res], 0)
+        assert np.allclose(mean, fx["loss%d" % s], rtol=1e-4, atol=1e-6), (s, mean, fx["loss%d" % s])
+    for r in res[1:]:            # replicas stay identical
+        for k, v in res[0]["G"].items():
+            assert torch.equal(v, r["G"][k]), k
+    for name, key in (("G1/", "G"), ("D1/", "D")):
+        sd = res[0][key]
+        for k, v in state(fx, name).items():
+            got = sd[k].double()
+            if name == "G1/" and k.endswith("bias") and "conv" in k and k != "final.conv.bias":
+                assert (got - v.double()).abs().max() <= 2 * 2e-4 * steps + 1e-7, k
+            else:
+                assert rel_l2(got, v.double()) < 2e-3, (k, rel_l2(got, v.double()))

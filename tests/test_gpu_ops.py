@@ -263,3 +263,32 @@ def test_adam_ema_matches_oracle_adam():
         ops.adam_ema_step(pg, gr.to(cuda), m, v, ema, 2e-4, 0.0, 0.999, 1e-8, t, 0.999)
     assert rel_l2(pg.cpu(), pr.detach()) < 1e-6
     assert rel_l2(ema.cpu(), er) < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["replicate", "zeros"])
+def test_conv_with_separate_vertical_padding(mode):
+    """pad_h=0 with horizontal padding 1 (the conv of a row-sharded band whose halo rows were
+    concatenated by the caller): forward, data gradient, weight and bias gradient."""
+    import torch.nn.functional as F
+    from infinite_texture_gans_amd import ops
+    torch.manual_seed(5)
+    n, cin, cout, H, W = 2, 12, 20, 10, 16
+    x = torch.randn(n, cin, H + 2, W, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True) * 0.2
+    w.retain_grad()
+    b = torch.randn(cout, dtype=torch.float64, requires_grad=True)
+    ref = F.conv2d(F.pad(x, (1, 1, 0, 0), mode="replicate" if mode == "replicate" else "constant"), w, b)
+    gy = torch.randn_like(ref)
+    ref.backward(gy)
+    xg = x.detach().float().to(cuda).requires_grad_(True)
+    wg = w.detach().float().to(cuda).requires_grad_(True)
+    bg = b.detach().float().to(cuda).requires_grad_(True)
+    y = ops.conv(ops.to_grid(xg, 1, 1, merged=True), wg, bg, stride=1, pad=1,
+                 pad_mode=ops.PAD_REPLICATE if mode == "replicate" else ops.PAD_ZERO, pad_h=0)
+    out = ops.to_nchw(y, merged=True)
+    assert out.shape == ref.shape
+    out.backward(gy.float().to(cuda))
+    assert rel_l2(out.detach().cpu(), ref.detach()) < 1e-5
+    assert rel_l2(xg.grad.cpu(), x.grad) < 1e-5
+    assert rel_l2(wg.grad.cpu(), w.grad) < 1e-5
+    assert rel_l2(bg.grad.cpu(), b.grad) < 1e-5
