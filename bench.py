@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 NECESSARY_GF_PER_STEP = 855.5      # SURVEY.md section 8d, config 1, batch 8 / 8 images
+NECESSARY_GF_CONFIG4 = 1463.2      # 4x4 patch grid, fake 512^2, batch 8 in total
 FP32_MFMA_PEAK_TF = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU @ 2.4 GHz
 FLAGS = ["--n_layers_G", "6", "--n_layers_D", "4", "--type_norm", "BN", "--padding_mode", "local",
          "--outer_padding", "replicate", "--num_images", "8", "--batch_size", "8", "--leak_G", "0.02",
@@ -35,7 +36,8 @@ FLAGS = ["--n_layers_G", "6", "--n_layers_D", "4", "--type_norm", "BN", "--paddi
 def gpu_leg(a):
     import torch.distributed as dist
     from infinite_texture_gans_amd import ops, utils as U
-    from infinite_texture_gans_amd.engine import Trainer
+    from infinite_texture_gans_amd.engine import Trainer, BandTrainer
+    from infinite_texture_gans_amd.dist import BandComm
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -52,16 +54,27 @@ def gpu_leg(a):
         else:
             dist.init_process_group(backend)
         group = dist.group.WORLD
-    args = U.prepare_parser().parse_args(FLAGS)
+    band = a.workload == "config4"
+    args = U.prepare_parser().parse_args(FLAGS + (["--num_patches_height", "4", "--num_patches_width", "4"] if band else []))
     args.beta1 = float(args.beta1)
     torch.manual_seed(args.seed)               # identical initial weights on every rank
     netG, netD = U.prepare_models(args, dev)
     netG.train(), netD.train()
-    tr = Trainer(netG, netD, args, dev, dist_group=group)
-    g = torch.Generator().manual_seed(args.seed + 1 + rank)
     n_in = a.steps + a.warmup + 2
-    reals = [(torch.rand(args.batch_size, 3, 192, 192, generator=g) * 2 - 1).to(dev) for _ in range(2)]
-    zs = [torch.randn(args.num_images, args.z_dim, 14, 14, generator=g).to(dev) for _ in range(n_in)]
+    if band:
+        # config 4: ONE batch of 8 fake 512^2 images whose 4x4 patch grid is sharded by rows over the ranks
+        # (strong scaling); latents are the same full tensors on every rank, real crops are sharded.
+        tr = BandTrainer(netG, netD, args, dev, BandComm(rank, world, group))
+        g = torch.Generator().manual_seed(args.seed + 1)
+        k = args.batch_size // world
+        reals = [(torch.rand(args.batch_size, 3, 192, 192, generator=g) * 2 - 1)[rank * k:(rank + 1) * k].to(dev)
+                 for _ in range(2)]
+        zs = [torch.randn(args.num_images, args.z_dim, 18, 18, generator=g).to(dev) for _ in range(n_in)]
+    else:
+        tr = Trainer(netG, netD, args, dev, dist_group=group)
+        g = torch.Generator().manual_seed(args.seed + 1 + rank)
+        reals = [(torch.rand(args.batch_size, 3, 192, 192, generator=g) * 2 - 1).to(dev) for _ in range(2)]
+        zs = [torch.randn(args.num_images, args.z_dim, 14, 14, generator=g).to(dev) for _ in range(n_in)]
 
     def sync():
         torch.cuda.synchronize()
@@ -72,6 +85,7 @@ def gpu_leg(a):
     # One iteration is ~600 kernel launches: on one GPU it is recorded once into a hipGraph (after the
     # warm-up iterations) and replayed; multi-GPU runs stay eager unless ITG_GRAPH=1 (RCCL inside capture).
     use_graph = os.environ.get("ITG_GRAPH", "1" if world == 1 else "0") == "1"
+    nec_gf = NECESSARY_GF_CONFIG4 / world if band else NECESSARY_GF_PER_STEP
     if use_graph:
         tr.capture(reals[0], zs[0], warmup=max(1, a.warmup))
         step = tr.step_graphed
@@ -113,8 +127,8 @@ def gpu_leg(a):
                 "launches_per_step": nl, "avg_launch_us": round(sec / nl * 1e6, 1),
                 "flops_per_launch": round(fl / nl / 1e9, 3),
                 "conv_time_share": {k: round(v[2] / sum(x[2] for x in agg.values()), 3) for k, v in agg.items()},
-                "step_necessary_gflop": NECESSARY_GF_PER_STEP,
-                "step_frac_of_mfma_peak": round(NECESSARY_GF_PER_STEP * 1e9 / (dt / a.steps) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
+                "step_necessary_gflop": round(nec_gf, 1),
+                "step_frac_of_mfma_peak": round(nec_gf * 1e9 / (dt / a.steps) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
     if world > 1:
         dist.barrier()
     return rank, world, dt, args, losses, roof
@@ -170,6 +184,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["config1", "config4"], default="config1",
+                    help="config1 (default, the headline metric): batch 8 per GPU, data parallel.  config4: 4x4 patch "
+                         "grid of ONE batch sharded by patch rows over <= 4 GPUs with halo exchange (strong scaling)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", 1))
     if a.gpus != world:
@@ -180,6 +197,21 @@ def main():
     if rank != 0:
         return
     ms = dt / a.steps * 1e3
+    if a.workload == "config4":
+        out = {"metric": "G+D train-step real 192x192x3 crops/sec (batch 8 in total, 4x4 patch grid sharded by rows)",
+               "value": round(args.batch_size * a.steps / dt, 3), "unit": "crops/s", "n_gpus": world, "steps": a.steps,
+               "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "config 4: 192x192 crops, n_layers_G=6 n_layers_D=4, BN, padding_mode=local, 4x4 patch "
+                                      "grid (128 G-patches, fake 512^2), batch 8 + 8 generated images in total",
+                          "global_batch": args.batch_size, "g_patches_per_sec": round(128 * a.steps / dt, 1),
+                          "parallelism": "patch rows over %d rank(s): halo-row exchange per conv fwd+bwd, sync-BN, "
+                                         "band gather -> image-parallel D, flat grad all-reduce" % world,
+                          "last_losses": losses,
+                          "launch": "hipGraph replay" if os.environ.get("ITG_GRAPH", "1" if world == 1 else "0") == "1" else "eager"},
+               "roofline": roof}
+        print(json.dumps(out), flush=True)
+        return
     out = {"metric": "G+D train-step real 192x192x3 crops/sec (batch 8 per GPU)", "value": round(args.batch_size * world * a.steps / dt, 3),
            "unit": "crops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -82,6 +82,8 @@ class RowHalo:
     def exchange(self, first_row, last_row):
         """-> (top, bottom): the row above this band / below it, or None at the grid's outer border."""
         import torch.distributed as dist
+        if self.world == 1:
+            return None, None
         if first_row.is_cuda and dist.get_backend(self.group) == "gloo":
             # rehearsal of the protocol with several ranks on ONE GPU (gloo has no device send/recv):
             # stage the rows through host memory.  RCCL runs take the direct path below.
@@ -158,6 +160,8 @@ class BandComm(RowHalo):
 
     def all_gather(self, t):
         """list of every rank's tensor (bands may have different heights: sizes are exchanged first)."""
+        if self.world == 1:
+            return [t]
         if t.is_cuda and self.dist.get_backend(self.group) == "gloo":      # one-GPU rehearsal, see exchange()
             return [o.to(t.device) for o in self.all_gather(t.cpu())]
         sizes = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(self.world)]
