@@ -12,7 +12,7 @@ import torch
 
 from . import utils as U
 from .data import SingleImageCrops
-from .engine import Trainer
+from .engine import Trainer, BandTrainer
 
 
 def train(args):
@@ -31,8 +31,11 @@ def train(args):
         print(args)
     if args.data != "single_image":
         raise NotImplementedError("--data %s: only single_image is on the hot path" % args.data)
+    band = bool(getattr(args, "shard_patch_rows", False)) and world > 1
+    if band and args.batch_size % world:
+        raise ValueError("--shard_patch_rows: batch_size %d does not split over %d ranks" % (args.batch_size, world))
     data = SingleImageCrops(args.data_path, args.data_ext, args.sampling, args.random_crop, args.center_crop,
-                            args.batch_size, device, seed=seed + 17 * rank)
+                            args.batch_size // world if band else args.batch_size, device, seed=seed + 17 * rank)
     netG, netD = U.prepare_models(args, device)          # same seed -> same initial weights on every rank
     netG_ema = None
     if args.ema:
@@ -44,7 +47,11 @@ def train(args):
         print("# Params. G: ", sum(p.numel() for p in netG.parameters()))
         print("# Params. D: ", sum(p.numel() for p in netD.parameters()))
     netG.train(), netD.train()
-    tr = Trainer(netG, netD, args, device, netG_ema=netG_ema, dist_group=group)
+    if band:      # one batch, patch rows of every fake image spread over the ranks (BASELINE config 4)
+        from .dist import BandComm
+        tr = BandTrainer(netG, netD, args, device, BandComm(rank, world, group), netG_ema=netG_ema)
+    else:
+        tr = Trainer(netG, netD, args, device, netG_ema=netG_ema, dist_group=group)
     gammas = None
     if args.decay_lr == "exp":
         gammas = lambda e: 0.99 ** e                                          # noqa: E731
@@ -53,7 +60,7 @@ def train(args):
     filename = U.prepare_filename(args)
     start = time.time()
     G_losses, D_losses = [], []
-    torch.manual_seed(seed + 1000 * rank)                # latents: disjoint CPU RNG stream per rank
+    torch.manual_seed(seed if band else seed + 1000 * rank)   # latents: per-rank CPU RNG stream (shared when sharding rows)
     print("Starting Training Loop...")
     for epoch in range(args.epochs):
         d_run = torch.zeros((), device=device)

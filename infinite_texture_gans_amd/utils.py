@@ -66,6 +66,8 @@ _FLAGS = [
     ("dev_num", int, 0, "GPU index when a single GPU is used"),
     ("num_workers", int, 0, "data loader workers"),
     ("fname", str, "models_cp", "folder for checkpoints"),
+    ("shard_patch_rows", "flag", False, "build-side extra: multi-GPU runs shard the patch grid of ONE batch by patch "
+                                        "rows (halo exchange) instead of replicating the batch per GPU"),
 ]
 
 
