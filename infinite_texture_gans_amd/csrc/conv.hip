@@ -55,7 +55,10 @@ __device__ __forceinline__ void decode_m(int m, int MT, int MU, int& n, int& t, 
   u = r - t * MU;
 }
 
-template <int BCO, int BPIX, int WCO, int WPIX, int TBK>
+// DEPTH = number of K stages whose global loads are in flight while one stage is computed.  Wide tiles
+// compute ~2048 MFMA cycles per stage and hide the memory latency with DEPTH 1; narrow tiles (<= 32
+// filter rows: 256-512 cycles per stage) are latency-bound unless two stages are in flight.
+template <int BCO, int BPIX, int WCO, int WPIX, int TBK, int DEPTH, bool TAB>
 __global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 && (BCO + BPIX) <= 192 ? 5 : 3)) void conv_nt_kernel(const ConvP p) {
   // per-class geometry (class 0 for ordinary launches); all wave-uniform scalars
   const int cls = blockIdx.y;
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 && (BCO + BPIX)
   // patch-grid address arithmetic.  Slot [ntaps] holds the out-of-range marker for the K padding.
   extern __shared__ unsigned taptab[];
   const int TS = p.ntaps + 1;
-  const bool use_tab = p.use_tab != 0;       // narrow layers only: wide ones change tap rarely and need the LDS
+  constexpr bool use_tab = TAB;               // narrow layers only: wide ones change tap rarely and need the LDS
   auto tap_offset = [&](int i, int tt) -> unsigned {
     const int tky = tt / p.kw, tkx = tt - tky * p.kw;
     int iy = py[i] + tky, ix = px[i] + tkx;
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 && (BCO + BPIX)
     unsigned o = (unsigned)grid_off(p.in, pn[i], iy, ix) * 4u;
     return ok ? o : p.in_bytes;
   };
-  if (use_tab) {
+  if constexpr (use_tab) {
     for (int tt = kg; tt <= p.ntaps; tt += KG) {
 #pragma unroll
       for (int i = 0; i < PL; ++i) taptab[(lrow + i * RPP) * TS + tt] = tap_offset(i, tt);
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 && (BCO + BPIX)
     __syncthreads();
   }
   auto locate = [&]() {
-    if (use_tab) {
+    if constexpr (use_tab) {
 #pragma unroll
       for (int i = 0; i < PL; ++i) poff[i] = taptab[(lrow + i * RPP) * TS + min(tap, p.ntaps)];
     } else {
@@ -151,29 +154,32 @@ __global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 && (BCO + BPIX)
   };
   locate();
 
-  f32x4 rp[PL], rw[WL];
-  auto load_tiles = [&](int kk) {
+  f32x4 rp[DEPTH][PL], rw[DEPTH][WL];
+  auto load_tiles = [&](int kk, f32x4 (&rp_)[PL], f32x4 (&rw_v)[WL]) {
 #pragma unroll
     for (int i = 0; i < PL; ++i)
-      rp[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, poff[i] + (unsigned)cc * 4u, 0, 0));
+      rp_[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, poff[i] + (unsigned)cc * 4u, 0, 0));
     const int ksoff = kk * TBK * 4;
 #pragma unroll
     for (int i = 0; i < WL; ++i)
-      rw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw_, woff[i], ksoff, 0));
+      rw_v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw_, woff[i], ksoff, 0));
     cc += TBK;
-    if (__any(cc >= p.cin_ld)) {       // wave-uniform: some lane moves on to the next filter tap
+    if constexpr (use_tab) {           // narrow layers: (almost) every stage crosses a tap, no wave-uniform test
+      while (cc >= p.cin_ld) { cc -= p.cin_ld; ++tap; }
+      locate();
+    } else if (__any(cc >= p.cin_ld)) {       // wave-uniform: some lane moves on to the next filter tap
       while (cc >= p.cin_ld) { cc -= p.cin_ld; ++tap; }
       locate();
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, const f32x4 (&rp_)[PL], const f32x4 (&rw_v)[WL]) {
 #pragma unroll
     for (int i = 0; i < PL; ++i)
-      *reinterpret_cast<f32x4*>(Ps + (buf * BPIX + lrow + i * RPP) * LDT + kg * 4) = rp[i];
+      *reinterpret_cast<f32x4*>(Ps + (buf * BPIX + lrow + i * RPP) * LDT + kg * 4) = rp_[i];
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
       int row = lrow + i * RPP;
-      if (row < BCO) *reinterpret_cast<f32x4*>(Ws + (buf * BCO + row) * LDT + kg * 4) = rw[i];
+      if (row < BCO) *reinterpret_cast<f32x4*>(Ws + (buf * BCO + row) * LDT + kg * 4) = rw_v[i];
     }
   };
 
@@ -183,13 +189,8 @@ __global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 && (BCO + BPIX)
 #pragma unroll
     for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_tiles(kk0);
-  store_tiles(0);
-  __syncthreads();
   const int frow = lane & 15, fk = (lane >> 4) * 4;
-  for (int kk = kk0; kk < kk1; ++kk) {
-    const int buf = (kk - kk0) & 1;
-    if (kk + 1 < kk1) load_tiles(kk + 1);
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int c16 = 0; c16 < TBK; c16 += 16) {
       f32x4 a[FI], b[FJ];
@@ -207,8 +208,35 @@ __global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 && (BCO + BPIX)
           for (int j = 0; j < FJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     }
-    if (kk + 1 < kk1) store_tiles(buf ^ 1);
+  };
+  if constexpr (DEPTH == 1) {
+    load_tiles(kk0, rp[0], rw[0]);
+    store_tiles(0, rp[0], rw[0]);
     __syncthreads();
+    for (int kk = kk0; kk < kk1; ++kk) {
+      const int buf = (kk - kk0) & 1;
+      if (kk + 1 < kk1) load_tiles(kk + 1, rp[0], rw[0]);
+      compute(buf);
+      if (kk + 1 < kk1) store_tiles(buf ^ 1, rp[0], rw[0]);
+      __syncthreads();
+    }
+  } else {
+    // two stages in flight: register set A holds stage kk+2 while set B (stage kk+1) drains into LDS
+    load_tiles(kk0, rp[0], rw[0]);
+    if (kk0 + 1 < kk1) load_tiles(kk0 + 1, rp[1], rw[1]);
+    store_tiles(0, rp[0], rw[0]);
+    __syncthreads();
+    for (int kk = kk0; kk < kk1; kk += 2) {
+      if (kk + 2 < kk1) load_tiles(kk + 2, rp[0], rw[0]);
+      compute(0);
+      if (kk + 1 < kk1) store_tiles(1, rp[1], rw[1]);
+      __syncthreads();
+      if (kk + 1 >= kk1) break;
+      if (kk + 3 < kk1) load_tiles(kk + 3, rp[1], rw[1]);
+      compute(1);
+      if (kk + 2 < kk1) store_tiles(0, rp[0], rw[0]);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: lane holds 4 consecutive output channels of one pixel per fragment
@@ -526,13 +554,13 @@ NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1) {
   pl.bpix = 128; pl.ksplit = 1;
   double best_eff = 0.0;
   const int cands_big[3] = {256, 128, 64};
-  const int cand_ks[7] = {1, 2, 3, 4, 6, 8, 12};
+  const int cand_ks[13] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16};
   for (int ci = 0; ci < 3; ++ci) {
     int bp = cands_big[ci];
     if (pl.bco >= 112 && bp == 256) continue;              // 128x256 / 112x256 are not instantiated
     int64_t blocks = ((M + bp - 1) / bp) * nco * ncls;
     double pen = bp >= 256 ? 1.0 : (bp == 128 ? (pl.bco >= 112 ? 1.0 : 1.04) : (pl.bco >= 112 ? 1.08 : 1.12));
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < 13; ++i) {
       int ks = cand_ks[i];
       if (ks > 1 && nk * pl.tbk / ks < 256) break;
       double b = (double)blocks * ks / 256.0;
@@ -561,7 +589,20 @@ int launch_nt(const ConvP& p, int tbk, hipStream_t s) {
   size_t tab_bytes = (size_t)BPIX * (p.ntaps + 1) * sizeof(unsigned);
   q.use_tab = (p.cin_ld < 64 && tab_bytes <= 24 * 1024) ? 1 : 0;
   if (!q.use_tab) tab_bytes = 0;
-  hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16>), grid, dim3(256), tab_bytes, s, q);
+  static const int depth_narrow = env_int("ITG_NT_DEPTH", 2);
+  static const int depth_wide = env_int("ITG_NT_DEPTH_WIDE", 2);
+  const int depth = BCO <= 32 ? depth_narrow : depth_wide;
+  if (q.use_tab) {
+    if (depth == 2)
+      hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16, 2, true>), grid, dim3(256), tab_bytes, s, q);
+    else
+      hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16, 1, true>), grid, dim3(256), tab_bytes, s, q);
+  } else {
+    if (depth == 2)
+      hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16, 2, false>), grid, dim3(256), 0, s, q);
+    else
+      hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16, 1, false>), grid, dim3(256), 0, s, q);
+  }
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }
@@ -918,7 +959,8 @@ TnPlan plan_tn(int64_t M, int co_ld, int Ktot) {
   TnPlan t;
   t.co_rows = round_up(co_ld, 16);
   t.Kpad = round_up(Ktot, 16);
-  if (t.co_rows <= 16) { t.bco = 16; t.bcol = 256; }
+  if (t.Kpad <= 64 && t.co_rows > 16 && t.co_rows <= 64) { t.bco = 64; t.bcol = 64; }   // 3-channel input layer: K = taps * 4
+  else if (t.co_rows <= 16) { t.bco = 16; t.bcol = 256; }
   else if (t.co_rows <= 32) { t.bco = 32; t.bcol = 256; }
   else if (t.co_rows <= 64) { t.bco = 64; t.bcol = 256; }
   else { t.bco = 128; t.bcol = 128; }
@@ -934,6 +976,76 @@ TnPlan plan_tn(int64_t M, int co_ld, int Ktot) {
   t.ngroups = t.splits > RED_GROUP ? (t.splits + RED_GROUP - 1) / RED_GROUP : 0;
   t.ws_floats = t.slab_floats + (int64_t)t.ngroups * t.co_rows * t.Kpad;
   return t;
+}
+
+
+// ------------------------------------------------------------------------------- single-output-channel convs
+// The discriminator's logit layer (512 -> 1, 4x4, stride 1) has ONE output channel: the implicit GEMM
+// above would spend 15 of its 16 MFMA rows on zeros (and the weight-gradient 15 of 16 columns).  Here the
+// 16 filter taps take the place of the 16 rows:
+//   forward   P[i][t] = x[i] . w[t]  for every INPUT pixel i (a 1x1 conv with 16 "channels", K = cin), then
+//             y[o] = b + sum_t P[o + t][t]                              (tap_gather_fwd_kernel)
+//   wgrad     Q[i][t] = dy[i - t]  (tap_scatter_dy_kernel), dW[t][c] = sum_i Q[i][t] x[i][c] (1x1 wgrad),
+//             transposed into the OIHW gradient; the bias gradient is the column of the tap that sees
+//             every dy pixel exactly once (ky = pad_h, kx = pad).
+__global__ void tap_gather_fwd_kernel(const float* __restrict__ P, int H, int W, GridT out, const float* __restrict__ bias,
+                                      int kh, int kw, int pad_h, int pad_w, int act, float slope) {
+  const int64_t total = (int64_t)out.n * out.H * out.W;
+  const int ntaps = kh * kw;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int ox = (int)(i % out.W);
+    int64_t r = i / out.W;
+    int oy = (int)(r % out.H);
+    int n = (int)(r / out.H);
+    float v = bias ? bias[0] : 0.f;
+    for (int ky = 0; ky < kh; ++ky) {
+      int iy = oy - pad_h + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kx = 0; kx < kw; ++kx) {
+        int ix = ox - pad_w + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        v += P[(((size_t)n * H + iy) * W + ix) * ntaps + ky * kw + kx];
+      }
+    }
+    v = act_apply(v, act, slope);
+    *reinterpret_cast<f32x4*>(out.p + grid_off(out, n, oy, ox)) = f32x4{v, 0.f, 0.f, 0.f};
+  }
+}
+
+__global__ void tap_scatter_dy_kernel(GridT dy, float* __restrict__ Q, int H, int W, int kh, int kw, int pad_h, int pad_w) {
+  const int ntaps = kh * kw;
+  const int64_t total = (int64_t)dy.n * H * W * ntaps;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int t = (int)(i % ntaps);
+    int64_t r = i / ntaps;
+    int ix = (int)(r % W); r /= W;
+    int iy = (int)(r % H);
+    int n = (int)(r / H);
+    int ky = t / kw, kx = t - ky * kw;
+    int oy = iy + pad_h - ky, ox = ix + pad_w - kx;
+    float v = 0.f;
+    if ((unsigned)oy < (unsigned)dy.H && (unsigned)ox < (unsigned)dy.W) v = dy.p[grid_off(dy, n, oy, ox)];
+    Q[i] = v;
+  }
+}
+
+// dw[c][t] (+)= tmp[t][c]; db[0] (+)= dbtmp[tdb]
+__global__ void tap_wgrad_finish_kernel(const float* __restrict__ tmp, const float* __restrict__ dbtmp, float* __restrict__ dw,
+                                        float* __restrict__ db, int ci, int ntaps, int tdb, int accumulate) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ci * ntaps) {
+    int c = i / ntaps, t = i - c * ntaps;
+    float v = tmp[(size_t)t * ci + c];
+    dw[i] = accumulate ? dw[i] + v : v;
+  }
+  if (i == 0 && db) db[0] = accumulate ? db[0] + dbtmp[tdb] : dbtmp[tdb];
+}
+
+inline bool thin_out_conv(const itg_tensor* in, const itg_tensor* out, const itg_conv_geom* g) {
+  static const int enable = env_int("ITG_THIN_CONV", 1);
+  const int ph = g->pad_h >= 0 ? g->pad_h : g->pad;
+  return enable && out->c == 1 && g->kh * g->kw == 16 && g->stride == 1 && g->pad_mode == ITG_PAD_ZERO &&
+         (in->ld % 16) == 0 && ph < g->kh && g->pad < g->kw && 2 * ph <= g->kh - 1 && 2 * g->pad <= g->kw - 1;
 }
 
 int conv_out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
@@ -989,6 +1101,10 @@ int itg_pack_dgrad(const float* w, const float* scale, float* out, int co, int c
 
 int64_t itg_conv2d_fwd_workspace(const itg_tensor* in, const itg_tensor* out, const itg_conv_geom* g) {
   if (!in || !out || !g) return 0;
+  if (thin_out_conv(in, out, g)) {
+    int64_t Min = grid_pixels(in);
+    return Min * 16 + plan_nt(Min, 16, round_up(in->ld, BK)).ws_floats;
+  }
   return plan_nt(grid_pixels(out), round_up(out->c, 16), round_up(g->kh * g->kw * in->ld, BK)).ws_floats;
 }
 
@@ -1011,6 +1127,26 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   int rc;
   if ((rc = check_tensor(in)) || (rc = check_tensor(out))) return rc;
   if (!w_packed || !g || g->kh <= 0 || g->kw <= 0 || g->stride <= 0 || g->pad < 0) return ITG_ERR_ARG;
+  if (thin_out_conv(in, out, g) && !(residual && residual->ptr)) {
+    // taps-as-rows path (see tap_gather_fwd_kernel): a 1x1 conv into P[pixel][16], then the tap gather
+    const int H = in->gh * in->ph, W = in->gw * in->pw;
+    if (in->n != out->n || conv_out_dim(H, g->kh, 1, pad_v(g)) != out->gh * out->ph ||
+        conv_out_dim(W, g->kw, 1, g->pad) != out->gw * out->pw) return ITG_ERR_ARG;
+    const int64_t Min = grid_pixels(in), pf = Min * 16;
+    if (!workspace || workspace_floats < pf || pf >= ((int64_t)1 << 31)) return ITG_ERR_WORKSPACE;
+    itg_tensor P = {workspace, in->n, 1, 1, H, W, 16, 16};
+    itg_conv_geom g1 = {1, 1, 1, 0, ITG_PAD_ZERO, 0};
+    // row 0 of the packed filter is (tap, ci)-ordered with ci_ld a multiple of 16: read as 16 rows of ci_ld
+    if ((rc = itg_conv2d_fwd(in, w_packed, nullptr, nullptr, &P, &g1, ITG_ACT_NONE, 0.f, workspace + pf,
+                             workspace_floats - pf, stream))) return rc;
+    GridT og = make_grid(out);
+    int64_t total = (int64_t)og.n * og.H * og.W;
+    int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(tap_gather_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, H, W,
+                       og, bias, g->kh, g->kw, pad_v(g), g->pad, act, slope);
+    ITG_CHECK_LAUNCH();
+    return ITG_OK;
+  }
   ConvP p;
   p.ncls = 1;
   p.in = make_grid(in);
@@ -1117,6 +1253,11 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const it
 
 int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g) {
   if (!x || !dy || !g) return 0;
+  if (thin_out_conv(x, dy, g)) {
+    int64_t Min = grid_pixels(x);
+    TnPlan t = plan_tn(Min, 16, x->ld);
+    return Min * 16 + 16 * (int64_t)x->c + 16 + t.ws_floats + (int64_t)t.splits * t.co_rows;
+  }
   int64_t M = grid_pixels(dy);
   TnPlan t = plan_tn(M, dy->ld, g->kh * g->kw * x->ld);
   return t.ws_floats + (int64_t)t.splits * t.co_rows;
@@ -1129,6 +1270,28 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
   if (!dw || !g || !workspace) return ITG_ERR_ARG;
   if (x->n != dy->n) return ITG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  if (thin_out_conv(x, dy, g)) {
+    const int H = x->gh * x->ph, W = x->gw * x->pw;
+    if (conv_out_dim(H, g->kh, 1, pad_v(g)) != dy->gh * dy->ph || conv_out_dim(W, g->kw, 1, g->pad) != dy->gw * dy->pw)
+      return ITG_ERR_ARG;
+    const int64_t Min = grid_pixels(x), qf = Min * 16, tf = 16 * (int64_t)x->c + 16;
+    if (workspace_floats < qf + tf || qf >= ((int64_t)1 << 31)) return ITG_ERR_WORKSPACE;
+    float* Q = workspace;
+    float* tmp = workspace + qf;            // [16][ci] then [16] bias partial
+    int blocks = (int)((qf + 255) / 256 < 8192 ? (qf + 255) / 256 : 8192);
+    hipLaunchKernelGGL(tap_scatter_dy_kernel, dim3(blocks), dim3(256), 0, s, make_grid(dy), Q, H, W, g->kh, g->kw, pad_v(g),
+                       g->pad);
+    ITG_CHECK_LAUNCH();
+    itg_tensor Qt = {Q, x->n, 1, 1, H, W, 16, 16};
+    itg_conv_geom g1 = {1, 1, 1, 0, ITG_PAD_ZERO, 0};
+    if ((rc = itg_conv2d_wgrad(x, &Qt, tmp, tmp + 16 * (int64_t)x->c, &g1, 0, workspace + qf + tf,
+                               workspace_floats - qf - tf, stream))) return rc;
+    int n = x->c * 16;
+    hipLaunchKernelGGL(tap_wgrad_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)tmp,
+                       (const float*)(tmp + 16 * (int64_t)x->c), dw, db, x->c, 16, pad_v(g) * g->kw + g->pad, accumulate);
+    ITG_CHECK_LAUNCH();
+    return ITG_OK;
+  }
   WgP p;
   p.x = make_grid(x);
   p.dy = make_grid(dy);
@@ -1152,7 +1315,8 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
     if (xb >= 0xFFFF0000LL || yb >= 0xFFFF0000LL) return ITG_ERR_ARG;
     p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
   }
-  if (t.bco == 16) rc = launch_tn<256, 16, 64, 16>(p, t.splits, s);
+  if (t.bcol == 64) rc = launch_tn<64, 64, 32, 32>(p, t.splits, s);
+  else if (t.bco == 16) rc = launch_tn<256, 16, 64, 16>(p, t.splits, s);
   else if (t.bco == 32) rc = launch_tn<256, 32, 64, 32>(p, t.splits, s);
   else if (t.bco == 64) rc = launch_tn<256, 64, 64, 64>(p, t.splits, s);
   else rc = launch_tn<128, 128, 64, 64>(p, t.splits, s);

@@ -1,5 +1,7 @@
 """GPU parity, op level: every C-ABI kernel family against the CPU oracle (torch-CPU primitives
 + oracle.patches) on the same seeded inputs.  fp32 tolerances are written at each check."""
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -76,6 +78,9 @@ CONV_CASES = [
     ("lp3x3_rep_128_64_splitk", 1, (3, 3), 4, 128, 64, 3, 1, 1, "replicate"),      # small M, long K: split-K + fold
     ("lp3x3_rep_8_8_manysplits", 2, (3, 3), 32, 8, 8, 3, 1, 1, "replicate"),       # wgrad two-stage slab reduce
     ("d4x4_s2_32_48_mid", 2, (1, 1), 40, 32, 48, 4, 2, 1, "zeros"),
+    ("d4x4_s1_32_1_taps_as_rows", 2, (1, 1), 13, 32, 1, 4, 1, 1, "zeros"),          # logit layer: single output channel
+    ("d4x4_s1_64_1_taps_as_rows_grid", 1, (2, 3), 6, 64, 1, 4, 1, 1, "zeros"),
+    ("d4x4_s2_3_64_first_layer", 1, (1, 1), 36, 3, 64, 4, 2, 1, "zeros"),           # K = 16 taps x 4: 64x64 wgrad tile
 ]
 
 
@@ -84,7 +89,7 @@ def test_conv_fwd_dgrad_wgrad(case):
     ops = _ops()
     from oracle import patches as P
     name, n, (gh, gw), p, cin, cout, k, stride, pad, mode = case
-    g = _gen(hash(name) % 1000)
+    g = _gen(zlib.crc32(name.encode()) % 1000)      # stable across processes (str hash is salted)
     x = torch.randn(n * gh * gw, cin, p, p, generator=g)
     w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
     b = torch.randn(cout, generator=g) * 0.1
@@ -109,7 +114,10 @@ def test_conv_fwd_dgrad_wgrad(case):
     dxg, dwg, dbg = torch.autograd.grad(yg, (xg, wg, bg), dy.to(cuda))
     assert rel_l2(dxg.cpu(), dxr) < 5e-6
     assert rel_l2(dwg.cpu(), dwr) < 5e-6
-    assert rel_l2(dbg.cpu(), dbr) < 5e-6
+    # a bias gradient is one fp32 sum per channel: bound the error by the magnitude of the summed terms
+    # (with one output channel the rel-L2 of a single cancelling sum is not a meaningful measure)
+    dyl = dy * torch.where(yr.detach() > 0, 1.0, 0.2)
+    assert float((dbg.cpu() - dbr).abs().max()) <= 2e-6 * float(dyl.abs().sum((0, 2, 3)).max())
 
 
 def test_conv_start_layer_valid_on_merged_latent_and_residual_tanh():

@@ -32,12 +32,24 @@ SHAPES = [
 
 
 def timeit(fn, iters=10):
+    """GPU time per call: the calls are recorded into a hipGraph so that host launch overhead (which
+    exceeds the kernel time of the small layers) does not enter."""
     fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        fn()
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e-3
@@ -62,13 +74,13 @@ def main():
         flops = 2.0 * npix * co * ci * k * k
         dy = torch.randn_like(y.t)
         t_f = timeit(lambda: ops.conv(ops.GT(x.detach(), ci), w.detach(), b, k, k, s, pad, pm, out_grid=og))
-        # dgrad only / wgrad only through autograd with selective requires_grad
+        # dgrad only / wgrad only: (forward + backward) recorded together, forward time subtracted
         xg = x.detach().requires_grad_(True)
-        yd = ops.conv(ops.GT(xg, ci), w.detach(), None, k, k, s, pad, pm, out_grid=og)
-        t_d = timeit(lambda: torch.autograd.grad(yd.t, xg, dy, retain_graph=True))
+        t_d = timeit(lambda: torch.autograd.grad(
+            ops.conv(ops.GT(xg, ci), w.detach(), None, k, k, s, pad, pm, out_grid=og).t, xg, dy)) - t_f
         wg = w.detach().requires_grad_(True)
-        yw = ops.conv(ops.GT(x.detach(), ci), wg, None, k, k, s, pad, pm, out_grid=og)
-        t_w = timeit(lambda: torch.autograd.grad(yw.t, wg, dy, retain_graph=True))
+        t_w = timeit(lambda: torch.autograd.grad(
+            ops.conv(ops.GT(x.detach(), ci), wg, None, k, k, s, pad, pm, out_grid=og).t, wg, dy)) - t_f
         tot[0] += t_f; tot[1] += t_d; tot[2] += t_w
         print("%-24s %7.2f GF | fwd %7.1f us %6.1f TF | dgrad %7.1f us %6.1f TF | wgrad %7.1f us %6.1f TF" % (
             name, flops / 1e9, t_f * 1e6, flops / t_f / 1e12, t_d * 1e6, flops / t_d / 1e12, t_w * 1e6,
