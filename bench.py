@@ -26,6 +26,11 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 NECESSARY_GF_PER_STEP = 855.5      # SURVEY.md section 8d, config 1, batch 8 / 8 images
+NECESSARY_GF_CONFIG3 = 340.9       # nl_G 5 + attention, fake 192^2, real 128^2, batch 8
+BF16_MFMA_PEAK_TF = 2500.0         # MI355X_MICROARCH.md dense bf16 peak
+FLAGS3 = ["--n_layers_G", "5", "--n_layers_D", "4", "--type_norm", "BN", "--padding_mode", "local", "--attention",
+          "--outer_padding", "replicate", "--num_images", "8", "--batch_size", "8", "--leak_G", "0.02",
+          "--spec_norm_D", "--smooth", "--random_crop", "128", "--seed", "1234", "--bf16"]
 NECESSARY_GF_CONFIG4 = 1463.2      # 4x4 patch grid, fake 512^2, batch 8 in total
 FP32_MFMA_PEAK_TF = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU @ 2.4 GHz
 FLAGS = ["--n_layers_G", "6", "--n_layers_D", "4", "--type_norm", "BN", "--padding_mode", "local",
@@ -55,7 +60,12 @@ def gpu_leg(a):
             dist.init_process_group(backend)
         group = dist.group.WORLD
     band = a.workload == "config4"
-    args = U.prepare_parser().parse_args(FLAGS + (["--num_patches_height", "4", "--num_patches_width", "4"] if band else []))
+    cfg3 = a.workload == "config3"
+    args = U.prepare_parser().parse_args(
+        FLAGS3 if cfg3 else FLAGS + (["--num_patches_height", "4", "--num_patches_width", "4"] if band else []))
+    if args.bf16:
+        ops.mfma_precision("bf16").set()
+    crop = args.random_crop
     args.beta1 = float(args.beta1)
     torch.manual_seed(args.seed)               # identical initial weights on every rank
     netG, netD = U.prepare_models(args, dev)
@@ -73,7 +83,7 @@ def gpu_leg(a):
     else:
         tr = Trainer(netG, netD, args, dev, dist_group=group)
         g = torch.Generator().manual_seed(args.seed + 1 + rank)
-        reals = [(torch.rand(args.batch_size, 3, 192, 192, generator=g) * 2 - 1).to(dev) for _ in range(2)]
+        reals = [(torch.rand(args.batch_size, 3, crop, crop, generator=g) * 2 - 1).to(dev) for _ in range(2)]
         zs = [torch.randn(args.num_images, args.z_dim, 14, 14, generator=g).to(dev) for _ in range(n_in)]
 
     def sync():
@@ -85,7 +95,8 @@ def gpu_leg(a):
     # One iteration is ~600 kernel launches: on one GPU it is recorded once into a hipGraph (after the
     # warm-up iterations) and replayed; multi-GPU runs stay eager unless ITG_GRAPH=1 (RCCL inside capture).
     use_graph = os.environ.get("ITG_GRAPH", "1" if world == 1 else "0") == "1"
-    nec_gf = NECESSARY_GF_CONFIG4 / world if band else NECESSARY_GF_PER_STEP
+    nec_gf = NECESSARY_GF_CONFIG4 / world if band else (NECESSARY_GF_CONFIG3 if cfg3 else NECESSARY_GF_PER_STEP)
+    peak_tf = BF16_MFMA_PEAK_TF if args.bf16 else FP32_MFMA_PEAK_TF
     if use_graph:
         tr.capture(reals[0], zs[0], warmup=max(1, a.warmup))
         step = tr.step_graphed
@@ -122,13 +133,13 @@ def gpu_leg(a):
         ops.PROFILE = None
         tag, (nl, fl, sec) = max(agg.items(), key=lambda kv: kv[1][2])
         ach = fl / sec / 1e12
-        roof = {"bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TF,
-                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+        roof = {"bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": peak_tf,
+                "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4), "traffic": None,
                 "launches_per_step": nl, "avg_launch_us": round(sec / nl * 1e6, 1),
                 "flops_per_launch": round(fl / nl / 1e9, 3),
                 "conv_time_share": {k: round(v[2] / sum(x[2] for x in agg.values()), 3) for k, v in agg.items()},
                 "step_necessary_gflop": round(nec_gf, 1),
-                "step_frac_of_mfma_peak": round(nec_gf * 1e9 / (dt / a.steps) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
+                "step_frac_of_mfma_peak": round(nec_gf * 1e9 / (dt / a.steps) / 1e12 / peak_tf, 4)}
     if world > 1:
         dist.barrier()
     return rank, world, dt, args, losses, roof
@@ -184,8 +195,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["config1", "config4"], default="config1",
-                    help="config1 (default, the headline metric): batch 8 per GPU, data parallel.  config4: 4x4 patch "
+    ap.add_argument("--workload", choices=["config1", "config3", "config4"], default="config1",
+                    help="config1 (default, the headline metric): batch 8 per GPU, data parallel.  config3: 128^2 crops, "
+                         "n_layers_G=5 + attention, convolutions on bf16-operand MFMA.  config4: 4x4 patch "
                          "grid of ONE batch sharded by patch rows over <= 4 GPUs with halo exchange (strong scaling)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -197,6 +209,20 @@ def main():
     if rank != 0:
         return
     ms = dt / a.steps * 1e3
+    if a.workload == "config3":
+        out = {"metric": "G+D train-step real 128x128x3 crops/sec (batch 8 per GPU, bf16 MFMA path)",
+               "value": round(args.batch_size * world * a.steps / dt, 3), "unit": "crops/s", "n_gpus": world, "steps": a.steps,
+               "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "config 3: 34.jpg-shaped 128x128 crops, n_layers_G=5 n_layers_D=4, attention, BN, "
+                                      "padding_mode=local, 3x3 patch grid of 64^2 (fake 192^2), conv operands bf16 / fp32 "
+                                      "accumulate, everything else fp32, batch 8 + 8 generated images per GPU",
+                          "global_batch": args.batch_size * world, "g_patches_per_sec": round(72 * world * a.steps / dt, 1),
+                          "parallelism": "dp%d (sync-BN + flat grad all-reduce)" % world, "last_losses": losses,
+                          "launch": "hipGraph replay" if os.environ.get("ITG_GRAPH", "1" if world == 1 else "0") == "1" else "eager"},
+               "roofline": roof}
+        print(json.dumps(out), flush=True)
+        return
     if a.workload == "config4":
         out = {"metric": "G+D train-step real 192x192x3 crops/sec (batch 8 in total, 4x4 patch grid sharded by rows)",
                "value": round(args.batch_size * a.steps / dt, 3), "unit": "crops/s", "n_gpus": world, "steps": a.steps,

@@ -49,7 +49,13 @@ typedef struct {
   int32_t kh, kw, stride, pad;
   int32_t pad_mode; /* ITG_PAD_*: how reads outside the merged image resolve */
   int32_t pad_h;    /* vertical padding when it differs from `pad` (row-sharded grids: 0); < 0 = same as pad */
+  int32_t precision; /* ITG_PREC_*: MFMA operand type of the contraction (tensors are fp32 in memory either way) */
 } itg_conv_geom;
+
+/* ITG_PREC_F32: v_mfma_f32_16x16x4_f32, the reference's arithmetic (BASELINE configs 1, 2, 4, 5).
+ * ITG_PREC_BF16: operands rounded to bf16 while staged into LDS, v_mfma_f32_16x16x32_bf16 with fp32
+ * accumulation (BASELINE config 3's "bf16 MFMA path"); parity tolerance 1e-2 rel-L2 per conv. */
+enum { ITG_PREC_F32 = 0, ITG_PREC_BF16 = 1 };
 
 int itg_version(void);
 

@@ -18,12 +18,15 @@ class Tensor(C.Structure):
                 ("ph", C.c_int32), ("pw", C.c_int32), ("c", C.c_int32), ("ld", C.c_int32)]
 
 
+PREC_F32, PREC_BF16 = 0, 1      # itg.h ITG_PREC_*
+
+
 class ConvGeom(C.Structure):
     _fields_ = [("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
-                ("pad_mode", C.c_int32), ("pad_h", C.c_int32)]
+                ("pad_mode", C.c_int32), ("pad_h", C.c_int32), ("precision", C.c_int32)]
 
-    def __init__(self, kh, kw, stride, pad, pad_mode, pad_h=-1):
-        super().__init__(kh, kw, stride, pad, pad_mode, pad_h)
+    def __init__(self, kh, kw, stride, pad, pad_mode, pad_h=-1, precision=0):
+        super().__init__(kh, kw, stride, pad, pad_mode, pad_h, precision)
 
 
 _P = C.c_void_p

@@ -38,6 +38,7 @@ struct ConvP {
   int co_rows, nco_tiles;
   unsigned in_bytes, w_bytes;   // buffer-resource extents of the pixel operand / packed weights
   int use_tab;                  // per-row tap-offset table in LDS (narrow layers)
+  int prec;                     // ITG_PREC_F32 | ITG_PREC_BF16
   float* partial;      // split-K slabs [ksplit][M][co_rows] (ksplit > 1)
   int ksplit, kchunks; // K chunks (of BK) per split
   // stride-2 input-gradient: the 4 output-parity classes run as ONE grid (blockIdx.y = class)
@@ -55,9 +56,21 @@ __device__ __forceinline__ void decode_m(int m, int MT, int MU, int& n, int& t, 
   u = r - t * MU;
 }
 
-// DEPTH = number of K stages whose global loads are in flight while one stage is computed.  Wide tiles
-// compute ~2048 MFMA cycles per stage and hide the memory latency with DEPTH 1; narrow tiles (<= 32
-// filter rows: 256-512 cycles per stage) are latency-bound unless two stages are in flight.
+// DEPTH = number of K stages whose global loads are in flight while one stage is computed.
+// TBK = K elements per stage: 16 -> fp32 operands on v_mfma_f32_16x16x4_f32; 32 -> operands rounded to
+// bf16 when they are staged into LDS (tensors stay fp32 in HBM) and contracted by ONE
+// v_mfma_f32_16x16x32_bf16 per fragment pair and stage, fp32 accumulation (BASELINE config 3's path).
+// Either way a tile row occupies 16 dwords of a 20-dword LDS row and lane group g reads dwords 4g..4g+3.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint2 pack_bf16x4(f32x4 v) {
+  bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  return __builtin_bit_cast(uint2, h);
+}
+
 template <int BCO, int BPIX, int WCO, int WPIX, int TBK, int DEPTH, bool TAB>
 __global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 && (BCO + BPIX) <= 192 ? 5 : 3)) void conv_nt_kernel(const ConvP p) {
   // per-class geometry (class 0 for ordinary launches); all wave-uniform scalars
@@ -70,7 +83,9 @@ __global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 && (BCO + BPIX)
   constexpr int FI = WCO / 16, FJ = WPIX / 16;
   constexpr int WAVES_CO = BCO / WCO;
   static_assert(WAVES_CO * (BPIX / WPIX) == 4, "4 waves per workgroup");
-  constexpr int LDT = TBK + 4;               // LDS row pitch 20 floats (16-B aligned rows); pitch 24 is conflict-free but costs a workgroup of occupancy: measured slower
+  constexpr bool BF = TBK == 32;
+  static_assert(TBK == 16 || TBK == 32, "fp32 stages hold 16 K elements, bf16 stages 32");
+  constexpr int LDT = 20;                    // LDS row pitch 20 floats (16-B aligned rows); pitch 24 is conflict-free but costs a workgroup of occupancy: measured slower
   constexpr int KG = TBK / 4;                // float4 groups per tile row
   constexpr int RPP = 256 / KG;              // tile rows covered per load pass
   constexpr int PL = BPIX / RPP;
@@ -174,12 +189,19 @@ __global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 && (BCO + BPIX)
   };
   auto store_tiles = [&](int buf, const f32x4 (&rp_)[PL], const f32x4 (&rw_v)[WL]) {
 #pragma unroll
-    for (int i = 0; i < PL; ++i)
-      *reinterpret_cast<f32x4*>(Ps + (buf * BPIX + lrow + i * RPP) * LDT + kg * 4) = rp_[i];
+    for (int i = 0; i < PL; ++i) {
+      float* dst = Ps + (buf * BPIX + lrow + i * RPP) * LDT;
+      if constexpr (BF) *reinterpret_cast<uint2*>(dst + kg * 2) = pack_bf16x4(rp_[i]);
+      else *reinterpret_cast<f32x4*>(dst + kg * 4) = rp_[i];
+    }
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
       int row = lrow + i * RPP;
-      if (row < BCO) *reinterpret_cast<f32x4*>(Ws + (buf * BCO + row) * LDT + kg * 4) = rw_v[i];
+      if (row < BCO) {
+        float* dst = Ws + (buf * BCO + row) * LDT;
+        if constexpr (BF) *reinterpret_cast<uint2*>(dst + kg * 2) = pack_bf16x4(rw_v[i]);
+        else *reinterpret_cast<f32x4*>(dst + kg * 4) = rw_v[i];
+      }
     }
   };
 
@@ -191,22 +213,30 @@ __global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 && (BCO + BPIX)
 
   const int frow = lane & 15, fk = (lane >> 4) * 4;
   auto compute = [&](int buf) {
-#pragma unroll
-    for (int c16 = 0; c16 < TBK; c16 += 16) {
+    {
       f32x4 a[FI], b[FJ];
 #pragma unroll
       for (int i = 0; i < FI; ++i)
-        a[i] = *reinterpret_cast<const f32x4*>(Ws + (buf * BCO + wco0 + 16 * i + frow) * LDT + c16 + fk);
+        a[i] = *reinterpret_cast<const f32x4*>(Ws + (buf * BCO + wco0 + 16 * i + frow) * LDT + fk);
 #pragma unroll
       for (int j = 0; j < FJ; ++j)
-        b[j] = *reinterpret_cast<const f32x4*>(Ps + (buf * BPIX + wpix0 + 16 * j + frow) * LDT + c16 + fk);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
+        b[j] = *reinterpret_cast<const f32x4*>(Ps + (buf * BPIX + wpix0 + 16 * j + frow) * LDT + fk);
+      if constexpr (BF) {
 #pragma unroll
         for (int i = 0; i < FI; ++i)
 #pragma unroll
           for (int j = 0; j < FJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]),
+                                                                __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+      }
     }
   };
   if constexpr (DEPTH == 1) {
@@ -529,12 +559,12 @@ int try_conv_tile(const ConvP& p, hipStream_t s, int* rc) {
 // ceil(blocks / 256) * tile work, then split K when the grid still under-fills the chip.
 struct NtPlan { int bco, bpix, tbk, ksplit, kchunks; int64_t ws_floats; };
 
-NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1) {
+NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = ITG_PREC_F32) {
   NtPlan pl;
   const int64_t M = M_total / ncls;      // per-class pixel count (classes are launched as one grid)
   static const int force_bk = env_int("ITG_NT_BK", 0);   // tuning override: 16 | 32
   (void)force_bk;
-  pl.tbk = 16;
+  pl.tbk = prec == ITG_PREC_BF16 ? 32 : 16;
   if (co_rows <= 16) pl.bco = 16;
   else if (co_rows <= 32) pl.bco = 32;
   else if (co_rows <= 64) pl.bco = 64;
@@ -585,23 +615,15 @@ int launch_nt(const ConvP& p, int tbk, hipStream_t s) {
   int64_t blocks = npix * q.nco_tiles;
   if (blocks <= 0 || blocks > 0x7fffffff) return ITG_ERR_ARG;
   dim3 grid((unsigned)blocks, (unsigned)(p.ncls > 1 ? p.ncls : 1), (unsigned)p.ksplit);
-  (void)tbk;   // only the BK = 16 pipeline is instantiated (BK = 32 measured 3-8 % slower: LDS-limited occupancy)
   size_t tab_bytes = (size_t)BPIX * (p.ntaps + 1) * sizeof(unsigned);
   q.use_tab = (p.cin_ld < 64 && tab_bytes <= 24 * 1024) ? 1 : 0;
   if (!q.use_tab) tab_bytes = 0;
-  static const int depth_narrow = env_int("ITG_NT_DEPTH", 2);
-  static const int depth_wide = env_int("ITG_NT_DEPTH_WIDE", 2);
-  const int depth = BCO <= 32 ? depth_narrow : depth_wide;
-  if (q.use_tab) {
-    if (depth == 2)
-      hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16, 2, true>), grid, dim3(256), tab_bytes, s, q);
-    else
-      hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16, 1, true>), grid, dim3(256), tab_bytes, s, q);
+  if (tbk == 32) {
+    if (q.use_tab) hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 32, 2, true>), grid, dim3(256), tab_bytes, s, q);
+    else hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 32, 2, false>), grid, dim3(256), 0, s, q);
   } else {
-    if (depth == 2)
-      hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16, 2, false>), grid, dim3(256), 0, s, q);
-    else
-      hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16, 1, false>), grid, dim3(256), 0, s, q);
+    if (q.use_tab) hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16, 2, true>), grid, dim3(256), tab_bytes, s, q);
+    else hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16, 2, false>), grid, dim3(256), 0, s, q);
   }
   ITG_CHECK_LAUNCH();
   return ITG_OK;
@@ -618,7 +640,7 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
     p.cioy[0] = p.ioy; p.ciox[0] = p.iox; p.cooy[0] = p.ooy; p.coox[0] = p.oox;
     p.cwoff[0] = 0;
   }
-  NtPlan pl = plan_nt((int64_t)p.M * ncls_, p.co_rows, p.Kpad, ncls_);
+  NtPlan pl = plan_nt((int64_t)p.M * ncls_, p.co_rows, p.Kpad, ncls_, p.prec);
   if (pl.ws_floats > workspace_floats || (pl.ws_floats && !workspace)) return ITG_ERR_WORKSPACE;
   p.ksplit = pl.ksplit; p.kchunks = pl.kchunks; p.partial = workspace;
   for (int c = 0; c < 4; ++c) p.cpoff[c] = (unsigned)((size_t)c * pl.ksplit * p.M * p.co_rows);
@@ -723,19 +745,29 @@ struct WgP {
   unsigned x_bytes, dy_bytes;
 };
 
-constexpr int BKP = 16;  // pixels per pipeline stage
+constexpr int BKP = 16;  // pixels per pipeline stage (fp32 operands; 32 with bf16 operands)
 
-template <int BCOL, int BCO, int WCOL, int WCO>
+// BF = false: fp32 operands, v_mfma_f32_16x16x4_f32, fragments read element-wise from pixel-major tiles.
+// BF = true : operands rounded to bf16 when staged (pixel-major rows of bf16), fragments fetched with the
+//             gfx950 transposing LDS read (ds_read_b64_tr_b16: a 4-pixel x 16-column block arrives
+//             column-major, i.e. as the K-contiguous MFMA operand) and contracted 32 pixels at a time by
+//             v_mfma_f32_16x16x32_bf16 with fp32 accumulation.
+template <int BCOL, int BCO, int WCOL, int WCO, bool BF>
 __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
   constexpr int FI = WCOL / 16, FJ = WCO / 16;
   constexpr int WAVES_COL = BCOL / WCOL;
   static_assert(WAVES_COL * (BCO / WCO) == 4, "4 waves per workgroup");
-  constexpr int LDX = BCOL + 16, LDY = BCO + 16;
+  constexpr int KP = BF ? 32 : BKP;                  // pixels per stage
+  constexpr int LDX = BCOL + 16, LDY = BCO + 16;     // fp32 tiles: row pitch in floats
+  constexpr int LHX = BCOL + 8, LHY = BCO + 8;       // bf16 tiles: row pitch in halfwords (8-B aligned rows)
   constexpr int XG = BCOL / 4, YG = BCO / 4;         // float4 groups per pixel row
-  constexpr int XL = (BKP * XG + 255) / 256, YL = (BKP * YG + 255) / 256;
+  constexpr int XL = (KP * XG + 255) / 256, YL = (KP * YG + 255) / 256;
   __shared__ __attribute__((aligned(16))) float smem[2 * BKP * (LDX + LDY)];
+  static_assert(2 * 32 * (LHX + LHY) * 2 <= 2 * BKP * (LDX + LDY) * 4, "bf16 tiles fit the fp32 allocation");
   float* Xs = smem;
   float* Ys = smem + 2 * BKP * LDX;
+  unsigned short* Xh = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Yh = Xh + 2 * KP * LHX;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col_tile = blockIdx.x % p.ncol_tiles;
@@ -766,8 +798,8 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
     xci[i] = col - tap * p.cin_ld;
     xky[i] = tap / p.kw;
     xkx[i] = tap - xky[i] * p.kw;
-    xok[i] = (xr[i] < BKP) && (col < p.Ktot);
-    int m = chunk_begin * BKP + xr[i];
+    xok[i] = (xr[i] < KP) && (col < p.Ktot);
+    int m = chunk_begin * KP + xr[i];
     decode_m(m < p.M ? m : 0, p.MT, p.MU, xn[i], xt[i], xu[i]);
     if (m >= p.M) xn[i] = p.x.n;  // marks invalid
   }
@@ -779,13 +811,13 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
     yr[i] = idx / YG;
     int g = idx - yr[i] * YG;
     yc[i] = g * 4;
-    yok[i] = (yr[i] < BKP) && (co0 + g * 4 < p.dy.ld);
-    int m = chunk_begin * BKP + yr[i];
+    yok[i] = (yr[i] < KP) && (co0 + g * 4 < p.dy.ld);
+    int m = chunk_begin * KP + yr[i];
     decode_m(m < p.M ? m : 0, p.MT, p.MU, yn[i], yt[i], yu[i]);
     if (m >= p.M) yn[i] = p.x.n;
   }
   auto advance = [&](int& n, int& t, int& u) {
-    u += BKP;
+    u += KP;
     while (u >= p.MU) { u -= p.MU; if (++t == p.MT) { t = 0; ++n; } }
   };
 
@@ -816,10 +848,16 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
   auto store_tiles = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < XL; ++i)
-      if (xr[i] < BKP) *reinterpret_cast<f32x4*>(Xs + (buf * BKP + xr[i]) * LDX + xcol[i]) = rx[i];
+      if (xr[i] < KP) {
+        if constexpr (BF) *reinterpret_cast<uint2*>(Xh + (buf * KP + xr[i]) * LHX + xcol[i]) = pack_bf16x4(rx[i]);
+        else *reinterpret_cast<f32x4*>(Xs + (buf * KP + xr[i]) * LDX + xcol[i]) = rx[i];
+      }
 #pragma unroll
     for (int i = 0; i < YL; ++i) {
-      if (yr[i] < BKP) *reinterpret_cast<f32x4*>(Ys + (buf * BKP + yr[i]) * LDY + yc[i]) = ry[i];
+      if (yr[i] < KP) {
+        if constexpr (BF) *reinterpret_cast<uint2*>(Yh + (buf * KP + yr[i]) * LHY + yc[i]) = pack_bf16x4(ry[i]);
+        else *reinterpret_cast<f32x4*>(Ys + (buf * KP + yr[i]) * LDY + yc[i]) = ry[i];
+      }
       if (do_db) dbacc += ry[i];
     }
   };
@@ -836,23 +874,51 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
     store_tiles(0);
     __syncthreads();
     const int fr = lane & 15, fkk = lane >> 4;
+    // transposing read: lane 4q+pp of 16-lane group g addresses pixel row 8g+q (then 8g+4+q), columns 4pp..4pp+3
+    const int trq = (lane & 15) >> 2, trp = lane & 3;
     for (int kk = 0; kk < nk; ++kk) {
       const int buf = kk & 1;
       if (kk + 1 < nk) load_tiles();
+      if constexpr (BF) {
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        bf16x8 a[FI], b[FJ];
+        const unsigned short* xb = Xh + (buf * KP + 8 * fkk + trq) * LHX + wcol0 + 4 * trp;
+        const unsigned short* yb = Yh + (buf * KP + 8 * fkk + trq) * LHY + wco0 + 4 * trp;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        float a[FI], b[FJ];
-        const float* xrow = Xs + (buf * BKP + 4 * s + fkk) * LDX + wcol0 + fr;
-        const float* yrow = Ys + (buf * BKP + 4 * s + fkk) * LDY + wco0 + fr;
+        for (int i = 0; i < FI; ++i) {
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 16 * i));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 16 * i + 4 * LHX));
+          s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          a[i] = __builtin_bit_cast(bf16x8, v);
+        }
 #pragma unroll
-        for (int i = 0; i < FI; ++i) a[i] = xrow[16 * i];
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) b[j] = yrow[16 * j];
+        for (int j = 0; j < FJ; ++j) {
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb + 16 * j));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb + 16 * j + 4 * LHY));
+          s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          b[j] = __builtin_bit_cast(bf16x8, v);
+        }
 #pragma unroll
         for (int i = 0; i < FI; ++i)
 #pragma unroll
           for (int j = 0; j < FJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          float a[FI], b[FJ];
+          const float* xrow = Xs + (buf * KP + 4 * s + fkk) * LDX + wcol0 + fr;
+          const float* yrow = Ys + (buf * KP + 4 * s + fkk) * LDY + wco0 + fr;
+#pragma unroll
+          for (int i = 0; i < FI; ++i) a[i] = xrow[16 * i];
+#pragma unroll
+          for (int j = 0; j < FJ; ++j) b[j] = yrow[16 * j];
+#pragma unroll
+          for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
       }
       if (kk + 1 < nk) store_tiles(buf ^ 1);
       __syncthreads();
@@ -863,12 +929,11 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
     f32x4* red = reinterpret_cast<f32x4*>(smem);
     red[tid] = dbacc;
     __syncthreads();
-    constexpr int RP = (256 / YG) < 1 ? 1 : (256 / YG);      // pixel rows covered per load pass
     if (tid < BCO && co0 + tid < p.co_rows) {
+      // thread t staged column group (t % YG) in each of its YL passes: every thread with that group holds
+      // a partial of the same 4 channels
       float sdb = 0.f;
-      if (YG <= 256) {
-        for (int r = 0; r < RP; ++r) sdb += red[r * YG + (tid >> 2)][tid & 3];
-      }
+      for (int r = (tid >> 2); r < 256; r += YG) sdb += red[r][tid & 3];
       p.dbslab[(size_t)split * p.co_rows + co0 + tid] = sdb;
     }
   }
@@ -943,11 +1008,12 @@ __global__ void slab_group_reduce_kernel(const f32x4* __restrict__ in, f32x4* __
 }
 
 template <int BCOL, int BCO, int WCOL, int WCO>
-int launch_tn(WgP p, int splits, hipStream_t s) {
+int launch_tn(WgP p, int splits, int prec, hipStream_t s) {
   p.ncol_tiles = (p.Kpad + BCOL - 1) / BCOL;
   p.nco_tiles = (p.co_rows + BCO - 1) / BCO;
   dim3 grid((unsigned)(p.ncol_tiles * p.nco_tiles), 1, (unsigned)splits);
-  hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO>), grid, dim3(256), 0, s, p);
+  if (prec == ITG_PREC_BF16) hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, true>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false>), grid, dim3(256), 0, s, p);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }
@@ -955,7 +1021,8 @@ int launch_tn(WgP p, int splits, hipStream_t s) {
 constexpr int RED_GROUP = 16;   // slabs summed per thread in either reduce stage
 struct TnPlan { int bcol, bco, splits, chunks_per_split, nchunks, co_rows, Kpad, ngroups; int64_t slab_floats, ws_floats; };
 
-TnPlan plan_tn(int64_t M, int co_ld, int Ktot) {
+TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec = ITG_PREC_F32) {
+  const int kp = prec == ITG_PREC_BF16 ? 32 : BKP;
   TnPlan t;
   t.co_rows = round_up(co_ld, 16);
   t.Kpad = round_up(Ktot, 16);
@@ -965,7 +1032,7 @@ TnPlan plan_tn(int64_t M, int co_ld, int Ktot) {
   else if (t.co_rows <= 64) { t.bco = 64; t.bcol = 256; }
   else { t.bco = 128; t.bcol = 128; }
   int tiles = ((t.Kpad + t.bcol - 1) / t.bcol) * ((t.co_rows + t.bco - 1) / t.bco);
-  t.nchunks = (int)((M + BKP - 1) / BKP);
+  t.nchunks = (int)((M + kp - 1) / kp);
   int want = (1024 + tiles - 1) / tiles;            // ~4 workgroups per CU overall
   int max_splits = (t.nchunks + 7) / 8;             // at least 8 chunks per split
   int splits = want < max_splits ? want : max_splits;
@@ -1052,6 +1119,7 @@ int conv_out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1;
 // vertical padding may differ from the horizontal one (row-sharded patch grids carry their halo rows
 // explicitly and pad only the columns): pad_h < 0 means "same as pad"
 inline int pad_v(const itg_conv_geom* g) { return g->pad_h >= 0 ? g->pad_h : g->pad; }
+inline int prec_of(const itg_conv_geom* g) { return g->precision == ITG_PREC_BF16 ? ITG_PREC_BF16 : ITG_PREC_F32; }
 
 }  // namespace
 
@@ -1103,9 +1171,9 @@ int64_t itg_conv2d_fwd_workspace(const itg_tensor* in, const itg_tensor* out, co
   if (!in || !out || !g) return 0;
   if (thin_out_conv(in, out, g)) {
     int64_t Min = grid_pixels(in);
-    return Min * 16 + plan_nt(Min, 16, round_up(in->ld, BK)).ws_floats;
+    return Min * 16 + plan_nt(Min, 16, round_up(in->ld, BK), 1, prec_of(g)).ws_floats;
   }
-  return plan_nt(grid_pixels(out), round_up(out->c, 16), round_up(g->kh * g->kw * in->ld, BK)).ws_floats;
+  return plan_nt(grid_pixels(out), round_up(out->c, 16), round_up(g->kh * g->kw * in->ld, BK), 1, prec_of(g)).ws_floats;
 }
 
 int64_t itg_conv2d_dgrad_workspace(const itg_tensor* dy, const itg_tensor* dx, const itg_conv_geom* g) {
@@ -1114,11 +1182,11 @@ int64_t itg_conv2d_dgrad_workspace(const itg_tensor* dy, const itg_tensor* dx, c
   int64_t H = (int64_t)dx->gh * dx->ph, W = (int64_t)dx->gw * dx->pw;
   if (g->stride == 1) {
     int eh = (g->pad_mode == ITG_PAD_REPLICATE) ? 2 * pad_v(g) : 0, ew = (g->pad_mode == ITG_PAD_REPLICATE) ? 2 * g->pad : 0;
-    return plan_nt((int64_t)dx->n * (H + eh) * (W + ew), co_rows, round_up(g->kh * g->kw * dy->ld, BK)).ws_floats;
+    return plan_nt((int64_t)dx->n * (H + eh) * (W + ew), co_rows, round_up(g->kh * g->kw * dy->ld, BK), 1, prec_of(g)).ws_floats;
   }
   int Kpad = round_up((g->kh / 2) * (g->kw / 2) * dy->ld, BK);
   int64_t Mmax = (int64_t)dx->n * ((H + 1) / 2) * ((W + 1) / 2);
-  return plan_nt(Mmax * 4, co_rows, Kpad, 4).ws_floats;
+  return plan_nt(Mmax * 4, co_rows, Kpad, 4, prec_of(g)).ws_floats;
 }
 
 int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bias, const itg_tensor* residual,
@@ -1135,7 +1203,7 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
     const int64_t Min = grid_pixels(in), pf = Min * 16;
     if (!workspace || workspace_floats < pf || pf >= ((int64_t)1 << 31)) return ITG_ERR_WORKSPACE;
     itg_tensor P = {workspace, in->n, 1, 1, H, W, 16, 16};
-    itg_conv_geom g1 = {1, 1, 1, 0, ITG_PAD_ZERO, 0};
+    itg_conv_geom g1 = {1, 1, 1, 0, ITG_PAD_ZERO, 0, prec_of(g)};
     // row 0 of the packed filter is (tap, ci)-ordered with ci_ld a multiple of 16: read as 16 rows of ci_ld
     if ((rc = itg_conv2d_fwd(in, w_packed, nullptr, nullptr, &P, &g1, ITG_ACT_NONE, 0.f, workspace + pf,
                              workspace_floats - pf, stream))) return rc;
@@ -1149,6 +1217,7 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   }
   ConvP p;
   p.ncls = 1;
+  p.prec = prec_of(g);
   p.in = make_grid(in);
   p.out = make_grid(out);
   p.res = null_grid();
@@ -1184,6 +1253,7 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const it
   hipStream_t s = (hipStream_t)stream;
   ConvP p;
   p.ncls = 1;
+  p.prec = prec_of(g);
   p.in = make_grid(dy);
   p.out = make_grid(dx);
   p.res = null_grid();
@@ -1255,11 +1325,11 @@ int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, co
   if (!x || !dy || !g) return 0;
   if (thin_out_conv(x, dy, g)) {
     int64_t Min = grid_pixels(x);
-    TnPlan t = plan_tn(Min, 16, x->ld);
+    TnPlan t = plan_tn(Min, 16, x->ld, prec_of(g));
     return Min * 16 + 16 * (int64_t)x->c + 16 + t.ws_floats + (int64_t)t.splits * t.co_rows;
   }
   int64_t M = grid_pixels(dy);
-  TnPlan t = plan_tn(M, dy->ld, g->kh * g->kw * x->ld);
+  TnPlan t = plan_tn(M, dy->ld, g->kh * g->kw * x->ld, prec_of(g));
   return t.ws_floats + (int64_t)t.splits * t.co_rows;
 }
 
@@ -1283,7 +1353,7 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
                        g->pad);
     ITG_CHECK_LAUNCH();
     itg_tensor Qt = {Q, x->n, 1, 1, H, W, 16, 16};
-    itg_conv_geom g1 = {1, 1, 1, 0, ITG_PAD_ZERO, 0};
+    itg_conv_geom g1 = {1, 1, 1, 0, ITG_PAD_ZERO, 0, prec_of(g)};
     if ((rc = itg_conv2d_wgrad(x, &Qt, tmp, tmp + 16 * (int64_t)x->c, &g1, 0, workspace + qf + tf,
                                workspace_floats - qf - tf, stream))) return rc;
     int n = x->c * 16;
@@ -1302,7 +1372,8 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
   if (M >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
   p.ntaps = g->kh * g->kw; p.kw = g->kw; p.cin_ld = x->ld;
   p.Ktot = p.ntaps * x->ld;
-  TnPlan t = plan_tn(M, dy->ld, p.Ktot);
+  const int prec = prec_of(g);
+  TnPlan t = plan_tn(M, dy->ld, p.Ktot, prec);
   if (t.ws_floats + (int64_t)t.splits * t.co_rows > workspace_floats) return ITG_ERR_WORKSPACE;
   p.Kpad = t.Kpad; p.co_rows = t.co_rows;
   p.slab = workspace;
@@ -1315,11 +1386,11 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
     if (xb >= 0xFFFF0000LL || yb >= 0xFFFF0000LL) return ITG_ERR_ARG;
     p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
   }
-  if (t.bcol == 64) rc = launch_tn<64, 64, 32, 32>(p, t.splits, s);
-  else if (t.bco == 16) rc = launch_tn<256, 16, 64, 16>(p, t.splits, s);
-  else if (t.bco == 32) rc = launch_tn<256, 32, 64, 32>(p, t.splits, s);
-  else if (t.bco == 64) rc = launch_tn<256, 64, 64, 64>(p, t.splits, s);
-  else rc = launch_tn<128, 128, 64, 64>(p, t.splits, s);
+  if (t.bcol == 64) rc = launch_tn<64, 64, 32, 32>(p, t.splits, prec, s);
+  else if (t.bco == 16) rc = launch_tn<256, 16, 64, 16>(p, t.splits, prec, s);
+  else if (t.bco == 32) rc = launch_tn<256, 32, 64, 32>(p, t.splits, prec, s);
+  else if (t.bco == 64) rc = launch_tn<256, 64, 64, 64>(p, t.splits, prec, s);
+  else rc = launch_tn<128, 128, 64, 64>(p, t.splits, prec, s);
   if (rc) return rc;
   const float* red_src = workspace;
   int red_n = t.splits;

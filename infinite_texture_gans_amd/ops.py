@@ -6,6 +6,7 @@ tensors: a contiguous fp32 CUDA tensor of shape (n, gh, gw, ph, pw, ld) plus the
 channel count ``c`` (ld = c rounded up to 4, pad channels are zero) - see :class:`GT`.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -20,6 +21,34 @@ def ld_for(c):
 # Optional launch profiler (bench.py): a list that receives (kernel_tag, n_launches, flops, ev0, ev1)
 # per convolution call, with HIP events recorded on the launching stream.  None = off.
 PROFILE = None
+
+# MFMA operand type of every convolution launched without an explicit ``precision``: PREC_F32 is the
+# reference's arithmetic; PREC_BF16 rounds the operands to bf16 on their way into LDS (fp32 tensors,
+# fp32 accumulation) - BASELINE config 3's "bf16 MFMA path", parity tolerance 1e-2 per conv.
+from ._lib import PREC_F32, PREC_BF16  # noqa: E402
+MFMA_PRECISION = PREC_BF16 if os.environ.get("ITG_MFMA", "f32").lower() == "bf16" else PREC_F32
+
+
+class mfma_precision:
+    """``with ops.mfma_precision("bf16"): ...`` (also usable as a plain setter: ``ops.mfma_precision("bf16").set()``)."""
+
+    def __init__(self, name):
+        self.value = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16}[str(name).lower()]
+
+    def set(self):
+        global MFMA_PRECISION
+        MFMA_PRECISION = self.value
+        return self
+
+    def __enter__(self):
+        global MFMA_PRECISION
+        self.prev, MFMA_PRECISION = MFMA_PRECISION, self.value
+        return self
+
+    def __exit__(self, *a):
+        global MFMA_PRECISION
+        MFMA_PRECISION = self.prev
+
 
 
 def _nt_tag(rows):
@@ -198,7 +227,7 @@ class _Conv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, residual, sn, c_in, geom, act, slope, out_grid, sinks=None):
-        kh, kw, stride, pad, pad_mode, pad_h = geom
+        kh, kw, stride, pad, pad_mode, pad_h, prec = geom
         pv = pad_h if pad_h >= 0 else pad
         n, gh, gw, ph, pw, ld = x.shape
         co, ci = w.shape[0], w.shape[1]
@@ -217,7 +246,7 @@ class _Conv(torch.autograd.Function):
         out = torch.empty((n, ogh, ogw, Ho // ogh, Wo // ogw, ld_for(co)), device=x.device, dtype=torch.float32)
         dx_, do_ = _desc(x, c_in), _desc(out, co)
         dr_ = _desc(residual, co) if residual is not None else _null_desc()
-        g = _G(kh, kw, stride, pad, pad_mode, pad_h)
+        g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec)
         nws = _lib.fn("itg_conv2d_fwd_workspace")(C.byref(dx_), C.byref(do_), C.byref(g))
         ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
         with _Prof(_nt_tag(co), 1, 2.0 * n * Ho * Wo * co * ci * kh * kw):
@@ -233,7 +262,7 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x, w, out = ctx.saved_tensors
-        kh, kw, stride, pad, pad_mode, pad_h = ctx.geom
+        kh, kw, stride, pad, pad_mode, pad_h, prec = ctx.geom
         co, ci = ctx.co, ctx.c_in
         st = _stream()
         dout = dout.contiguous()
@@ -243,7 +272,7 @@ class _Conv(torch.autograd.Function):
             _lib.call("itg_act_bwd", C.byref(a), C.byref(b), C.byref(c_), ctx.act, float(ctx.slope), st)
         else:
             dy = dout
-        g = _G(kh, kw, stride, pad, pad_mode, pad_h)
+        g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec)
         ddy = _desc(dy, co)
         inv_sigma = ctx.sn[0] if ctx.sn is not None else None
         gx = gw_ = gb = None
@@ -294,13 +323,14 @@ class _Conv(torch.autograd.Function):
 
 
 def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, residual=None,
-         sn=None, out_grid=None, sinks=None, pad_h=-1):
+         sn=None, out_grid=None, sinks=None, pad_h=-1, precision=None):
     """x: GT.  Returns GT with ``out_grid`` (default: the input grid).  ``sinks`` = (weight.grad, bias.grad)
     buffers: the backward then accumulates the parameter gradients straight into them (and reports no
     gradient to autograd), which removes one AccumulateGrad add kernel per parameter."""
     og = out_grid if out_grid is not None else (x.gh, x.gw)
     r = residual.t if residual is not None else None
-    t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode, pad_h), act, slope, og, sinks)
+    prec = MFMA_PRECISION if precision is None else precision
+    t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode, pad_h, prec), act, slope, og, sinks)
     return GT(t, w.shape[0])
 
 

@@ -25,6 +25,9 @@ def train(args):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
         group = dist.group.WORLD
+    if getattr(args, "bf16", False):
+        from . import ops
+        ops.mfma_precision("bf16").set()
     random.seed(seed), torch.manual_seed(seed), np.random.seed(seed)
     args.beta1, args.beta2 = float(args.beta1), float(args.beta2)    # the reference's int default breaks torch>=2
     if rank == 0:

@@ -66,6 +66,8 @@ _FLAGS = [
     ("dev_num", int, 0, "GPU index when a single GPU is used"),
     ("num_workers", int, 0, "data loader workers"),
     ("fname", str, "models_cp", "folder for checkpoints"),
+    ("bf16", "flag", False, "build-side extra: run the convolutions on bf16-operand MFMA (fp32 tensors and "
+                            "accumulation; BASELINE config 3)"),
     ("shard_patch_rows", "flag", False, "build-side extra: multi-GPU runs shard the patch grid of ONE batch by patch "
                                         "rows (halo exchange) instead of replicating the batch per GPU"),
 ]

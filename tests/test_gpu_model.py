@@ -328,3 +328,45 @@ def test_band_sharded_train_step_matches_reference_golden(world, tmp_path):
                 assert (got - v.double()).abs().max() <= 2 * 2e-4 * steps + 1e-7, k
             else:
                 assert rel_l2(got, v.double()) < 2e-3, (k, rel_l2(got, v.double()))
+
+
+def test_bf16_mfma_path_tracks_reference_golden():
+    """BASELINE config 3's path (attention generator, convolutions on bf16-operand MFMA with fp32
+    accumulation; tensors, BatchNorm, attention and the optimizer stay fp32).  Tolerances are bf16's:
+    forward images 2e-2 rel-L2, losses 3e-2 relative, first-step D gradients 5e-2 rel-L2."""
+    from infinite_texture_gans_amd import ops, utils as U
+    from infinite_texture_gans_amd.engine import FlatParams
+    fx = load("fwd_bn_nl5_att")
+    a = parse_flags(fx["argv"])
+    G, D = build(a, state(fx, "G0/"), state(fx, "D0/"))
+    G.train(), D.train()
+    with ops.mfma_precision("bf16"), torch.no_grad():
+        patches = G(torch.from_numpy(fx["z"]).to(cuda), None, "1st_row_1st_col")
+        fake = U.merge_patches_into_image(patches, a["num_patches_height"], a["num_patches_width"], cuda)
+        logit = D(fake)
+    e_img, e_logit = rel_l2(fake.cpu(), fx["fake"]), rel_l2(logit.cpu(), fx["d_fake"])
+    assert 1e-5 < e_img < 2e-2, e_img          # lower bound: the bf16 path really ran
+    assert e_logit < 2e-2, e_logit
+    # ---- training: losses of the reference's steps and the first D-step gradients
+    fx = load("train_bn_nl5_att")
+    a = parse_flags(fx["argv"])
+    G, D = build(a, state(fx, "G0/"), state(fx, "D0/"))
+    G.train(), D.train()
+    flat = FlatParams(D)
+    flat.zero_grad()
+    with ops.mfma_precision("bf16"):
+        ops.bce_with_logits(D(torch.from_numpy(fx["real_x0"]).to(cuda)), 0.9 if a["smooth"] else 1.0).backward()
+        fake = G.forward_grid(torch.from_numpy(fx["z0"]).to(cuda), None)
+        ops.bce_with_logits(ops.to_nchw(D.forward_grid(fake.detach())), 0.0).backward()
+    for k, p in D.named_parameters():
+        assert rel_l2(p.grad.cpu(), fx["gradD0/" + k]) < 5e-2, (k, rel_l2(p.grad.cpu(), fx["gradD0/" + k]))
+    G, D = build(a, state(fx, "G0/"), state(fx, "D0/"))
+    G.train(), D.train()
+    from infinite_texture_gans_amd.engine import Trainer
+    args = U.prepare_parser().parse_args([])
+    args.smooth, args.beta1 = a["smooth"], 0.0
+    tr = Trainer(G, D, args, cuda)
+    with ops.mfma_precision("bf16"):
+        for s_ in range(int(fx["steps"])):
+            l = tr.step(torch.from_numpy(fx["real_x%d" % s_]).to(cuda), torch.from_numpy(fx["z%d" % s_]).to(cuda), None)
+            assert np.allclose([float(v) for v in l], fx["loss%d" % s_], rtol=3e-2, atol=1e-3), (s_, l, fx["loss%d" % s_])
