@@ -74,6 +74,17 @@ int itg_pack_fwd(const float* w_oihw, const float* scale, float* out, int co, in
 int itg_pack_dgrad(const float* w_oihw, const float* scale, float* out, int co, int ci, int co_ld,
                    int kh, int kw, int stride, void* stream);
 
+/* Every panel of a model in ONE launch (the train step repacks a model once per optimizer step:
+ * 2 launches per iteration instead of ~65).  The job table is static for a model and lives in DEVICE
+ * memory (no per-launch upload, capturable in a hipGraph): n <= ITG_PACK_MAX_JOBS rows of 10 x int64
+ *   { w_oihw (pointer), out (pointer), co, ci, ld, kh, kw, stride, dgrad, start }
+ * ld = ci_ld for a forward panel (dgrad = 0, itg_pack_fwd layout) or co_ld for a dgrad panel (dgrad = 1,
+ * itg_pack_dgrad layout); row j owns flat elements [start_j, start_j + size_j) of the launch, `total` is
+ * the sum of the panel sizes (itg_pack_*_size).  No scale here: the spectral-norm 1/sigma of such
+ * panels is applied through `out_scale` below. */
+#define ITG_PACK_MAX_JOBS 48
+int itg_pack_multi(const int64_t* table_dev, int n, int64_t total, void* stream);
+
 /* ---- convolution (implicit GEMM on v_mfma_f32_16x16x4_f32) ----------------------
  * Replaces nn.Conv2d forward/backward at reference models/layers.py:25-34 (3x3 under
  * local padding: the 1-px halo of LocalPadder, layers.py:145-173, is read straight
@@ -82,20 +93,23 @@ int itg_pack_dgrad(const float* w_oihw, const float* scale, float* out, int co, 
  *   out = act( conv(in, w) + bias [+ residual] )
  * in/out are patch-grid tensors; the conv runs in merged-image coordinates.
  * act: ITG_ACT_* with slope for LRELU (slope 0 = ReLU).  bias may be NULL (length
- * out.ld, zero-padded); residual (same layout as out) may have ptr == NULL.        */
+ * out.ld, zero-padded); residual (same layout as out) may have ptr == NULL.
+ * out_scale: NULL or one device float multiplied into the contraction before the bias
+ * (1/sigma of a spectrally normalised layer whose panel was packed unscaled).       */
 /* workspace (floats) for the split-K path taken when the grid would under-fill the 256 CUs;
  * 0 when the call does not split.  The same sizes are re-derived inside the launch.            */
 int64_t itg_conv2d_fwd_workspace(const itg_tensor* in, const itg_tensor* out, const itg_conv_geom* g);
 int64_t itg_conv2d_dgrad_workspace(const itg_tensor* dy, const itg_tensor* dx, const itg_conv_geom* g);
-int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bias,
+int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bias, const float* out_scale,
                    const itg_tensor* residual, const itg_tensor* out, const itg_conv_geom* g,
                    int act, float slope, float* workspace, int64_t workspace_floats, void* stream);
 
 /* dX of the same conv: `dy` has the conv's output shape, `dx` its input shape.
  * With ITG_PAD_REPLICATE the gradient of the replicated border folds back onto the
  * edge pixels (the autograd of F.pad(..., 'replicate') at layers.py:82).           */
-int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const itg_tensor* dx,
-                     const itg_conv_geom* g, float* workspace, int64_t workspace_floats, void* stream);
+int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const float* out_scale,
+                     const itg_tensor* dx, const itg_conv_geom* g, float* workspace, int64_t workspace_floats,
+                     void* stream);
 
 /* dW (OIHW, accumulated into dw when accumulate != 0) and optional db (length co).
  * workspace: itg_conv2d_wgrad_workspace() floats (split-K slabs + fp64 bias scratch). */

@@ -29,6 +29,8 @@ class ConvGeom(C.Structure):
         super().__init__(kh, kw, stride, pad, pad_mode, pad_h, precision)
 
 
+PACK_MAX_JOBS = 48
+
 _P = C.c_void_p
 _TP = C.POINTER(Tensor)
 _GP = C.POINTER(ConvGeom)
@@ -43,8 +45,9 @@ SIGNATURES = {
     "itg_pack_dgrad": (_i, [_P, _P, _P, _i, _i, _i, _i, _i, _i, _P]),
     "itg_conv2d_fwd_workspace": (_l, [_TP, _TP, _GP]),
     "itg_conv2d_dgrad_workspace": (_l, [_TP, _TP, _GP]),
-    "itg_conv2d_fwd": (_i, [_TP, _P, _P, _TP, _TP, _GP, _i, _f, _P, _l, _P]),
-    "itg_conv2d_dgrad": (_i, [_TP, _P, _TP, _GP, _P, _l, _P]),
+    "itg_pack_multi": (_i, [_P, _i, _l, _P]),
+    "itg_conv2d_fwd": (_i, [_TP, _P, _P, _P, _TP, _TP, _GP, _i, _f, _P, _l, _P]),
+    "itg_conv2d_dgrad": (_i, [_TP, _P, _P, _TP, _GP, _P, _l, _P]),
     "itg_conv2d_wgrad_workspace": (_l, [_TP, _TP, _GP]),
     "itg_conv2d_wgrad": (_i, [_TP, _TP, _P, _P, _GP, _i, _P, _l, _P]),
     "itg_local_pad_fwd": (_i, [_P, _P, _i, _i, _i, _i, _i, _i, _i, _P]),

@@ -29,6 +29,7 @@ struct ConvP {
   GridT in, out, res;
   const float* w;
   const float* bias;
+  const float* scale;           // one device float multiplied into the contraction (1/sigma), or null
   int ntaps, kw, cin_ld, Kpad;
   int MT, MU, M;
   int isy, ioy, isx, iox;
@@ -71,8 +72,14 @@ __device__ __forceinline__ uint2 pack_bf16x4(f32x4 v) {
   return __builtin_bit_cast(uint2, h);
 }
 
+// Workgroups per CU the register budget is pinned to: 3 (168 VGPRs) for the wide tiles, 5 (96) for the
+// medium fp32 tiles, 4 (128) for the medium bf16 tiles (their stage holds twice the prefetch registers).
+constexpr int nt_min_blocks(int bco, int bpix, int wco, int wpix, int tbk) {
+  return ((wco / 16) * (wpix / 16) <= 8 && (bco + bpix) <= 192) ? (tbk == 32 ? 4 : 5) : 3;
+}
+
 template <int BCO, int BPIX, int WCO, int WPIX, int TBK, int DEPTH, bool TAB>
-__global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 && (BCO + BPIX) <= 192 ? 5 : 3)) void conv_nt_kernel(const ConvP p) {
+__global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void conv_nt_kernel(const ConvP p) {
   // per-class geometry (class 0 for ordinary launches); all wave-uniform scalars
   const int cls = blockIdx.y;
   const int cMT = p.cMT[cls], cMU = p.cMU[cls], cM = p.cM[cls];
@@ -271,6 +278,13 @@ __global__ __launch_bounds__(256, ((WCO / 16) * (WPIX / 16) <= 8 && (BCO + BPIX)
 
   // ---- epilogue: lane holds 4 consecutive output channels of one pixel per fragment
   const int cq = (lane >> 4) * 4;
+  if (p.scale && p.ksplit <= 1) {          // 1/sigma of an unscaled panel (split-K: applied by the second stage)
+    const float osc = *p.scale;
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) acc[i][j] *= osc;
+  }
   if (p.ksplit > 1) {
     float* slab = cpartial + (size_t)blockIdx.z * cM * p.co_rows;
 #pragma unroll
@@ -362,6 +376,7 @@ __global__ void splitk_epilogue_kernel(ConvP p) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     for (int z = 0; z < p.ksplit; ++z)
       v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)z * p.M + m) * p.co_rows + co);
+    if (p.scale) v *= *p.scale;
     int n, t, u;
     decode_m(m, p.MT, p.MU, n, t, u);
     int oy = t * p.osy + p.ooy, ox = u * p.osx + p.oox;
@@ -396,6 +411,7 @@ __global__ void splitk_epilogue_kernel(ConvP p) {
 }
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+__device__ __forceinline__ int round_up_d(int x, int m) { return (x + m - 1) / m * m; }
 // ------------------------------------------------------------------------------- small-channel 3x3 (LDS halo tile)
 // Stride-1 3x3 convolutions with <= 32 input and <= 32 output channels (the generator's last blocks
 // and `final`, forward and input-gradient).  The implicit-GEMM kernel above re-gathers every input
@@ -413,6 +429,7 @@ __device__ __forceinline__ void store_out(const ConvP& p, int n, int oy, int ox,
     oy = ty; ox = tx;
   }
   const int off = grid_off(p.out, n, oy, ox);
+  if (p.scale) v *= *p.scale;
   if (p.bias) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -618,12 +635,16 @@ int launch_nt(const ConvP& p, int tbk, hipStream_t s) {
   size_t tab_bytes = (size_t)BPIX * (p.ntaps + 1) * sizeof(unsigned);
   q.use_tab = (p.cin_ld < 64 && tab_bytes <= 24 * 1024) ? 1 : 0;
   if (!q.use_tab) tab_bytes = 0;
+  // two K stages in flight except for the medium fp32 tiles, whose 96-register budget has no room for
+  // the second prefetch set (it would spill into scratch inside the K loop)
+  constexpr int D32 = (nt_min_blocks(BCO, BPIX, WCO, WPIX, 32) == 3 && BCO >= 64) ? 1 : 2;   // wide bf16 stages: 16 prefetch registers per set
+  constexpr int D16 = (nt_min_blocks(BCO, BPIX, WCO, WPIX, 16) == 5 && BCO > 32) ? 1 : 2;
   if (tbk == 32) {
-    if (q.use_tab) hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 32, 2, true>), grid, dim3(256), tab_bytes, s, q);
-    else hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 32, 2, false>), grid, dim3(256), 0, s, q);
+    if (q.use_tab) hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 32, D32, true>), grid, dim3(256), tab_bytes, s, q);
+    else hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 32, D32, false>), grid, dim3(256), 0, s, q);
   } else {
-    if (q.use_tab) hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16, 2, true>), grid, dim3(256), tab_bytes, s, q);
-    else hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16, 2, false>), grid, dim3(256), 0, s, q);
+    if (q.use_tab) hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16, D16, true>), grid, dim3(256), tab_bytes, s, q);
+    else hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 16, D16, false>), grid, dim3(256), 0, s, q);
   }
   ITG_CHECK_LAUNCH();
   return ITG_OK;
@@ -729,6 +750,56 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, const float* __re
       v = w[(((size_t)o * ci + c_in) * kh + y) * kw + x] * sc;
     }
     out[i] = v;
+  }
+}
+
+
+// every packed panel of a model in one launch.  The job table lives in DEVICE memory (it is static for a
+// model: built once, no per-launch upload, capturable in a hipGraph): row j = 10 x int64
+// {w_oihw, out, co, ci, ld, kh, kw, stride, dgrad, start}; job j owns elements [start_j, start_{j+1}).
+constexpr int PACK_ROW = 10;
+
+__global__ void pack_multi_kernel(const long long* __restrict__ table, int n, long long total) {
+  __shared__ long long T[ITG_PACK_MAX_JOBS * PACK_ROW];
+  for (int i = threadIdx.x; i < n * PACK_ROW; i += blockDim.x) T[i] = table[i];
+  __syncthreads();
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {                       // last job with start <= i
+      int mid = (lo + hi + 1) >> 1;
+      if (T[mid * PACK_ROW + 9] <= i) lo = mid; else hi = mid - 1;
+    }
+    const long long* b = T + lo * PACK_ROW;
+    const float* w = reinterpret_cast<const float*>(b[0]);
+    float* out = reinterpret_cast<float*>(b[1]);
+    const int co = (int)b[2], ci = (int)b[3], ld = (int)b[4], kh = (int)b[5], kw = (int)b[6], stride = (int)b[7];
+    const long long e = i - b[9];
+    float v = 0.f;
+    if (!b[8]) {
+      const int Kpad = round_up_d(kh * kw * ld, BK);
+      int k = (int)(e % Kpad), o = (int)(e / Kpad);
+      int tap = k / ld, c = k - tap * ld;
+      if (o < co && tap < kh * kw && c < ci) {
+        int y = tap / kw, x = tap - y * kw;
+        v = w[(((size_t)o * ci + c) * kh + y) * kw + x];
+      }
+    } else {
+      const int skh = kh / stride, skw = kw / stride;
+      const int Kpad = round_up_d(skh * skw * ld, BK);
+      const int ci_pad = round_up_d(ci, 16);
+      int k = (int)(e % Kpad);
+      long long r = e / Kpad;
+      int c_in = (int)(r % ci_pad), cls = (int)(r / ci_pad);
+      int ry = cls / stride, rx = cls - ry * stride;
+      int tap = k / ld, o = k - tap * ld;
+      if (c_in < ci && o < co && tap < skh * skw) {
+        int jy = tap / skw, jx = tap - jy * skw;
+        int ay = (ry + 1) % stride, ax = (rx + 1) % stride;     // pad = 1 for stride-2 convs (ABI)
+        int y = ay + stride * (skh - 1 - jy), x = ax + stride * (skw - 1 - jx);
+        v = w[(((size_t)o * ci + c_in) * kh + y) * kw + x];
+      }
+    }
+    out[e] = v;
   }
 }
 
@@ -1056,7 +1127,8 @@ TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec = ITG_PREC_F32) {
 //             transposed into the OIHW gradient; the bias gradient is the column of the tap that sees
 //             every dy pixel exactly once (ky = pad_h, kx = pad).
 __global__ void tap_gather_fwd_kernel(const float* __restrict__ P, int H, int W, GridT out, const float* __restrict__ bias,
-                                      int kh, int kw, int pad_h, int pad_w, int act, float slope) {
+                                      const float* __restrict__ scale, int kh, int kw, int pad_h, int pad_w, int act,
+                                      float slope) {
   const int64_t total = (int64_t)out.n * out.H * out.W;
   const int ntaps = kh * kw;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1064,7 +1136,7 @@ __global__ void tap_gather_fwd_kernel(const float* __restrict__ P, int H, int W,
     int64_t r = i / out.W;
     int oy = (int)(r % out.H);
     int n = (int)(r / out.H);
-    float v = bias ? bias[0] : 0.f;
+    float v = 0.f;
     for (int ky = 0; ky < kh; ++ky) {
       int iy = oy - pad_h + ky;
       if ((unsigned)iy >= (unsigned)H) continue;
@@ -1074,6 +1146,8 @@ __global__ void tap_gather_fwd_kernel(const float* __restrict__ P, int H, int W,
         v += P[(((size_t)n * H + iy) * W + ix) * ntaps + ky * kw + kx];
       }
     }
+    if (scale) v *= *scale;
+    if (bias) v += bias[0];
     v = act_apply(v, act, slope);
     *reinterpret_cast<f32x4*>(out.p + grid_off(out, n, oy, ox)) = f32x4{v, 0.f, 0.f, 0.f};
   }
@@ -1167,6 +1241,15 @@ int itg_pack_dgrad(const float* w, const float* scale, float* out, int co, int c
   return ITG_OK;
 }
 
+int itg_pack_multi(const int64_t* table_dev, int n, int64_t total, void* stream) {
+  if (!table_dev || n <= 0 || n > ITG_PACK_MAX_JOBS || total <= 0) return ITG_ERR_ARG;
+  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const long long*)table_dev, n,
+                     (long long)total);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
 int64_t itg_conv2d_fwd_workspace(const itg_tensor* in, const itg_tensor* out, const itg_conv_geom* g) {
   if (!in || !out || !g) return 0;
   if (thin_out_conv(in, out, g)) {
@@ -1189,9 +1272,9 @@ int64_t itg_conv2d_dgrad_workspace(const itg_tensor* dy, const itg_tensor* dx, c
   return plan_nt(Mmax * 4, co_rows, Kpad, 4, prec_of(g)).ws_floats;
 }
 
-int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bias, const itg_tensor* residual,
-                   const itg_tensor* out, const itg_conv_geom* g, int act, float slope, float* workspace,
-                   int64_t workspace_floats, void* stream) {
+int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bias, const float* out_scale,
+                   const itg_tensor* residual, const itg_tensor* out, const itg_conv_geom* g, int act, float slope,
+                   float* workspace, int64_t workspace_floats, void* stream) {
   int rc;
   if ((rc = check_tensor(in)) || (rc = check_tensor(out))) return rc;
   if (!w_packed || !g || g->kh <= 0 || g->kw <= 0 || g->stride <= 0 || g->pad < 0) return ITG_ERR_ARG;
@@ -1205,13 +1288,13 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
     itg_tensor P = {workspace, in->n, 1, 1, H, W, 16, 16};
     itg_conv_geom g1 = {1, 1, 1, 0, ITG_PAD_ZERO, 0, prec_of(g)};
     // row 0 of the packed filter is (tap, ci)-ordered with ci_ld a multiple of 16: read as 16 rows of ci_ld
-    if ((rc = itg_conv2d_fwd(in, w_packed, nullptr, nullptr, &P, &g1, ITG_ACT_NONE, 0.f, workspace + pf,
+    if ((rc = itg_conv2d_fwd(in, w_packed, nullptr, nullptr, nullptr, &P, &g1, ITG_ACT_NONE, 0.f, workspace + pf,
                              workspace_floats - pf, stream))) return rc;
     GridT og = make_grid(out);
     int64_t total = (int64_t)og.n * og.H * og.W;
     int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(tap_gather_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, H, W,
-                       og, bias, g->kh, g->kw, pad_v(g), g->pad, act, slope);
+                       og, bias, out_scale, g->kh, g->kw, pad_v(g), g->pad, act, slope);
     ITG_CHECK_LAUNCH();
     return ITG_OK;
   }
@@ -1230,7 +1313,7 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   int Ho = conv_out_dim(p.in.H, g->kh, g->stride, pad_v(g)), Wo = conv_out_dim(p.in.W, g->kw, g->stride, g->pad);
   if (Ho != p.out.H || Wo != p.out.W) return ITG_ERR_ARG;
   if (g->pad_mode == ITG_PAD_REPLICATE && g->stride != 1) return ITG_ERR_ARG;
-  p.w = w_packed; p.bias = bias;
+  p.w = w_packed; p.bias = bias; p.scale = out_scale;
   p.ntaps = g->kh * g->kw; p.kw = g->kw; p.cin_ld = in->ld;
   p.Kpad = round_up(p.ntaps * in->ld, BK);
   p.MT = Ho; p.MU = Wo;
@@ -1244,8 +1327,8 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   return dispatch_nt(p, workspace, workspace_floats, (hipStream_t)stream);
 }
 
-int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const itg_tensor* dx, const itg_conv_geom* g,
-                     float* workspace, int64_t workspace_floats, void* stream) {
+int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const float* out_scale, const itg_tensor* dx,
+                     const itg_conv_geom* g, float* workspace, int64_t workspace_floats, void* stream) {
   int rc;
   if ((rc = check_tensor(dy)) || (rc = check_tensor(dx))) return rc;
   if (!w_packed_dgrad || !g) return ITG_ERR_ARG;
@@ -1260,7 +1343,7 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const it
   const int padh = pad_v(g);
   int Ho = conv_out_dim(p.out.H, g->kh, g->stride, padh), Wo = conv_out_dim(p.out.W, g->kw, g->stride, g->pad);
   if (Ho != p.in.H || Wo != p.in.W) return ITG_ERR_ARG;
-  p.bias = nullptr; p.act = ITG_ACT_NONE; p.slope = 0.f;
+  p.bias = nullptr; p.scale = out_scale; p.act = ITG_ACT_NONE; p.slope = 0.f;
   p.cin_ld = dy->ld;
   p.co_rows = round_up(dx->c, 16);
   p.pad_mode = ITG_PAD_ZERO;

@@ -68,6 +68,25 @@ class FlatAdam:
                           self.betas[1], self.eps, self.t, self.ema_decay, step_dev=self.t_dev)
 
 
+class PackSet:
+    """The packed filter panels of every conv of a model, refreshed with ONE launch whenever the
+    optimizer has changed the weights (instead of two pack launches per conv call).  Layers find their
+    panels in ``_packed``; ``release()`` returns them to per-call packing (weights edited by hand)."""
+
+    def __init__(self, net):
+        from .models.layers import _ConvParams
+        self.layers = [m for m in net.modules() if isinstance(m, _ConvParams)]
+        self.jobs = [j for m in self.layers for j in m.pack_jobs()]      # keeps the weight / panel tensors alive
+        self.tables = ops.pack_tables(self.jobs, self.jobs[0][0].device) if self.jobs else []
+
+    def repack(self):
+        ops.pack_multi(self.tables)
+
+    def release(self):
+        for m in self.layers:
+            m._packed = None
+
+
 class Trainer:
     """One G+D iteration of reference train.py:122-180 on the HIP kernels."""
 
@@ -100,6 +119,13 @@ class Trainer:
                              ema_decay=args.ema_decay)
         self.label_t = 0.9 if args.smooth else 1.0
         self.hinge = getattr(args, "loss", "standard") == "hinge"
+        self.packG, self.packD = PackSet(netG), PackSet(netD)
+        self.repack()
+
+    def repack(self):
+        """Refresh the packed filter panels (call after changing weights outside the optimizer steps)."""
+        self.packG.repack()
+        self.packD.repack()
 
     # ---- loss heads
     def _d_loss(self, logit, real):
@@ -132,6 +158,7 @@ class Trainer:
         d_fake.backward()
         self._allreduce(self.flatD)
         self.optD.step()
+        self.packD.repack()
         # ---------------- G step (train.py:161-169).  D's weight gradients of this pass are never
         # read (zeroed at the next D step), so they are not computed.
         self.flatG.zero_grad()
@@ -145,6 +172,7 @@ class Trainer:
                 p.requires_grad_(True)
         self._allreduce(self.flatG)
         self.optG.step()                                        # + EMA of the parameters (train.py:176-180)
+        self.packG.repack()
         if self.netG_ema is not None:
             self._ema_buffers()
         return d_real.detach(), d_fake.detach(), g_loss.detach()
@@ -248,6 +276,7 @@ class BandTrainer(Trainer):
         d_fake.backward()
         self._allreduce(self.flatD)
         self.optD.step()
+        self.packD.repack()
         self.flatG.zero_grad()
         for p in self.flatD.params:
             p.requires_grad_(False)
@@ -259,6 +288,7 @@ class BandTrainer(Trainer):
                 p.requires_grad_(True)
         self._allreduce(self.flatG)
         self.optG.step()
+        self.packG.repack()
         if self.netG_ema is not None:
             self._ema_buffers()
         return d_real.detach(), d_fake.detach(), g_loss.detach()

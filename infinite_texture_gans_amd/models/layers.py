@@ -50,6 +50,18 @@ class _ConvParams(nn.Module):
     # the (flat) .grad buffers instead of being handed to autograd's AccumulateGrad.
     grad_sinks = False
     _preset_inv = None      # 1/sigma computed ahead by a model-level batched power iteration
+    _packed = None          # (forward panel, dgrad panel) kept current by engine.PackSet, else packed per call
+
+    def pack_jobs(self):
+        """Allocate this layer's persistent panels and return its two ops.pack_multi jobs."""
+        w = self.weight_orig if self.SN else self.weight
+        co, ci, k, st = w.shape[0], w.shape[1], self.k, self.stride
+        nf, nd = ops.pack_sizes(co, ci, k, k, st)
+        if self._packed is None or self._packed[0].device != w.device:
+            self._packed = (torch.empty(nf, device=w.device, dtype=torch.float32),
+                            torch.empty(nd, device=w.device, dtype=torch.float32))
+        return [(w, self._packed[0], co, ci, ops.ld_for(ci), k, k, 1, 0),
+                (w, self._packed[1], co, ci, ops.ld_for(co), k, k, st, 1)]
 
     def weight_and_sn(self):
         """(weight tensor, sn tuple or None); runs the power iteration in training mode.  u / v are not
@@ -72,7 +84,7 @@ class _ConvParams(nn.Module):
             pad_h=-1):
         w, sn = self.weight_and_sn()
         return ops.conv(x, w, self.bias, self.k, self.k, self.stride, self.padding if pad is None else pad,
-                        pad_mode, act, slope, residual, sn, out_grid, self._sinks(w), pad_h)
+                        pad_mode, act, slope, residual, sn, out_grid, self._sinks(w), pad_h, packed=self._packed)
 
     def forward(self, x):
         """Plain conv on an NCHW image batch (zero padding), as the reference's nn.Conv2d."""

@@ -226,7 +226,7 @@ class _Conv(torch.autograd.Function):
     coordinates).  ``sn`` = (inv_sigma, u, v) makes ``w`` the spectral-norm ``weight_orig``."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, sn, c_in, geom, act, slope, out_grid, sinks=None):
+    def forward(ctx, x, w, bias, residual, sn, c_in, geom, act, slope, out_grid, sinks=None, packed=None):
         kh, kw, stride, pad, pad_mode, pad_h, prec = geom
         pv = pad_h if pad_h >= 0 else pad
         n, gh, gw, ph, pw, ld = x.shape
@@ -241,8 +241,11 @@ class _Conv(torch.autograd.Function):
         x = x.contiguous()
         st = _stream()
         inv_sigma = sn[0] if sn is not None else None
-        wp = torch.empty(_lib.fn("itg_pack_fwd_size")(co, ld, kh, kw), device=x.device, dtype=torch.float32)
-        _lib.call("itg_pack_fwd", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, ld, kh, kw, st)
+        if packed is not None:      # panels packed once per optimizer step (engine.PackSet): 1/sigma rides in the epilogue
+            wp, out_scale = packed[0], inv_sigma
+        else:
+            wp, out_scale = torch.empty(_lib.fn("itg_pack_fwd_size")(co, ld, kh, kw), device=x.device, dtype=torch.float32), None
+            _lib.call("itg_pack_fwd", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, ld, kh, kw, st)
         out = torch.empty((n, ogh, ogw, Ho // ogh, Wo // ogw, ld_for(co)), device=x.device, dtype=torch.float32)
         dx_, do_ = _desc(x, c_in), _desc(out, co)
         dr_ = _desc(residual, co) if residual is not None else _null_desc()
@@ -250,12 +253,13 @@ class _Conv(torch.autograd.Function):
         nws = _lib.fn("itg_conv2d_fwd_workspace")(C.byref(dx_), C.byref(do_), C.byref(g))
         ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
         with _Prof(_nt_tag(co), 1, 2.0 * n * Ho * Wo * co * ci * kh * kw):
-            _lib.call("itg_conv2d_fwd", C.byref(dx_), _ptr(wp), _ptr(bias), C.byref(dr_), C.byref(do_), C.byref(g),
-                      act, float(slope), _ptr(ws), nws, st)
+            _lib.call("itg_conv2d_fwd", C.byref(dx_), _ptr(wp), _ptr(bias), _ptr(out_scale), C.byref(dr_), C.byref(do_),
+                      C.byref(g), act, float(slope), _ptr(ws), nws, st)
         ctx.geom, ctx.act, ctx.slope, ctx.c_in, ctx.co = geom, act, slope, c_in, co
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.sn = sn
         ctx.sinks = sinks          # (weight.grad, bias.grad) buffers to accumulate into, or None
+        ctx.packed = packed
         ctx.save_for_backward(x, w, out if act != ACT_NONE else None)
         return out
 
@@ -277,16 +281,19 @@ class _Conv(torch.autograd.Function):
         inv_sigma = ctx.sn[0] if ctx.sn is not None else None
         gx = gw_ = gb = None
         if ctx.needs_input_grad[0]:
-            wp = torch.empty(_lib.fn("itg_pack_dgrad_size")(ci, dy.shape[5], kh, kw, stride), device=x.device,
-                             dtype=torch.float32)
-            _lib.call("itg_pack_dgrad", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, dy.shape[5], kh, kw, stride, st)
+            if ctx.packed is not None:
+                wp, out_scale = ctx.packed[1], inv_sigma
+            else:
+                wp, out_scale = torch.empty(_lib.fn("itg_pack_dgrad_size")(ci, dy.shape[5], kh, kw, stride), device=x.device,
+                                            dtype=torch.float32), None
+                _lib.call("itg_pack_dgrad", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, dy.shape[5], kh, kw, stride, st)
             gx = torch.empty_like(x)
             ddx = _desc(gx, ci)
             npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
             nws = _lib.fn("itg_conv2d_dgrad_workspace")(C.byref(ddy), C.byref(ddx), C.byref(g))
             ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
             with _Prof(_nt_tag(ci), stride * stride, 2.0 * npix_out * co * ci * kh * kw):
-                _lib.call("itg_conv2d_dgrad", C.byref(ddy), _ptr(wp), C.byref(ddx), C.byref(g), _ptr(ws), nws, st)
+                _lib.call("itg_conv2d_dgrad", C.byref(ddy), _ptr(wp), _ptr(out_scale), C.byref(ddx), C.byref(g), _ptr(ws), nws, st)
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if need_w or need_b:
@@ -319,18 +326,18 @@ class _Conv(torch.autograd.Function):
             if not need_w:
                 gw_ = None
         gres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
-        return gx, gw_, gb, gres, None, None, None, None, None, None, None
+        return gx, gw_, gb, gres, None, None, None, None, None, None, None, None
 
 
 def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, residual=None,
-         sn=None, out_grid=None, sinks=None, pad_h=-1, precision=None):
+         sn=None, out_grid=None, sinks=None, pad_h=-1, precision=None, packed=None):
     """x: GT.  Returns GT with ``out_grid`` (default: the input grid).  ``sinks`` = (weight.grad, bias.grad)
     buffers: the backward then accumulates the parameter gradients straight into them (and reports no
     gradient to autograd), which removes one AccumulateGrad add kernel per parameter."""
     og = out_grid if out_grid is not None else (x.gh, x.gw)
     r = residual.t if residual is not None else None
     prec = MFMA_PRECISION if precision is None else precision
-    t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode, pad_h, prec), act, slope, og, sinks)
+    t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode, pad_h, prec), act, slope, og, sinks, packed)
     return GT(t, w.shape[0])
 
 
@@ -654,6 +661,31 @@ def local_pad_grid(x, pad_mode=PAD_REPLICATE, left=None, top=None, bottom=None):
     _lib.call("itg_local_pad_stream_fwd", C.byref(a), _ptr(left), _ptr(top), _ptr(bottom), C.byref(b), pad_mode,
               _stream())
     return GT(y, x.c)
+
+
+def pack_tables(jobs, device):
+    """jobs: list of (w OIHW tensor, out buffer, co, ci, ld, kh, kw, stride, dgrad) -> list of
+    (device int64 table, n, total) for itg_pack_multi, one per _lib.PACK_MAX_JOBS panels."""
+    tables = []
+    for i in range(0, len(jobs), _lib.PACK_MAX_JOBS):
+        rows, start = [], 0
+        for (w, o, co, ci, ld, kh, kw, stride, dg) in jobs[i:i + _lib.PACK_MAX_JOBS]:
+            rows.append([w.data_ptr(), o.data_ptr(), co, ci, ld, kh, kw, stride, dg, start])
+            start += o.numel()
+        tables.append((torch.tensor(rows, dtype=torch.int64).to(device), len(rows), start))
+    return tables
+
+
+def pack_multi(tables):
+    st = _stream()
+    for t, n, total in tables:
+        _lib.call("itg_pack_multi", _ptr(t), n, total, st)
+
+
+def pack_sizes(co, ci, kh, kw, stride):
+    """(floats of the forward panel, floats of the dgrad panel) for a conv between patch-grid tensors."""
+    return (_lib.fn("itg_pack_fwd_size")(co, ld_for(ci), kh, kw),
+            _lib.fn("itg_pack_dgrad_size")(ci, ld_for(co), kh, kw, stride))
 
 
 # ------------------------------------------------------------------------------- row-sharded grids (training)
