@@ -107,9 +107,12 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
 /* dX of the same conv: `dy` has the conv's output shape, `dx` its input shape.
  * With ITG_PAD_REPLICATE the gradient of the replicated border folds back onto the
  * edge pixels (the autograd of F.pad(..., 'replicate') at layers.py:82).           */
+/* act_out (may be NULL / ptr NULL) + act + slope: the conv's input was `act_out = act(u)` (the fused
+ * activation of the producing layer); dx is then multiplied by act'(u), expressed through act_out as in
+ * itg_act_bwd, i.e. the producing layer's activation backward is fused into this epilogue.          */
 int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const float* out_scale,
-                     const itg_tensor* dx, const itg_conv_geom* g, float* workspace, int64_t workspace_floats,
-                     void* stream);
+                     const itg_tensor* dx, const itg_tensor* act_out, int act, float slope,
+                     const itg_conv_geom* g, float* workspace, int64_t workspace_floats, void* stream);
 
 /* dW (OIHW, accumulated into dw when accumulate != 0) and optional db (length co).
  * workspace: itg_conv2d_wgrad_workspace() floats (split-K slabs + fp64 bias scratch). */

@@ -47,7 +47,7 @@ SIGNATURES = {
     "itg_conv2d_dgrad_workspace": (_l, [_TP, _TP, _GP]),
     "itg_pack_multi": (_i, [_P, _i, _l, _P]),
     "itg_conv2d_fwd": (_i, [_TP, _P, _P, _P, _TP, _TP, _GP, _i, _f, _P, _l, _P]),
-    "itg_conv2d_dgrad": (_i, [_TP, _P, _P, _TP, _GP, _P, _l, _P]),
+    "itg_conv2d_dgrad": (_i, [_TP, _P, _P, _TP, _TP, _i, _f, _GP, _P, _l, _P]),
     "itg_conv2d_wgrad_workspace": (_l, [_TP, _TP, _GP]),
     "itg_conv2d_wgrad": (_i, [_TP, _TP, _P, _P, _GP, _i, _P, _l, _P]),
     "itg_local_pad_fwd": (_i, [_P, _P, _i, _i, _i, _i, _i, _i, _i, _P]),

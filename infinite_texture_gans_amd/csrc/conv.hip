@@ -36,6 +36,8 @@ struct ConvP {
   int osy, ooy, osx, oox;
   int pad_mode, out_mode, act;
   float slope;
+  int res_mode;                 // 0: out += res;  ITG_ACT_*: out *= act'(res), res = the activation's OUTPUT (fused act backward)
+  float res_slope;
   int co_rows, nco_tiles;
   unsigned in_bytes, w_bytes;   // buffer-resource extents of the pixel operand / packed weights
   int use_tab;                  // per-row tap-offset table in LDS (narrow layers)
@@ -48,6 +50,14 @@ struct ConvP {
   unsigned cwoff[4];   // float offset of the class's packed sub-kernel
   unsigned cpoff[4];   // float offset of the class's split-K slabs
 };
+
+// derivative of an activation expressed through its OUTPUT o (as itg_act_bwd does)
+__device__ __forceinline__ f32x4 act_deriv(f32x4 o, int act, float slope) {
+  f32x4 d;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) d[e] = act == ITG_ACT_LRELU ? (o[e] > 0.f ? 1.f : slope) : (act == ITG_ACT_TANH ? 1.f - o[e] * o[e] : 1.f);
+  return d;
+}
 
 __device__ __forceinline__ void decode_m(int m, int MT, int MU, int& n, int& t, int& u) {
   int per = MT * MU;
@@ -326,7 +336,8 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
       }
       if (p.res.p) {
         f32x4 r = *reinterpret_cast<const f32x4*>(p.res.p + roff + co);
-        v += r;
+        if (p.res_mode == 0) v += r;
+        else v *= act_deriv(r, p.res_mode, p.res_slope);
       }
       if (p.act != ITG_ACT_NONE) {
 #pragma unroll
@@ -392,7 +403,11 @@ __global__ void splitk_epilogue_kernel(ConvP p) {
       for (int e = 0; e < 4; ++e)
         if (co + e < p.out.c) v[e] += p.bias[co + e];
     }
-    if (p.res.p) v += *reinterpret_cast<const f32x4*>(p.res.p + grid_off(p.res, n, oy, ox) + co);
+    if (p.res.p) {
+      f32x4 r = *reinterpret_cast<const f32x4*>(p.res.p + grid_off(p.res, n, oy, ox) + co);
+      if (p.res_mode == 0) v += r;
+      else v *= act_deriv(r, p.res_mode, p.res_slope);
+    }
     if (p.act != ITG_ACT_NONE) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act, p.slope);
@@ -435,7 +450,11 @@ __device__ __forceinline__ void store_out(const ConvP& p, int n, int oy, int ox,
     for (int e = 0; e < 4; ++e)
       if (co + e < p.out.c) v[e] += p.bias[co + e];
   }
-  if (p.res.p) v += *reinterpret_cast<const f32x4*>(p.res.p + grid_off(p.res, n, oy, ox) + co);
+  if (p.res.p) {
+    f32x4 r = *reinterpret_cast<const f32x4*>(p.res.p + grid_off(p.res, n, oy, ox) + co);
+    if (p.res_mode == 0) v += r;
+    else v *= act_deriv(r, p.res_mode, p.res_slope);
+  }
   if (p.act != ITG_ACT_NONE) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act, p.slope);
@@ -1104,7 +1123,8 @@ TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec = ITG_PREC_F32) {
   else { t.bco = 128; t.bcol = 128; }
   int tiles = ((t.Kpad + t.bcol - 1) / t.bcol) * ((t.co_rows + t.bco - 1) / t.bco);
   t.nchunks = (int)((M + kp - 1) / kp);
-  int want = (1024 + tiles - 1) / tiles;            // ~4 workgroups per CU overall
+  static const int want_blocks = env_int("ITG_TN_BLOCKS", 1024);
+  int want = (want_blocks + tiles - 1) / tiles;      // ~4 workgroups per CU overall
   int max_splits = (t.nchunks + 7) / 8;             // at least 8 chunks per split
   int splits = want < max_splits ? want : max_splits;
   if (splits < 1) splits = 1;
@@ -1313,7 +1333,7 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   int Ho = conv_out_dim(p.in.H, g->kh, g->stride, pad_v(g)), Wo = conv_out_dim(p.in.W, g->kw, g->stride, g->pad);
   if (Ho != p.out.H || Wo != p.out.W) return ITG_ERR_ARG;
   if (g->pad_mode == ITG_PAD_REPLICATE && g->stride != 1) return ITG_ERR_ARG;
-  p.w = w_packed; p.bias = bias; p.scale = out_scale;
+  p.w = w_packed; p.bias = bias; p.scale = out_scale; p.res_mode = 0; p.res_slope = 0.f;
   p.ntaps = g->kh * g->kw; p.kw = g->kw; p.cin_ld = in->ld;
   p.Kpad = round_up(p.ntaps * in->ld, BK);
   p.MT = Ho; p.MU = Wo;
@@ -1328,7 +1348,8 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
 }
 
 int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const float* out_scale, const itg_tensor* dx,
-                     const itg_conv_geom* g, float* workspace, int64_t workspace_floats, void* stream) {
+                     const itg_tensor* act_out, int act, float slope, const itg_conv_geom* g, float* workspace,
+                     int64_t workspace_floats, void* stream) {
   int rc;
   if ((rc = check_tensor(dy)) || (rc = check_tensor(dx))) return rc;
   if (!w_packed_dgrad || !g) return ITG_ERR_ARG;
@@ -1340,6 +1361,13 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
   p.in = make_grid(dy);
   p.out = make_grid(dx);
   p.res = null_grid();
+  p.res_mode = 0; p.res_slope = 0.f;
+  if (act_out && act_out->ptr && act != ITG_ACT_NONE) {
+    // dx is the gradient w.r.t. act(.)'s output `act_out`: hand back the gradient w.r.t. its input instead
+    if ((rc = check_tensor(act_out))) return rc;
+    if (!same_shape(act_out, dx)) return ITG_ERR_ARG;
+    p.res = make_grid(act_out); p.res_mode = act; p.res_slope = slope;
+  }
   const int padh = pad_v(g);
   int Ho = conv_out_dim(p.out.H, g->kh, g->stride, padh), Wo = conv_out_dim(p.out.W, g->kw, g->stride, g->pad);
   if (Ho != p.in.H || Wo != p.in.W) return ITG_ERR_ARG;

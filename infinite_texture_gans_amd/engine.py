@@ -121,6 +121,7 @@ class Trainer:
         self.hinge = getattr(args, "loss", "standard") == "hinge"
         self.packG, self.packD = PackSet(netG), PackSet(netD)
         self.repack()
+        self.arena = ops.ZeroArena(device)
 
     def repack(self):
         """Refresh the packed filter panels (call after changing weights outside the optimizer steps)."""
@@ -148,6 +149,8 @@ class Trainer:
         """real_x: (B,3,crop,crop) on the device; z/maps: latents (see utils.sample_latents_train).
         Returns (d_loss_real, d_loss_fake, g_loss) as 0-dim device tensors (no host sync)."""
         netG, netD = self.netG, self.netD
+        self.arena.reset()                                      # BatchNorm statistics scratch of this iteration
+        ops.ARENA = self.arena
         # ---------------- D step (train.py:124-154, disc_iters handled by the caller)
         self.flatD.zero_grad()
         d_real = self._d_loss(netD(real_x), True)
@@ -175,6 +178,7 @@ class Trainer:
         self.packG.repack()
         if self.netG_ema is not None:
             self._ema_buffers()
+        ops.ARENA = None
         return d_real.detach(), d_fake.detach(), g_loss.detach()
 
     # ---- hipGraph: the whole iteration (~600 launches) as one graph replay
@@ -268,6 +272,8 @@ class BandTrainer(Trainer):
     def step(self, real_x, z, maps=None):
         """real_x: this rank's shard of real crops; z: the full merged latent (same on all ranks)."""
         netD = self.netD
+        self.arena.reset()
+        ops.ARENA = self.arena
         self.flatD.zero_grad()
         d_real = self._d_loss(netD(real_x), True)
         d_real.backward()
@@ -291,4 +297,5 @@ class BandTrainer(Trainer):
         self.packG.repack()
         if self.netG_ema is not None:
             self._ema_buffers()
+        ops.ARENA = None
         return d_real.detach(), d_fake.detach(), g_loss.detach()

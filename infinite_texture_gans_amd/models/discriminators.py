@@ -2,11 +2,12 @@
 (reference models/discriminators.py:156-210) on the HIP conv kernels.  The other
 discriminator classes of the reference are dead code there (utils.py:205-207) and are
 not provided."""
+import torch
 import torch.nn as nn
 
 from .. import ops
 from ..ops import GT
-from .layers import conv4x4, conv3x3, _BNParams, batched_power_iteration
+from .layers import conv4x4, conv3x3, _BNParams, _ConvParams, batched_power_iteration
 
 
 class PatchDiscriminator(nn.Module):
@@ -40,19 +41,26 @@ class PatchDiscriminator(nn.Module):
         """x: GT image (any patch grid).  Returns the logit map as a 1x1-grid GT."""
         mods = list(self.model)
         batched_power_iteration(self.model)      # every layer's spectral norm up front, 4 launches
-        h, i = x, 0
+        # conv -> LeakyReLU -> conv: the activation is fused into the first conv's epilogue, and its backward
+        # into the second conv's input-gradient epilogue (the mask is the sign of the tensor both share)
+        h, i, in_act = x, 0, None
         while i < len(mods):
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < len(mods) else None
             if isinstance(nxt, nn.LeakyReLU):
-                h = m.run(h, act=ops.ACT_LRELU, slope=nxt.negative_slope, out_grid=(1, 1))
+                chained = i + 2 < len(mods) and isinstance(mods[i + 2], _ConvParams) and torch.is_grad_enabled()
+                h = m.run(h, act=ops.ACT_LRELU, slope=nxt.negative_slope, out_grid=(1, 1), in_act=in_act,
+                          defer_act_bwd=chained)
+                in_act = (ops.ACT_LRELU, nxt.negative_slope) if chained else None
                 i += 2
             elif isinstance(nxt, _BNParams):
-                h = m.run(h, out_grid=(1, 1))
+                h = m.run(h, out_grid=(1, 1), in_act=in_act)
                 h = nxt.run(h, act=ops.ACT_LRELU, slope=mods[i + 2].negative_slope)
+                in_act = None
                 i += 3
             else:
-                h = m.run(h, out_grid=(1, 1))
+                h = m.run(h, out_grid=(1, 1), in_act=in_act)
+                in_act = None
                 i += 1
         return h
 

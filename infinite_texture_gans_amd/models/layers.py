@@ -81,10 +81,11 @@ class _ConvParams(nn.Module):
         return (w.grad, b.grad if (b is not None and b.grad is not None) else None)
 
     def run(self, x, pad=None, pad_mode=ops.PAD_ZERO, act=ops.ACT_NONE, slope=0.0, residual=None, out_grid=None,
-            pad_h=-1):
+            pad_h=-1, in_act=None, defer_act_bwd=False):
         w, sn = self.weight_and_sn()
         return ops.conv(x, w, self.bias, self.k, self.k, self.stride, self.padding if pad is None else pad,
-                        pad_mode, act, slope, residual, sn, out_grid, self._sinks(w), pad_h, packed=self._packed)
+                        pad_mode, act, slope, residual, sn, out_grid, self._sinks(w), pad_h, packed=self._packed,
+                        in_act=in_act, defer_act_bwd=defer_act_bwd)
 
     def forward(self, x):
         """Plain conv on an NCHW image batch (zero padding), as the reference's nn.Conv2d."""

@@ -226,7 +226,7 @@ class _Conv(torch.autograd.Function):
     coordinates).  ``sn`` = (inv_sigma, u, v) makes ``w`` the spectral-norm ``weight_orig``."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, sn, c_in, geom, act, slope, out_grid, sinks=None, packed=None):
+    def forward(ctx, x, w, bias, residual, sn, c_in, geom, act, slope, out_grid, sinks=None, packed=None, fuse=(None, False)):
         kh, kw, stride, pad, pad_mode, pad_h, prec = geom
         pv = pad_h if pad_h >= 0 else pad
         n, gh, gw, ph, pw, ld = x.shape
@@ -260,6 +260,10 @@ class _Conv(torch.autograd.Function):
         ctx.sn = sn
         ctx.sinks = sinks          # (weight.grad, bias.grad) buffers to accumulate into, or None
         ctx.packed = packed
+        # fuse = (in_act, defer): in_act = (act, slope) of the layer that produced x -> this backward returns the
+        # gradient w.r.t. that layer's PRE-activation; defer = the consumer of this layer's output does the same
+        # for us, so our own activation backward is skipped.  The two always come in pairs (see callers).
+        ctx.in_act, ctx.defer_act = fuse
         ctx.save_for_backward(x, w, out if act != ACT_NONE else None)
         return out
 
@@ -270,7 +274,7 @@ class _Conv(torch.autograd.Function):
         co, ci = ctx.co, ctx.c_in
         st = _stream()
         dout = dout.contiguous()
-        if ctx.act != ACT_NONE:
+        if ctx.act != ACT_NONE and not ctx.defer_act:
             dy = torch.empty_like(dout)
             a, b, c_ = _desc(out, co), _desc(dout, co), _desc(dy, co)
             _lib.call("itg_act_bwd", C.byref(a), C.byref(b), C.byref(c_), ctx.act, float(ctx.slope), st)
@@ -293,7 +297,11 @@ class _Conv(torch.autograd.Function):
             nws = _lib.fn("itg_conv2d_dgrad_workspace")(C.byref(ddy), C.byref(ddx), C.byref(g))
             ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
             with _Prof(_nt_tag(ci), stride * stride, 2.0 * npix_out * co * ci * kh * kw):
-                _lib.call("itg_conv2d_dgrad", C.byref(ddy), _ptr(wp), _ptr(out_scale), C.byref(ddx), C.byref(g), _ptr(ws), nws, st)
+                ia = ctx.in_act
+                dact = _desc(x, ci) if ia is not None else _null_desc()
+                _lib.call("itg_conv2d_dgrad", C.byref(ddy), _ptr(wp), _ptr(out_scale), C.byref(ddx), C.byref(dact),
+                          ia[0] if ia is not None else ACT_NONE, float(ia[1]) if ia is not None else 0.0, C.byref(g),
+                          _ptr(ws), nws, st)
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if need_w or need_b:
@@ -326,23 +334,53 @@ class _Conv(torch.autograd.Function):
             if not need_w:
                 gw_ = None
         gres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
-        return gx, gw_, gb, gres, None, None, None, None, None, None, None, None
+        return gx, gw_, gb, gres, None, None, None, None, None, None, None, None, None
 
 
 def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, residual=None,
-         sn=None, out_grid=None, sinks=None, pad_h=-1, precision=None, packed=None):
+         sn=None, out_grid=None, sinks=None, pad_h=-1, precision=None, packed=None, in_act=None, defer_act_bwd=False):
     """x: GT.  Returns GT with ``out_grid`` (default: the input grid).  ``sinks`` = (weight.grad, bias.grad)
     buffers: the backward then accumulates the parameter gradients straight into them (and reports no
     gradient to autograd), which removes one AccumulateGrad add kernel per parameter."""
     og = out_grid if out_grid is not None else (x.gh, x.gw)
     r = residual.t if residual is not None else None
     prec = MFMA_PRECISION if precision is None else precision
-    t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode, pad_h, prec), act, slope, og, sinks, packed)
+    t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode, pad_h, prec), act, slope, og, sinks, packed,
+                    (in_act, bool(defer_act_bwd)))
     return GT(t, w.shape[0])
 
 
 # ------------------------------------------------------------------------------- batch norm (+act, +upsample)
 from .dist import SyncGroup  # noqa: E402,F401  (sync-BN statistics exchange)
+
+
+class ZeroArena:
+    """fp64 scratch that is zeroed ONCE per train step (engine.Trainer) and handed out in slices to the
+    BatchNorm statistics kernels, replacing one memset launch per BatchNorm call (26 per step).  The
+    slices of a step are taken in a fixed order, so the layout is identical under hipGraph replay."""
+
+    def __init__(self, device, doubles=1 << 16):
+        self.buf = torch.zeros(doubles, device=device, dtype=torch.float64)
+        self.cur = 0
+
+    def reset(self):
+        self.buf.zero_()
+        self.cur = 0
+
+    def take(self, n):
+        if self.cur + n > self.buf.numel():
+            return None
+        t = self.buf[self.cur:self.cur + n]
+        self.cur += n
+        return t
+
+
+ARENA = None      # set by engine.Trainer for the duration of a step
+
+
+def _zeros_f64(n, device):
+    t = ARENA.take(n) if ARENA is not None and ARENA.buf.device == device else None
+    return t if t is not None else torch.zeros(n, device=device, dtype=torch.float64)
 
 
 class _BNAct(torch.autograd.Function):
@@ -356,7 +394,7 @@ class _BNAct(torch.autograd.Function):
         count = float(x.numel() // ld)
         sums = None
         if training:
-            sums = torch.zeros(2 * ld, device=dev, dtype=torch.float64)
+            sums = _zeros_f64(2 * ld, dev)
             _lib.call("itg_bn_stats", C.byref(dx_), _ptr(sums), st)
             if sync is not None and sync.world > 1:
                 sync.all_reduce(sums)
@@ -385,7 +423,7 @@ class _BNAct(torch.autograd.Function):
         dy = dy.contiguous()
         st = _stream()
         dx_, ddy_ = _desc(x, c), _desc(dy, c)
-        sums = torch.zeros(2 * ld, device=x.device, dtype=torch.float64)
+        sums = _zeros_f64(2 * ld, x.device)
         _lib.call("itg_bn_bwd_reduce", C.byref(dx_), C.byref(ddy_), _ptr(ab), _ptr(mean_rstd), act, float(slope),
                   _ptr(sums), st)
         if sync is not None and sync.world > 1:

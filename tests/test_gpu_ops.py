@@ -312,3 +312,27 @@ def test_conv_with_separate_vertical_padding(mode):
     assert rel_l2(xg.grad.cpu(), x.grad) < 1e-5
     assert rel_l2(wg.grad.cpu(), w.grad) < 1e-5
     assert rel_l2(bg.grad.cpu(), b.grad) < 1e-5
+
+
+def test_conv_chain_with_activation_backward_fused_into_consumer_dgrad():
+    """conv -> LeakyReLU -> conv (stride 2, 4 output-parity classes) -> tanh-less head: the first conv's
+    activation backward runs in the second conv's input-gradient epilogue (itg_conv2d_dgrad act_out)."""
+    ops = _ops()
+    g = _gen(77)
+    x = torch.randn(2, 5, 20, 20, generator=g)
+    w1 = torch.randn(12, 5, 4, 4, generator=g) * 0.2
+    b1 = torch.randn(12, generator=g) * 0.1
+    w2 = torch.randn(7, 12, 4, 4, generator=g) * 0.1
+    xr, w1r, b1r, w2r = (t.clone().requires_grad_(True) for t in (x, w1, b1, w2))
+    yr = F.conv2d(F.leaky_relu(F.conv2d(xr, w1r, b1r, stride=2, padding=1), 0.2), w2r, None, stride=2, padding=1)
+    dy = torch.randn(yr.shape, generator=g)
+    ref = torch.autograd.grad(yr, (xr, w1r, b1r, w2r), dy)
+    xg, w1g, b1g, w2g = (t.to(cuda).requires_grad_(True) for t in (x, w1, b1, w2))
+    h = ops.conv(ops.to_grid(xg, 1, 1, merged=True), w1g, b1g, 4, 4, 2, 1, ops.PAD_ZERO, ops.ACT_LRELU, 0.2,
+                 defer_act_bwd=True)
+    y = ops.conv(h, w2g, None, 4, 4, 2, 1, ops.PAD_ZERO, in_act=(ops.ACT_LRELU, 0.2))
+    out = ops.to_nchw(y, merged=True)
+    assert rel_l2(out.detach().cpu(), yr.detach()) < 2e-6
+    got = torch.autograd.grad(out, (xg, w1g, b1g, w2g), dy.to(cuda))
+    for a, b in zip(got, ref):
+        assert rel_l2(a.cpu(), b) < 5e-6
