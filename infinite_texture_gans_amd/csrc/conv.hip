@@ -1202,6 +1202,63 @@ __global__ void tap_wgrad_finish_kernel(const float* __restrict__ tmp, const flo
   if (i == 0 && db) db[0] = accumulate ? db[0] + dbtmp[tdb] : dbtmp[tdb];
 }
 
+
+// ------------------------------------------------------------------------------- few-input-channel stride-2 convs
+// Input gradient of the discriminator's first layer (3 -> 64, 4x4, stride 2): the parity-class implicit
+// GEMM would fill 3 of its 16 MFMA rows.  Instead Q[o][(class, c, tap')] = dy[o] . w[., c, tap] for every
+// OUTPUT pixel o (a 1x1 conv with 4*c*4 <= 64 rows, K = cout), then each input pixel gathers its 4 taps.
+// compact panel row r = (cls * cin + c) * 4 + tap'  <-  dgrad panel row (cls * ci_pad + c), columns tap' * co_ld ..
+__global__ void thin_dgrad_panel_kernel(const float* __restrict__ wd, float* __restrict__ out, int cin, int ci_pad, int co_ld,
+                                        int rows_pad) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows_pad * co_ld) return;
+  int o = i % co_ld, r = i / co_ld;
+  float v = 0.f;
+  if (r < 16 * cin) {
+    int tap = r & 3, cc = r >> 2;
+    int c = cc % cin, cls = cc / cin;
+    v = wd[((size_t)(cls * ci_pad + c) * 4 + tap) * co_ld + o];
+  }
+  out[i] = v;
+}
+
+__global__ void thin_dgrad_gather_kernel(const float* __restrict__ Q, int Ho, int Wo, int qld, GridT dx, GridT act_out,
+                                         int act, float slope) {
+  const int64_t total = (int64_t)dx.n * dx.H * dx.W;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int ix = (int)(i % dx.W);
+    int64_t r = i / dx.W;
+    int iy = (int)(r % dx.H);
+    int n = (int)(r / dx.H);
+    const int ry = iy & 1, rx = ix & 1, t = iy >> 1, u = ix >> 1;
+    const int by = (ry + 1 - ((ry + 1) & 1)) >> 1, bx = (rx + 1 - ((rx + 1) & 1)) >> 1;
+    const int cls = ry * 2 + rx;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jy = 0; jy < 2; ++jy) {
+      int oy = t + by - 1 + jy;
+      if ((unsigned)oy >= (unsigned)Ho) continue;
+#pragma unroll
+      for (int jx = 0; jx < 2; ++jx) {
+        int ox = u + bx - 1 + jx;
+        if ((unsigned)ox >= (unsigned)Wo) continue;
+        const float* q = Q + (((size_t)n * Ho + oy) * Wo + ox) * qld + (size_t)cls * dx.c * 4 + jy * 2 + jx;
+        for (int c = 0; c < dx.c; ++c) v[c] += q[c * 4];
+      }
+    }
+    const int off = grid_off(dx, n, iy, ix);
+    if (act_out.p) v *= act_deriv(*reinterpret_cast<const f32x4*>(act_out.p + grid_off(act_out, n, iy, ix)), act, slope);
+    *reinterpret_cast<f32x4*>(dx.p + off) = v;
+  }
+}
+
+inline bool thin_in_conv(const itg_tensor* dy, const itg_tensor* dx, const itg_conv_geom* g) {
+  static const int enable = env_int("ITG_THIN_CONV", 1);
+  const int ph = g->pad_h >= 0 ? g->pad_h : g->pad;
+  return enable && dx->c <= 4 && dx->ld == 4 && g->kh == 4 && g->kw == 4 && g->stride == 2 && g->pad == 1 && ph == 1 &&
+         g->pad_mode == ITG_PAD_ZERO && (dy->ld % 16) == 0;
+}
+
 inline bool thin_out_conv(const itg_tensor* in, const itg_tensor* out, const itg_conv_geom* g) {
   static const int enable = env_int("ITG_THIN_CONV", 1);
   const int ph = g->pad_h >= 0 ? g->pad_h : g->pad;
@@ -1281,6 +1338,11 @@ int64_t itg_conv2d_fwd_workspace(const itg_tensor* in, const itg_tensor* out, co
 
 int64_t itg_conv2d_dgrad_workspace(const itg_tensor* dy, const itg_tensor* dx, const itg_conv_geom* g) {
   if (!dy || !dx || !g) return 0;
+  if (thin_in_conv(dy, dx, g)) {
+    const int rows = round_up(16 * dx->c, 16);
+    const int64_t Mo = grid_pixels(dy);
+    return Mo * rows + (int64_t)rows * dy->ld + plan_nt(Mo, rows, round_up(dy->ld, BK), 1, prec_of(g)).ws_floats;
+  }
   int co_rows = round_up(dx->c, 16);
   int64_t H = (int64_t)dx->gh * dx->ph, W = (int64_t)dx->gw * dx->pw;
   if (g->stride == 1) {
@@ -1355,6 +1417,38 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
   if (!w_packed_dgrad || !g) return ITG_ERR_ARG;
   if (dy->n != dx->n) return ITG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  if (thin_in_conv(dy, dx, g)) {
+    const int Ho = dy->gh * dy->ph, Wo = dy->gw * dy->pw, H = dx->gh * dx->ph, W = dx->gw * dx->pw;
+    if (conv_out_dim(H, 4, 2, 1) != Ho || conv_out_dim(W, 4, 2, 1) != Wo) return ITG_ERR_ARG;
+    const int rows = round_up(16 * dx->c, 16);
+    const int64_t Mo = grid_pixels(dy), qf = Mo * rows, pf = (int64_t)rows * dy->ld;
+    if (!workspace || workspace_floats < qf + pf || qf >= ((int64_t)1 << 31)) return ITG_ERR_WORKSPACE;
+    float* Q = workspace;
+    float* panel = workspace + qf;
+    {
+      int tot = rows * dy->ld;
+      hipLaunchKernelGGL(thin_dgrad_panel_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, w_packed_dgrad, panel, dx->c,
+                         round_up(dx->c, 16), dy->ld, rows);
+      ITG_CHECK_LAUNCH();
+    }
+    itg_tensor Qt = {Q, dy->n, 1, 1, Ho, Wo, rows, rows};
+    itg_conv_geom g1 = {1, 1, 1, 0, ITG_PAD_ZERO, 0, prec_of(g)};
+    if ((rc = itg_conv2d_fwd(dy, panel, nullptr, out_scale, nullptr, &Qt, &g1, ITG_ACT_NONE, 0.f, workspace + qf + pf,
+                             workspace_floats - qf - pf, stream))) return rc;
+    GridT ao = null_grid();
+    if (act_out && act_out->ptr && act != ITG_ACT_NONE) {
+      if ((rc = check_tensor(act_out))) return rc;
+      if (!same_shape(act_out, dx)) return ITG_ERR_ARG;
+      ao = make_grid(act_out);
+    }
+    GridT gx = make_grid(dx);
+    int64_t total = (int64_t)gx.n * gx.H * gx.W;
+    int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(thin_dgrad_gather_kernel, dim3(blocks), dim3(256), 0, s, (const float*)Q, Ho, Wo, rows, gx, ao, act,
+                       slope);
+    ITG_CHECK_LAUNCH();
+    return ITG_OK;
+  }
   ConvP p;
   p.ncls = 1;
   p.prec = prec_of(g);
