@@ -121,6 +121,8 @@ def gpu_leg(a):
     roof = None
     if rank == 0:
         ops.PROFILE = []
+    if hasattr(tr, "set_overlap"):
+        tr.set_overlap(False)      # kernels timed one at a time: concurrent streams would stretch each other's events
     tr.step(reals[0], zs[-1])
     torch.cuda.synchronize()
     if rank == 0:
@@ -133,16 +135,35 @@ def gpu_leg(a):
         ops.PROFILE = None
         tag, (nl, fl, sec) = max(agg.items(), key=lambda kv: kv[1][2])
         ach = fl / sec / 1e12
+        tot_sec = sum(x[2] for x in agg.values())
         roof = {"bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": peak_tf,
-                "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4), "traffic": hbm_traffic(tag),
                 "launches_per_step": nl, "avg_launch_us": round(sec / nl * 1e6, 1),
                 "flops_per_launch": round(fl / nl / 1e9, 3),
-                "conv_time_share": {k: round(v[2] / sum(x[2] for x in agg.values()), 3) for k, v in agg.items()},
+                "timing": "HIP events around each conv call of one un-overlapped iteration (a split-K call includes its "
+                          "second-stage launch, a weight-gradient call its slab reduce)",
+                "conv_stack": {"time_ms": round(tot_sec * 1e3, 3), "tflops": round(sum(x[1] for x in agg.values()) / tot_sec / 1e12, 2),
+                               "frac_of_peak": round(sum(x[1] for x in agg.values()) / tot_sec / 1e12 / peak_tf, 4)},
+                "conv_time_share": {k: round(v[2] / tot_sec, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:8]},
                 "step_necessary_gflop": round(nec_gf, 1),
                 "step_frac_of_mfma_peak": round(nec_gf * 1e9 / (dt / a.steps) / 1e12 / peak_tf, 4)}
     if world > 1:
         dist.barrier()
     return rank, world, dt, args, losses, roof
+
+
+def hbm_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` from the committed PMC summary (separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes, gfx950 corrections applied by tools/prof_summary.py), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if not files:
+        return None
+    try:
+        t = json.load(open(files[-1])).get(kernel)
+        return None if t is None else int(t["fetch_bytes"] + t["write_bytes"])
+    except Exception:
+        return None
 
 
 def host_cores():

@@ -59,6 +59,10 @@ enum { ITG_PREC_F32 = 0, ITG_PREC_BF16 = 1 };
 
 int itg_version(void);
 
+/* Name of the implicit-GEMM kernel instantiation the calling thread's last itg_conv2d_* call launched,
+ * spelled as rocprofv3 prints it (bench.py labels its HIP-event timings with it).                    */
+const char* itg_last_conv_kernel(void);
+
 /* ---- weight packing ------------------------------------------------------------
  * OIHW master weights (nn.Conv2d.weight, reference models/layers.py:178-200) ->
  * K-contiguous packed forms.  `scale` points to one device float multiplied into

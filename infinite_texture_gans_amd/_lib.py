@@ -39,6 +39,7 @@ _i, _f, _d, _l = C.c_int, C.c_float, C.c_double, C.c_int64
 # name -> (restype, argtypes); mirrors include/itg.h one to one
 SIGNATURES = {
     "itg_version": (_i, []),
+    "itg_last_conv_kernel": (C.c_char_p, []),
     "itg_pack_fwd_size": (_l, [_i, _i, _i, _i]),
     "itg_pack_dgrad_size": (_l, [_i, _i, _i, _i, _i]),
     "itg_pack_fwd": (_i, [_P, _P, _P, _i, _i, _i, _i, _i, _P]),

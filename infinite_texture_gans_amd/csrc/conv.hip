@@ -12,6 +12,7 @@
 // The pixel operand is gathered in merged-image coordinates from a patch-grid NHWC tensor, so
 // the LocalPadder halo (reference models/layers.py:145-173) is a neighbour-patch read and the
 // outer replicate / zero padding (layers.py:82) a clamp / predicate; nothing is materialised.
+#include <cstdio>
 #include <cstdlib>
 #include "itg_common.h"
 
@@ -19,6 +20,9 @@ namespace {
 
 constexpr int BK = 16;    // K elements per pipeline stage
 constexpr int LDK = 20;   // LDS row pitch (floats): BK + 4 keeps rows 16-B aligned
+
+// name of the GEMM kernel instantiation launched by this thread's last conv call, exactly as a profiler prints it
+thread_local char g_last_launch[96] = "";
 
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -658,6 +662,8 @@ int launch_nt(const ConvP& p, int tbk, hipStream_t s) {
   // the second prefetch set (it would spill into scratch inside the K loop)
   constexpr int D32 = (nt_min_blocks(BCO, BPIX, WCO, WPIX, 32) == 3 && BCO >= 64) ? 1 : 2;   // wide bf16 stages: 16 prefetch registers per set
   constexpr int D16 = (nt_min_blocks(BCO, BPIX, WCO, WPIX, 16) == 5 && BCO > 32) ? 1 : 2;
+  snprintf(g_last_launch, sizeof(g_last_launch), "conv_nt_kernel<%d, %d, %d, %d, %d, %d, %s>", BCO, BPIX, WCO, WPIX, tbk,
+           tbk == 32 ? D32 : D16, q.use_tab ? "true" : "false");
   if (tbk == 32) {
     if (q.use_tab) hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 32, D32, true>), grid, dim3(256), tab_bytes, s, q);
     else hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 32, D32, false>), grid, dim3(256), 0, s, q);
@@ -1102,6 +1108,8 @@ int launch_tn(WgP p, int splits, int prec, hipStream_t s) {
   p.ncol_tiles = (p.Kpad + BCOL - 1) / BCOL;
   p.nco_tiles = (p.co_rows + BCO - 1) / BCO;
   dim3 grid((unsigned)(p.ncol_tiles * p.nco_tiles), 1, (unsigned)splits);
+  snprintf(g_last_launch, sizeof(g_last_launch), "conv_tn_kernel<%d, %d, %d, %d, %s>", BCOL, BCO, WCOL, WCO,
+           prec == ITG_PREC_BF16 ? "true" : "false");
   if (prec == ITG_PREC_BF16) hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, true>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false>), grid, dim3(256), 0, s, p);
   ITG_CHECK_LAUNCH();
@@ -1278,6 +1286,8 @@ inline int prec_of(const itg_conv_geom* g) { return g->precision == ITG_PREC_BF1
 extern "C" {
 
 int itg_version(void) { return 100; }
+
+const char* itg_last_conv_kernel(void) { return g_last_launch; }
 
 int64_t itg_pack_fwd_size(int co, int ci_ld, int kh, int kw) {
   return (int64_t)round_up(co, 16) * round_up(kh * kw * ci_ld, BK);

@@ -8,6 +8,8 @@ MI355X-first choices (vs the reference's per-tensor torch.optim.Adam and nn.Data
   * one process per GPU; BatchNorm statistics are summed over ranks (fp64 sum/sumsq pairs), so
     an N-GPU step has the single-process semantics of a batch N times larger.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -122,6 +124,20 @@ class Trainer:
         self.packG, self.packD = PackSet(netG), PackSet(netD)
         self.repack()
         self.arena = ops.ZeroArena(device)
+        # two-stream overlap (D(real) beside the generator forward, weight gradients beside the input-gradient
+        # chain).  Single-GPU only: with collectives in the step it is unmeasured on RCCL (ITG_OVERLAP=1 forces it)
+        self.overlap = os.environ.get("ITG_OVERLAP", "1" if self.world == 1 else "0") == "1"
+        self.side, self._wstream, self.wstream = None, None, None
+        self.set_overlap(self.overlap)
+
+    def set_overlap(self, on):
+        """Two-stream overlap on / off (off: every kernel runs alone on the current stream, e.g. to time it)."""
+        self.overlap = bool(on)
+        if on and self.side is None:
+            self.side = torch.cuda.Stream(device=self.device)
+        if on and getattr(self, "_wstream", None) is None:
+            self._wstream = torch.cuda.Stream(device=self.device)
+        self.wstream = self._wstream if on else None
 
     def repack(self):
         """Refresh the packed filter panels (call after changing weights outside the optimizer steps)."""
@@ -151,14 +167,31 @@ class Trainer:
         netG, netD = self.netG, self.netD
         self.arena.reset()                                      # BatchNorm statistics scratch of this iteration
         ops.ARENA = self.arena
+        ops.WGRAD_STREAM = self.wstream
+        if self.wstream is not None:
+            self.wstream.wait_stream(torch.cuda.current_stream())
         # ---------------- D step (train.py:124-154, disc_iters handled by the caller)
         self.flatD.zero_grad()
-        d_real = self._d_loss(netD(real_x), True)
-        d_real.backward()
-        fake = self.sample_fake(z, maps)                       # GT patches, graph kept for the G step
+        if self.overlap:
+            # D(real) forward+backward and the generator forward are independent and neither fills the chip
+            # on its own (small grids, latency-bound normalisation kernels): run them on two HIP streams
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)
+            keep, ops.WGRAD_STREAM = ops.WGRAD_STREAM, None    # this branch already runs beside the generator
+            with torch.cuda.stream(self.side):
+                d_real = self._d_loss(netD(real_x), True)
+                d_real.backward()
+            ops.WGRAD_STREAM = keep
+            fake = self.sample_fake(z, maps)
+            main.wait_stream(self.side)                        # D(fake) continues D's spectral-norm state and .grad
+        else:
+            d_real = self._d_loss(netD(real_x), True)
+            d_real.backward()
+            fake = self.sample_fake(z, maps)                   # GT patches, graph kept for the G step
         fake_logit = ops.to_nchw(netD.forward_grid(fake.detach()))
         d_fake = self._d_loss(fake_logit, False)
         d_fake.backward()
+        self._join()
         self._allreduce(self.flatD)
         self.optD.step()
         self.packD.repack()
@@ -173,13 +206,21 @@ class Trainer:
         finally:
             for p in self.flatD.params:
                 p.requires_grad_(True)
+        self._join()
         self._allreduce(self.flatG)
         self.optG.step()                                        # + EMA of the parameters (train.py:176-180)
         self.packG.repack()
         if self.netG_ema is not None:
             self._ema_buffers()
         ops.ARENA = None
+        ops.WGRAD_STREAM = None
         return d_real.detach(), d_fake.detach(), g_loss.detach()
+
+    def _join(self):
+        """The weight-gradient stream has to drain before gradients are exchanged / consumed by Adam."""
+        if self.wstream is not None:
+            torch.cuda.current_stream().wait_stream(self.wstream)
+            ops.WGRAD_KEEPALIVE.clear()
 
     # ---- hipGraph: the whole iteration (~600 launches) as one graph replay
     def capture(self, real_x, z, maps=None, warmup=2):

@@ -69,6 +69,9 @@ class _Prof:
     def __exit__(self, *a):
         if self.rec:
             self.item[4].record()
+            name = _lib.fn("itg_last_conv_kernel")()
+            if name:
+                self.item[0] = name.decode()
             PROFILE.append(tuple(self.item))
 
 
@@ -184,6 +187,8 @@ def to_nchw(g, merged=True):
 def sn_power_iter(w_orig, u, v, training=True, eps=1e-12):
     """One power iteration in place on (u, v) (training) and 1/sigma as a 1-element tensor.
     torch.nn.utils.spectral_norm semantics as used at reference models/layers.py:190-194."""
+    if WGRAD_STREAM is not None:
+        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
     rows = w_orig.shape[0]
     cols = w_orig.numel() // rows
     ws = torch.empty(rows + 8 * cols + 2, device=w_orig.device, dtype=torch.float32)
@@ -197,6 +202,8 @@ def sn_power_iter(w_orig, u, v, training=True, eps=1e-12):
 def sn_power_iter_multi(layers, training=True, eps=1e-12):
     """Power iteration for several (w_orig, u, v) triples in 4 launches; returns the list of 1/sigma
     tensors.  Falls back to per-layer calls above 8 layers."""
+    if WGRAD_STREAM is not None:
+        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
     if len(layers) > 8:
         return [sn_power_iter(w, u, v, training, eps) for (w, u, v) in layers]
     n = len(layers)
@@ -296,7 +303,7 @@ class _Conv(torch.autograd.Function):
             npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
             nws = _lib.fn("itg_conv2d_dgrad_workspace")(C.byref(ddy), C.byref(ddx), C.byref(g))
             ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
-            with _Prof(_nt_tag(ci), stride * stride, 2.0 * npix_out * co * ci * kh * kw):
+            with _Prof(_nt_tag(ci), 1, 2.0 * npix_out * co * ci * kh * kw):
                 ia = ctx.in_act
                 dact = _desc(x, ci) if ia is not None else _null_desc()
                 _lib.call("itg_conv2d_dgrad", C.byref(ddy), _ptr(wp), _ptr(out_scale), C.byref(ddx), C.byref(dact),
@@ -305,34 +312,49 @@ class _Conv(torch.autograd.Function):
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if need_w or need_b:
-            dxd = _desc(x, ci)
-            nws = _lib.fn("itg_conv2d_wgrad_workspace")(C.byref(dxd), C.byref(ddy), C.byref(g))
-            ws = torch.empty(nws, device=x.device, dtype=torch.float32)
             wsink, bsink = ctx.sinks if ctx.sinks is not None else (None, None)
-            direct_w = wsink is not None and ctx.sn is None and need_w
-            direct_b = bsink is not None and need_b
-            fresh = torch.zeros_like if (direct_w or direct_b) else torch.empty_like   # accumulate flag is shared
-            gw_ = wsink if direct_w else fresh(w)
-            gb = bsink if direct_b else (fresh(w[:, 0, 0, 0]) if need_b else None)
-            npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
-            with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1, 2.0 * npix_out * co * ci * kh * kw):
-                # one accumulate flag covers dw and db: a sink for one of them implies sinks for both
-                _lib.call("itg_conv2d_wgrad", C.byref(dxd), C.byref(ddy), _ptr(gw_), _ptr(gb), C.byref(g),
-                          int(direct_w or direct_b), _ptr(ws), nws, st)
-            if ctx.sn is not None and need_w:
-                _, u, v = ctx.sn
-                rows, cols = co, w.numel() // co
-                d_orig = wsink if wsink is not None else torch.empty_like(w)
-                ws2 = torch.empty(2, device=x.device, dtype=torch.float64)
-                _lib.call("itg_spectral_norm_bwd", _ptr(gw_), _ptr(w), _ptr(u), _ptr(v), _ptr(inv_sigma), rows, cols,
-                          _ptr(d_orig), int(wsink is not None), _ptr(ws2), st)
-                gw_ = None if wsink is not None else d_orig
-            elif direct_w:
-                gw_ = None
-            if direct_b:
-                gb = None
-            if not need_w:
-                gw_ = None
+            # Everything below only writes into the flat gradient buffers when sinks cover the requested
+            # gradients: such a weight-gradient can run on the side stream, next to the input-gradient chain.
+            side = WGRAD_STREAM
+            if side is not None and ((need_w and wsink is None) or (need_b and bsink is None)):
+                side = None
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                # the operands were allocated on the main stream: keep them referenced until the owner of the side
+                # stream has joined it (engine.Trainer._join clears the list), so the allocator cannot hand their
+                # memory to a later main-stream kernel while the weight-gradient still reads it
+                WGRAD_KEEPALIVE.append((x, dy, inv_sigma))
+                side.wait_event(ev)
+            with (torch.cuda.stream(side) if side is not None else _NullCtx()):
+                st = _stream()
+                dxd = _desc(x, ci)
+                nws = _lib.fn("itg_conv2d_wgrad_workspace")(C.byref(dxd), C.byref(ddy), C.byref(g))
+                ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+                direct_w = wsink is not None and ctx.sn is None and need_w
+                direct_b = bsink is not None and need_b
+                fresh = torch.zeros_like if (direct_w or direct_b) else torch.empty_like   # accumulate flag is shared
+                gw_ = wsink if direct_w else fresh(w)
+                gb = bsink if direct_b else (fresh(w[:, 0, 0, 0]) if need_b else None)
+                npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
+                with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1, 2.0 * npix_out * co * ci * kh * kw):
+                    # one accumulate flag covers dw and db: a sink for one of them implies sinks for both
+                    _lib.call("itg_conv2d_wgrad", C.byref(dxd), C.byref(ddy), _ptr(gw_), _ptr(gb), C.byref(g),
+                              int(direct_w or direct_b), _ptr(ws), nws, st)
+                if ctx.sn is not None and need_w:
+                    _, u, v = ctx.sn
+                    rows, cols = co, w.numel() // co
+                    d_orig = wsink if wsink is not None else torch.empty_like(w)
+                    ws2 = torch.empty(2, device=x.device, dtype=torch.float64)
+                    _lib.call("itg_spectral_norm_bwd", _ptr(gw_), _ptr(w), _ptr(u), _ptr(v), _ptr(inv_sigma), rows, cols,
+                              _ptr(d_orig), int(wsink is not None), _ptr(ws2), st)
+                    gw_ = None if wsink is not None else d_orig
+                elif direct_w:
+                    gw_ = None
+                if direct_b:
+                    gb = None
+                if not need_w:
+                    gw_ = None
         gres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
         return gx, gw_, gb, gres, None, None, None, None, None, None, None, None, None
 
@@ -352,6 +374,21 @@ def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=AC
 
 # ------------------------------------------------------------------------------- batch norm (+act, +upsample)
 from .dist import SyncGroup  # noqa: E402,F401  (sync-BN statistics exchange)
+
+
+# Side stream for weight-gradient kernels (set by engine.Trainer for the duration of a step).  The power
+# iteration of a spectrally normalised layer rewrites u / v in place, which a still-running weight-gradient of
+# the previous pass reads: sn_power_iter* therefore waits for this stream first.
+WGRAD_STREAM = None
+WGRAD_KEEPALIVE = []
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 class ZeroArena:
