@@ -475,69 +475,97 @@ __device__ __forceinline__ void store_out(const ConvP& p, int n, int oy, int ox,
   }
 }
 
-template <int FI>
-__global__ __launch_bounds__(256) void conv_tile_kernel(const ConvP p, int tiles_x, int tiles_y, int cpt, int nch) {
+// Persistent workgroups: the filter bank is staged into LDS once per workgroup, then the workgroup walks
+// over tiles; the global loads of the NEXT tile are issued into registers before the current tile's MFMA
+// phase and drained into the (single) LDS tile buffer after it.
+// LDS: Wl[nch][16*FI][20] (K chunk q of the packed panel, 16 k per row) | koff[nch][4] | Xt[TT_PIX][cpt].
+// K index k = 16 q + 4 g + e maps to (tap, c) = divmod(k, cin_ld); cin_ld % 4 == 0 keeps the four e of a lane
+// in one tap, so lane group g of chunk q reads 16 B at pixel * cpt + koff[q][g].
+// NLD = b128 loads per thread and tile = ceil(340 * (cin_ld / 4) / 256): 6 up to cin_ld 16, 11 up to 32
+template <int FI, int NLD>
+__global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(const ConvP p, int tiles_x, int tiles_y, int ntiles, int cpt, int nch) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Xt = lds;                                   // [TT_PIX][cpt] (+ slack)
-  float* Wl = lds + TT_PIX * cpt + 16;               // [9][nch][16*FI][20]
+  const int co_rows = 16 * FI;
+  float* Wl = lds;
+  int* koff = reinterpret_cast<int*>(lds + nch * co_rows * 20);
+  float* Xt = lds + nch * co_rows * 20 + ((nch * 4 + 3) & ~3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int b = blockIdx.x;
-  const int tx_i = b % tiles_x; b /= tiles_x;
-  const int ty_i = b % tiles_y;
-  const int n = b / tiles_y;
-  const int t0 = ty_i * TT_H, u0 = tx_i * TT_W;
   const int q4 = p.cin_ld >> 2;
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in.p, 0, p.in_bytes, 0x00020000);
-  // ---- stage the halo tile
-  for (int e = tid; e < TT_PIX * q4; e += 256) {
-    int pix = e / q4, c4 = e - pix * q4;
-    int r = pix / (TT_W + 2), c = pix - r * (TT_W + 2);
-    int iy = t0 + p.ioy + r, ix = u0 + p.iox + c;
-    bool ok = true;
-    if (p.pad_mode != ITG_PAD_REPLICATE) ok = (unsigned)iy < (unsigned)p.in.H && (unsigned)ix < (unsigned)p.in.W;
-    iy = min(max(iy, 0), p.in.H - 1); ix = min(max(ix, 0), p.in.W - 1);
-    unsigned o = ((unsigned)grid_off(p.in, n, iy, ix) + (unsigned)c4 * 4u) * 4u;
-    f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? o : p.in_bytes, 0, 0));
-    *reinterpret_cast<f32x4*>(Xt + pix * cpt + c4 * 4) = v;
-  }
-  if (tid < 16) Xt[TT_PIX * cpt + tid] = 0.f;        // slack read by the last pixel's K-chunk overrun
-  // ---- filter bank: Wl[tap][chunk][co][k16], zero beyond cin_ld
-  const int co_rows = 16 * FI;
-  for (int e = tid; e < 9 * nch * co_rows * 16; e += 256) {
-    int k16 = e & 15;
-    int r = e >> 4;
-    int co = r % co_rows; r /= co_rows;
-    int c = r % nch;
-    int tap = r / nch;
-    int ci = c * 16 + k16;
-    float v = 0.f;
-    if (ci < p.cin_ld && co < p.co_rows) v = p.w[(size_t)co * p.Kpad + tap * p.cin_ld + ci];
-    Wl[((tap * nch + c) * co_rows + co) * 20 + k16] = v;
-  }
-  __syncthreads();
-  // ---- compute: wave w owns tile rows 2w, 2w+1; fragment f = (row 2w + f/2, columns 16*(f&1) ..)
-  f32x4 acc[FI][4];
+  // what a thread fetches is the same for every tile: (halo pixel row / column, channel group) and its LDS slot
+  int e_r[NLD], e_c[NLD], e_lds[NLD];
+  unsigned e_cb[NLD];
 #pragma unroll
-  for (int i = 0; i < FI; ++i)
+  for (int i = 0; i < NLD; ++i) {
+    int e = tid + i * 256;
+    bool live = e < TT_PIX * q4;
+    int pix = live ? e / q4 : 0, c4 = live ? e - pix * q4 : 0;
+    e_r[i] = live ? pix / (TT_W + 2) : -1;
+    e_c[i] = pix - (pix / (TT_W + 2)) * (TT_W + 2);
+    e_lds[i] = pix * cpt + c4 * 4;
+    e_cb[i] = (unsigned)c4 * 16u;
+  }
+  // ---- filter bank + K-chunk offset table (once)
+  for (int e = tid; e < nch * co_rows * 16; e += 256) {
+    int k16 = e & 15, r = e >> 4;
+    int row = r % co_rows, q = r / co_rows;
+    int k = q * 16 + k16;
+    float v = (row < p.co_rows && k < p.Kpad) ? p.w[(size_t)row * p.Kpad + k] : 0.f;
+    Wl[(q * co_rows + row) * 20 + k16] = v;
+  }
+  for (int e = tid; e < nch * 4; e += 256) {
+    int k = (e >> 2) * 16 + (e & 3) * 4;
+    int tap = k / p.cin_ld, c = k - tap * p.cin_ld;
+    int ky = tap / 3, kx = tap - ky * 3;
+    koff[e] = tap < 9 ? (ky * (TT_W + 2) + kx) * cpt + c : 0;      // K padding: weights are zero, read something finite
+  }
+  // ---- tile loader (global -> registers -> LDS)
+  f32x4 rt[NLD];
+  auto load_tile = [&](int tile) {
+    int b = tile;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+    const int y0 = ty_i * TT_H + p.ioy, x0 = tx_i * TT_W + p.iox;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int fj = lane & 15, g4 = (lane >> 4) * 4;
+    for (int i = 0; i < NLD; ++i) {
+      int iy = y0 + e_r[i], ix = x0 + e_c[i];
+      bool ok = e_r[i] >= 0;
+      if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.in.H && (unsigned)ix < (unsigned)p.in.W;
+      iy = min(max(iy, 0), p.in.H - 1); ix = min(max(ix, 0), p.in.W - 1);
+      unsigned o = (unsigned)grid_off(p.in, n, iy, ix) * 4u + e_cb[i];
+      rt[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? o : p.in_bytes, 0, 0));
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      if (e_r[i] >= 0) *reinterpret_cast<f32x4*>(Xt + e_lds[i]) = rt[i];
+  };
+  const int fj = lane & 15, g = lane >> 4;
   int pbase[4];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) pbase[f] = ((2 * wave + (f >> 1)) * (TT_W + 2) + 16 * (f & 1) + fj) * cpt + g4;
-  for (int tap = 0; tap < 9; ++tap) {
-    const int ky = tap / 3, kx = tap - ky * 3;
-    const int toff = (ky * (TT_W + 2) + kx) * cpt;
-    for (int c = 0; c < nch; ++c) {
+  for (int f = 0; f < 4; ++f) pbase[f] = ((2 * wave + (f >> 1)) * (TT_W + 2) + 16 * (f & 1) + fj) * cpt;
+  int tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile);
+  __syncthreads();                                    // Wl / koff visible
+  for (; tile < ntiles; tile += gridDim.x) {
+    store_tile();
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < ntiles) load_tile(next);               // in flight during the MFMA phase
+    f32x4 acc[FI][4];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < nch; ++q) {
+      const int ko = koff[q * 4 + g];
       f32x4 a[FI], bq[4];
 #pragma unroll
-      for (int i = 0; i < FI; ++i)
-        a[i] = *reinterpret_cast<const f32x4*>(Wl + ((tap * nch + c) * co_rows + 16 * i + fj) * 20 + g4);
+      for (int i = 0; i < FI; ++i) a[i] = *reinterpret_cast<const f32x4*>(Wl + (q * co_rows + 16 * i + fj) * 20 + g * 4);
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        const float* src = Xt + pbase[f] + toff + c * 16;
-        bq[f] = f32x4{src[0], src[1], src[2], src[3]};     // pitch is only 4-float aligned for some cin_ld
-      }
+      for (int f = 0; f < 4; ++f) bq[f] = *reinterpret_cast<const f32x4*>(Xt + pbase[f] + ko);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -546,48 +574,70 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvP p, int tiles
           for (int f = 0; f < 4; ++f)
             acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], bq[f][s], acc[i][f], 0, 0, 0);
     }
-  }
-  // ---- epilogue
+    // ---- epilogue
+    int b = tile;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+    const int t0 = ty_i * TT_H, u0 = tx_i * TT_W;
 #pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    int t = t0 + 2 * wave + (f >> 1), u = u0 + 16 * (f & 1) + fj;
-    if (t >= p.MT || u >= p.MU) continue;
+    for (int f = 0; f < 4; ++f) {
+      int t = t0 + 2 * wave + (f >> 1), u = u0 + 16 * (f & 1) + fj;
+      if (t >= p.MT || u >= p.MU) continue;
 #pragma unroll
-    for (int i = 0; i < FI; ++i) {
-      int co = 16 * i + g4;
-      if (co < p.out.ld) store_out(p, n, t * p.osy + p.ooy, u * p.osx + p.oox, co, acc[i][f]);
+      for (int i = 0; i < FI; ++i) {
+        int co = 16 * i + g * 4;
+        if (co < p.out.ld) store_out(p, n, t * p.osy + p.ooy, u * p.osx + p.oox, co, acc[i][f]);
+      }
     }
+    __syncthreads();                                  // every wave is done reading Xt
   }
 }
 
 // eligibility + launch of the halo-tile kernel; returns 1 when it handled the call
 int try_conv_tile(const ConvP& p, hipStream_t s, int* rc) {
-  static const int enable = env_int("ITG_CONV_TILE", 0);   // experimental: only pays with a persistent pipeline
+  static const int enable = env_int("ITG_CONV_TILE", 1);
   if (!enable || p.ncls > 1 || p.ntaps != 9 || p.kw != 3 || p.isy != 1 || p.isx != 1 || p.osy != 1 || p.osx != 1)
     return 0;
-  if (p.cin_ld > 32 || p.co_rows > 32) return 0;
+  if (p.prec != ITG_PREC_F32 || p.cin_ld > 32 || p.co_rows > 32) return 0;
   if ((int64_t)p.MT * p.MU < 64 * 64) return 0;          // tiny images: the gather kernel with split-K wins
   ConvP q = p;
   int64_t ib = (int64_t)p.in.n * p.in.gh * p.in.gw * p.in.ph * p.in.pw * p.in.ld * 4;
   if (ib >= 0xFFFF0000LL) return 0;
   q.in_bytes = (unsigned)ib;
-  const int cpt = (p.cin_ld % 16 == 0) ? p.cin_ld + 4 : p.cin_ld;
-  const int nch = (p.cin_ld + 15) / 16;
+  q.scale = p.scale;
+  const int cpt = (p.cin_ld % 8 == 4) ? p.cin_ld : p.cin_ld + 4;     // conflict-free b128 fragment reads
+  const int nch = (9 * p.cin_ld + 15) / 16;
   const int FI = p.co_rows / 16;
   const int tiles_x = (p.MU + TT_W - 1) / TT_W, tiles_y = (p.MT + TT_H - 1) / TT_H;
-  const int64_t blocks = (int64_t)p.in.n * tiles_x * tiles_y;
-  const size_t lds = ((size_t)TT_PIX * cpt + 16 + (size_t)9 * nch * 16 * FI * 20) * sizeof(float);
-  if (blocks > 0x7fffffff || lds > 96 * 1024) return 0;
+  const int64_t ntiles = (int64_t)p.in.n * tiles_x * tiles_y;
+  const size_t lds = ((size_t)nch * 16 * FI * 20 + ((nch * 4 + 3) & ~3) + (size_t)TT_PIX * cpt) * sizeof(float);
+  const int nld = (TT_PIX * (p.cin_ld >> 2) + 255) / 256;
+  if (ntiles > 0x7fffffff || lds > 64 * 1024 || nld > 11) return 0;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<1, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<2, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<1, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<2, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     attr_done = true;
   }
-  if (FI == 1)
-    hipLaunchKernelGGL(conv_tile_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, s, q, tiles_x, tiles_y, cpt, nch);
+  // persistent grid = what is resident at once (register budget: 4 workgroups per CU with 6 loads, 3 with 11)
+  int per_cu = (int)((160 * 1024) / lds);
+  const int reg_cu = nld <= 6 ? 4 : 3;
+  if (per_cu > reg_cu) per_cu = reg_cu;
+  if (per_cu < 1) per_cu = 1;
+  const int64_t want = 256 * (int64_t)per_cu;
+  const unsigned blocks = (unsigned)(ntiles < want ? ntiles : want);
+  snprintf(g_last_launch, sizeof(g_last_launch), "conv_tile_kernel<%d, %d>", FI, nld <= 6 ? 6 : 11);
+  if (FI == 1 && nld <= 6)
+    hipLaunchKernelGGL((conv_tile_kernel<1, 6>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles, cpt, nch);
+  else if (FI == 1)
+    hipLaunchKernelGGL((conv_tile_kernel<1, 11>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles, cpt, nch);
+  else if (nld <= 6)
+    hipLaunchKernelGGL((conv_tile_kernel<2, 6>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles, cpt, nch);
   else
-    hipLaunchKernelGGL(conv_tile_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, s, q, tiles_x, tiles_y, cpt, nch);
+    hipLaunchKernelGGL((conv_tile_kernel<2, 11>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles, cpt, nch);
   *rc = hipGetLastError() == hipSuccess ? ITG_OK : ITG_ERR_LAUNCH;
   return 1;
 }
@@ -1049,6 +1099,198 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------- narrow 3x3 weight gradient (halo tiles)
+// dW[(tap, c)][co] = sum_pixel X[pixel + tap][c] * dY[pixel][co] for stride-1 3x3 convs with <= 32 input and <= 16
+// output channels (the generator's last block and `final`).  The generic kernel above spends most of its
+// issue slots on gather addresses (16 MFMAs per 16-pixel stage); here a persistent workgroup stages an
+// (8+2) x (32+2) halo tile of X and the 8 x 32 tile of dY in LDS and every wave contracts its 64 pixels
+// against ALL 9 * cin_ld (tap, c) rows: per 4 pixels MF ds_read_b32 + 1 and MF MFMAs, no address arithmetic.
+// The 4 waves' accumulators are summed in a fixed order through LDS; one slab per workgroup, reduced by the
+// same two-stage reduction as the generic path.
+template <int MF, int NLD>
+__global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgP p, int tiles_x, int tiles_y, int ntiles, int cpt) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int CPD = 16;                                  // dY tile pitch (co_rows = 16)
+  float* Xt = lds;                                         // [TT_PIX][cpt]
+  float* Yt = lds + TT_PIX * cpt;                          // [TT_H * TT_W][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = p.cin_ld >> 2, yq4 = p.dy.ld >> 2;
+  const __amdgpu_buffer_rsrc_t rxr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x.p, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ryr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy.p, 0, p.dy_bytes, 0x00020000);
+  int e_r[NLD], e_c[NLD], e_lds[NLD];
+  unsigned e_cb[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    int e = tid + i * 256;
+    bool live = e < TT_PIX * q4;
+    int pix = live ? e / q4 : 0, c4 = live ? e - pix * q4 : 0;
+    e_r[i] = live ? pix / (TT_W + 2) : -1;
+    e_c[i] = pix - (pix / (TT_W + 2)) * (TT_W + 2);
+    e_lds[i] = pix * cpt + c4 * 4;
+    e_cb[i] = (unsigned)c4 * 16u;
+  }
+  // dY: thread -> (pixel, channel group); yq4 in {1, 2, 4} divides 256, so a thread's channel group is fixed
+  constexpr int YLD = 4;
+  int y_r[YLD], y_c[YLD], y_lds[YLD];
+  const unsigned y_cb = (unsigned)(tid % yq4) * 16u;
+#pragma unroll
+  for (int i = 0; i < YLD; ++i) {
+    int e = tid + i * 256;
+    bool live = e < TT_H * TT_W * yq4;
+    int pix = live ? e / yq4 : 0;
+    y_r[i] = live ? pix / TT_W : -1;
+    y_c[i] = pix - (pix / TT_W) * TT_W;
+    y_lds[i] = pix * CPD + (e % yq4) * 4;
+  }
+  for (int e = tid; e < TT_H * TT_W * CPD; e += 256) Yt[e] = 0.f;     // channel groups >= dy.ld stay zero
+  f32x4 rt[NLD], ry[YLD];
+  auto load_tile = [&](int tile) {
+    int b = tile;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+    const int t0 = ty_i * TT_H, u0 = tx_i * TT_W;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      int iy = t0 - p.pad_h + e_r[i], ix = u0 - p.pad + e_c[i];
+      bool ok = e_r[i] >= 0;
+      if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.x.H && (unsigned)ix < (unsigned)p.x.W;
+      iy = min(max(iy, 0), p.x.H - 1); ix = min(max(ix, 0), p.x.W - 1);
+      unsigned o = (unsigned)grid_off(p.x, n, iy, ix) * 4u + e_cb[i];
+      rt[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxr, ok ? o : p.x_bytes, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < YLD; ++i) {
+      int t = t0 + y_r[i], u = u0 + y_c[i];
+      bool ok = y_r[i] >= 0 && t < p.MT && u < p.MU;
+      unsigned o = (unsigned)grid_off(p.dy, n, ok ? t : 0, ok ? u : 0) * 4u + y_cb;
+      ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ryr, ok ? o : p.dy_bytes, 0, 0));
+    }
+  };
+  f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      if (e_r[i] >= 0) *reinterpret_cast<f32x4*>(Xt + e_lds[i]) = rt[i];
+#pragma unroll
+    for (int i = 0; i < YLD; ++i)
+      if (y_r[i] >= 0) { *reinterpret_cast<f32x4*>(Yt + y_lds[i]) = ry[i]; dbacc += ry[i]; }
+  };
+  // per-lane row offsets: MFMA row m = 16 i + (lane & 15) is (tap, c) = divmod(m, cin_ld)
+  const int fr = lane & 15, g = lane >> 4;
+  int moff[MF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    int m = 16 * i + fr;
+    int tap = m / p.cin_ld, c = m - tap * p.cin_ld;
+    int ky = tap / 3, kx = tap - ky * 3;
+    moff[i] = tap < 9 ? (ky * (TT_W + 2) + kx) * cpt + c : 0;         // rows past 9 * cin_ld: never read back
+  }
+  f32x4 acc[MF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile);
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    store_tile();
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < ntiles) load_tile(next);
+#pragma unroll 1
+    for (int rr = 0; rr < 2; ++rr) {
+      const float* xrow = Xt + ((2 * wave + rr) * (TT_W + 2) + g) * cpt;
+      const float* yrow = Yt + ((2 * wave + rr) * TT_W + g) * CPD + fr;
+#pragma unroll 2
+      for (int s4 = 0; s4 < TT_W / 4; ++s4) {
+        const float bv = yrow[s4 * 4 * CPD];
+        const float* xs = xrow + s4 * 4 * cpt;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[moff[i]], bv, acc[i], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- sum the 4 waves' accumulators in wave order through LDS: R[m][16]
+  float* R = lds;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float* dst = R + (16 * i + 4 * g + e) * 16 + fr;
+          *dst = (w == 0 ? 0.f : *dst) + acc[i][e];
+        }
+    }
+    __syncthreads();
+  }
+  float* slab = p.slab + (size_t)blockIdx.x * p.co_rows * p.Kpad;
+  for (int idx = tid; idx < p.co_rows * p.Kpad; idx += 256) {
+    int co = idx / p.Kpad, m = idx - co * p.Kpad;
+    slab[idx] = m < MF * 16 ? R[m * 16 + co] : 0.f;
+  }
+  if (p.dbslab) {       // bias gradient: per-thread sums of the staged dY rows -> fixed-order sum per channel
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(lds) + (MF * 16 * 16 + 3) / 4;
+    red[tid] = dbacc;
+    __syncthreads();
+    if (tid < 16) {
+      float sdb = 0.f;
+      if ((tid >> 2) < yq4)
+        for (int r = (tid >> 2); r < 256; r += yq4) sdb += red[r][tid & 3];
+      p.dbslab[(size_t)blockIdx.x * p.co_rows + tid] = sdb;
+    }
+  }
+}
+
+struct TileWgPlan { int ok, mf, nld, cpt, tiles_x, tiles_y, blocks; int64_t ntiles; size_t lds; };
+
+TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g) {
+  TileWgPlan t;
+  t.ok = 0;
+  static const int enable = env_int("ITG_WGRAD_TILE", 1);
+  const int ph = g->pad_h >= 0 ? g->pad_h : g->pad;
+  if (!enable || g->kh != 3 || g->kw != 3 || g->stride != 1 || g->pad != 1 || ph != 1) return t;
+  if (g->precision == ITG_PREC_BF16 || x->ld > 32 || dy->ld > 16 || (dy->ld != 4 && dy->ld != 8 && dy->ld != 16)) return t;
+  const int H = dy->gh * dy->ph, W = dy->gw * dy->pw;
+  if ((int64_t)H * W < 64 * 64) return t;
+  const int M = 9 * x->ld;
+  t.mf = M <= 48 ? 3 : M <= 144 ? 9 : M <= 256 ? 16 : 18;
+  if (t.mf * 16 < M) return t;
+  t.nld = (TT_PIX * (x->ld >> 2) + 255) / 256;
+  t.nld = t.nld <= 6 ? 6 : 11;
+  if ((TT_PIX * (x->ld >> 2) + 255) / 256 > 11) return t;
+  t.cpt = (x->ld % 8 == 4) ? x->ld : x->ld + 4;
+  t.tiles_x = (W + TT_W - 1) / TT_W; t.tiles_y = (H + TT_H - 1) / TT_H;
+  t.ntiles = (int64_t)dy->n * t.tiles_x * t.tiles_y;
+  size_t fl = (size_t)TT_PIX * t.cpt + (size_t)TT_H * TT_W * 16;
+  size_t red = (size_t)t.mf * 16 * 16 + 4 + 256 * 4;            // reduction buffer + bias partials reuse the tiles' space
+  if (red > fl) fl = red;
+  t.lds = fl * sizeof(float);
+  if (t.lds > 64 * 1024 || t.ntiles > 0x7fffffff) return t;
+  int per_cu = (int)((160 * 1024) / t.lds);
+  if (per_cu > 2) per_cu = 2;
+  int64_t want = 256 * (int64_t)(per_cu < 1 ? 1 : per_cu);
+  t.blocks = (int)(t.ntiles < want ? t.ntiles : want);
+  t.ok = 1;
+  return t;
+}
+
+template <int MF, int NLD>
+void launch_wgrad_tile(const WgP& p, const TileWgPlan& t, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<MF, NLD>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr_done = true;
+  }
+  snprintf(g_last_launch, sizeof(g_last_launch), "wgrad_tile_kernel<%d, %d>", MF, NLD);
+  hipLaunchKernelGGL((wgrad_tile_kernel<MF, NLD>), dim3((unsigned)t.blocks), dim3(256), t.lds, s, p, t.tiles_x, t.tiles_y,
+                     (int)t.ntiles, t.cpt);
+}
+
 // dW[co][ci][ky][kx] (+)= sum_z slab[z][co][(ky*kw+kx)*ci_ld + ci]
 // One workgroup per (o, 64-channel chunk): slab reads are coalesced along ci, the (ci, tap) tile is
 // transposed through LDS so that the OIHW store is one contiguous run of 64*taps floats.
@@ -1272,6 +1514,19 @@ inline bool thin_out_conv(const itg_tensor* in, const itg_tensor* out, const itg
   const int ph = g->pad_h >= 0 ? g->pad_h : g->pad;
   return enable && out->c == 1 && g->kh * g->kw == 16 && g->stride == 1 && g->pad_mode == ITG_PAD_ZERO &&
          (in->ld % 16) == 0 && ph < g->kh && g->pad < g->kw && 2 * ph <= g->kh - 1 && 2 * g->pad <= g->kw - 1;
+}
+
+// TnPlan of the halo-tile weight gradient: one slab per persistent workgroup, same reduction stages
+TnPlan tn_plan_for_tiles(const TileWgPlan& tw, int co_ld, int Ktot) {
+  TnPlan t;
+  t.bcol = -1; t.bco = 16;
+  t.co_rows = round_up(co_ld, 16);
+  t.Kpad = round_up(Ktot, 16);
+  t.splits = tw.blocks; t.chunks_per_split = 0; t.nchunks = 0;
+  t.slab_floats = (int64_t)t.splits * t.co_rows * t.Kpad;
+  t.ngroups = t.splits > RED_GROUP ? (t.splits + RED_GROUP - 1) / RED_GROUP : 0;
+  t.ws_floats = t.slab_floats + (int64_t)t.ngroups * t.co_rows * t.Kpad;
+  return t;
 }
 
 int conv_out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
@@ -1544,7 +1799,8 @@ int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, co
     return Min * 16 + 16 * (int64_t)x->c + 16 + t.ws_floats + (int64_t)t.splits * t.co_rows;
   }
   int64_t M = grid_pixels(dy);
-  TnPlan t = plan_tn(M, dy->ld, g->kh * g->kw * x->ld, prec_of(g));
+  TileWgPlan tw = plan_wgrad_tile(x, dy, g);
+  TnPlan t = tw.ok ? tn_plan_for_tiles(tw, dy->ld, g->kh * g->kw * x->ld) : plan_tn(M, dy->ld, g->kh * g->kw * x->ld, prec_of(g));
   return t.ws_floats + (int64_t)t.splits * t.co_rows;
 }
 
@@ -1588,7 +1844,8 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
   p.ntaps = g->kh * g->kw; p.kw = g->kw; p.cin_ld = x->ld;
   p.Ktot = p.ntaps * x->ld;
   const int prec = prec_of(g);
-  TnPlan t = plan_tn(M, dy->ld, p.Ktot, prec);
+  const TileWgPlan tw = plan_wgrad_tile(x, dy, g);
+  TnPlan t = tw.ok ? tn_plan_for_tiles(tw, dy->ld, p.Ktot) : plan_tn(M, dy->ld, p.Ktot, prec);
   if (t.ws_floats + (int64_t)t.splits * t.co_rows > workspace_floats) return ITG_ERR_WORKSPACE;
   p.Kpad = t.Kpad; p.co_rows = t.co_rows;
   p.slab = workspace;
@@ -1601,7 +1858,14 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
     if (xb >= 0xFFFF0000LL || yb >= 0xFFFF0000LL) return ITG_ERR_ARG;
     p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
   }
-  if (t.bcol == 64) rc = launch_tn<64, 64, 32, 32>(p, t.splits, prec, s);
+  if (tw.ok) {
+    rc = ITG_OK;
+    if (tw.mf == 3) launch_wgrad_tile<3, 6>(p, tw, s);
+    else if (tw.mf == 9) launch_wgrad_tile<9, 6>(p, tw, s);
+    else if (tw.mf == 16) launch_wgrad_tile<16, 11>(p, tw, s);
+    else launch_wgrad_tile<18, 11>(p, tw, s);
+    ITG_CHECK_LAUNCH();
+  } else if (t.bcol == 64) rc = launch_tn<64, 64, 32, 32>(p, t.splits, prec, s);
   else if (t.bco == 16) rc = launch_tn<256, 16, 64, 16>(p, t.splits, prec, s);
   else if (t.bco == 32) rc = launch_tn<256, 32, 64, 32>(p, t.splits, prec, s);
   else if (t.bco == 64) rc = launch_tn<256, 64, 64, 64>(p, t.splits, prec, s);

@@ -82,6 +82,11 @@ CONV_CASES = [
     ("d4x4_s1_64_1_taps_as_rows_grid", 1, (2, 3), 6, 64, 1, 4, 1, 1, "zeros"),
     ("d4x4_s2_3_64_first_layer", 1, (1, 1), 36, 3, 64, 4, 2, 1, "zeros"),           # K = 16 taps x 4: 64x64 wgrad tile
     ("fake_grid_into_D_16ch", 2, (3, 3), 6, 3, 16, 4, 2, 1, "zeros"),                # taps-as-rows input gradient, odd size
+    # narrow 3x3 layers on images >= 64x64: the persistent halo-tile kernels (forward / input gradient / weight gradient)
+    ("tile3x3_rep_13_3", 2, (3, 3), 32, 13, 3, 3, 1, 1, "replicate"),
+    ("tile3x3_rep_26_13", 1, (3, 3), 24, 26, 13, 3, 1, 1, "replicate"),              # 72x72: partial tiles, cin_ld 28
+    ("tile3x3_zero_13_26", 1, (2, 3), 40, 13, 26, 3, 1, 1, "constant"),              # 80x120, 32 filter rows
+    ("tile3x3_rep_3_13", 1, (3, 3), 32, 3, 13, 3, 1, 1, "replicate"),                # cin_ld 4: four taps per K chunk
 ]
 
 
