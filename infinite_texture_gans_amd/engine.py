@@ -125,7 +125,10 @@ class Trainer:
         self.repack()
         self.arena = ops.ZeroArena(device)
         # two-stream overlap (D(real) beside the generator forward, weight gradients beside the input-gradient
-        # chain).  Single-GPU only: with collectives in the step it is unmeasured on RCCL (ITG_OVERLAP=1 forces it)
+        # chain).  Default: single-GPU runs only.  With collectives in the step every collective would still be
+        # issued from the main stream in program order (the side branch is D(real), collective-free unless D has
+        # sync-BatchNorm), but that combination has only been rehearsed over gloo, not measured on RCCL:
+        # ITG_OVERLAP=1 turns it on for multi-GPU runs.
         self.overlap = os.environ.get("ITG_OVERLAP", "1" if self.world == 1 else "0") == "1"
         self.side, self._wstream, self.wstream = None, None, None
         self.set_overlap(self.overlap)
