@@ -747,6 +747,10 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
     p.in_bytes = (unsigned)ib; p.w_bytes = (unsigned)wb;
   }
   const int k = pl.tbk;
+  static const int plan_debug = env_int("ITG_PLAN_DEBUG", 0);
+  if (plan_debug)
+    fprintf(stderr, "[nt] M=%d x%d co_rows=%d Kpad=%d -> bco=%d bpix=%d ksplit=%d kchunks=%d\n", p.M, ncls_, p.co_rows, p.Kpad,
+            pl.bco, pl.bpix, pl.ksplit, pl.kchunks);
   int rc;
   if (pl.bco == 16) {
     rc = pl.bpix == 256 ? launch_nt<16, 256, 16, 64>(p, k, s) : pl.bpix == 128 ? launch_nt<16, 128, 16, 32>(p, k, s)
@@ -1457,17 +1461,17 @@ __global__ void tap_wgrad_finish_kernel(const float* __restrict__ tmp, const flo
 // Input gradient of the discriminator's first layer (3 -> 64, 4x4, stride 2): the parity-class implicit
 // GEMM would fill 3 of its 16 MFMA rows.  Instead Q[o][(class, c, tap')] = dy[o] . w[., c, tap] for every
 // OUTPUT pixel o (a 1x1 conv with 4*c*4 <= 64 rows, K = cout), then each input pixel gathers its 4 taps.
-// compact panel row r = (cls * cin + c) * 4 + tap'  <-  dgrad panel row (cls * ci_pad + c), columns tap' * co_ld ..
+// compact panel row r = (cls * 4 + tap') * 4 + c  <-  dgrad panel row (cls * ci_pad + c), columns tap' * co_ld ..
+// (c padded to 4: the gather then reads one 16-byte vector per tap)
 __global__ void thin_dgrad_panel_kernel(const float* __restrict__ wd, float* __restrict__ out, int cin, int ci_pad, int co_ld,
                                         int rows_pad) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows_pad * co_ld) return;
   int o = i % co_ld, r = i / co_ld;
   float v = 0.f;
-  if (r < 16 * cin) {
-    int tap = r & 3, cc = r >> 2;
-    int c = cc % cin, cls = cc / cin;
-    v = wd[((size_t)(cls * ci_pad + c) * 4 + tap) * co_ld + o];
+  if (r < 64) {
+    int c = r & 3, tap = (r >> 2) & 3, cls = r >> 4;
+    if (c < cin) v = wd[((size_t)(cls * ci_pad + c) * 4 + tap) * co_ld + o];
   }
   out[i] = v;
 }
@@ -1492,8 +1496,7 @@ __global__ void thin_dgrad_gather_kernel(const float* __restrict__ Q, int Ho, in
       for (int jx = 0; jx < 2; ++jx) {
         int ox = u + bx - 1 + jx;
         if ((unsigned)ox >= (unsigned)Wo) continue;
-        const float* q = Q + (((size_t)n * Ho + oy) * Wo + ox) * qld + (size_t)cls * dx.c * 4 + jy * 2 + jx;
-        for (int c = 0; c < dx.c; ++c) v[c] += q[c * 4];
+        v += *reinterpret_cast<const f32x4*>(Q + (((size_t)n * Ho + oy) * Wo + ox) * qld + (cls * 4 + jy * 2 + jx) * 4);
       }
     }
     const int off = grid_off(dx, n, iy, ix);
@@ -1604,7 +1607,7 @@ int64_t itg_conv2d_fwd_workspace(const itg_tensor* in, const itg_tensor* out, co
 int64_t itg_conv2d_dgrad_workspace(const itg_tensor* dy, const itg_tensor* dx, const itg_conv_geom* g) {
   if (!dy || !dx || !g) return 0;
   if (thin_in_conv(dy, dx, g)) {
-    const int rows = round_up(16 * dx->c, 16);
+    const int rows = 64;
     const int64_t Mo = grid_pixels(dy);
     return Mo * rows + (int64_t)rows * dy->ld + plan_nt(Mo, rows, round_up(dy->ld, BK), 1, prec_of(g)).ws_floats;
   }
@@ -1685,7 +1688,7 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
   if (thin_in_conv(dy, dx, g)) {
     const int Ho = dy->gh * dy->ph, Wo = dy->gw * dy->pw, H = dx->gh * dx->ph, W = dx->gw * dx->pw;
     if (conv_out_dim(H, 4, 2, 1) != Ho || conv_out_dim(W, 4, 2, 1) != Wo) return ITG_ERR_ARG;
-    const int rows = round_up(16 * dx->c, 16);
+    const int rows = 64;     // 4 parity classes x 4 taps x 4 (padded) input channels
     const int64_t Mo = grid_pixels(dy), qf = Mo * rows, pf = (int64_t)rows * dy->ld;
     if (!workspace || workspace_floats < qf + pf || qf >= ((int64_t)1 << 31)) return ITG_ERR_WORKSPACE;
     float* Q = workspace;
@@ -1858,6 +1861,10 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
     if (xb >= 0xFFFF0000LL || yb >= 0xFFFF0000LL) return ITG_ERR_ARG;
     p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
   }
+  static const int plan_debug = env_int("ITG_PLAN_DEBUG", 0);
+  if (plan_debug)
+    fprintf(stderr, "[tn] M=%lld co_rows=%d Kpad=%d -> bcol=%d bco=%d splits=%d ngroups=%d tile=%d\n", (long long)M, t.co_rows,
+            t.Kpad, t.bcol, t.bco, t.splits, t.ngroups, tw.ok);
   if (tw.ok) {
     rc = ITG_OK;
     if (tw.mf == 3) launch_wgrad_tile<3, 6>(p, tw, s);
