@@ -1316,18 +1316,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (int z = threadIdx.x; z < dbsplits; z += 256) sdb += dbslab[(size_t)z * co_rows + o];
     part[threadIdx.x] = sdb;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      float t = 0.f;
-      for (int i = 0; i < 256; ++i) t += part[i];
-      db[o] = accumulate ? db[o] + t : t;
+    for (int w = 128; w > 0; w >>= 1) {               // fixed-shape tree: deterministic
+      if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+      __syncthreads();
     }
+    if (threadIdx.x == 0) db[o] = accumulate ? db[o] + part[0] : part[0];
     __syncthreads();
   }
   for (int idx = threadIdx.x; idx < 64 * taps; idx += 256) {
     int c = idx & 63, t = idx >> 6;
     float s = 0.f;
-    if (c < cn)
-      for (int z = 0; z < splits; ++z) s += src[(size_t)z * zstride + (size_t)t * ci_ld + c];
+    if (c < cn) {
+      const float* q = src + (size_t)t * ci_ld + c;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four loads in flight, summed in a fixed order
+      int z = 0;
+      for (; z + 4 <= splits; z += 4) {
+        s0 += q[(size_t)z * zstride];
+        s1 += q[(size_t)(z + 1) * zstride];
+        s2 += q[(size_t)(z + 2) * zstride];
+        s3 += q[(size_t)(z + 3) * zstride];
+      }
+      for (; z < splits; ++z) s0 += q[(size_t)z * zstride];
+      s = (s0 + s1) + (s2 + s3);
+    }
     tile[c * taps + t] = s;
   }
   __syncthreads();
