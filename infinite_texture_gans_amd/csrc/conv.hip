@@ -389,8 +389,20 @@ __global__ void splitk_epilogue_kernel(ConvP p) {
     int m = (int)(i / q4);
     int co = c4 * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < p.ksplit; ++z)
-      v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)z * p.M + m) * p.co_rows + co);
+    {
+      const float* q = p.partial + (size_t)m * p.co_rows + co;
+      const size_t zs = (size_t)p.M * p.co_rows;
+      f32x4 v1 = v, v2 = v, v3 = v;                       // four slab loads in flight, fixed summation order
+      int z = 0;
+      for (; z + 4 <= p.ksplit; z += 4) {
+        v += *reinterpret_cast<const f32x4*>(q + (size_t)z * zs);
+        v1 += *reinterpret_cast<const f32x4*>(q + (size_t)(z + 1) * zs);
+        v2 += *reinterpret_cast<const f32x4*>(q + (size_t)(z + 2) * zs);
+        v3 += *reinterpret_cast<const f32x4*>(q + (size_t)(z + 3) * zs);
+      }
+      for (; z < p.ksplit; ++z) v += *reinterpret_cast<const f32x4*>(q + (size_t)z * zs);
+      v = (v + v1) + (v2 + v3);
+    }
     if (p.scale) v *= *p.scale;
     int n, t, u;
     decode_m(m, p.MT, p.MU, n, t, u);
@@ -671,6 +683,7 @@ NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = 
   //   fill          < 2 workgroups per CU leaves the MFMA pipe idle between phases
   //   split cost    the second stage's slab round trip ~ ks * 100 / K of the kernel's own time
   //   tile penalty  narrower tiles re-read the weight panel more often and carry more issue overhead
+  static const double split_cost = (double)env_int("ITG_SPLIT_COST", 100);
   pl.bpix = 128; pl.ksplit = 1;
   double best_eff = 0.0;
   const int cands_big[3] = {256, 128, 64};
@@ -686,7 +699,7 @@ NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = 
       double b = (double)blocks * ks / 256.0;
       double eff = b / (double)((int64_t)(b + 0.999999));
       if (b < 2.0) eff *= b / 2.0;
-      if (ks > 1) eff /= 1.0 + ks * 100.0 / (double)Kpad;
+      if (ks > 1) eff /= 1.0 + ks * split_cost / (double)Kpad;
       eff /= pen;
       if (eff > best_eff * 1.02) { best_eff = eff; pl.bpix = bp; pl.ksplit = ks; }
     }
