@@ -61,6 +61,7 @@ def gpu_leg(a):
         group = dist.group.WORLD
     band = a.workload == "config4"
     cfg3 = a.workload == "config3"
+    _WORKLOAD[0] = a.workload
     args = U.prepare_parser().parse_args(
         FLAGS3 if cfg3 else FLAGS + (["--num_patches_height", "4", "--num_patches_width", "4"] if band else []))
     if args.bf16:
@@ -92,9 +93,10 @@ def gpu_leg(a):
             dist.barrier()
         torch.cuda.synchronize()
 
-    # One iteration is ~600 kernel launches: on one GPU it is recorded once into a hipGraph (after the
-    # warm-up iterations) and replayed; multi-GPU runs stay eager unless ITG_GRAPH=1 (RCCL inside capture).
-    use_graph = os.environ.get("ITG_GRAPH", "1" if world == 1 else "0") == "1"
+    # One iteration is ~380 kernel launches (5-7 ms of host time against 11 ms on the GPU).  Default: eager
+    # launches - with the step's three HIP streams the eager queue overlaps better than a replayed hipGraph
+    # (measured 11.07 vs 11.47 ms); ITG_GRAPH=1 records the iteration once (engine.Trainer.capture) and replays it.
+    use_graph = graph_mode()
     nec_gf = NECESSARY_GF_CONFIG4 / world if band else (NECESSARY_GF_CONFIG3 if cfg3 else NECESSARY_GF_PER_STEP)
     peak_tf = BF16_MFMA_PEAK_TF if args.bf16 else FP32_MFMA_PEAK_TF
     if use_graph:
@@ -150,6 +152,14 @@ def gpu_leg(a):
     if world > 1:
         dist.barrier()
     return rank, world, dt, args, losses, roof
+
+
+GRAPH_DEFAULT = {"config1": "0", "config3": "1", "config4": "0"}   # config 3's 5.5 ms step is shorter than its host time
+_WORKLOAD = ["config1"]
+
+
+def graph_mode():
+    return os.environ.get("ITG_GRAPH", GRAPH_DEFAULT[_WORKLOAD[0]]) == "1" and int(os.environ.get("WORLD_SIZE", 1)) == 1
 
 
 def hbm_traffic(kernel):
@@ -240,7 +250,7 @@ def main():
                                       "accumulate, everything else fp32, batch 8 + 8 generated images per GPU",
                           "global_batch": args.batch_size * world, "g_patches_per_sec": round(72 * world * a.steps / dt, 1),
                           "parallelism": "dp%d (sync-BN + flat grad all-reduce)" % world, "last_losses": losses,
-                          "launch": "hipGraph replay" if os.environ.get("ITG_GRAPH", "1" if world == 1 else "0") == "1" else "eager"},
+                          "launch": "hipGraph replay" if graph_mode() else "eager"},
                "roofline": roof}
         print(json.dumps(out), flush=True)
         return
@@ -255,7 +265,7 @@ def main():
                           "parallelism": "patch rows over %d rank(s): halo-row exchange per conv fwd+bwd, sync-BN, "
                                          "band gather -> image-parallel D, flat grad all-reduce" % world,
                           "last_losses": losses,
-                          "launch": "hipGraph replay" if os.environ.get("ITG_GRAPH", "1" if world == 1 else "0") == "1" else "eager"},
+                          "launch": "hipGraph replay" if graph_mode() else "eager"},
                "roofline": roof}
         print(json.dumps(out), flush=True)
         return
@@ -267,7 +277,7 @@ def main():
                                   "spec_norm_D, smooth, batch 8 + 8 generated images per GPU",
                       "global_batch": args.batch_size * world, "g_patches_per_sec": round(72 * world * a.steps / dt, 1),
                       "parallelism": "dp%d (sync-BN + flat grad all-reduce)" % world, "last_losses": losses,
-                      "launch": "hipGraph replay" if os.environ.get("ITG_GRAPH", "1" if world == 1 else "0") == "1" else "eager"},
+                      "launch": "hipGraph replay" if graph_mode() else "eager"},
            "roofline": roof}
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_leg()
