@@ -139,7 +139,8 @@ class Trainer:
         if on and self.side is None:
             self.side = torch.cuda.Stream(device=self.device)
         if on and getattr(self, "_wstream", None) is None:
-            self._wstream = torch.cuda.Stream(device=self.device)
+            nws = int(os.environ.get("ITG_WGRAD_STREAMS", "2"))
+            self._wstream = [torch.cuda.Stream(device=self.device) for _ in range(max(1, nws))]
         self.wstream = self._wstream if on else None
 
     def repack(self):
@@ -172,7 +173,8 @@ class Trainer:
         ops.ARENA = self.arena
         ops.WGRAD_STREAM = self.wstream
         if self.wstream is not None:
-            self.wstream.wait_stream(torch.cuda.current_stream())
+            for ws in self.wstream:
+                ws.wait_stream(torch.cuda.current_stream())
         # ---------------- D step (train.py:124-154, disc_iters handled by the caller)
         self.flatD.zero_grad()
         if self.overlap:
@@ -180,7 +182,9 @@ class Trainer:
             # on its own (small grids, latency-bound normalisation kernels): run them on two HIP streams
             main = torch.cuda.current_stream()
             self.side.wait_stream(main)
-            keep, ops.WGRAD_STREAM = ops.WGRAD_STREAM, None    # this branch already runs beside the generator
+            keep = ops.WGRAD_STREAM
+            if torch.cuda.is_current_stream_capturing() or os.environ.get("ITG_NESTED_FORK", "1") != "1":
+                ops.WGRAD_STREAM = None                        # hipStreamEndCapture crashes on a fork of a forked stream
             with torch.cuda.stream(self.side):
                 d_real = self._d_loss(netD(real_x), True)
                 d_real.backward()
@@ -222,7 +226,8 @@ class Trainer:
     def _join(self):
         """The weight-gradient stream has to drain before gradients are exchanged / consumed by Adam."""
         if self.wstream is not None:
-            torch.cuda.current_stream().wait_stream(self.wstream)
+            for ws in self.wstream:
+                torch.cuda.current_stream().wait_stream(ws)
             ops.WGRAD_KEEPALIVE.clear()
 
     # ---- hipGraph: the whole iteration (~600 launches) as one graph replay

@@ -187,8 +187,7 @@ def to_nchw(g, merged=True):
 def sn_power_iter(w_orig, u, v, training=True, eps=1e-12):
     """One power iteration in place on (u, v) (training) and 1/sigma as a 1-element tensor.
     torch.nn.utils.spectral_norm semantics as used at reference models/layers.py:190-194."""
-    if WGRAD_STREAM is not None:
-        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
+    wgrad_streams_join()
     rows = w_orig.shape[0]
     cols = w_orig.numel() // rows
     ws = torch.empty(rows + 8 * cols + 2, device=w_orig.device, dtype=torch.float32)
@@ -202,8 +201,7 @@ def sn_power_iter(w_orig, u, v, training=True, eps=1e-12):
 def sn_power_iter_multi(layers, training=True, eps=1e-12):
     """Power iteration for several (w_orig, u, v) triples in 4 launches; returns the list of 1/sigma
     tensors.  Falls back to per-layer calls above 8 layers."""
-    if WGRAD_STREAM is not None:
-        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
+    wgrad_streams_join()
     if len(layers) > 8:
         return [sn_power_iter(w, u, v, training, eps) for (w, u, v) in layers]
     n = len(layers)
@@ -315,7 +313,7 @@ class _Conv(torch.autograd.Function):
             wsink, bsink = ctx.sinks if ctx.sinks is not None else (None, None)
             # Everything below only writes into the flat gradient buffers when sinks cover the requested
             # gradients: such a weight-gradient can run on the side stream, next to the input-gradient chain.
-            side = WGRAD_STREAM
+            side = wgrad_stream_next()
             if side is not None and ((need_w and wsink is None) or (need_b and bsink is None)):
                 side = None
             if side is not None:
@@ -379,8 +377,29 @@ from .dist import SyncGroup  # noqa: E402,F401  (sync-BN statistics exchange)
 # Side stream for weight-gradient kernels (set by engine.Trainer for the duration of a step).  The power
 # iteration of a spectrally normalised layer rewrites u / v in place, which a still-running weight-gradient of
 # the previous pass reads: sn_power_iter* therefore waits for this stream first.
-WGRAD_STREAM = None
+WGRAD_STREAM = None          # one stream or a list of streams used round-robin (consecutive layers overlap each other too)
 WGRAD_KEEPALIVE = []
+_wgrad_rr = [0]
+
+
+def wgrad_stream_next():
+    w = WGRAD_STREAM
+    if w is None:
+        return None
+    if isinstance(w, (list, tuple)):
+        _wgrad_rr[0] = (_wgrad_rr[0] + 1) % len(w)
+        return w[_wgrad_rr[0]]
+    return w
+
+
+def wgrad_streams_join():
+    """The current stream waits for every weight-gradient stream."""
+    w = WGRAD_STREAM
+    if w is None:
+        return
+    cur = torch.cuda.current_stream()
+    for s_ in (w if isinstance(w, (list, tuple)) else (w,)):
+        cur.wait_stream(s_)
 
 
 class _NullCtx:
