@@ -50,7 +50,7 @@ def gpu_leg(a):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     group = None
-    if world > 1:
+    if world > 1 or os.environ.get("ITG_FORCE_COLLECTIVES", "0") == "1":      # one-rank RCCL rehearsal of the collectives
         # "nccl" is RCCL over xGMI.  ITG_DIST_BACKEND=gloo (+ ITG_FORCE_DEVICE=0) lets the multi-rank code path
         # be rehearsed with several ranks on a single GPU.
         backend = os.environ.get("ITG_DIST_BACKEND", "nccl")
@@ -249,7 +249,8 @@ def main():
                                       "padding_mode=local, 3x3 patch grid of 64^2 (fake 192^2), conv operands bf16 / fp32 "
                                       "accumulate, everything else fp32, batch 8 + 8 generated images per GPU",
                           "global_batch": args.batch_size * world, "g_patches_per_sec": round(72 * world * a.steps / dt, 1),
-                          "parallelism": "dp%d (sync-BN + flat grad all-reduce)" % world, "last_losses": losses,
+                          "parallelism": "dp%d (%s BatchNorm statistics, one flat gradient all-reduce per model)" % (
+                          world, "all-reduced" if os.environ.get("ITG_SYNC_BN", "0") == "1" else "per-rank"), "last_losses": losses,
                           "launch": "hipGraph replay" if graph_mode() else "eager"},
                "roofline": roof}
         print(json.dumps(out), flush=True)
@@ -276,7 +277,8 @@ def main():
                                   "padding_mode=local (replicate), G_ch=52 D_ch=64, 3x3 patch grid of 128^2, "
                                   "spec_norm_D, smooth, batch 8 + 8 generated images per GPU",
                       "global_batch": args.batch_size * world, "g_patches_per_sec": round(72 * world * a.steps / dt, 1),
-                      "parallelism": "dp%d (sync-BN + flat grad all-reduce)" % world, "last_losses": losses,
+                      "parallelism": "dp%d (%s BatchNorm statistics, one flat gradient all-reduce per model)" % (
+                          world, "all-reduced" if os.environ.get("ITG_SYNC_BN", "0") == "1" else "per-rank"), "last_losses": losses,
                       "launch": "hipGraph replay" if graph_mode() else "eager"},
            "roofline": roof}
     if world == 1 and not a.no_cpu_baseline:

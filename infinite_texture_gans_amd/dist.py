@@ -20,6 +20,16 @@ world-size times larger:
 import torch
 
 
+def _active(sync):
+    """Collectives are issued when there is more than one rank - or, for rehearsing the RCCL path on a single GPU,
+    when ITG_FORCE_COLLECTIVES=1 (a one-rank all-reduce leaves the data unchanged)."""
+    return sync.world > 1 or _FORCE
+
+
+import os as _os
+_FORCE = _os.environ.get("ITG_FORCE_COLLECTIVES", "0") == "1"
+
+
 class SyncGroup:
     """Process group over which per-channel statistics are summed."""
 
@@ -30,7 +40,7 @@ class SyncGroup:
 
     def all_reduce(self, t):
         """In-place SUM over ranks (fp64 statistics buffers)."""
-        if self.world > 1:
+        if self.world > 1 or _FORCE:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
@@ -41,7 +51,7 @@ class SyncGroup:
 
 def average_flat_gradient(flat_grad, sync):
     """ONE all-reduce of a model's flat gradient buffer, then the 1/world factor of the global mean."""
-    if sync is not None and sync.world > 1:
+    if sync is not None and _active(sync):
         sync.all_reduce(flat_grad)
         flat_grad.mul_(1.0 / sync.world)
     return flat_grad
@@ -55,7 +65,7 @@ def rank_seed(base_seed, rank, stream=0):
 def max_over_ranks(seconds, device, sync):
     """Wall time of the slowest rank (the bench contract's max-over-ranks timing)."""
     t = torch.tensor([seconds], device=device, dtype=torch.float64)
-    if sync is not None and sync.world > 1:
+    if sync is not None and _active(sync):
         sync.dist.all_reduce(t, op=sync.dist.ReduceOp.MAX, group=sync.group)
     return float(t)
 

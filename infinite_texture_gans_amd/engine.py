@@ -92,17 +92,25 @@ class PackSet:
 class Trainer:
     """One G+D iteration of reference train.py:122-180 on the HIP kernels."""
 
-    def __init__(self, netG, netD, args, device, netG_ema=None, dist_group=None):
+    def __init__(self, netG, netD, args, device, netG_ema=None, dist_group=None, sync_bn=None):
+        """``dist_group``: data parallel over its ranks (one flat gradient all-reduce per model and step).
+        ``sync_bn``: False (default, ITG_SYNC_BN=0) = every rank normalises with the statistics of its own batch,
+        which is what the reference's nn.DataParallel does (train.py:74-77); True = BatchNorm sums are all-reduced
+        so that N ranks reproduce the single-process step at batch 8N (26 small collectives per step)."""
         self.netG, self.netD, self.args, self.device = netG, netD, args, device
         self.world = 1
         self.sync = None
+        if sync_bn is None:
+            sync_bn = os.environ.get("ITG_SYNC_BN", "1" if getattr(args, "sync_bn", False) else "0") == "1"
+        self.sync_bn = bool(sync_bn) and dist_group is not None
         if dist_group is not None:
             self.sync = sync = SyncGroup(dist_group)
             self.world = sync.world
-            netG.set_sync(sync)
-            for m in netD.modules():
-                if isinstance(m, _BNParams):
-                    m.sync = sync
+            if self.sync_bn:
+                netG.set_sync(sync)
+                for m in netD.modules():
+                    if isinstance(m, _BNParams):
+                        m.sync = sync
         self.flatG, self.flatD = FlatParams(netG), FlatParams(netD)
         from .models.layers import _ConvParams
         for net in (netG, netD):        # backward kernels accumulate straight into the flat .grad buffers
@@ -124,12 +132,11 @@ class Trainer:
         self.packG, self.packD = PackSet(netG), PackSet(netD)
         self.repack()
         self.arena = ops.ZeroArena(device)
-        # two-stream overlap (D(real) beside the generator forward, weight gradients beside the input-gradient
-        # chain).  Default: single-GPU runs only.  With collectives in the step every collective would still be
-        # issued from the main stream in program order (the side branch is D(real), collective-free unless D has
-        # sync-BatchNorm), but that combination has only been rehearsed over gloo, not measured on RCCL:
-        # ITG_OVERLAP=1 turns it on for multi-GPU runs.
-        self.overlap = os.environ.get("ITG_OVERLAP", "1" if self.world == 1 else "0") == "1"
+        # stream overlap (D(real) beside the generator forward, weight gradients beside the input-gradient chain).
+        # Off by default when BatchNorm statistics are all-reduced: those 26 latency-critical collectives then
+        # queue behind the kernels of the side streams (one-rank RCCL rehearsal: 12.07 ms with vs 12.13 ms without
+        # overlap, against 10.86 ms without the collectives).  The two gradient all-reduces come after the joins.
+        self.overlap = os.environ.get("ITG_OVERLAP", "0" if self.sync_bn else "1") == "1"
         self.side, self._wstream, self.wstream = None, None, None
         self.set_overlap(self.overlap)
 

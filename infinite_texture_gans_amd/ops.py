@@ -371,7 +371,7 @@ def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=AC
 
 
 # ------------------------------------------------------------------------------- batch norm (+act, +upsample)
-from .dist import SyncGroup  # noqa: E402,F401  (sync-BN statistics exchange)
+from .dist import SyncGroup, _active  # noqa: E402,F401  (sync-BN statistics exchange)
 
 
 # Side stream for weight-gradient kernels (set by engine.Trainer for the duration of a step).  The power
@@ -452,7 +452,7 @@ class _BNAct(torch.autograd.Function):
         if training:
             sums = _zeros_f64(2 * ld, dev)
             _lib.call("itg_bn_stats", C.byref(dx_), _ptr(sums), st)
-            if sync is not None and sync.world > 1:
+            if sync is not None and _active(sync):
                 sync.all_reduce(sums)
                 count = sync.global_count(count)
         stat = torch.empty(4 * ld, device=dev, dtype=torch.float32)
@@ -482,7 +482,7 @@ class _BNAct(torch.autograd.Function):
         sums = _zeros_f64(2 * ld, x.device)
         _lib.call("itg_bn_bwd_reduce", C.byref(dx_), C.byref(ddy_), _ptr(ab), _ptr(mean_rstd), act, float(slope),
                   _ptr(sums), st)
-        if sync is not None and sync.world > 1:
+        if sync is not None and _active(sync):
             # dgamma/dbeta are the LOCAL sums (the gradient all-reduce adds the ranks up later);
             # the dx formula needs the GLOBAL ones.
             local = sums.clone()
@@ -526,7 +526,7 @@ def bn_stats_only(x, rm, rv, nbt, training=True, eps=1e-5, momentum=0.1, sync=No
     if training:
         sums = torch.zeros(2 * ld, device=t.device, dtype=torch.float64)
         _lib.call("itg_bn_stats", C.byref(dx_), _ptr(sums), st)
-        if sync is not None and sync.world > 1:
+        if sync is not None and _active(sync):
             sync.all_reduce(sums)
             count = sync.global_count(count)
     stat = torch.empty(4 * ld, device=t.device, dtype=torch.float32)
@@ -573,7 +573,7 @@ class _SSM(torch.autograd.Function):
         ab = stat[2 * ld:]
         sums = torch.zeros(2 * ld, device=x.device, dtype=torch.float64)
         _lib.call("itg_bn_bwd_reduce", C.byref(a), C.byref(h), _ptr(ab), _ptr(mean_rstd), ACT_NONE, 0.0, _ptr(sums), st)
-        if sync is not None and sync.world > 1:
+        if sync is not None and _active(sync):
             sync.all_reduce(sums)
         gx = torch.empty_like(x)
         dgx = _desc(gx, c)

@@ -68,6 +68,8 @@ _FLAGS = [
     ("fname", str, "models_cp", "folder for checkpoints"),
     ("bf16", "flag", False, "build-side extra: run the convolutions on bf16-operand MFMA (fp32 tensors and "
                             "accumulation; BASELINE config 3)"),
+    ("sync_bn", "flag", False, "build-side extra: all-reduce the BatchNorm statistics over the data-parallel ranks "
+                               "(default: per-rank statistics, as the reference's nn.DataParallel)"),
     ("shard_patch_rows", "flag", False, "build-side extra: multi-GPU runs shard the patch grid of ONE batch by patch "
                                         "rows (halo exchange) instead of replicating the batch per GPU"),
 ]
