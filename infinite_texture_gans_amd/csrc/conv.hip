@@ -664,8 +664,6 @@ struct NtPlan { int bco, bpix, tbk, ksplit, kchunks; int64_t ws_floats; };
 NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = ITG_PREC_F32) {
   NtPlan pl;
   const int64_t M = M_total / ncls;      // per-class pixel count (classes are launched as one grid)
-  static const int force_bk = env_int("ITG_NT_BK", 0);   // tuning override: 16 | 32
-  (void)force_bk;
   pl.tbk = prec == ITG_PREC_BF16 ? 32 : 16;
   if (co_rows <= 16) pl.bco = 16;
   else if (co_rows <= 32) pl.bco = 32;
