@@ -175,10 +175,19 @@ class Trainer:
     def step(self, real_x, z, maps=None):
         """real_x: (B,3,crop,crop) on the device; z/maps: latents (see utils.sample_latents_train).
         Returns (d_loss_real, d_loss_fake, g_loss) as 0-dim device tensors (no host sync)."""
-        netG, netD = self.netG, self.netD
         self.arena.reset()                                      # BatchNorm statistics scratch of this iteration
         ops.ARENA = self.arena
         ops.WGRAD_STREAM = self.wstream
+        try:
+            return self._step(real_x, z, maps)
+        finally:                                                # never leave the process-wide hooks set behind an exception
+            ops.ARENA = None
+            ops.WGRAD_STREAM = None
+            if self.wstream is not None and not torch.cuda.is_current_stream_capturing():
+                ops.WGRAD_KEEPALIVE.clear()
+
+    def _step(self, real_x, z, maps):
+        netG, netD = self.netG, self.netD
         if self.wstream is not None:
             for ws in self.wstream:
                 ws.wait_stream(torch.cuda.current_stream())
@@ -226,8 +235,6 @@ class Trainer:
         self.packG.repack()
         if self.netG_ema is not None:
             self._ema_buffers()
-        ops.ARENA = None
-        ops.WGRAD_STREAM = None
         return d_real.detach(), d_fake.detach(), g_loss.detach()
 
     def _join(self):
@@ -298,6 +305,7 @@ class BandTrainer(Trainer):
             raise ValueError("row sharding is defined for padding_mode='local'")
         if netG.attention or netG.type_norm != 'BN':
             raise NotImplementedError("band training covers the BN generator without attention")
+        self.set_overlap(False)                          # the band step is a plain single-stream schedule
         self.comm, self.sync, self.world = comm, comm, comm.world
         self.total_rows = netG.num_patches_h
         self.band = comm.band(self.total_rows)
@@ -325,11 +333,10 @@ class BandTrainer(Trainer):
         full = ops.gather_rows(band, self.comm)
         return full[self._mine(full.shape[0])].contiguous()
 
-    def step(self, real_x, z, maps=None):
-        """real_x: this rank's shard of real crops; z: the full merged latent (same on all ranks)."""
+    def _step(self, real_x, z, maps=None):
+        """real_x: this rank's shard of real crops; z: the full merged latent (same on all ranks).
+        (Called through Trainer.step, which owns the per-step arena / hooks.)"""
         netD = self.netD
-        self.arena.reset()
-        ops.ARENA = self.arena
         self.flatD.zero_grad()
         d_real = self._d_loss(netD(real_x), True)
         d_real.backward()
@@ -353,5 +360,4 @@ class BandTrainer(Trainer):
         self.packG.repack()
         if self.netG_ema is not None:
             self._ema_buffers()
-        ops.ARENA = None
         return d_real.detach(), d_fake.detach(), g_loss.detach()
