@@ -89,7 +89,7 @@ __device__ __forceinline__ uint2 pack_bf16x4(f32x4 v) {
 // Workgroups per CU the register budget is pinned to: 3 (168 VGPRs) for the wide tiles, 5 (96) for the
 // medium fp32 tiles, 4 (128) for the medium bf16 tiles (their stage holds twice the prefetch registers).
 constexpr int nt_min_blocks(int bco, int bpix, int wco, int wpix, int tbk) {
-  return ((wco / 16) * (wpix / 16) <= 8 && (bco + bpix) <= 192) ? (tbk == 32 ? 4 : 5) : 3;
+  return ((wco / 16) * (wpix / 16) <= 8 && (bco + bpix) <= 192) ? 4 : 3;
 }
 
 template <int BCO, int BPIX, int WCO, int WPIX, int TBK, int DEPTH, bool TAB>
@@ -722,7 +722,7 @@ int launch_nt(const ConvP& p, int tbk, hipStream_t s) {
   // two K stages in flight except for the medium fp32 tiles, whose 96-register budget has no room for
   // the second prefetch set (it would spill into scratch inside the K loop)
   constexpr int D32 = (nt_min_blocks(BCO, BPIX, WCO, WPIX, 32) == 3 && BCO >= 64) ? 1 : 2;   // wide bf16 stages: 16 prefetch registers per set
-  constexpr int D16 = (nt_min_blocks(BCO, BPIX, WCO, WPIX, 16) == 5 && BCO > 32) ? 1 : 2;
+  constexpr int D16 = 2;
   snprintf(g_last_launch, sizeof(g_last_launch), "conv_nt_kernel<%d, %d, %d, %d, %d, %d, %s>", BCO, BPIX, WCO, WPIX, tbk,
            tbk == 32 ? D32 : D16, q.use_tab ? "true" : "false");
   if (tbk == 32) {
