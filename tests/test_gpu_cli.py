@@ -35,3 +35,23 @@ def test_train_then_sample_cli(tmp_path):
             "--output_resolution_width", "170", "--output_name", "gen.png"])
     img = Image.open(out / "gen.png")
     assert img.size == (170, 100)
+
+
+def test_train_cli_bf16_flag(tmp_path):
+    """--bf16 (BASELINE config 3's MFMA path) through the command line; the process-wide precision is restored."""
+    from PIL import Image
+    from infinite_texture_gans_amd import ops, train as T
+    rng = np.random.RandomState(1)
+    Image.fromarray(rng.randint(0, 255, (96, 96, 3), dtype=np.uint8)).save(tmp_path / "tex.jpg")
+    out = tmp_path / "cp"
+    prev = ops.MFMA_PRECISION
+    try:
+        T.main(["--data_path", str(tmp_path / "tex.jpg"), "--random_crop", "48", "--padding_mode", "local",
+                "--type_norm", "BN", "--G_ch", "4", "--D_ch", "4", "--z_dim", "8", "--n_layers_G", "5", "--attention",
+                "--n_layers_D", "3", "--batch_size", "4", "--num_images", "2", "--sampling", "8", "--epochs", "1",
+                "--saving_rate", "1", "--spec_norm_D", "--seed", "3", "--bf16", "--fname", str(out)])
+        assert ops.MFMA_PRECISION == ops.PREC_BF16
+    finally:
+        ops.MFMA_PRECISION = prev
+    ck = torch.load(out / "1_1.pth", map_location="cpu", weights_only=False)
+    assert all(np.isfinite(ck["Gloss"])) and all(np.isfinite(ck["Dloss"]))
