@@ -4,13 +4,14 @@ tested without GPUs).
 
 The reference's multi-GPU path is single-process nn.DataParallel with per-replica BatchNorm
 statistics (reference train.py:74-77).  This build shards the work units (images, and with them
-their 3x3 patch grids) across ranks and keeps the SINGLE-PROCESS semantics of a batch that is
-world-size times larger:
+their 3x3 patch grids) across ranks:
 
-  * BatchNorm: every rank reduces its pixels to per-channel fp64 (sum, sumsq) pairs; ONE all-reduce of
-    2*C doubles per norm layer makes the statistics global.  Backward likewise all-reduces
-    (sum dy, sum dy*xhat).  The affine-parameter gradients stay local sums: they are added up across
-    ranks by the gradient all-reduce like every other parameter gradient.
+  * BatchNorm: per-rank statistics by default (the reference's replica semantics).  With sync-BN
+    (engine.Trainer(sync_bn=True) / --sync_bn) every rank reduces its pixels to per-channel fp64
+    (sum, sumsq) pairs and ONE all-reduce of 2*C doubles per norm layer makes the statistics global -
+    the SINGLE-PROCESS semantics of a batch that is world-size times larger.  Backward likewise
+    all-reduces (sum dy, sum dy*xhat); the affine-parameter gradients stay local sums: they are added up
+    across ranks by the gradient all-reduce like every other parameter gradient.
   * gradients: each model's parameters live in one flat fp32 buffer, so the exchange is ONE
     all-reduce per model per step (G 21 MB, D 11 MB), followed by 1/world scaling because each rank's
     loss is a mean over its own shard.

@@ -5,8 +5,11 @@ MI355X-first choices (vs the reference's per-tensor torch.optim.Adam and nn.Data
   * every model's parameters are views into ONE contiguous fp32 buffer, their gradients views
     into another: zero_grad is one memset, Adam(+EMA) one kernel launch, and the data-parallel
     gradient exchange one RCCL all-reduce over xGMI per model (G 21 MB, D 11 MB);
-  * one process per GPU; BatchNorm statistics are summed over ranks (fp64 sum/sumsq pairs), so
-    an N-GPU step has the single-process semantics of a batch N times larger.
+  * one process per GPU; BatchNorm uses per-rank statistics like the reference's DataParallel replicas, or
+    (sync_bn) statistics summed over ranks as fp64 sum/sumsq pairs, which gives an N-GPU step the
+    single-process semantics of a batch N times larger;
+  * the step is scheduled over four HIP streams on one GPU (D(real) beside the generator forward, weight
+    gradients on two streams beside the input-gradient chain) and can be captured into a hipGraph.
 """
 import os
 
