@@ -168,6 +168,13 @@ int itg_bn_finalize(const double* sums, double count, double count_scale, const 
                     const float* beta, float eps, float momentum, float* running_mean,
                     float* running_var, int64_t* num_batches_tracked, float* mean_rstd, float* ab,
                     int c, int ld, int training, void* stream);
+/* itg_bn_finalize + itg_bn_apply of a training-mode BatchNorm in one launch (the statistics sums are
+ * complete, e.g. after the cross-rank all-reduce): writes mean_rstd / ab for the backward, updates the
+ * running statistics and num_batches_tracked exactly as itg_bn_finalize does.                       */
+int itg_bn_finalize_apply(const itg_tensor* x, const double* sums, double count, double count_scale,
+                          const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                          float* running_var, int64_t* num_batches_tracked, float* mean_rstd, float* ab,
+                          const itg_tensor* y, int act, float slope, void* stream);
 int itg_bn_apply(const itg_tensor* x, const float* ab, const itg_tensor* y, int act, float slope,
                  void* stream);
 int itg_bn_bwd_reduce(const itg_tensor* x, const itg_tensor* dy, const float* ab, const float* mean_rstd,

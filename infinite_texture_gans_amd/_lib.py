@@ -59,6 +59,7 @@ SIGNATURES = {
     "itg_grid_to_nchw": (_i, [_TP, _P, _i, _P]),
     "itg_bn_stats": (_i, [_TP, _P, _P]),
     "itg_bn_finalize": (_i, [_P, _d, _d, _P, _P, _f, _f, _P, _P, _P, _P, _P, _i, _i, _i, _P]),
+    "itg_bn_finalize_apply": (_i, [_TP, _P, _d, _d, _P, _P, _f, _f, _P, _P, _P, _P, _P, _TP, _i, _f, _P]),
     "itg_bn_apply": (_i, [_TP, _P, _TP, _i, _f, _P]),
     "itg_bn_bwd_reduce": (_i, [_TP, _TP, _P, _P, _i, _f, _P, _P]),
     "itg_bn_bwd_apply": (_i, [_TP, _TP, _P, _P, _P, _P, _d, _i, _f, _TP, _P, _P, _i, _P]),

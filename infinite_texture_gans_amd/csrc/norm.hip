@@ -118,6 +118,72 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   }
 }
 
+// bn_finalize + bn_apply in one launch (training): every thread derives the affine coefficients of its 4
+// channels from the fp64 sums; the first q4 threads also publish mean / rstd / (a, b) for the backward and
+// update the running statistics.
+template <bool UPS>
+__global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                const double* __restrict__ sums, double count,
+                                                                double count_scale, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps, float momentum,
+                                                                float* running_mean, float* running_var, int64_t* nbt,
+                                                                float* __restrict__ mean_rstd, float* __restrict__ ab,
+                                                                int64_t npix, int c, int ld, int ph, int pw, int act,
+                                                                float slope) {
+  const int q4 = ld >> 2;
+  const int64_t T = (int64_t)gridDim.x * 256;
+  const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int cg = (int)(gt % q4);
+  const int64_t step = T / q4;
+  f32x4 a, b, mean4, rstd4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = cg * 4 + e;
+    float mean = 0.f, rstd = 0.f, av = 0.f, bv = 0.f;
+    if (i < c) {
+      double m = sums[i] / count;
+      double var = sums[ld + i] / count - m * m;
+      if (var < 0) var = 0;
+      mean = (float)m;
+      rstd = (float)(1.0 / sqrt(var + (double)eps));
+      if (gt < q4 && running_mean) {
+        double n = count * count_scale;
+        double unb = n > 1 ? var * n / (n - 1) : var;
+        running_mean[i] = (1.f - momentum) * running_mean[i] + momentum * mean;
+        running_var[i] = (1.f - momentum) * running_var[i] + momentum * (float)unb;
+      }
+      float g = gamma ? gamma[i] : 1.f;
+      av = g * rstd;
+      bv = (beta ? beta[i] : 0.f) - mean * av;
+    }
+    a[e] = av; b[e] = bv; mean4[e] = mean; rstd4[e] = rstd;
+  }
+  if (gt < q4) {
+    *reinterpret_cast<f32x4*>(mean_rstd + cg * 4) = mean4;
+    *reinterpret_cast<f32x4*>(mean_rstd + ld + cg * 4) = rstd4;
+    *reinterpret_cast<f32x4*>(ab + cg * 4) = a;
+    *reinterpret_cast<f32x4*>(ab + ld + cg * 4) = b;
+    if (gt == 0 && nbt) *nbt += 1;
+  }
+  for (int64_t pix = gt / q4; pix < npix; pix += step) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * ld + cg * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_apply(fmaf(v[e], a[e], b[e]), act, slope);
+    if (!UPS) {
+      *reinterpret_cast<f32x4*>(y + pix * ld + cg * 4) = v;
+    } else {
+      int64_t blk = pix / (ph * pw);
+      int r = (int)(pix - blk * ph * pw);
+      int yy = r / pw, xx = r - yy * pw;
+      float* o = y + ((blk * 2 * ph + 2 * yy) * (2 * pw) + 2 * xx) * (int64_t)ld + cg * 4;
+      *reinterpret_cast<f32x4*>(o) = v;
+      *reinterpret_cast<f32x4*>(o + ld) = v;
+      *reinterpret_cast<f32x4*>(o + (int64_t)2 * pw * ld) = v;
+      *reinterpret_cast<f32x4*>(o + (int64_t)2 * pw * ld + ld) = v;
+    }
+  }
+}
+
 template <bool UPS>
 __device__ __forceinline__ f32x4 load_dy(const float* __restrict__ dy, int64_t pix, int ld, int cg, int ph, int pw) {
   if (!UPS) return *reinterpret_cast<const f32x4*>(dy + pix * ld + cg * 4);
@@ -316,6 +382,30 @@ static int ups_mode(const itg_tensor* small, const itg_tensor* big, bool* ups) {
   if (small->ph == big->ph && small->pw == big->pw) { *ups = false; return ITG_OK; }
   if (2 * small->ph == big->ph && 2 * small->pw == big->pw) { *ups = true; return ITG_OK; }
   return ITG_ERR_ARG;
+}
+
+int itg_bn_finalize_apply(const itg_tensor* x, const double* sums, double count, double count_scale, const float* gamma,
+                          const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                          int64_t* nbt, float* mean_rstd, float* ab, const itg_tensor* y, int act, float slope,
+                          void* stream) {
+  int rc;
+  if ((rc = check_tensor(x)) || (rc = check_tensor(y))) return rc;
+  bool ups;
+  if (!sums || !mean_rstd || !ab || count <= 0 || (rc = ups_mode(x, y, &ups))) return rc ? rc : ITG_ERR_ARG;
+  int64_t npix = grid_pixels(x);
+  int q4 = x->ld >> 2;
+  int blocks = sweep_blocks(npix * q4, q4, 4, 4096);
+  if ((int64_t)blocks * 256 < q4) return ITG_ERR_ARG;
+  if (ups)
+    hipLaunchKernelGGL(bn_finalize_apply_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr,
+                       (float*)y->ptr, sums, count, count_scale, gamma, beta, eps, momentum, running_mean, running_var, nbt,
+                       mean_rstd, ab, npix, x->c, x->ld, x->ph, x->pw, act, slope);
+  else
+    hipLaunchKernelGGL(bn_finalize_apply_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr,
+                       (float*)y->ptr, sums, count, count_scale, gamma, beta, eps, momentum, running_mean, running_var, nbt,
+                       mean_rstd, ab, npix, x->c, x->ld, x->ph, x->pw, act, slope);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
 }
 
 int itg_bn_apply(const itg_tensor* x, const float* ab, const itg_tensor* y, int act, float slope, void* stream) {

@@ -457,12 +457,17 @@ class _BNAct(torch.autograd.Function):
                 count = sync.global_count(count)
         stat = torch.empty(4 * ld, device=dev, dtype=torch.float32)
         mean_rstd, ab = stat[:2 * ld], stat[2 * ld:]
-        _lib.call("itg_bn_finalize", _ptr(sums), count, 4.0 if ups else 1.0, _ptr(gamma), _ptr(beta), float(eps),
-                  float(momentum), _ptr(rm), _ptr(rv), _ptr(nbt), _ptr(mean_rstd), _ptr(ab), c, ld, int(training), st)
         s = 2 if ups else 1
         y = torch.empty((n, gh, gw, ph * s, pw * s, ld), device=dev, dtype=torch.float32)
         dy_ = _desc(y, c)
-        _lib.call("itg_bn_apply", C.byref(dx_), _ptr(ab), C.byref(dy_), act, float(slope), st)
+        if training:      # coefficients, running statistics and the normalised output in one launch
+            _lib.call("itg_bn_finalize_apply", C.byref(dx_), _ptr(sums), count, 4.0 if ups else 1.0, _ptr(gamma), _ptr(beta),
+                      float(eps), float(momentum), _ptr(rm), _ptr(rv), _ptr(nbt), _ptr(mean_rstd), _ptr(ab), C.byref(dy_),
+                      act, float(slope), st)
+        else:
+            _lib.call("itg_bn_finalize", _ptr(sums), count, 4.0 if ups else 1.0, _ptr(gamma), _ptr(beta), float(eps),
+                      float(momentum), _ptr(rm), _ptr(rv), _ptr(nbt), _ptr(mean_rstd), _ptr(ab), c, ld, int(training), st)
+            _lib.call("itg_bn_apply", C.byref(dx_), _ptr(ab), C.byref(dy_), act, float(slope), st)
         ctx.meta = (c, act, slope, count, sync, training, gamma is not None)
         ctx.sinks = sinks
         ctx.save_for_backward(x, stat)
