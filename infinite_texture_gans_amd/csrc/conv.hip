@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
   constexpr int LDT = 20;                    // LDS row pitch 20 floats (16-B aligned rows); pitch 24 is conflict-free but costs a workgroup of occupancy: measured slower
   constexpr int KG = TBK / 4;                // float4 groups per tile row
   constexpr int RPP = 256 / KG;              // tile rows covered per load pass
-  constexpr int PL = BPIX / RPP;
+  constexpr int PL = (BPIX + RPP - 1) / RPP;         // the last pass may cover rows past the tile (96-pixel tiles)
   constexpr int WL = (BCO + RPP - 1) / RPP;
   __shared__ __attribute__((aligned(16))) float smem[2 * (BCO + BPIX) * LDT];
   float* Ws = smem;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
 #pragma unroll
   for (int i = 0; i < PL; ++i) {
     int m = m0 + lrow + i * RPP;
-    pv[i] = m < cM;
+    pv[i] = m < cM && lrow + i * RPP < BPIX;
     int n, t, u;
     decode_m(pv[i] ? m : 0, cMT, cMU, n, t, u);
     pn[i] = n;
@@ -175,14 +175,15 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
   if constexpr (use_tab) {
     for (int tt = kg; tt <= p.ntaps; tt += KG) {
 #pragma unroll
-      for (int i = 0; i < PL; ++i) taptab[(lrow + i * RPP) * TS + tt] = tap_offset(i, tt);
+      for (int i = 0; i < PL; ++i)
+        if (lrow + i * RPP < BPIX) taptab[(lrow + i * RPP) * TS + tt] = tap_offset(i, tt);
     }
     __syncthreads();
   }
   auto locate = [&]() {
     if constexpr (use_tab) {
 #pragma unroll
-      for (int i = 0; i < PL; ++i) poff[i] = taptab[(lrow + i * RPP) * TS + min(tap, p.ntaps)];
+      for (int i = 0; i < PL; ++i) poff[i] = lrow + i * RPP < BPIX ? taptab[(lrow + i * RPP) * TS + min(tap, p.ntaps)] : p.in_bytes;
     } else {
 #pragma unroll
       for (int i = 0; i < PL; ++i) poff[i] = tap_offset(i, tap);
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
   auto store_tiles = [&](int buf, const f32x4 (&rp_)[PL], const f32x4 (&rw_v)[WL]) {
 #pragma unroll
     for (int i = 0; i < PL; ++i) {
+      if (BPIX % RPP != 0 && lrow + i * RPP >= BPIX) continue;
       float* dst = Ps + (buf * BPIX + lrow + i * RPP) * LDT;
       if constexpr (BF) *reinterpret_cast<uint2*>(dst + kg * 2) = pack_bf16x4(rp_[i]);
       else *reinterpret_cast<f32x4*>(dst + kg * 4) = rp_[i];
@@ -684,13 +686,16 @@ NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = 
   static const double split_cost = (double)env_int("ITG_SPLIT_COST", 100);
   pl.bpix = 128; pl.ksplit = 1;
   double best_eff = 0.0;
-  const int cands_big[3] = {256, 128, 64};
+  const int cands_big[4] = {256, 128, 96, 64};
   const int cand_ks[13] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16};
-  for (int ci = 0; ci < 3; ++ci) {
+  static const int allow96 = env_int("ITG_NT_96", 1);
+  static const double pen96 = env_int("ITG_PEN96", 104) / 100.0;
+  for (int ci = 0; ci < 4; ++ci) {
     int bp = cands_big[ci];
     if (pl.bco >= 112 && bp == 256) continue;              // 128x256 / 112x256 are not instantiated
+    if (bp == 96 && (pl.bco != 128 || !allow96 || pl.tbk != 16)) continue;   // 128x96 (fp32): 3 workgroups per CU exactly on M = 73728
     int64_t blocks = ((M + bp - 1) / bp) * nco * ncls;
-    double pen = bp >= 256 ? 1.0 : (bp == 128 ? (pl.bco >= 112 ? 1.0 : 1.04) : (pl.bco >= 112 ? 1.08 : 1.12));
+    double pen = bp >= 256 ? 1.0 : (bp == 128 ? (pl.bco >= 112 ? 1.0 : 1.04) : bp == 96 ? pen96 : (pl.bco >= 112 ? 1.08 : 1.12));
     for (int i = 0; i < 13; ++i) {
       int ks = cand_ks[i];
       if (ks > 1 && nk * pl.tbk / ks < 256) break;
@@ -775,7 +780,8 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
   } else if (pl.bco == 112) {
     rc = pl.bpix == 128 ? launch_nt<112, 128, 112, 32>(p, k, s) : launch_nt<112, 64, 112, 16>(p, k, s);
   } else {
-    rc = pl.bpix == 128 ? launch_nt<128, 128, 64, 64>(p, k, s) : launch_nt<128, 64, 64, 32>(p, k, s);
+    rc = pl.bpix == 128 ? launch_nt<128, 128, 64, 64>(p, k, s)
+         : pl.bpix == 96 ? launch_nt<128, 96, 64, 48>(p, k, s) : launch_nt<128, 64, 64, 32>(p, k, s);
   }
   if (rc || pl.ksplit == 1) return rc;
   const int ncls = p.ncls > 1 ? p.ncls : 1;
