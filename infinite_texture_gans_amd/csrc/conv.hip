@@ -1405,7 +1405,7 @@ TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec = ITG_PREC_F32) {
   else { t.bco = 128; t.bcol = 128; }
   int tiles = ((t.Kpad + t.bcol - 1) / t.bcol) * ((t.co_rows + t.bco - 1) / t.bco);
   t.nchunks = (int)((M + kp - 1) / kp);
-  static const int want_blocks = env_int("ITG_TN_BLOCKS", 1024);
+  static const int want_blocks = env_int("ITG_TN_BLOCKS", 768);
   int want = (want_blocks + tiles - 1) / tiles;      // ~4 workgroups per CU overall
   int max_splits = (t.nchunks + 7) / 8;             // at least 8 chunks per split
   int splits = want < max_splits ? want : max_splits;
