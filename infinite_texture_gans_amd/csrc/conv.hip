@@ -638,7 +638,8 @@ int try_conv_tile(const ConvP& p, hipStream_t s, int* rc) {
   }
   // persistent grid = what is resident at once (register budget: 4 workgroups per CU with 6 loads, 3 with 11)
   int per_cu = (int)((160 * 1024) / lds);
-  const int reg_cu = nld <= 6 ? 4 : 3;
+  static const int tile_cu = env_int("ITG_TILE_CU", 0);       // tuning override of the persistent workgroups per CU
+  const int reg_cu = tile_cu > 0 ? tile_cu : (nld <= 6 ? 4 : 3);
   if (per_cu > reg_cu) per_cu = reg_cu;
   if (per_cu < 1) per_cu = 1;
   const int64_t want = 256 * (int64_t)per_cu;
@@ -688,6 +689,7 @@ NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = 
   double best_eff = 0.0;
   const int cands_big[4] = {256, 128, 96, 64};
   const int cand_ks[13] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16};
+  static const double fill_min = env_int("ITG_FILL_MIN", 200) / 100.0;
   static const int allow96 = env_int("ITG_NT_96", 1);
   static const double pen96 = env_int("ITG_PEN96", 104) / 100.0;
   for (int ci = 0; ci < 4; ++ci) {
@@ -701,7 +703,7 @@ NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = 
       if (ks > 1 && nk * pl.tbk / ks < 256) break;
       double b = (double)blocks * ks / 256.0;
       double eff = b / (double)((int64_t)(b + 0.999999));
-      if (b < 2.0) eff *= b / 2.0;
+      if (b < fill_min) eff *= b / fill_min;
       if (ks > 1) eff /= 1.0 + ks * split_cost / (double)Kpad;
       eff /= pen;
       if (eff > best_eff * 1.02) { best_eff = eff; pl.bpix = bp; pl.ksplit = ks; }
@@ -1292,8 +1294,9 @@ TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_
   if (red > fl) fl = red;
   t.lds = fl * sizeof(float);
   if (t.lds > 64 * 1024 || t.ntiles > 0x7fffffff) return t;
+  static const int wtile_cu = env_int("ITG_WTILE_CU", 1);
   int per_cu = (int)((160 * 1024) / t.lds);
-  if (per_cu > 2) per_cu = 2;
+  if (per_cu > wtile_cu) per_cu = wtile_cu;
   int64_t want = 256 * (int64_t)(per_cu < 1 ? 1 : per_cu);
   t.blocks = (int)(t.ntiles < want ? t.ntiles : want);
   t.ok = 1;
