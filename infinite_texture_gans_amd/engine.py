@@ -175,6 +175,12 @@ class Trainer:
     def sample_fake(self, z, maps):
         return self.netG.forward_grid(z, maps, "1st_row_1st_col")
 
+    def _d_logits(self, fake):
+        """D on the generator's output: a patch grid (consumed in place, no merge copy) or whole NCHW images."""
+        if isinstance(fake, ops.GT):
+            return ops.to_nchw(self.netD.forward_grid(fake))
+        return self.netD(fake)
+
     def step(self, real_x, z, maps=None):
         """real_x: (B,3,crop,crop) on the device; z/maps: latents (see utils.sample_latents_train).
         Returns (d_loss_real, d_loss_fake, g_loss) as 0-dim device tensors (no host sync)."""
@@ -214,8 +220,7 @@ class Trainer:
             d_real = self._d_loss(netD(real_x), True)
             d_real.backward()
             fake = self.sample_fake(z, maps)                   # GT patches, graph kept for the G step
-        fake_logit = ops.to_nchw(netD.forward_grid(fake.detach()))
-        d_fake = self._d_loss(fake_logit, False)
+        d_fake = self._d_loss(self._d_logits(fake.detach()), False)
         d_fake.backward()
         self._join()
         self._allreduce(self.flatD)
@@ -227,7 +232,7 @@ class Trainer:
         for p in self.flatD.params:
             p.requires_grad_(False)
         try:
-            g_loss = self._g_loss(ops.to_nchw(netD.forward_grid(fake)))
+            g_loss = self._g_loss(self._d_logits(fake))
             g_loss.backward()
         finally:
             for p in self.flatD.params:
@@ -308,8 +313,11 @@ class BandTrainer(Trainer):
             raise ValueError("row sharding is defined for padding_mode='local'")
         if netG.attention or netG.type_norm != 'BN':
             raise NotImplementedError("band training covers the BN generator without attention")
-        self.set_overlap(False)                          # the band step is a plain single-stream schedule
+        # the step itself is Trainer's (real_x: this rank's shard of real crops; z: the FULL merged latent); with more
+        # than one rank the generator's forward/backward carries halo exchanges and band-wide BatchNorm sums, which
+        # must not queue behind side-stream kernels: stream overlap only for a single rank
         self.comm, self.sync, self.world = comm, comm, comm.world
+        self.set_overlap(os.environ.get("ITG_OVERLAP", "1" if comm.world == 1 else "0") == "1")
         self.total_rows = netG.num_patches_h
         self.band = comm.band(self.total_rows)
         netG.set_sync(comm.band_sync(self.total_rows))
@@ -336,31 +344,3 @@ class BandTrainer(Trainer):
         full = ops.gather_rows(band, self.comm)
         return full[self._mine(full.shape[0])].contiguous()
 
-    def _step(self, real_x, z, maps=None):
-        """real_x: this rank's shard of real crops; z: the full merged latent (same on all ranks).
-        (Called through Trainer.step, which owns the per-step arena / hooks.)"""
-        netD = self.netD
-        self.flatD.zero_grad()
-        d_real = self._d_loss(netD(real_x), True)
-        d_real.backward()
-        fake = self.sample_fake(z)
-        d_fake = self._d_loss(netD(fake.detach()), False)
-        d_fake.backward()
-        self._allreduce(self.flatD)
-        self.optD.step()
-        self.packD.repack()
-        self.flatG.zero_grad()
-        for p in self.flatD.params:
-            p.requires_grad_(False)
-        try:
-            g_loss = self._g_loss(netD(fake))
-            g_loss.backward()
-        finally:
-            for p in self.flatD.params:
-                p.requires_grad_(True)
-        self._allreduce(self.flatG)
-        self.optG.step()
-        self.packG.repack()
-        if self.netG_ema is not None:
-            self._ema_buffers()
-        return d_real.detach(), d_fake.detach(), g_loss.detach()
