@@ -8,8 +8,10 @@
 One step = reference train.py:122-171 with disc_iters=1: D(real) fwd+bwd, G fwd of 8 images x 3x3
 patches of 128^2, D(fake) fwd+bwd, Adam(D), D(fake) fwd, bwd through D and G, Adam(G).  Inputs
 (real crops, latents) are synthetic and resident in HBM before the timed region.  With N > 1 every
-rank runs batch 8 (weak scaling): BatchNorm statistics are summed over ranks and each model's flat
-gradient is all-reduced once per step over RCCL, i.e. the single-process semantics at batch 8N.
+rank runs batch 8 (weak scaling) and each model's flat gradient is all-reduced once per step over RCCL;
+BatchNorm uses per-rank statistics like the reference's nn.DataParallel replicas (ITG_SYNC_BN=1 all-reduces
+the statistics instead, which gives the single-process semantics at batch 8N).  `python bench.py --gpus N`
+without a launcher starts the N ranks itself.
 
 Prints ONE JSON line on rank 0; see DESIGN.md section "Measurement" for the roofline numerator
 (855.5 GF of necessary conv MACs x2 per step of batch 8) and the cpu_baseline definition.
@@ -224,6 +226,26 @@ def cpu_leg():
                       "LocalPadder, torch-CPU fp32 (%.2f s/step)" % (nsteps, dt)}
 
 
+def relaunch(n):
+    """`python bench.py --gpus N` without a launcher: run the same command line under torch.distributed.run as N
+    fresh child processes (one rank per GPU over RCCL) and pass their output through.  This parent has not touched
+    the GPU (torch.cuda.device_count() does not initialise HIP on this image) and never execs."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print("bench.py: --gpus %d requested but only %d GPU(s) are visible" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,11 +257,11 @@ def main():
                          "n_layers_G=5 + attention, convolutions on bf16-operand MFMA.  config4: 4x4 patch "
                          "grid of ONE batch sharded by patch rows over <= 4 GPUs with halo exchange (strong scaling)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch(a.gpus))          # plain `python bench.py --gpus N`: start N ranks, relay rank 0's line
     world = int(os.environ.get("WORLD_SIZE", 1))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                     "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (a.gpus, a.gpus))
+        sys.exit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (a.gpus, world))
     rank, world, dt, args, losses, roof = gpu_leg(a)
     if rank != 0:
         return

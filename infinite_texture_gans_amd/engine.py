@@ -141,6 +141,9 @@ class Trainer:
         # overlap, against 10.86 ms without the collectives).  The two gradient all-reduces come after the joins.
         self.overlap = os.environ.get("ITG_OVERLAP", "0" if self.sync_bn else "1") == "1"
         self.side, self._wstream, self.wstream = None, None, None
+        # D(real)'s weight gradients may leave their branch stream for the weight-gradient streams (a fork of a fork)
+        self.nested_fork = os.environ.get("ITG_NESTED_FORK", "1") == "1"
+        self.nested_fork_in_capture = os.environ.get("ITG_NESTED_FORK_CAPTURE", "0") == "1"
         self.set_overlap(self.overlap)
 
     def set_overlap(self, on):
@@ -175,32 +178,52 @@ class Trainer:
     def sample_fake(self, z, maps):
         return self.netG.forward_grid(z, maps, "1st_row_1st_col")
 
+    record = None       # a list: every logit map the loss heads see is appended to it (parity tests)
+
     def _d_logits(self, fake):
         """D on the generator's output: a patch grid (consumed in place, no merge copy) or whole NCHW images."""
-        if isinstance(fake, ops.GT):
-            return ops.to_nchw(self.netD.forward_grid(fake))
-        return self.netD(fake)
+        logit = ops.to_nchw(self.netD.forward_grid(fake)) if isinstance(fake, ops.GT) else self.netD(fake)
+        if self.record is not None:
+            self.record.append(logit.detach())
+        return logit
+
+    def _d_real_logits(self, real_x):
+        logit = self.netD(real_x)
+        if self.record is not None:
+            self.record.append(logit.detach())
+        return logit
 
     def step(self, real_x, z, maps=None):
-        """real_x: (B,3,crop,crop) on the device; z/maps: latents (see utils.sample_latents_train).
-        Returns (d_loss_real, d_loss_fake, g_loss) as 0-dim device tensors (no host sync)."""
+        """real_x: (B,3,crop,crop) on the device; z/maps: latents (see utils.sample_latents_train), or LISTS of
+        them: ``--disc_iters`` = len(z) discriminator updates on the same real batch with fresh latents each, then
+        ONE generator update on the last fake batch (reference train.py:124-169).
+        Returns (d_loss_real, d_loss_fake, g_loss) of the last D iteration as 0-dim device tensors (no host sync);
+        ``self.d_losses`` holds the (real, fake) pair of every D iteration."""
         self.arena.reset()                                      # BatchNorm statistics scratch of this iteration
         ops.ARENA = self.arena
         ops.WGRAD_STREAM = self.wstream
         try:
-            return self._step(real_x, z, maps)
+            zs = list(z) if isinstance(z, (list, tuple)) else [z]
+            ms = list(maps) if isinstance(z, (list, tuple)) else [maps]
+            self.d_losses = []
+            for zi, mi in zip(zs, ms):
+                d_real, d_fake, fake = self.d_step(real_x, zi, mi)
+                self.d_losses.append((d_real, d_fake))
+            g_loss = self.g_step(fake)
+            return d_real, d_fake, g_loss
         finally:                                                # never leave the process-wide hooks set behind an exception
             ops.ARENA = None
             ops.WGRAD_STREAM = None
             if self.wstream is not None and not torch.cuda.is_current_stream_capturing():
                 ops.WGRAD_KEEPALIVE.clear()
 
-    def _step(self, real_x, z, maps):
+    def d_step(self, real_x, z, maps=None):
+        """One discriminator update (reference train.py:126-153): D(real) fwd+bwd, G forward (graph kept for the
+        generator update), D(fake.detach()) fwd+bwd, Adam(D).  -> (d_loss_real, d_loss_fake, fake)."""
         netG, netD = self.netG, self.netD
         if self.wstream is not None:
             for ws in self.wstream:
                 ws.wait_stream(torch.cuda.current_stream())
-        # ---------------- D step (train.py:124-154, disc_iters handled by the caller)
         self.flatD.zero_grad()
         if self.overlap:
             # D(real) forward+backward and the generator forward are independent and neither fills the chip
@@ -208,16 +231,16 @@ class Trainer:
             main = torch.cuda.current_stream()
             self.side.wait_stream(main)
             keep = ops.WGRAD_STREAM
-            if torch.cuda.is_current_stream_capturing() or os.environ.get("ITG_NESTED_FORK", "1") != "1":
-                ops.WGRAD_STREAM = None                        # hipStreamEndCapture crashes on a fork of a forked stream
+            if not self.nested_fork or (torch.cuda.is_current_stream_capturing() and not self.nested_fork_in_capture):
+                ops.WGRAD_STREAM = None                        # D(real)'s weight gradients stay on the branch stream
             with torch.cuda.stream(self.side):
-                d_real = self._d_loss(netD(real_x), True)
+                d_real = self._d_loss(self._d_real_logits(real_x), True)
                 d_real.backward()
             ops.WGRAD_STREAM = keep
             fake = self.sample_fake(z, maps)
             main.wait_stream(self.side)                        # D(fake) continues D's spectral-norm state and .grad
         else:
-            d_real = self._d_loss(netD(real_x), True)
+            d_real = self._d_loss(self._d_real_logits(real_x), True)
             d_real.backward()
             fake = self.sample_fake(z, maps)                   # GT patches, graph kept for the G step
         d_fake = self._d_loss(self._d_logits(fake.detach()), False)
@@ -226,8 +249,11 @@ class Trainer:
         self._allreduce(self.flatD)
         self.optD.step()
         self.packD.repack()
-        # ---------------- G step (train.py:161-169).  D's weight gradients of this pass are never
-        # read (zeroed at the next D step), so they are not computed.
+        return d_real.detach(), d_fake.detach(), fake
+
+    def g_step(self, fake):
+        """The generator update on ``fake`` (reference train.py:161-169, + EMA :176-180).  D's weight gradients of
+        this pass are never read (zeroed at the next D step), so they are not computed."""
         self.flatG.zero_grad()
         for p in self.flatD.params:
             p.requires_grad_(False)
@@ -243,7 +269,7 @@ class Trainer:
         self.packG.repack()
         if self.netG_ema is not None:
             self._ema_buffers()
-        return d_real.detach(), d_fake.detach(), g_loss.detach()
+        return g_loss.detach()
 
     def _join(self):
         """The weight-gradient stream has to drain before gradients are exchanged / consumed by Adam."""

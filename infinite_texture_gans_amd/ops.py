@@ -313,9 +313,9 @@ class _Conv(torch.autograd.Function):
             wsink, bsink = ctx.sinks if ctx.sinks is not None else (None, None)
             # Everything below only writes into the flat gradient buffers when sinks cover the requested
             # gradients: such a weight-gradient can run on the side stream, next to the input-gradient chain.
-            side = wgrad_stream_next()
-            if side is not None and ((need_w and wsink is None) or (need_b and bsink is None)):
-                side = None
+            side = None
+            if not ((need_w and wsink is None) or (need_b and bsink is None)):
+                side = wgrad_stream_for((wsink if wsink is not None else bsink).data_ptr())
             if side is not None:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
@@ -382,13 +382,23 @@ WGRAD_KEEPALIVE = []
 _wgrad_rr = [0]
 
 
-def wgrad_stream_next():
+_wgrad_slot = {}
+
+
+def wgrad_stream_for(sink_key):
+    """The weight-gradient stream of the layer whose gradient sink starts at ``sink_key``.  A layer keeps its
+    stream for the life of the process (slots are dealt round-robin on first sight): the read-modify-write
+    accumulations of D(real)'s and D(fake)'s weight gradients into the same flat .grad slice are then ordered
+    by the stream itself, whatever else the step overlaps."""
     w = WGRAD_STREAM
     if w is None:
         return None
     if isinstance(w, (list, tuple)):
-        _wgrad_rr[0] = (_wgrad_rr[0] + 1) % len(w)
-        return w[_wgrad_rr[0]]
+        slot = _wgrad_slot.get(sink_key)
+        if slot is None:
+            _wgrad_rr[0] += 1
+            slot = _wgrad_slot[sink_key] = _wgrad_rr[0]
+        return w[slot % len(w)]
     return w
 
 

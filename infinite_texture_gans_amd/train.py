@@ -11,8 +11,46 @@ import numpy as np
 import torch
 
 from . import utils as U
-from .data import SingleImageCrops
 from .engine import Trainer, BandTrainer
+
+
+def lr_factor(decay_lr, epochs_done):
+    """Learning-rate multiplier after ``epochs_done`` scheduler steps: ExponentialLR(gamma=0.99) for 'exp',
+    MultiStepLR(milestones=[40, 80, 120], gamma=0.5) for 'step' (reference train.py:60-70, stepped once per epoch
+    at :183-185)."""
+    if decay_lr == "exp":
+        return 0.99 ** epochs_done
+    if decay_lr == "step":
+        return 0.5 ** sum(epochs_done >= m for m in (40, 80, 120))
+    return 1.0
+
+
+def plot_losses(G_losses, D_losses, path):
+    """The loss curve the reference writes after the last epoch (train.py:220-227)."""
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except Exception as e:      # noqa: BLE001  (matplotlib is optional on a training box)
+        print("loss plot skipped:", e)
+        return
+    fig = plt.figure(figsize=(10, 5))
+    plt.title("Generator and Discriminator Loss During Training")
+    plt.plot(G_losses, label="G")
+    plt.plot(D_losses, label="D")
+    plt.xlabel("iterations")
+    plt.ylabel("Loss")
+    plt.legend()
+    fig.savefig(path)
+    plt.close(fig)
+
+
+def argparse_copy(args, **kw):
+    import copy
+    a = copy.copy(args)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
 
 
 def train(args):
@@ -32,13 +70,16 @@ def train(args):
     args.beta1, args.beta2 = float(args.beta1), float(args.beta2)    # the reference's int default breaks torch>=2
     if rank == 0:
         print(args)
-    if args.data != "single_image":
-        raise NotImplementedError("--data %s: only single_image is on the hot path" % args.data)
     band = bool(getattr(args, "shard_patch_rows", False)) and world > 1
     if band and args.batch_size % world:
         raise ValueError("--shard_patch_rows: batch_size %d does not split over %d ranks" % (args.batch_size, world))
-    data = SingleImageCrops(args.data_path, args.data_ext, args.sampling, args.random_crop, args.center_crop,
-                            args.batch_size // world if band else args.batch_size, device, seed=seed + 17 * rank)
+    if band:
+        args_data = argparse_copy(args, batch_size=args.batch_size // world)
+    else:
+        args_data = args
+    data, train_data = U.prepare_data(args_data, device, seed=seed + 17 * rank)
+    if rank == 0:
+        print('Training samples: ', len(train_data))
     netG, netD = U.prepare_models(args, device)          # same seed -> same initial weights on every rank
     netG_ema = None
     if args.ema:
@@ -55,15 +96,18 @@ def train(args):
         tr = BandTrainer(netG, netD, args, device, BandComm(rank, world, group), netG_ema=netG_ema)
     else:
         tr = Trainer(netG, netD, args, device, netG_ema=netG_ema, dist_group=group)
-    gammas = None
-    if args.decay_lr == "exp":
-        gammas = lambda e: 0.99 ** e                                          # noqa: E731
-    elif args.decay_lr == "step":
-        gammas = lambda e: 0.5 ** sum(e >= m for m in (40, 80, 120))          # noqa: E731
     filename = U.prepare_filename(args)
     start = time.time()
     G_losses, D_losses = [], []
     torch.manual_seed(seed if band else seed + 1000 * rank)   # latents: per-rank CPU RNG stream (shared when sharding rows)
+    local = args.padding_mode == 'local'
+
+    def sample():
+        if local:
+            return U.sample_latents_train(netG, args.z_dim, args.base_res, args.map_dim, args.num_images,
+                                          args.num_patches_height, args.num_patches_width, device)
+        return U.sample_latents_zeros(netG, args.z_dim, args.base_res, args.map_dim, args.num_images, device)
+
     print("Starting Training Loop...")
     for epoch in range(args.epochs):
         d_run = torch.zeros((), device=device)
@@ -72,16 +116,17 @@ def train(args):
         for data_b in data:
             real_x = data_b[0]
             b = real_x.shape[0]
-            for _ in range(args.disc_iters):
-                z, maps = U.sample_latents_train(netG, args.z_dim, args.base_res, args.map_dim, args.num_images,
-                                                 args.num_patches_height, args.num_patches_width, device)
-                d_real, d_fake, g_loss = tr.step(real_x, z, maps)
-            d_run += d_fake * args.num_images + d_real * b
+            # --disc_iters D updates with fresh latents each, then ONE G update on the last fake (train.py:124-169)
+            lat = [sample() for _ in range(args.disc_iters)]
+            _, _, g_loss = tr.step(real_x, [l[0] for l in lat], [l[1] for l in lat])
+            for d_real, d_fake in tr.d_losses:
+                d_run += d_fake * args.num_images + d_real * b
             g_run += g_loss * args.num_images
             n_d += b
             n_g += args.num_images
-        if gammas is not None:
-            tr.optD.lr, tr.optG.lr = args.lr_D * gammas(epoch + 1), args.lr_G * gammas(epoch + 1)
+        if args.decay_lr:
+            f = lr_factor(args.decay_lr, epoch + 1)
+            tr.optD.lr, tr.optG.lr = args.lr_D * f, args.lr_G * f
         d_l, g_l = float(d_run) / n_d, float(g_run) / n_g      # the only host sync of the epoch
         if rank == 0:
             print('[%d/%d]\tLoss_D: %.4f\tLoss_G: %.4f, elapsed_time = %.4f min'
@@ -94,6 +139,8 @@ def train(args):
                        filename + str(epoch + 1) + ".pth")
         if rank == 0 and last and args.ema:
             torch.save({'netG_state_dict': netG_ema.state_dict(), 'args': args}, filename + "_ema.pth")
+        if rank == 0 and last:
+            plot_losses(G_losses, D_losses, filename + 'losses.png')
 
 
 def main(argv=None):

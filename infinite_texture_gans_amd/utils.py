@@ -102,6 +102,29 @@ def prepare_seed(args):
     return seed
 
 
+def prepare_data(args, device=None, seed=None):
+    """-> (loader, dataset) as reference utils.py:158-191.  The loader yields ``{0: batch}`` dicts with the batch
+    already on ``device`` (default: the current GPU); ``len(dataset)`` is ``--sampling``."""
+    from . import data as D
+    print(" laoding " + args.data + " ...")
+    resize = None if args.resize_h is None and args.resize_w is None else (args.resize_h, args.resize_w)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if args.data == "single_image":
+        train_data = D.single_image(path=args.data_path, ext=args.data_ext, sampling=args.sampling,
+                                    random_crop=args.random_crop, center_crop=args.center_crop, device=device)
+    elif args.data == "multiple_images":
+        train_data = D.multiple_images(path=args.data_path, ext=args.data_ext, sampling=args.sampling,
+                                       random_crop=args.random_crop, center_crop=args.center_crop, resize=resize,
+                                       device=device)
+    else:
+        print("no data named :", args.data)
+        raise SystemExit(1)
+    loader = D.CropLoader(train_data, args.batch_size, seed=seed)
+    print("Finished data loading")
+    return loader, train_data
+
+
 def prepare_models(args, device="cpu"):
     netG = ResidualPatchGenerator(
         z_dim=args.z_dim, G_ch=args.G_ch, base_res=args.base_res, n_layers_G=args.n_layers_G,
@@ -205,6 +228,18 @@ def sample_latents_train(netG, z_dim=128, base_res=4, map_dim=1, num_images=1, n
     return z, maps
 
 
+def sample_latents_zeros(netG, z_dim=128, base_res=4, map_dim=1, num_images=1, device="cpu"):
+    """Latents of the non-local baseline (padding_mode='zeros'): z (N, z_dim, b, b), then the SSM maps
+    (N, map_dim, r, r) of layer 0..nl-1 (reference utils.py:556-566)."""
+    g = _unwrap(netG)
+    z = torch.randn(num_images, z_dim, base_res, base_res).to(device)
+    maps = [None] * g.n_layers_G
+    if g.type_norm == "SSM":
+        maps = [torch.randn(num_images, map_dim, (2 ** i) * base_res, (2 ** i) * base_res).to(device)
+                for i in range(g.n_layers_G)]
+    return z, maps
+
+
 def sample_from_gen_PatchByPatch_train(netG, z_dim=128, base_res=4, map_dim=1, num_images=1, num_patches_height=3,
                                        num_patches_width=3, device="cpu"):
     """Generate ``num_images`` images patch by patch (training).  reference utils.py:475-527."""
@@ -217,18 +252,39 @@ def sample_from_gen_PatchByPatch_train(netG, z_dim=128, base_res=4, map_dim=1, n
     return ops.to_nchw(g, merged=True)
 
 
-def sample_from_gen(netG, z_dim=128, base_res=4, map_dim=1, num_images=1, tiles=False, device="cpu"):
-    """Non-local baseline sampler (padding_mode='zeros').  reference utils.py:530-575 (without tiling)."""
+def tile_process(img, model, scale=4, tile_size=32, tile_pad=8):
+    """Real-ESRGAN style tiling of the latent ``img`` (reference utils.py:401-470): every tile_size^2 block is run
+    through ``model`` with up to ``tile_pad`` latent pixels of context per side and its own scale x region of the
+    result is pasted into the output."""
+    n, _, h, w = img.shape
+    out = img.new_zeros((n, 3, h * scale, w * scale))
+    with torch.no_grad():
+        for y0 in range(0, h, tile_size):
+            for x0 in range(0, w, tile_size):
+                y1, x1 = min(y0 + tile_size, h), min(x0 + tile_size, w)
+                ya, xa = max(y0 - tile_pad, 0), max(x0 - tile_pad, 0)
+                yb, xb = min(y1 + tile_pad, h), min(x1 + tile_pad, w)
+                t = model(img[:, :, ya:yb, xa:xb].contiguous())
+                oy, ox = (y0 - ya) * scale, (x0 - xa) * scale
+                out[:, :, y0 * scale:y1 * scale, x0 * scale:x1 * scale] = \
+                    t[:, :, oy:oy + (y1 - y0) * scale, ox:ox + (x1 - x0) * scale]
+    return out
+
+
+def sample_from_gen(netG, z_dim=128, base_res=4, map_dim=1, num_images=1, tiles=False, device="cpu", z=None):
+    """Non-local baseline sampler (padding_mode='zeros'), reference utils.py:530-575: one zero-padded forward over
+    the whole latent, or - ``tiles`` - tile_process(z, netG, 2**(nl-1), 32, 16).  ``z`` injects the latent."""
     g = _unwrap(netG)
-    z = torch.randn(num_images, z_dim, base_res, base_res).to(device)
+    if z is None:
+        z = torch.randn(num_images, z_dim, base_res, base_res)
+    z = z.to(device)
     maps = [None] * g.n_layers_G
     if g.type_norm == "SSM":
         maps = [torch.randn(num_images, map_dim, (2 ** i) * base_res, (2 ** i) * base_res).to(device)
                 for i in range(g.n_layers_G)]
     if tiles:
-        raise NotImplementedError("--tiles (Real-ESRGAN style tiling, reference utils.py:401-470) is outside the "
-                                  "local-padding hot path")
-    return netG(z, maps)
+        return tile_process(z, netG, 2 ** (g.n_layers_G - 1), 32, 16)
+    return netG(z, maps, image_location="1st_row_1st_col")
 
 
 # ------------------------------------------------------------------------------- inference tiling

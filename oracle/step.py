@@ -5,7 +5,8 @@ Restates:
   * sample_from_gen_PatchByPatch_train        reference utils.py:475-527
   * build_z / build_maps                      reference utils.py:221-256
   * sample_from_gen_PatchByPatch_test         reference utils.py:258-397
-  * the train iteration                       reference train.py:122-180
+  * the train iteration                       reference train.py:122-180 (incl. --disc_iters > 1, --ema)
+  * sample_from_gen / tile_process            reference utils.py:530-575, 401-470 (padding_mode='zeros' baseline)
   * torch.optim.Adam (lr, betas, eps 1e-8, no weight decay, bias correction) as the
     reference configures it at train.py:57-58
   * hinge loss: NOT in the reference (utils.py:85 flag is never read) - parity unpinned.
@@ -35,8 +36,11 @@ def sample_latents(cfg, num_images, generator=None):
 
 
 def g_sample_train(sd, cfg, z, maps, loops=False):
-    """G forward on given latents + merge -> (N, C, gh*P, gw*P).  utils.py:523-527."""
+    """G forward on given latents + merge -> (N, C, gh*P, gw*P).  utils.py:523-527.
+    padding_mode='zeros': z is (N, z_dim, b, b) and G's output already is the image (utils.py:556-573)."""
     patches = g_forward(sd, cfg, z, maps, training=True, loops=loops)
+    if cfg.padding_mode != "local":
+        return patches
     mg = P.merge_loops if loops else P.merge
     return mg(patches, cfg.num_patches_h, cfg.num_patches_w)
 
@@ -101,13 +105,8 @@ def zero_grads(sd):
 
 
 # --------------------------------------------------------------------------- train step
-def train_step(gsd, dsd, gcfg, dcfg, optG, optD, real_x, z, maps, smooth=True, loops=False,
-               ema_sd=None, ema_decay=0.999):
-    """One iteration of reference train.py:122-180 with disc_iters=1 and injected
-    real_x / latents.  Mutates the state dicts (params, BN buffers, SN u/v) in place.
-    Returns dict(d_loss_real, d_loss_fake, g_loss, fake) as python floats / tensor."""
-    label_t = 0.9 if smooth else 1.0
-    # ---- D step
+def d_step(gsd, dsd, gcfg, dcfg, optD, real_x, z, maps, label_t, loops=False):
+    """One discriminator update, reference train.py:126-153.  Returns (d_real, d_fake, fake, logits)."""
     zero_grads(dsd)
     real_logit = d_forward(dsd, dcfg, real_x, training=True)
     d_real = bce_logits(real_logit, label_t)
@@ -117,17 +116,38 @@ def train_step(gsd, dsd, gcfg, dcfg, optG, optD, real_x, z, maps, smooth=True, l
     d_fake = bce_logits(fake_logit, 0.0)
     d_fake.backward()
     optD.step()
-    # ---- G step
+    return d_real, d_fake, fake, real_logit, fake_logit
+
+
+def g_step(gsd, dsd, dcfg, optG, fake, label_t):
+    """The generator update on the LAST fake batch of the D loop, reference train.py:161-169."""
     zero_grads(gsd)
     fake_logit2 = d_forward(dsd, dcfg, fake, training=True)
     g_loss = bce_logits(fake_logit2, label_t)
     g_loss.backward()
     optG.step()
+    return g_loss, fake_logit2
+
+
+def train_step(gsd, dsd, gcfg, dcfg, optG, optD, real_x, z, maps, smooth=True, loops=False,
+               ema_sd=None, ema_decay=0.999):
+    """One iteration of reference train.py:122-180 with injected real_x / latents.  ``z`` / ``maps`` may be
+    lists of equal length: --disc_iters = len(z) discriminator updates (fresh latents each, the same real_x),
+    then ONE generator update on the last fake batch.  Mutates the state dicts (params, BN buffers, SN u/v) in
+    place.  Returns dict(d_loss_real, d_loss_fake, g_loss, fake, ...) of the last D iteration (+ d_losses: all)."""
+    label_t = 0.9 if smooth else 1.0
+    zs = z if isinstance(z, (list, tuple)) else [z]
+    ms = maps if isinstance(z, (list, tuple)) else [maps]
+    d_losses = []
+    for zi, mi in zip(zs, ms):
+        d_real, d_fake, fake, real_logit, fake_logit = d_step(gsd, dsd, gcfg, dcfg, optD, real_x, zi, mi, label_t, loops)
+        d_losses += [float(d_real.detach()), float(d_fake.detach())]
+    g_loss, fake_logit2 = g_step(gsd, dsd, dcfg, optG, fake, label_t)
     if ema_sd is not None:
         ema_update(ema_sd, gsd, ema_decay)
     return dict(d_loss_real=float(d_real.detach()), d_loss_fake=float(d_fake.detach()), g_loss=float(g_loss.detach()),
                 fake=fake.detach(), real_logit=real_logit.detach(), fake_logit=fake_logit.detach(),
-                fake_logit2=fake_logit2.detach())
+                fake_logit2=fake_logit2.detach(), d_losses=d_losses)
 
 
 @torch.no_grad()
@@ -227,3 +247,32 @@ def infer_oneshot(sd, cfg, z_full, maps_full, out_h, out_w):
     patches = nets.g_forward(sd, big, z_full, maps, training=False, loc="1st_row_1st_col_last_row_last_col",
                              padders=ctx_padders)
     return P.merge(patches, t_h, t_w)[:, :, :out_h, :out_w]
+
+
+# --------------------------------------------------------------------------- non-local baseline sampler
+@torch.no_grad()
+def tile_process(z, model, scale, tile_size=32, tile_pad=8):
+    """Real-ESRGAN style tiling of the latent: every tile_size x tile_size block of ``z`` is run through
+    ``model`` together with up to ``tile_pad`` latent pixels of context per side, and the block's own
+    scale x region of the result is pasted into the output.  reference utils.py:401-470."""
+    n, _, h, w = z.shape
+    out = z.new_zeros((n, 3, h * scale, w * scale))
+    for y0 in range(0, h, tile_size):
+        for x0 in range(0, w, tile_size):
+            y1, x1 = min(y0 + tile_size, h), min(x0 + tile_size, w)
+            ya, xa = max(y0 - tile_pad, 0), max(x0 - tile_pad, 0)
+            yb, xb = min(y1 + tile_pad, h), min(x1 + tile_pad, w)
+            t = model(z[:, :, ya:yb, xa:xb])
+            oy, ox = (y0 - ya) * scale, (x0 - xa) * scale
+            out[:, :, y0 * scale:y1 * scale, x0 * scale:x1 * scale] = \
+                t[:, :, oy:oy + (y1 - y0) * scale, ox:ox + (x1 - x0) * scale]
+    return out
+
+
+@torch.no_grad()
+def sample_zeros(sd, cfg, z, maps=None, tiles=False, training=False):
+    """sample_from_gen on an injected latent (N, z_dim, b, b), reference utils.py:530-575: the whole image in
+    one zero-padded forward, or - ``tiles`` - tile_process(z, G, 2**(nl-1), 32, 16) (utils.py:568-570)."""
+    if tiles:
+        return tile_process(z, lambda t: g_forward(sd, cfg, t, None, training=training), 2 ** (cfg.n_layers_G - 1), 32, 16)
+    return g_forward(sd, cfg, z, maps, training=training)

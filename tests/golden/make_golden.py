@@ -110,9 +110,16 @@ def build(args, seed):
 
 
 def latents(args, netG, seed):
-    """Replays the RNG draws of utils.py:503-519 and records them."""
+    """Replays the RNG draws of utils.py:503-519 (local padding) / utils.py:556-566 (zeros) and records them."""
     gh, gw, b = args.num_patches_height, args.num_patches_width, args.base_res
     torch.manual_seed(seed)
+    if args.padding_mode != "local":
+        z = torch.randn(args.num_images, args.z_dim, b, b)
+        maps_full = []
+        if netG.type_norm == "SSM":
+            for i in range(netG.n_layers_G):
+                maps_full.append(torch.randn(args.num_images, args.map_dim, (2 ** i) * b, (2 ** i) * b))
+        return z, maps_full
     z = torch.randn(args.num_images, args.z_dim, gh * b + 2, gw * b + 2)
     maps_full = []
     if netG.type_norm == "SSM":
@@ -124,6 +131,8 @@ def latents(args, netG, seed):
 
 def ref_sampler(args, netG, seed):
     torch.manual_seed(seed)
+    if args.padding_mode != "local":      # reference train.py:143-144
+        return R.sample_from_gen(netG, args.z_dim, args.base_res, num_images=args.num_images, device="cpu")
     return R.sample_from_gen_PatchByPatch_train(
         netG, args.z_dim, args.base_res, args.map_dim, num_images=args.num_images,
         num_patches_height=args.num_patches_height, num_patches_width=args.num_patches_width, device="cpu")
@@ -151,40 +160,55 @@ def gen_forward(tag, extra, seed):
 
 # --------------------------------------------------------------------------- 3. train-step fixtures
 def gen_train(tag, extra, seed, steps=2):
+    """The iteration of reference train.py:122-180 incl. --disc_iters > 1 (D step repeated with fresh
+    latents, then ONE G step on the last fake_x) and --ema (train.py:38-45,176-180)."""
     args = make_args(extra)
     netG, netD = build(args, seed)
     netG.train(), netD.train()
     out = dict(argv=np.array(extra), steps=np.array(steps))
     out.update(sd_np(netG.state_dict(), "G0/"))
     out.update(sd_np(netD.state_dict(), "D0/"))
+    netG_ema = None
+    if args.ema:        # train.py:38-45
+        netG_ema, _ = R.prepare_models(args, torch.device("cpu"))
+        with torch.no_grad():
+            for key in netG_ema.state_dict():
+                netG_ema.state_dict()[key].data.copy_(netG.state_dict()[key].data)
     optD = torch.optim.Adam(netD.parameters(), lr=args.lr_D, betas=(args.beta1, args.beta2))
     optG = torch.optim.Adam(netG.parameters(), lr=args.lr_G, betas=(args.beta1, args.beta2))
     crit = torch.nn.BCEWithLogitsLoss()
     lt = 0.9 if args.smooth else 1
     crop = args.random_crop
     g = torch.Generator().manual_seed(seed + 3)
+    di = args.disc_iters
     for s in range(steps):
         real_x = torch.rand(args.batch_size, 3, crop, crop, generator=g) * 2 - 1
-        z, maps_full = latents(args, netG, seed + 100 + s)
         out["real_x%d" % s] = npy(real_x)
-        out["z%d" % s] = npy(z)
-        for i, m in enumerate(maps_full):
-            out["map%d_%d" % (s, i)] = npy(m)
-        # ---- reference train.py:124-153 (disc_iters = 1)
-        netD.zero_grad()
-        real_logit = netD(real_x)
-        lab = torch.FloatTensor(1).fill_(lt).expand_as(real_logit)
-        d_real = crit(real_logit, lab)
-        d_real.backward()
-        fake_x = ref_sampler(args, netG, seed + 100 + s)
-        fake_logit = netD(fake_x.detach())
-        lab = torch.FloatTensor(1).fill_(0).expand_as(fake_logit)
-        d_fake = crit(fake_logit, lab)
-        d_fake.backward()
-        if s == 0:
-            for k, p in netD.named_parameters():
-                out["gradD0/" + k] = npy(p.grad)
-        optD.step()
+        d_losses = []
+        for d in range(di):
+            # latent seed and key names of the disc_iters == 1 fixtures are kept (z0, z1, map0_1 ...)
+            lseed = seed + 100 + s if di == 1 else seed + 100 + 10 * s + d
+            sfx = "%d" % s if di == 1 else "%d_%d" % (s, d)
+            z, maps_full = latents(args, netG, lseed)
+            out["z" + sfx] = npy(z)
+            for i, m in enumerate(maps_full):
+                out["map%s_%d" % (sfx, i)] = npy(m)
+            # ---- reference train.py:124-153
+            netD.zero_grad()
+            real_logit = netD(real_x)
+            lab = torch.FloatTensor(1).fill_(lt).expand_as(real_logit)
+            d_real = crit(real_logit, lab)
+            d_real.backward()
+            fake_x = ref_sampler(args, netG, lseed)
+            fake_logit = netD(fake_x.detach())
+            lab = torch.FloatTensor(1).fill_(0).expand_as(fake_logit)
+            d_fake = crit(fake_logit, lab)
+            d_fake.backward()
+            if s == 0 and d == 0:
+                for k, p in netD.named_parameters():
+                    out["gradD0/" + k] = npy(p.grad)
+            optD.step()
+            d_losses += [d_real.item(), d_fake.item()]
         # ---- reference train.py:161-169
         netG.zero_grad()
         fake_logit = netD(fake_x)
@@ -195,10 +219,19 @@ def gen_train(tag, extra, seed, steps=2):
             for k, p in netG.named_parameters():
                 out["gradG0/" + k] = npy(p.grad)
         optG.step()
-        out["loss%d" % s] = np.array([d_real.item(), d_fake.item(), g_loss.item()], dtype=np.float64)
+        if netG_ema is not None:    # train.py:176-180
+            with torch.no_grad():
+                for key in netG.state_dict():
+                    netG_ema.state_dict()[key].data.copy_(netG_ema.state_dict()[key].data * args.ema_decay
+                                                          + netG.state_dict()[key].data * (1 - args.ema_decay))
+        out["loss%d" % s] = np.array(d_losses[-2:] + [g_loss.item()], dtype=np.float64)
+        if di > 1:
+            out["dloss%d" % s] = np.array(d_losses, dtype=np.float64)    # every D iteration: real, fake, real, fake ...
     out["fake_last"] = npy(fake_x)
     out.update(sd_np(netG.state_dict(), "G1/"))
     out.update(sd_np(netD.state_dict(), "D1/"))
+    if netG_ema is not None:
+        out.update(sd_np(netG_ema.state_dict(), "E1/"))
     save("train_" + tag, **out)
 
 
@@ -238,6 +271,34 @@ def gen_infer(tag, extra, seed, out_h, out_w):
     save("infer_" + tag, **out)
 
 
+# --------------------------------------------------------------------------- 5. non-local baseline sampler (+ tiling)
+def gen_zeros_infer(tag, extra, seed, base_res_out):
+    """padding_mode='zeros' generator in eval mode through reference utils.sample_from_gen, plain and with
+    --tiles (tile_process, utils.py:401-470), as test_sample.py:70-73 calls it."""
+    args = make_args(extra)
+    netG, _ = build(args, seed)
+    g = torch.Generator().manual_seed(seed + 5)
+    with torch.no_grad():
+        for k, v in netG.state_dict().items():
+            if k.endswith("running_mean"):
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+            if k.endswith("running_var"):
+                v.copy_(1 + 0.2 * torch.rand(v.shape, generator=g))
+    netG.eval()
+    out = dict(argv=np.array(extra), base_res_out=np.array(base_res_out))
+    out.update(sd_np(netG.state_dict(), "G0/"))
+    torch.manual_seed(seed + 9)
+    out["z"] = npy(torch.randn(1, args.z_dim, base_res_out, base_res_out))
+    with torch.no_grad():
+        torch.manual_seed(seed + 9)
+        out["image"] = npy(R.sample_from_gen(netG, z_dim=args.z_dim, base_res=base_res_out, num_images=1,
+                                             tiles=False, device="cpu"))
+        torch.manual_seed(seed + 9)
+        out["image_tiles"] = npy(R.sample_from_gen(netG, z_dim=args.z_dim, base_res=base_res_out, num_images=1,
+                                                   tiles=True, device="cpu"))
+    save("infer_" + tag, **out)
+
+
 if __name__ == "__main__":
     gen_patch_ops()
     gen_forward("bn_nl4", ["--n_layers_G", "4", "--type_norm", "BN"], 101)
@@ -248,10 +309,27 @@ if __name__ == "__main__":
     gen_train("bn_nl4_sn", ["--n_layers_G", "4", "--type_norm", "BN", "--spec_norm_D", "--smooth",
                             "--random_crop", "32"], 201)
     gen_train("ssm_nl4", ["--n_layers_G", "4", "--type_norm", "SSM", "--random_crop", "32", "--G_ch", "2",
-                          "--num_images", "1"], 202, steps=1)
+                          "--num_images", "1"], 202, steps=2)
     gen_train("bn_nl5_att", ["--n_layers_G", "5", "--type_norm", "BN", "--attention", "--spec_norm_D",
                              "--smooth", "--random_crop", "48", "--num_patches_height", "4",
-                             "--num_patches_width", "4", "--base_res", "2", "--num_images", "1"], 203, steps=1)
+                             "--num_patches_width", "4", "--base_res", "2", "--num_images", "1"], 203, steps=2)
+    # BASELINE config 4's workload shape: 4x4 patch grid, BN, no attention; 4 images / 4 real crops so that the
+    # row-sharded step can be run on 2 and on 4 ranks
+    gen_train("bn_nl4_g44", ["--n_layers_G", "4", "--type_norm", "BN", "--spec_norm_D", "--smooth",
+                             "--random_crop", "32", "--num_patches_height", "4", "--num_patches_width", "4",
+                             "--base_res", "2", "--num_images", "4", "--batch_size", "4"], 204, steps=2)
+    # --disc_iters 2 (D step twice with fresh latents, one G step on the last fake) and --ema (whole state_dict
+    # incl. BatchNorm buffers and the int64 counters)
+    gen_train("bn_nl4_di2_ema", ["--n_layers_G", "4", "--type_norm", "BN", "--spec_norm_D", "--smooth",
+                                 "--random_crop", "32", "--disc_iters", "2", "--ema", "--ema_decay", "0.9"], 205,
+              steps=3)
+    # D without spectral norm (the CLI default): weight gradients of D(real) and D(fake) accumulate into one buffer
+    gen_train("bn_nl4_nosn", ["--n_layers_G", "4", "--type_norm", "BN", "--random_crop", "32"], 206, steps=2)
+    # non-local baseline (padding_mode zeros): train step and the eval samplers of test_sample.py:70-73
+    gen_train("bn_nl4_zeros", ["--n_layers_G", "4", "--type_norm", "BN", "--padding_mode", "zeros", "--spec_norm_D",
+                               "--random_crop", "32"], 207, steps=2)
+    gen_zeros_infer("bn_nl4_zeros_tiles", ["--n_layers_G", "4", "--type_norm", "BN", "--padding_mode", "zeros"],
+                    304, 40)
     gen_infer("bn_nl4", ["--n_layers_G", "4", "--type_norm", "BN"], 301, 150, 230)
     gen_infer("ssm_nl4", ["--n_layers_G", "4", "--type_norm", "SSM", "--G_ch", "2"], 302, 100, 164)
     gen_infer("bn_nl4_att", ["--n_layers_G", "4", "--type_norm", "BN", "--attention"], 303, 96, 160)

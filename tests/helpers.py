@@ -11,7 +11,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 _BASE = {"G_ch": 4, "D_ch": 4, "z_dim": 8, "leak_G": 0.02, "batch_size": 2, "num_images": 2,
          "n_layers_G": 6, "n_layers_D": 4, "type_norm": "BN", "outer_padding": "replicate",
          "base_res": 4, "num_patches_height": 3, "num_patches_width": 3, "map_dim": 1,
-         "attention": False, "spec_norm_D": False, "smooth": False, "random_crop": None}
+         "attention": False, "spec_norm_D": False, "smooth": False, "random_crop": None,
+         "padding_mode": "local", "disc_iters": 1, "ema": False, "ema_decay": 0.999}
 
 
 def load(name):
@@ -25,7 +26,7 @@ def parse_flags(argv):
     i = 0
     while i < len(argv):
         k = argv[i].lstrip("-")
-        if k in ("attention", "spec_norm_D", "smooth"):
+        if k in ("attention", "spec_norm_D", "smooth", "ema"):
             a[k] = True
             i += 1
             continue
@@ -38,7 +39,7 @@ def parse_flags(argv):
 def cfgs(a):
     g = GCfg(z_dim=a["z_dim"], G_ch=a["G_ch"], base_res=a["base_res"], n_layers_G=a["n_layers_G"],
              attention=a["attention"], img_ch=3, leak=a["leak_G"], SN=False, type_norm=a["type_norm"],
-             map_dim=a["map_dim"], padding_mode="local", outer_padding=a["outer_padding"],
+             map_dim=a["map_dim"], padding_mode=a["padding_mode"], outer_padding=a["outer_padding"],
              num_patches_h=a["num_patches_height"], num_patches_w=a["num_patches_width"])
     d = DCfg(img_ch=3, base_ch=a["D_ch"], n_layers_D=a["n_layers_D"], SN=a["spec_norm_D"])
     return g, d

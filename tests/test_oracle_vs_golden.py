@@ -49,48 +49,126 @@ def test_forward_matches_reference(tag):
         assert rel_l2(dsd[k].double(), v.double()) < 1e-5, k
 
 
-def _run_train(tag, loops=False):
+def fixture_latents(fx, a, gcfg, s):
+    """(z, maps) of train step ``s`` as train_step takes them: tensors for disc_iters == 1, lists otherwise."""
+    def one(sfx):
+        maps = None
+        if gcfg.type_norm == "SSM":
+            maps = crop_maps(gcfg, [torch.from_numpy(fx["map%s_%d" % (sfx, i)]) for i in range(gcfg.n_layers_G)])
+        return torch.from_numpy(fx["z" + sfx]), maps
+    if a["disc_iters"] == 1:
+        return one("%d" % s)
+    zs, ms = zip(*[one("%d_%d" % (s, d)) for d in range(a["disc_iters"])])
+    return list(zs), list(ms)
+
+
+def _run_train(tag, loops=False, steps=None):
     fx = load("train_" + tag)
     a = parse_flags(fx["argv"])
     gcfg, dcfg = cfgs(a)
     gsd = step.as_leaf_params(state(fx, "G0/"))
     dsd = step.as_leaf_params(state(fx, "D0/"))
+    esd = {k: v.detach().clone() for k, v in gsd.items()} if a["ema"] else None
     optD = step.Adam([dsd[k] for k in step.trainable(dsd)])
     optG = step.Adam([gsd[k] for k in step.trainable(gsd)])
     outs = []
-    for s in range(int(fx["steps"])):
-        maps = None
-        if gcfg.type_norm == "SSM":
-            maps = crop_maps(gcfg, [torch.from_numpy(fx["map%d_%d" % (s, i)]) for i in range(gcfg.n_layers_G)])
-        grads = {}
-        r = step.train_step(gsd, dsd, gcfg, dcfg, optG, optD, torch.from_numpy(fx["real_x%d" % s]),
-                            torch.from_numpy(fx["z%d" % s]), maps, smooth=a["smooth"], loops=loops)
+    for s in range(int(fx["steps"]) if steps is None else steps):
+        z, maps = fixture_latents(fx, a, gcfg, s)
+        r = step.train_step(gsd, dsd, gcfg, dcfg, optG, optD, torch.from_numpy(fx["real_x%d" % s]), z, maps,
+                            smooth=a["smooth"], loops=loops, ema_sd=esd, ema_decay=a["ema_decay"])
         outs.append(r)
+    if esd is not None:
+        gsd["__ema__"] = esd
     return fx, gsd, dsd, outs
 
 
-@pytest.mark.parametrize("tag", ["bn_nl4_sn", "ssm_nl4", "bn_nl5_att"])
+ZERO_GRAD_G = ("mlp_shared.0.bias", "embed.bias", "attention.phi.bias", "attention.g.bias", "attention.o.bias")
+
+
+def zero_grad_bias(k):
+    """G parameters whose gradient is mathematically zero."""
+    return (k.endswith("bias") and "conv" in k and k != "final.conv.bias") or any(t in k for t in ZERO_GRAD_G)
+
+
+@pytest.mark.parametrize("tag", ["bn_nl4_sn", "ssm_nl4", "bn_nl5_att", "bn_nl4_g44", "bn_nl4_di2_ema", "bn_nl4_nosn",
+                                 "bn_nl4_zeros"])
 def test_train_step_matches_reference(tag):
     fx, gsd, dsd, outs = _run_train(tag)
+    esd = gsd.pop("__ema__", None)
     for s, r in enumerate(outs):
         want = fx["loss%d" % s]
         got = np.array([r["d_loss_real"], r["d_loss_fake"], r["g_loss"]])
         assert np.allclose(got, want, rtol=2e-5, atol=1e-6), (s, got, want)
+        if "dloss%d" % s in fx:      # every D iteration of --disc_iters > 1
+            assert np.allclose(r["d_losses"], fx["dloss%d" % s], rtol=2e-5, atol=1e-6), (s, r["d_losses"])
     assert rel_l2(outs[-1]["fake"], fx["fake_last"]) < 1e-4
     # post-step parameters, BN buffers and SN vectors.  Conv biases that feed a BatchNorm
     # have mathematically zero gradient (SURVEY.md F11): with Adam(beta1=0) their update is
     # sign-of-noise * lr, so they are compared only to within the 2*lr*steps they can drift.
     steps = int(fx["steps"])
-    for name, sd in (("G1/", gsd), ("D1/", dsd)):
+    for name, sd in (("G1/", gsd), ("D1/", dsd), ("E1/", esd)):
+        if sd is None:
+            continue
         for k, v in state(fx, name).items():
             got = sd[k].detach().double()
-            if name == "G1/" and k.endswith("bias") and ("conv" in k) and k != "final.conv.bias":
+            if name in ("G1/", "E1/") and zero_grad_bias(k):
                 assert (got - v.double()).abs().max() <= 2 * 2e-4 * steps + 1e-7, k
                 continue
-            if name == "G1/" and ("mlp_shared.0.bias" in k or "embed.bias" in k or k in ("attention.phi.bias", "attention.g.bias", "attention.o.bias")):
-                assert (got - v.double()).abs().max() <= 2 * 2e-4 * steps + 1e-7, k
+            if v.dtype == torch.int64:
+                assert torch.equal(sd[k], v), (k, sd[k], v)       # incl. the EMA's truncated counters
                 continue
             assert rel_l2(got, v.double()) < 2e-3, (k, rel_l2(got, v.double()))
+
+
+@pytest.mark.parametrize("tag", ["bn_nl4_sn", "ssm_nl4", "bn_nl5_att", "bn_nl4_g44", "bn_nl4_nosn"])
+def test_first_step_generator_and_discriminator_gradients_match_reference(tag):
+    """Gradient MAGNITUDES (the post-Adam parameters of a beta1=0 first step only carry signs)."""
+    fx = load("train_" + tag)
+    a = parse_flags(fx["argv"])
+    gcfg, dcfg = cfgs(a)
+    gsd, dsd = step.as_leaf_params(state(fx, "G0/")), step.as_leaf_params(state(fx, "D0/"))
+    optD = step.Adam([dsd[k] for k in step.trainable(dsd)])
+    optG = step.Adam([gsd[k] for k in step.trainable(gsd)])
+    z, maps = fixture_latents(fx, a, gcfg, 0)
+    lt = 0.9 if a["smooth"] else 1.0
+    _, _, fake, _, _ = step.d_step(gsd, dsd, gcfg, dcfg, optD, torch.from_numpy(fx["real_x0"]), z, maps, lt)
+    for k in step.trainable(dsd):       # D's gradients of the D step (the G step adds to them afterwards)
+        assert rel_l2(dsd[k].grad, fx["gradD0/" + k]) < 1e-4, k
+    step.g_step(gsd, dsd, dcfg, optG, fake, lt)
+    for k in step.trainable(gsd):
+        want = torch.from_numpy(fx["gradG0/" + k])
+        if float(want.abs().max()) < 1e-6:      # rounding noise around a mathematically zero gradient (F11)
+            assert zero_grad_bias(k), k
+            continue
+        assert rel_l2(gsd[k].grad, want) < 1e-4, (k, rel_l2(gsd[k].grad, want))
+
+
+@pytest.mark.parametrize("tag", ["bn_nl4_sn", "ssm_nl4", "bn_nl4_g44"])
+def test_sampler_rng_order_matches_reference(tag):
+    """z first, then the SSM maps of layer 0..nl-1, from the global CPU generator (reference utils.py:503-519);
+    the fixture recorded the reference sampler's draws under the same seed."""
+    fx = load("train_" + tag)
+    a = parse_flags(fx["argv"])
+    gcfg, _ = cfgs(a)
+    seed = {"bn_nl4_sn": 201, "ssm_nl4": 202, "bn_nl4_g44": 204}[tag] + 100
+    torch.manual_seed(seed)
+    z, maps = step.sample_latents(gcfg, a["num_images"])
+    assert torch.equal(z, torch.from_numpy(fx["z0"]))
+    if gcfg.type_norm == "SSM":
+        want = crop_maps(gcfg, [torch.from_numpy(fx["map0_%d" % i]) for i in range(gcfg.n_layers_G)])
+        for m, w in zip(maps, want):
+            assert torch.equal(m, w)
+
+
+def test_zeros_mode_sampler_and_tiling_match_reference():
+    """padding_mode='zeros' baseline: sample_from_gen plain and with --tiles (reference utils.py:530-575, 401-470)."""
+    fx = load("infer_bn_nl4_zeros_tiles")
+    a = parse_flags(fx["argv"])
+    gcfg, _ = cfgs(a)
+    gsd = state(fx, "G0/")
+    z = torch.from_numpy(fx["z"])
+    assert rel_l2(step.sample_zeros(gsd, gcfg, z), fx["image"]) < 2e-6
+    assert rel_l2(step.sample_zeros(gsd, gcfg, z, tiles=True), fx["image_tiles"]) < 2e-6
 
 
 def test_loop_faithful_padder_gives_same_step():
