@@ -115,7 +115,7 @@ def _rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-def _fullsize_step(flags, nl_G, attention, crop, prec):
+def _fullsize_step(flags, nl_G, attention, crop, prec, fp64_truth=False):
     """One train iteration at a BASELINE configuration on identical seeded state / real_x / z: HIP Trainer vs the
     CPU oracle's train_step.  Returns the comparison numbers."""
     from oracle import step as ostep
@@ -136,6 +136,14 @@ def _fullsize_step(flags, nl_G, attention, crop, prec):
     real = torch.rand(8, 3, crop, crop, generator=g) * 2 - 1
     z = torch.randn(8, 128, 14, 14, generator=g)
     torch.set_num_threads(16)
+    truth = None
+    if fp64_truth:      # the same step in fp64 on the same initial state: the yardstick for gradient errors (F10)
+        g64 = ostep.as_leaf_params({k: (v.detach().double() if v.is_floating_point() else v.clone()) for k, v in gsd.items()})
+        d64 = ostep.as_leaf_params({k: (v.detach().double() if v.is_floating_point() else v.clone()) for k, v in dsd.items()})
+        o64D = ostep.Adam([d64[k] for k in ostep.trainable(d64)])
+        o64G = ostep.Adam([g64[k] for k in ostep.trainable(g64)])
+        ostep.train_step(g64, d64, gcfg, dcfg, o64G, o64D, real.double(), z.double(), None, smooth=True)
+        truth = {k: g64[k].grad for k in ostep.trainable(g64)}
     r = ostep.train_step(gsd, dsd, gcfg, dcfg, optG, optD, real, z, None, smooth=True)
     netG, netD = netG.to(cuda).train(), netD.to(cuda).train()
     with ops.mfma_precision(prec):
@@ -163,6 +171,7 @@ def _fullsize_step(flags, nl_G, attention, crop, prec):
     out["oracle"] = (gsd, dsd, gcfg, dcfg, real, z)
     out["gradG"] = {k: p.grad.clone() for k, p in netG.named_parameters()}
     out["gradG_ref"] = {k: gsd[k].grad for k in ostep.trainable(gsd)}
+    out["gradG_truth"] = truth
     return out
 
 
@@ -174,23 +183,31 @@ def test_config2_full_size_train_step_matches_cpu_oracle_within_1e3():
     with the fraction inside 1e-3 reported (a single LeakyReLU sign flip among millions of activations
     costs ~1e-3 on every upstream gradient, in the oracle against itself as well)."""
     import bench
-    o = _fullsize_step(bench.FLAGS, 6, False, 192, "f32")
+    o = _fullsize_step(bench.FLAGS, 6, False, 192, "f32", fp64_truth=True)
     got, want = o["losses"]
     print("config2 full-size: losses", got, want, "fake %.2e logits %s bn %.2e sn %.2e" % (o["fake"], o["logits"], o["bn"], o["sn"]))
     assert all(abs(a - b) <= 1e-3 * abs(b) for a, b in zip(got, want)), (got, want)
     assert o["fake"] < 1e-3, o["fake"]
     assert all(e < 1e-3 for e in o["logits"]), o["logits"]
     assert o["bn"] < 1e-3 and o["nbt"] and o["sn"] < 1e-3, (o["bn"], o["sn"])
-    errs = {}
+    # Gradients.  Yardstick: the oracle's own fp64 run of the same step.  Each LeakyReLU input whose sign differs
+    # between two arithmetic orders moves every upstream gradient by ~1e-3 rel-L2 (F10), for the fp32 oracle as
+    # much as for the HIP path - so the HIP gradients must be as close to the fp64 truth as the fp32 CPU oracle is
+    # (within 2x + 1e-4), and within 1e-2 of the fp32 oracle in any case (a wrong kernel is O(1) off).
+    rows = []
     for k, ref in o["gradG_ref"].items():
-        if float(ref.abs().max()) < 1e-7:      # mathematically zero gradients (F11)
+        t = o["gradG_truth"][k]
+        if float(t.abs().max()) < 1e-9:        # mathematically zero gradients (F11)
             continue
-        errs[k] = _rel(o["gradG"][k], ref)
-    inside = sum(e < 1e-3 for e in errs.values()) / len(errs)
-    worst = max(errs.items(), key=lambda kv: kv[1])
-    print("config2 full-size: G gradients: %d tensors, %.0f%% within 1e-3, worst %s %.2e" % (len(errs), 100 * inside, *worst))
-    assert worst[1] < 2e-2, worst          # a real kernel error would be O(1)
-    assert inside >= 0.5, (inside, worst)
+        rows.append((k, _rel(o["gradG"][k], t), _rel(ref, t), _rel(o["gradG"][k], ref)))
+    inside = sum(r[3] < 1e-3 for r in rows) / len(rows)
+    print("config2 full-size: G gradients, %d tensors: rel-L2 vs fp64 truth: HIP median %.2e max %.2e | fp32 CPU oracle "
+          "median %.2e max %.2e | HIP vs fp32 oracle: %.0f%% within 1e-3, max %.2e" % (
+              len(rows), sorted(r[1] for r in rows)[len(rows) // 2], max(r[1] for r in rows),
+              sorted(r[2] for r in rows)[len(rows) // 2], max(r[2] for r in rows), 100 * inside, max(r[3] for r in rows)))
+    for k, e_hip, e_cpu, e_rel in rows:
+        assert e_hip <= 2 * e_cpu + 1e-4, (k, e_hip, e_cpu)
+        assert e_rel < 1e-2, (k, e_rel)
 
 
 def test_config3_full_size_bf16_train_step_tracks_cpu_oracle():

@@ -458,4 +458,7 @@ def test_attention_module_backward_matches_oracle_autograd():
     ps = dict(att.named_parameters())
     got = torch.autograd.grad(yg, [xg] + [ps[k[2:]] for k in names], dy.to(cuda))
     for n_, a, b in zip(["x"] + names, got, ref):
+        if n_ == "a.phi.bias":      # a key-side bias shifts every logit of a query equally: softmax cancels it, gradient == 0
+            assert float(a.abs().max()) < 1e-5 and float(b.abs().max()) < 1e-5
+            continue
         assert rel_l2(a.cpu(), b) < 1e-5, (n_, rel_l2(a.cpu(), b))
