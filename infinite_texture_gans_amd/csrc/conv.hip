@@ -921,8 +921,9 @@ constexpr int BKP = 16;  // pixels per pipeline stage (fp32 operands; 32 with bf
 //             gfx950 transposing LDS read (ds_read_b64_tr_b16: a 4-pixel x 16-column block arrives
 //             column-major, i.e. as the K-contiguous MFMA operand) and contracted 32 pixels at a time by
 //             v_mfma_f32_16x16x32_bf16 with fp32 accumulation.
-template <int BCOL, int BCO, int WCOL, int WCO, bool BF>
-__global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
+// DEPTH = pixel stages whose global loads are in flight while one stage is computed (1 or 2).
+template <int BCOL, int BCO, int WCOL, int WCO, bool BF, int DEPTH>
+__global__ __launch_bounds__(256, (DEPTH == 2 ? 3 : (BF ? 2 : 4))) void conv_tn_kernel(WgP p, int otp) {
   constexpr int FI = WCOL / 16, FJ = WCO / 16;
   constexpr int WAVES_COL = BCOL / WCOL;
   static_assert(WAVES_COL * (BCO / WCO) == 4, "4 waves per workgroup");
@@ -951,11 +952,22 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
   // Raw buffer loads: an offset equal to the buffer size reads zeros (padding, rows past M, columns past K).
   // The bias gradient sum_pixel dY[pixel][co] is accumulated on the side by the col_tile 0 workgroups from
   // the dY values they stage anyway (dbslab[split][co]).
+  //
+  // Gather addresses come from a per-stage offset table in LDS: otab[stage & 1][pixel row][slot], slot j < nt = byte
+  // offset of input pixel (pixel + tap tap_lo + j) incl. padding / validity, slot nt = byte offset of the dY pixel.
+  // One thread per (pixel row, slot) - spread over the four waves - tracks its pixel and does the clamp / patch-grid
+  // address arithmetic ONCE per stage; a load is then a ds_read + add instead of ~40 VALU per load and stage
+  // (the kernel issued 2.3 VALU per MFMA that way and kept the MFMA pipe 58 % busy).
   const __amdgpu_buffer_rsrc_t rxr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x.p, 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ryr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy.p, 0, p.dy_bytes, 0x00020000);
-  int xr[XL], xcol[XL], xky[XL], xkx[XL], xci[XL];
+  extern __shared__ unsigned otab[];                           // [DEPTH + 1][KP][otp], otp = taps of a column tile + 1
+  const int OTP = otp;
+  const int tap_lo = col0 / p.cin_ld;
+  const int col_hi = min(col0 + BCOL, p.Ktot) - 1;
+  const int nt = col_hi >= col0 ? min(col_hi / p.cin_ld, p.ntaps - 1) - tap_lo + 1 : 0;
+  int xr[XL], xcol[XL], xj[XL];
+  unsigned xcb[XL];
   bool xok[XL];
-  int xn[XL], xt[XL], xu[XL];
 #pragma unroll
   for (int i = 0; i < XL; ++i) {
     int idx = tid + i * 256;
@@ -964,15 +976,12 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
     xcol[i] = g * 4;
     int col = col0 + g * 4;
     int tap = col / p.cin_ld;
-    xci[i] = col - tap * p.cin_ld;
-    xky[i] = tap / p.kw;
-    xkx[i] = tap - xky[i] * p.kw;
+    xcb[i] = (unsigned)(col - tap * p.cin_ld) * 4u;
+    xj[i] = tap - tap_lo;
     xok[i] = (xr[i] < KP) && (col < p.Ktot);
-    int m = chunk_begin * KP + xr[i];
-    decode_m(m < p.M ? m : 0, p.MT, p.MU, xn[i], xt[i], xu[i]);
-    if (m >= p.M) xn[i] = p.x.n;  // marks invalid
   }
-  int yr[YL], yc[YL], yn[YL], yt[YL], yu[YL];
+  int yr[YL], yc[YL];
+  unsigned ycb[YL];
   bool yok[YL];
 #pragma unroll
   for (int i = 0; i < YL; ++i) {
@@ -980,41 +989,67 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
     yr[i] = idx / YG;
     int g = idx - yr[i] * YG;
     yc[i] = g * 4;
+    ycb[i] = (unsigned)(co0 + g * 4) * 4u;
     yok[i] = (yr[i] < KP) && (co0 + g * 4 < p.dy.ld);
-    int m = chunk_begin * KP + yr[i];
-    decode_m(m < p.M ? m : 0, p.MT, p.MU, yn[i], yt[i], yu[i]);
-    if (m >= p.M) yn[i] = p.x.n;
   }
-  auto advance = [&](int& n, int& t, int& u) {
-    u += KP;
-    while (u >= p.MU) { u -= p.MU; if (++t == p.MT) { t = 0; ++n; } }
+  // ---- offset producers: entry e = (pixel row e % KP, slot e / KP); lane l of wave w owns e = 4 l + w (+ 256 ...)
+  constexpr int PE = (KP * 17 + 255) / 256;                   // producer passes (entries e, e + 256, ...): <= 16 taps + dY
+  const int pe0 = lane * 4 + wave;
+  const int prow = pe0 % KP;                                  // 256 % KP == 0: every pass of a thread has the same pixel row
+  int pky[PE], pkx[PE];
+  bool pact[PE], pdy[PE];
+#pragma unroll
+  for (int i = 0; i < PE; ++i) {
+    int j = (pe0 + i * 256) / KP;
+    pact[i] = j <= nt;
+    pdy[i] = j == nt;
+    int tap = tap_lo + min(j, nt > 0 ? nt - 1 : 0);
+    pky[i] = tap / p.kw;
+    pkx[i] = tap - pky[i] * p.kw;
+  }
+  int pn, pt_, pu;
+  {
+    int m = chunk_begin * KP + prow;
+    decode_m(m < p.M ? m : 0, p.MT, p.MU, pn, pt_, pu);
+    if (m >= p.M) pn = p.x.n;      // marks invalid
+  }
+  auto produce = [&](int buf) {
+    const bool live = pn < p.x.n;
+#pragma unroll
+    for (int i = 0; i < PE; ++i) {
+      if (!pact[i]) continue;
+      unsigned o;
+      if (pdy[i]) {
+        o = live ? (unsigned)grid_off(p.dy, pn, pt_, pu) * 4u : p.dy_bytes;
+      } else {
+        int iy = pt_ * p.stride - p.pad_h + pky[i], ix = pu * p.stride - p.pad + pkx[i];
+        bool ok = live;
+        if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.x.H && (unsigned)ix < (unsigned)p.x.W;
+        iy = min(max(iy, 0), p.x.H - 1); ix = min(max(ix, 0), p.x.W - 1);
+        o = ok ? (unsigned)grid_off(p.x, live ? pn : 0, iy, ix) * 4u : p.x_bytes;
+      }
+      otab[(buf * KP + prow) * OTP + (pe0 + i * 256) / KP] = o;
+    }
+    pu += KP;
+    while (pu >= p.MU) { pu -= p.MU; if (++pt_ == p.MT) { pt_ = 0; ++pn; } }
   };
 
-  f32x4 rx[XL], ry[YL];
-  auto load_tiles = [&]() {
+  f32x4 rxs[DEPTH][XL], rys[DEPTH][YL];
+  auto load_tiles = [&](int slot, f32x4 (&rx)[XL], f32x4 (&ry)[YL]) {
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
-      const bool live = xn[i] < p.x.n;
-      int iy = xt[i] * p.stride - p.pad_h + xky[i], ix = xu[i] * p.stride - p.pad + xkx[i];
-      bool ok = xok[i] && live;
-      if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.x.H && (unsigned)ix < (unsigned)p.x.W;
-      iy = min(max(iy, 0), p.x.H - 1); ix = min(max(ix, 0), p.x.W - 1);
-      unsigned o = ((unsigned)grid_off(p.x, live ? xn[i] : 0, iy, ix) + (unsigned)xci[i]) * 4u;
-      f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxr, ok ? o : p.x_bytes, 0, 0));
-      rx[i] = v;
-      advance(xn[i], xt[i], xu[i]);
+      unsigned o = xok[i] ? otab[(slot * KP + xr[i]) * OTP + xj[i]] + xcb[i] : p.x_bytes;
+      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxr, o, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < YL; ++i) {
-      const bool live = yn[i] < p.x.n;
-      unsigned o = ((unsigned)grid_off(p.dy, live ? yn[i] : 0, live ? yt[i] : 0, live ? yu[i] : 0) + (unsigned)(co0 + yc[i])) * 4u;
-      ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ryr, (yok[i] && live) ? o : p.dy_bytes, 0, 0));
-      advance(yn[i], yt[i], yu[i]);
+      unsigned o = yok[i] ? otab[(slot * KP + yr[i]) * OTP + nt] + ycb[i] : p.dy_bytes;
+      ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ryr, o, 0, 0));
     }
   };
   f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
   const bool do_db = p.dbslab != nullptr && col_tile == 0;
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, const f32x4 (&rx)[XL], const f32x4 (&ry)[YL]) {
 #pragma unroll
     for (int i = 0; i < XL; ++i)
       if (xr[i] < KP) {
@@ -1038,59 +1073,95 @@ __global__ __launch_bounds__(256) void conv_tn_kernel(WgP p) {
     for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = chunk_end - chunk_begin;
-  if (nk > 0) {
-    load_tiles();
-    store_tiles(0);
-    __syncthreads();
-    const int fr = lane & 15, fkk = lane >> 4;
-    // transposing read: lane 4q+pp of 16-lane group g addresses pixel row 8g+q (then 8g+4+q), columns 4pp..4pp+3
-    const int trq = (lane & 15) >> 2, trp = lane & 3;
-    for (int kk = 0; kk < nk; ++kk) {
-      const int buf = kk & 1;
-      if (kk + 1 < nk) load_tiles();
+  const int fr = lane & 15, fkk = lane >> 4;
+  // transposing read: lane 4q+pp of 16-lane group g addresses pixel row 8g+q (then 8g+4+q), columns 4pp..4pp+3
+  const int trq = (lane & 15) >> 2, trp = lane & 3;
+  auto compute = [&](int buf) {
       if constexpr (BF) {
-        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        bf16x8 a[FI], b[FJ];
-        const unsigned short* xb = Xh + (buf * KP + 8 * fkk + trq) * LHX + wcol0 + 4 * trp;
-        const unsigned short* yb = Yh + (buf * KP + 8 * fkk + trq) * LHY + wco0 + 4 * trp;
+      typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+      bf16x8 a[FI], b[FJ];
+      const unsigned short* xb = Xh + (buf * KP + 8 * fkk + trq) * LHX + wcol0 + 4 * trp;
+      const unsigned short* yb = Yh + (buf * KP + 8 * fkk + trq) * LHY + wco0 + 4 * trp;
 #pragma unroll
-        for (int i = 0; i < FI; ++i) {
-          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 16 * i));
-          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 16 * i + 4 * LHX));
-          s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          a[i] = __builtin_bit_cast(bf16x8, v);
-        }
+      for (int i = 0; i < FI; ++i) {
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 16 * i));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 16 * i + 4 * LHX));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        a[i] = __builtin_bit_cast(bf16x8, v);
+      }
 #pragma unroll
-        for (int j = 0; j < FJ; ++j) {
-          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb + 16 * j));
-          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb + 16 * j + 4 * LHY));
-          s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          b[j] = __builtin_bit_cast(bf16x8, v);
-        }
+      for (int j = 0; j < FJ; ++j) {
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb + 16 * j));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb + 16 * j + 4 * LHY));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        b[j] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float a[FI], b[FJ];
+        const float* xrow = Xs + (buf * KP + 4 * s + fkk) * LDX + wcol0 + fr;
+        const float* yrow = Ys + (buf * KP + 4 * s + fkk) * LDY + wco0 + fr;
+#pragma unroll
+        for (int i = 0; i < FI; ++i) a[i] = xrow[16 * i];
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) b[j] = yrow[16 * j];
 #pragma unroll
         for (int i = 0; i < FI; ++i)
 #pragma unroll
           for (int j = 0; j < FJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          float a[FI], b[FJ];
-          const float* xrow = Xs + (buf * KP + 4 * s + fkk) * LDX + wcol0 + fr;
-          const float* yrow = Ys + (buf * KP + 4 * s + fkk) * LDY + wco0 + fr;
-#pragma unroll
-          for (int i = 0; i < FI; ++i) a[i] = xrow[16 * i];
-#pragma unroll
-          for (int j = 0; j < FJ; ++j) b[j] = yrow[16 * j];
-#pragma unroll
-          for (int i = 0; i < FI; ++i)
-#pragma unroll
-            for (int j = 0; j < FJ; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
-      if (kk + 1 < nk) store_tiles(buf ^ 1);
+    }
+  };
+  if (nk > 0) {
+    if constexpr (DEPTH == 1) {
+      produce(0);
+      if (nk > 1) produce(1);
       __syncthreads();
+      load_tiles(0, rxs[0], rys[0]);
+      store_tiles(0, rxs[0], rys[0]);
+      __syncthreads();
+      for (int kk = 0; kk < nk; ++kk) {
+        const int buf = kk & 1;
+        if (kk + 1 < nk) load_tiles(buf ^ 1, rxs[0], rys[0]);   // table of stage kk + 1: written one barrier ago
+        if (kk + 2 < nk) produce(buf);                           // stage kk + 2 -> the slot stage kk's loads have finished with
+        compute(buf);
+        if (kk + 1 < nk) store_tiles(buf ^ 1, rxs[0], rys[0]);
+        __syncthreads();
+      }
+    } else {
+      // two stages in flight: register set A holds stage kk + 2 while set B (stage kk + 1) drains into LDS; the offset
+      // table runs three stages ahead in a ring of three slots (slot of stage s = s % 3)
+      produce(0);
+      if (nk > 1) produce(1);
+      if (nk > 2) produce(2);
+      __syncthreads();
+      load_tiles(0, rxs[0], rys[0]);
+      if (nk > 1) load_tiles(1, rxs[DEPTH - 1], rys[DEPTH - 1]);
+      store_tiles(0, rxs[0], rys[0]);
+      __syncthreads();
+      int s0 = 0;                                                // kk % 3
+      for (int kk = 0; kk < nk; kk += 2) {
+        const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+        if (kk + 2 < nk) load_tiles(s2, rxs[0], rys[0]);
+        if (kk + 3 < nk) produce(s0);                            // stage kk + 3
+        compute(0);
+        if (kk + 1 < nk) store_tiles(1, rxs[DEPTH - 1], rys[DEPTH - 1]);
+        __syncthreads();
+        if (kk + 1 >= nk) break;
+        if (kk + 3 < nk) load_tiles(s0, rxs[DEPTH - 1], rys[DEPTH - 1]);
+        if (kk + 4 < nk) produce(s1);                            // stage kk + 4
+        compute(1);
+        if (kk + 2 < nk) store_tiles(0, rxs[0], rys[0]);
+        __syncthreads();
+        s0 = s2;                                                 // (kk + 2) % 3
+      }
     }
   }
   if (do_db) {   // deterministic reduction of the per-thread dY sums over the staged pixel rows
@@ -1387,8 +1458,21 @@ int launch_tn(WgP p, int splits, int prec, hipStream_t s) {
   dim3 grid((unsigned)(p.ncol_tiles * p.nco_tiles), 1, (unsigned)splits);
   snprintf(g_last_launch, sizeof(g_last_launch), "conv_tn_kernel<%d, %d, %d, %d, %s>", BCOL, BCO, WCOL, WCO,
            prec == ITG_PREC_BF16 ? "true" : "false");
-  if (prec == ITG_PREC_BF16) hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, true>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false>), grid, dim3(256), 0, s, p);
+  // offset-table pitch: the taps one column tile can touch (+ the dY slot)
+  int taps_tile = (BCOL + p.cin_ld - 1) / p.cin_ld + 1;
+  if (taps_tile > p.ntaps) taps_tile = p.ntaps;
+  const int otp = taps_tile + 1;
+  // long per-workgroup pixel loops run best with the occupancy of the single-prefetch variant (4 waves per SIMD), short
+  // ones with two stages in flight (measured on D's 256->512 layer vs its 64->128 / 128->256 layers)
+  static const int depth_env = env_int("ITG_TN_DEPTH", 0);
+  const int depth = depth_env ? depth_env : (p.chunks_per_split >= 128 ? 1 : 2);
+  const int kp = prec == ITG_PREC_BF16 ? 32 : BKP;
+  if (prec == ITG_PREC_BF16)
+    hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, true, 1>), grid, dim3(256), (size_t)2 * kp * otp * 4, s, p, otp);
+  else if (depth == 2)
+    hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 2>), grid, dim3(256), (size_t)3 * kp * otp * 4, s, p, otp);
+  else
+    hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 1>), grid, dim3(256), (size_t)2 * kp * otp * 4, s, p, otp);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }
