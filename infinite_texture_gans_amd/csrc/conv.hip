@@ -45,6 +45,7 @@ struct ConvP {
   int co_rows, nco_tiles;
   unsigned in_bytes, w_bytes;   // buffer-resource extents of the pixel operand / packed weights
   int use_tab;                  // per-row tap-offset table in LDS (narrow layers)
+  int xcd_remap;                // deal contiguous runs of tiles to each XCD (its L2 then sees 1/8 of the pixel tiles)
   int prec;                     // ITG_PREC_F32 | ITG_PREC_BF16
   float* partial;      // split-K slabs [ksplit][M][co_rows] (ksplit > 1)
   int ksplit, kchunks; // K chunks (of BK) per split
@@ -100,13 +101,26 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
   const int cioy = p.cioy[cls], ciox = p.ciox[cls], cooy = p.cooy[cls], coox = p.coox[cls];
   const float* const cw = p.w + p.cwoff[cls];
   float* const cpartial = p.partial + p.cpoff[cls];
-  if ((int)(blockIdx.x / p.nco_tiles) * BPIX >= cM) return;
+  // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share an L2): hand every XCD one contiguous run of
+  // tile ids instead, so that an L2 serves neighbouring pixel tiles (shared halo rows, all output-channel tiles of a
+  // pixel tile) and not a 1-in-8 sample of the whole image.  Bijective for any grid size; speed only.
+  int bx = blockIdx.x;
+  if (p.xcd_remap) {
+    const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = bx & 7;
+    bx = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bx >> 3);
+  }
+  if ((int)(bx / p.nco_tiles) * BPIX >= cM) return;
   constexpr int FI = WCO / 16, FJ = WPIX / 16;
   constexpr int WAVES_CO = BCO / WCO;
   static_assert(WAVES_CO * (BPIX / WPIX) == 4, "4 waves per workgroup");
   constexpr bool BF = TBK == 32;
   static_assert(TBK == 16 || TBK == 32, "fp32 stages hold 16 K elements, bf16 stages 32");
-  constexpr int LDT = 20;                    // LDS row pitch 20 floats (16-B aligned rows); pitch 24 is conflict-free but costs a workgroup of occupancy: measured slower
+  // LDS rows hold 16 dwords with NO padding; the four 16-byte K groups of a row are XOR-swizzled with bit 3 of the
+  // row index (group g of row r sits at slot g ^ 2*((r >> 3) & 1)), which makes every 16-lane group of a
+  // ds_read_b128 fragment read (rows r..r+15 of one K group pair, MI355X_MICROARCH.md LDS table) hit 64 distinct
+  // banks.  The padded pitch-20 layout this replaces was 2-way conflicted on every read (SQ_LDS_BANK_CONFLICT =
+  // 50 % of the LDS cycles) and 25 % larger.
+  constexpr int LDT = 16;
   constexpr int KG = TBK / 4;                // float4 groups per tile row
   constexpr int RPP = 256 / KG;              // tile rows covered per load pass
   constexpr int PL = (BPIX + RPP - 1) / RPP;         // the last pass may cover rows past the tile (96-pixel tiles)
@@ -118,14 +132,17 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int co_tile = blockIdx.x % p.nco_tiles;
-  const int pix_tile = blockIdx.x / p.nco_tiles;
+  const int co_tile = bx % p.nco_tiles;
+  const int pix_tile = bx / p.nco_tiles;
   const int co0 = co_tile * BCO;
   const int m0 = pix_tile * BPIX;
   const int wco0 = (wave % WAVES_CO) * WCO;
   const int wpix0 = (wave / WAVES_CO) * WPIX;
   const int kg = tid % KG;
   const int lrow = tid / KG;
+  // dword offset of this thread's K group inside its (swizzled) LDS row; RPP is a multiple of 16, so bit 3 of the row
+  // index is the same in every load pass.  bf16 stages: a thread holds half of a 16-byte group (kg & 1).
+  const int swz = BF ? (((kg >> 1) ^ (((lrow >> 3) & 1) << 1)) * 4 + (kg & 1) * 2) : ((kg ^ (((lrow >> 3) & 1) << 1)) * 4);
 
   // ---- loader state.  Both operands are fetched with raw buffer loads: a lane's byte offset is
   // (pixel offset + channel offset); rows that read padding / lie past M carry an offset equal to the
@@ -213,17 +230,17 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
 #pragma unroll
     for (int i = 0; i < PL; ++i) {
       if (BPIX % RPP != 0 && lrow + i * RPP >= BPIX) continue;
-      float* dst = Ps + (buf * BPIX + lrow + i * RPP) * LDT;
-      if constexpr (BF) *reinterpret_cast<uint2*>(dst + kg * 2) = pack_bf16x4(rp_[i]);
-      else *reinterpret_cast<f32x4*>(dst + kg * 4) = rp_[i];
+      float* dst = Ps + (buf * BPIX + lrow + i * RPP) * LDT + swz;
+      if constexpr (BF) *reinterpret_cast<uint2*>(dst) = pack_bf16x4(rp_[i]);
+      else *reinterpret_cast<f32x4*>(dst) = rp_[i];
     }
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
       int row = lrow + i * RPP;
       if (row < BCO) {
-        float* dst = Ws + (buf * BCO + row) * LDT;
-        if constexpr (BF) *reinterpret_cast<uint2*>(dst + kg * 2) = pack_bf16x4(rw_v[i]);
-        else *reinterpret_cast<f32x4*>(dst + kg * 4) = rw_v[i];
+        float* dst = Ws + (buf * BCO + row) * LDT + swz;
+        if constexpr (BF) *reinterpret_cast<uint2*>(dst) = pack_bf16x4(rw_v[i]);
+        else *reinterpret_cast<f32x4*>(dst) = rw_v[i];
       }
     }
   };
@@ -234,7 +251,7 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
 #pragma unroll
     for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int frow = lane & 15, fk = (lane >> 4) * 4;
+  const int frow = lane & 15, fk = ((lane >> 4) ^ (((lane >> 3) & 1) << 1)) * 4;   // swizzled slot of K group lane >> 4 in row frow
   auto compute = [&](int buf) {
     {
       f32x4 a[FI], b[FJ];
@@ -725,6 +742,8 @@ int launch_nt(const ConvP& p, int tbk, hipStream_t s) {
   dim3 grid((unsigned)blocks, (unsigned)(p.ncls > 1 ? p.ncls : 1), (unsigned)p.ksplit);
   size_t tab_bytes = (size_t)BPIX * (p.ntaps + 1) * sizeof(unsigned);
   q.use_tab = (p.cin_ld < 64 && tab_bytes <= 24 * 1024) ? 1 : 0;
+  static const int xcd = env_int("ITG_NT_XCD", 1);
+  q.xcd_remap = xcd;
   if (!q.use_tab) tab_bytes = 0;
   // two K stages in flight except for the medium fp32 tiles, whose 96-register budget has no room for
   // the second prefetch set (it would spill into scratch inside the K loop)
