@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libitg_hip.so")
+LIB_PATH = os.environ.get("ITG_LIB", os.path.join(_HERE, "libitg_hip.so"))   # ITG_LIB: A/B another build of the same ABI
 
 PAD_ZERO, PAD_REPLICATE = 0, 1
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2

@@ -471,7 +471,11 @@ __device__ __forceinline__ int round_up_d(int x, int m) { return (x + m - 1) / m
 constexpr int TT_H = 8, TT_W = 32;
 constexpr int TT_PIX = (TT_H + 2) * (TT_W + 2);
 
-__device__ __forceinline__ void store_out(const ConvP& p, int n, int oy, int ox, int co, f32x4 v) {
+// Epilogue of the persistent tile kernels.  Bias and 1/sigma are loaded ONCE per workgroup and the residual tile is
+// fetched BEFORE the next tile's prefetch is issued: an epilogue that loads anything would wait vmcnt(0) and with it
+// drain the prefetch that is meant to stay in flight across the tile boundary.
+__device__ __forceinline__ void store_out(const ConvP& p, int n, int oy, int ox, int co, f32x4 v, float osc, f32x4 biasv,
+                                          bool has_res, f32x4 r) {
   bool border = false;
   if (p.out_mode == 1) {
     int ty = min(max(oy, 0), p.out.H - 1), tx = min(max(ox, 0), p.out.W - 1);
@@ -479,14 +483,8 @@ __device__ __forceinline__ void store_out(const ConvP& p, int n, int oy, int ox,
     oy = ty; ox = tx;
   }
   const int off = grid_off(p.out, n, oy, ox);
-  if (p.scale) v *= *p.scale;
-  if (p.bias) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (co + e < p.out.c) v[e] += p.bias[co + e];
-  }
-  if (p.res.p) {
-    f32x4 r = *reinterpret_cast<const f32x4*>(p.res.p + grid_off(p.res, n, oy, ox) + co);
+  v = v * osc + biasv;
+  if (has_res) {
     if (p.res_mode == 0) v += r;
     else v *= act_deriv(r, p.res_mode, p.res_slope);
   }
@@ -519,7 +517,8 @@ __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(cons
   const int co_rows = 16 * FI;
   float* Wl = lds;
   int* koff = reinterpret_cast<int*>(lds + nch * co_rows * 20);
-  float* Xt = lds + nch * co_rows * 20 + ((nch * 4 + 3) & ~3);
+  float* biasl = lds + nch * co_rows * 20 + ((nch * 4 + 3) & ~3);       // [32] bias per output row (zero past out.c)
+  float* Xt = biasl + 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = p.cin_ld >> 2;
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in.p, 0, p.in_bytes, 0x00020000);
@@ -577,14 +576,37 @@ __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(cons
   int pbase[4];
 #pragma unroll
   for (int f = 0; f < 4; ++f) pbase[f] = ((2 * wave + (f >> 1)) * (TT_W + 2) + 16 * (f & 1) + fj) * cpt;
+  // per-workgroup constants of the epilogue
+  const float osc = p.scale ? *p.scale : 1.f;
+  if (tid < 32) biasl[tid] = (p.bias && tid < p.out.c) ? p.bias[tid] : 0.f;
+  const bool has_res = p.res.p != nullptr;
   int tile = blockIdx.x;
   if (tile < ntiles) load_tile(tile);
   __syncthreads();                                    // Wl / koff visible
   for (; tile < ntiles; tile += gridDim.x) {
     store_tile();
     __syncthreads();
+    constexpr bool PRE = FI == 1;                     // wider tiles have no registers to hold the residual across the MFMA phase
+    f32x4 resv[PRE ? FI : 1][4];
+    if (PRE && has_res) {                             // this tile's residual values, requested ahead of the prefetch
+      int b = tile;
+      const int tx_i = b % tiles_x; b /= tiles_x;
+      const int ty_i = b % tiles_y;
+      const int n = b / tiles_y;
+      const int t0 = ty_i * TT_H, u0 = tx_i * TT_W;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int t = min(t0 + 2 * wave + (f >> 1), p.MT - 1), u = min(u0 + 16 * (f & 1) + fj, p.MU - 1);
+        int oy = t * p.osy + p.ooy, ox = u * p.osx + p.oox;
+        if (p.out_mode == 1) { oy = min(max(oy, 0), p.out.H - 1); ox = min(max(ox, 0), p.out.W - 1); }
+        const float* rp = p.res.p + grid_off(p.res, n, oy, ox) + g * 4;
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+          resv[i][f] = (16 * i + g * 4 < p.res.ld) ? *reinterpret_cast<const f32x4*>(rp + 16 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
     const int next = tile + gridDim.x;
-    if (next < ntiles) load_tile(next);               // in flight during the MFMA phase
+    if (next < ntiles) load_tile(next);               // in flight during the MFMA phase AND the epilogue
     f32x4 acc[FI][4];
 #pragma unroll
     for (int i = 0; i < FI; ++i)
@@ -618,7 +640,17 @@ __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(cons
 #pragma unroll
       for (int i = 0; i < FI; ++i) {
         int co = 16 * i + g * 4;
-        if (co < p.out.ld) store_out(p, n, t * p.osy + p.ooy, u * p.osx + p.oox, co, acc[i][f]);
+        if (co >= p.out.ld) continue;
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (PRE) {
+          r = resv[i][f];
+        } else if (has_res) {
+          int oy = t * p.osy + p.ooy, ox = u * p.osx + p.oox;
+          if (p.out_mode == 1) { oy = min(max(oy, 0), p.out.H - 1); ox = min(max(ox, 0), p.out.W - 1); }
+          r = *reinterpret_cast<const f32x4*>(p.res.p + grid_off(p.res, n, oy, ox) + co);
+        }
+        store_out(p, n, t * p.osy + p.ooy, u * p.osx + p.oox, co, acc[i][f], osc, *reinterpret_cast<const f32x4*>(biasl + co),
+                  has_res, r);
       }
     }
     __syncthreads();                                  // every wave is done reading Xt
@@ -642,7 +674,7 @@ int try_conv_tile(const ConvP& p, hipStream_t s, int* rc) {
   const int FI = p.co_rows / 16;
   const int tiles_x = (p.MU + TT_W - 1) / TT_W, tiles_y = (p.MT + TT_H - 1) / TT_H;
   const int64_t ntiles = (int64_t)p.in.n * tiles_x * tiles_y;
-  const size_t lds = ((size_t)nch * 16 * FI * 20 + ((nch * 4 + 3) & ~3) + (size_t)TT_PIX * cpt) * sizeof(float);
+  const size_t lds = ((size_t)nch * 16 * FI * 20 + ((nch * 4 + 3) & ~3) + 32 + (size_t)TT_PIX * cpt) * sizeof(float);
   const int nld = (TT_PIX * (p.cin_ld >> 2) + 255) / 256;
   if (ntiles > 0x7fffffff || lds > 64 * 1024 || nld > 11) return 0;
   static bool attr_done = false;
@@ -1221,8 +1253,9 @@ __global__ __launch_bounds__(256, (DEPTH == 2 ? 3 : (BF ? 2 : 4))) void conv_tn_
 // against ALL 9 * cin_ld (tap, c) rows: per 4 pixels MF ds_read_b32 + 1 and MF MFMAs, no address arithmetic.
 // The 4 waves' accumulators are summed in a fixed order through LDS; one slab per workgroup, reduced by the
 // same two-stage reduction as the generic path.
-template <int MF, int NLD>
+template <int NJ, int NLD>
 __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgP p, int tiles_x, int tiles_y, int ntiles, int cpt) {
+  constexpr int MF = 4 * NJ;                               // 16-row MFMA tiles of the (tap, c) dimension
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CPD = 16;                                  // dY tile pitch (co_rows = 16)
   float* Xt = lds;                                         // [TT_PIX][cpt]
@@ -1290,15 +1323,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgP p, int til
     for (int i = 0; i < YLD; ++i)
       if (y_r[i] >= 0) { *reinterpret_cast<f32x4*>(Yt + y_lds[i]) = ry[i]; dbacc += ry[i]; }
   };
-  // per-lane row offsets: MFMA row m = 16 i + (lane & 15) is (tap, c) = divmod(m, cin_ld)
+  // MFMA rows.  A lane's ds_read_b128 of pixel (x + g) at (tap, channels 4 c4 .. 4 c4 + 3) feeds FOUR row tiles at
+  // once: row fr of tile 4 j + e is (tap, c = 4 c4 + e) with (tap, c4) = divmod(16 j + fr, cin_ld / 4) - a permutation
+  // of the (tap, c) rows that the epilogue undoes.  (One ds_read_b32 per MFMA before: the kernel was LDS-latency bound
+  // at a quarter of the MFMA rate.)
   const int fr = lane & 15, g = lane >> 4;
-  int moff[MF];
+  const int nq = 9 * q4;
+  int qoff[NJ];
 #pragma unroll
-  for (int i = 0; i < MF; ++i) {
-    int m = 16 * i + fr;
-    int tap = m / p.cin_ld, c = m - tap * p.cin_ld;
+  for (int j = 0; j < NJ; ++j) {
+    int q = min(16 * j + fr, nq - 1);                      // rows past the last (tap, c4) group: computed, never stored
+    int tap = q / q4, c4 = q - tap * q4;
     int ky = tap / 3, kx = tap - ky * 3;
-    moff[i] = tap < 9 ? (ky * (TT_W + 2) + kx) * cpt + c : 0;         // rows past 9 * cin_ld: never read back
+    qoff[j] = (ky * (TT_W + 2) + kx) * cpt + 4 * c4;
   }
   f32x4 acc[MF];
 #pragma unroll
@@ -1320,34 +1357,53 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgP p, int til
       for (int s4 = 0; s4 < TT_W / 4; ++s4) {
         const float bv = yrow[s4 * 4 * CPD];
         const float* xs = xrow + s4 * 4 * cpt;
+        f32x4 av[NJ];
 #pragma unroll
-        for (int i = 0; i < MF; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[moff[i]], bv, acc[i], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) av[j] = *reinterpret_cast<const f32x4*>(xs + qoff[j]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[4 * j + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][e], bv, acc[4 * j + e], 0, 0, 0);
       }
     }
     __syncthreads();
   }
-  // ---- sum the 4 waves' accumulators in wave order through LDS: R[m][16]
+  // ---- sum the 4 waves' accumulators in wave order through LDS: R[m = tap * cin_ld + c][16]
   float* R = lds;
+  int rrow[NJ][4];                                         // R row of D row 4 g + e of the tiles 4 j .. 4 j + 3 (their c differs by the tile)
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int q = 16 * j + 4 * g + e;
+      int tap = q / q4, c4 = q - tap * q4;
+      rrow[j][e] = q < nq ? tap * p.cin_ld + 4 * c4 : -1;
+    }
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
 #pragma unroll
-      for (int i = 0; i < MF; ++i)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float* dst = R + (16 * i + 4 * g + e) * 16 + fr;
-          *dst = (w == 0 ? 0.f : *dst) + acc[i][e];
-        }
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (rrow[j][e] < 0) continue;
+            float* dst = R + (rrow[j][e] + t) * 16 + fr;
+            *dst = (w == 0 ? 0.f : *dst) + acc[4 * j + t][e];
+          }
     }
     __syncthreads();
   }
   float* slab = p.slab + (size_t)blockIdx.x * p.co_rows * p.Kpad;
+  const int mrows = 9 * p.cin_ld;
   for (int idx = tid; idx < p.co_rows * p.Kpad; idx += 256) {
     int co = idx / p.Kpad, m = idx - co * p.Kpad;
-    slab[idx] = m < MF * 16 ? R[m * 16 + co] : 0.f;
+    slab[idx] = m < mrows ? R[m * 16 + co] : 0.f;
   }
   if (p.dbslab) {       // bias gradient: per-thread sums of the staged dY rows -> fixed-order sum per channel
     __syncthreads();
-    f32x4* red = reinterpret_cast<f32x4*>(lds) + (MF * 16 * 16 + 3) / 4;
+    f32x4* red = reinterpret_cast<f32x4*>(lds) + (9 * 32 * 16 + 3) / 4;
     red[tid] = dbacc;
     __syncthreads();
     if (tid < 16) {
@@ -1370,9 +1426,9 @@ TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_
   if (g->precision == ITG_PREC_BF16 || x->ld > 32 || dy->ld > 16 || (dy->ld != 4 && dy->ld != 8 && dy->ld != 16)) return t;
   const int H = dy->gh * dy->ph, W = dy->gw * dy->pw;
   if ((int64_t)H * W < 64 * 64) return t;
-  const int M = 9 * x->ld;
-  t.mf = M <= 48 ? 3 : M <= 144 ? 9 : M <= 256 ? 16 : 18;
-  if (t.mf * 16 < M) return t;
+  const int nq = 9 * (x->ld >> 2);                       // (tap, 4-channel group) rows; 16 per group of 4 MFMA tiles
+  t.mf = (nq + 15) / 16;                                  // NJ
+  if (t.mf > 5) return t;
   t.nld = (TT_PIX * (x->ld >> 2) + 255) / 256;
   t.nld = t.nld <= 6 ? 6 : 11;
   if ((TT_PIX * (x->ld >> 2) + 255) / 256 > 11) return t;
@@ -1380,11 +1436,11 @@ TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_
   t.tiles_x = (W + TT_W - 1) / TT_W; t.tiles_y = (H + TT_H - 1) / TT_H;
   t.ntiles = (int64_t)dy->n * t.tiles_x * t.tiles_y;
   size_t fl = (size_t)TT_PIX * t.cpt + (size_t)TT_H * TT_W * 16;
-  size_t red = (size_t)t.mf * 16 * 16 + 4 + 256 * 4;            // reduction buffer + bias partials reuse the tiles' space
+  size_t red = (size_t)9 * 32 * 16 + 4 + 256 * 4;               // reduction buffer + bias partials reuse the tiles' space
   if (red > fl) fl = red;
   t.lds = fl * sizeof(float);
   if (t.lds > 64 * 1024 || t.ntiles > 0x7fffffff) return t;
-  static const int wtile_cu = env_int("ITG_WTILE_CU", 1);
+  static const int wtile_cu = env_int("ITG_WTILE_CU", 2);
   int per_cu = (int)((160 * 1024) / t.lds);
   if (per_cu > wtile_cu) per_cu = wtile_cu;
   int64_t want = 256 * (int64_t)(per_cu < 1 ? 1 : per_cu);
@@ -1393,15 +1449,15 @@ TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_
   return t;
 }
 
-template <int MF, int NLD>
+template <int NJ, int NLD>
 void launch_wgrad_tile(const WgP& p, const TileWgPlan& t, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<MF, NLD>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<NJ, NLD>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     attr_done = true;
   }
-  snprintf(g_last_launch, sizeof(g_last_launch), "wgrad_tile_kernel<%d, %d>", MF, NLD);
-  hipLaunchKernelGGL((wgrad_tile_kernel<MF, NLD>), dim3((unsigned)t.blocks), dim3(256), t.lds, s, p, t.tiles_x, t.tiles_y,
+  snprintf(g_last_launch, sizeof(g_last_launch), "wgrad_tile_kernel<%d, %d>", NJ, NLD);
+  hipLaunchKernelGGL((wgrad_tile_kernel<NJ, NLD>), dim3((unsigned)t.blocks), dim3(256), t.lds, s, p, t.tiles_x, t.tiles_y,
                      (int)t.ntiles, t.cpt);
 }
 
@@ -2001,10 +2057,13 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
             t.Kpad, t.bcol, t.bco, t.splits, t.ngroups, tw.ok);
   if (tw.ok) {
     rc = ITG_OK;
-    if (tw.mf == 3) launch_wgrad_tile<3, 6>(p, tw, s);
-    else if (tw.mf == 9) launch_wgrad_tile<9, 6>(p, tw, s);
-    else if (tw.mf == 16) launch_wgrad_tile<16, 11>(p, tw, s);
-    else launch_wgrad_tile<18, 11>(p, tw, s);
+    const bool small = tw.nld <= 6;
+    if (tw.mf == 1) launch_wgrad_tile<1, 6>(p, tw, s);
+    else if (tw.mf == 2) launch_wgrad_tile<2, 6>(p, tw, s);
+    else if (tw.mf == 3 && small) launch_wgrad_tile<3, 6>(p, tw, s);
+    else if (tw.mf == 3) launch_wgrad_tile<3, 11>(p, tw, s);
+    else if (tw.mf == 4) launch_wgrad_tile<4, 11>(p, tw, s);
+    else launch_wgrad_tile<5, 11>(p, tw, s);
     ITG_CHECK_LAUNCH();
   } else if (t.bcol == 64) rc = launch_tn<64, 64, 32, 32>(p, t.splits, prec, s);
   else if (t.bco == 16) rc = launch_tn<256, 16, 64, 16>(p, t.splits, prec, s);

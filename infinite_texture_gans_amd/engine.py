@@ -140,7 +140,7 @@ class Trainer:
         # queue behind the kernels of the side streams (one-rank RCCL rehearsal: 12.07 ms with vs 12.13 ms without
         # overlap, against 10.86 ms without the collectives).  The two gradient all-reduces come after the joins.
         self.overlap = os.environ.get("ITG_OVERLAP", "0" if self.sync_bn else "1") == "1"
-        self.side, self._wstream, self.wstream = None, None, None
+        self.side, self._wstream, self.wstream, self.sc_stream = None, None, None, None
         # D(real)'s weight gradients may leave their branch stream for the weight-gradient streams (a fork of a fork)
         self.nested_fork = os.environ.get("ITG_NESTED_FORK", "1") == "1"
         self.nested_fork_in_capture = os.environ.get("ITG_NESTED_FORK_CAPTURE", "0") == "1"
@@ -151,6 +151,8 @@ class Trainer:
         self.overlap = bool(on)
         if on and self.side is None:
             self.side = torch.cuda.Stream(device=self.device)
+            self.sc_stream = (torch.cuda.Stream(device=self.device)
+                              if os.environ.get("ITG_SC_STREAM", "1") == "1" else None)
         if on and getattr(self, "_wstream", None) is None:
             nws = int(os.environ.get("ITG_WGRAD_STREAMS", "2"))
             self._wstream = [torch.cuda.Stream(device=self.device) for _ in range(max(1, nws))]
@@ -202,6 +204,7 @@ class Trainer:
         self.arena.reset()                                      # BatchNorm statistics scratch of this iteration
         ops.ARENA = self.arena
         ops.WGRAD_STREAM = self.wstream
+        ops.SHORTCUT_STREAM = self.sc_stream if self.overlap else None
         try:
             zs = list(z) if isinstance(z, (list, tuple)) else [z]
             ms = list(maps) if isinstance(z, (list, tuple)) else [maps]
@@ -214,6 +217,7 @@ class Trainer:
         finally:                                                # never leave the process-wide hooks set behind an exception
             ops.ARENA = None
             ops.WGRAD_STREAM = None
+            ops.SHORTCUT_STREAM = None
             if self.wstream is not None and not torch.cuda.is_current_stream_capturing():
                 ops.WGRAD_KEEPALIVE.clear()
 

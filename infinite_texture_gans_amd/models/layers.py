@@ -468,6 +468,17 @@ class ResBlockGenerator(nn.Module):
             if upsample_input:
                 x = ops.upsample2x(x)
                 upsample_input = False
+        # The learnable 1x1 shortcut depends only on the block input: inside a Trainer step it runs on its own HIP stream
+        # beside bn1 -> conv1 -> bn2 (small latency-bound launches on both sides); autograd runs its backward there too.
+        side = ops.SHORTCUT_STREAM
+        forked = (self.learnable_sc and side is not None and self.type_norm == "BN" and x.t.is_cuda
+                  and not torch.cuda.is_current_stream_capturing())
+        if forked:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                sc = self._shortcut(x, map, upsample_input)
+        if self.type_norm == "SSM":
             out = self.bn1.run(x, map, act=A, slope=s)
         else:
             out = self.bn1.run(x, act=A, slope=s, upsample=upsample_input)
@@ -476,16 +487,21 @@ class ResBlockGenerator(nn.Module):
             out = self.bn2.run(out, map, act=A, slope=s)
         else:
             out = self.bn2.run(out, act=A, slope=s)
-        if self.learnable_sc:
-            sc = x
-            if self.type_norm == "SSM":
-                sc = self.bn3.run(sc, map)
-            sc = self.conv3.run(sc)
-            if upsample_input:
-                sc = ops.upsample2x(sc)
+        if forked:
+            main.wait_stream(side)
+            sc.t.record_stream(main)                 # allocated on the side stream, read by conv2's epilogue on this one
+        elif self.learnable_sc:
+            sc = self._shortcut(x, map, upsample_input)
         else:
             sc = ops.upsample2x(x) if upsample_input else x
         return self.conv2.forward_grid(out, image_location, residual=sc)
+
+    def _shortcut(self, x, map, upsample_input):
+        sc = x
+        if self.type_norm == "SSM":
+            sc = self.bn3.run(sc, map)
+        sc = self.conv3.run(sc)
+        return ops.upsample2x(sc) if upsample_input else sc
 
     def forward(self, x, map=None, image_location="1st_row_1st_col"):
         if isinstance(x, GT):

@@ -377,6 +377,7 @@ from .dist import SyncGroup, _active  # noqa: E402,F401  (sync-BN statistics exc
 # Side stream for weight-gradient kernels (set by engine.Trainer for the duration of a step).  The power
 # iteration of a spectrally normalised layer rewrites u / v in place, which a still-running weight-gradient of
 # the previous pass reads: sn_power_iter* therefore waits for this stream first.
+SHORTCUT_STREAM = None       # stream of the generator blocks' 1x1 shortcut branch (set by engine.Trainer for a step), or None
 WGRAD_STREAM = None          # one stream or a list of streams used round-robin (consecutive layers overlap each other too)
 WGRAD_KEEPALIVE = []
 _wgrad_rr = [0]

@@ -74,13 +74,14 @@ def main():
         flops = 2.0 * npix * co * ci * k * k
         dy = torch.randn_like(y.t)
         t_f = timeit(lambda: ops.conv(ops.GT(x.detach(), ci), w.detach(), b, k, k, s, pad, pm, out_grid=og))
-        # dgrad only / wgrad only: (forward + backward) recorded together, forward time subtracted
+        # dgrad only / wgrad only: (bias-free forward + backward) recorded together, the bias-free forward's time subtracted
+        t_f0 = timeit(lambda: ops.conv(ops.GT(x.detach(), ci), w.detach(), None, k, k, s, pad, pm, out_grid=og))
         xg = x.detach().requires_grad_(True)
         t_d = timeit(lambda: torch.autograd.grad(
-            ops.conv(ops.GT(xg, ci), w.detach(), None, k, k, s, pad, pm, out_grid=og).t, xg, dy)) - t_f
+            ops.conv(ops.GT(xg, ci), w.detach(), None, k, k, s, pad, pm, out_grid=og).t, xg, dy)) - t_f0
         wg = w.detach().requires_grad_(True)
         t_w = timeit(lambda: torch.autograd.grad(
-            ops.conv(ops.GT(x.detach(), ci), wg, None, k, k, s, pad, pm, out_grid=og).t, wg, dy)) - t_f
+            ops.conv(ops.GT(x.detach(), ci), wg, None, k, k, s, pad, pm, out_grid=og).t, wg, dy)) - t_f0
         tot[0] += t_f; tot[1] += t_d; tot[2] += t_w
         print("%-24s %7.2f GF | fwd %7.1f us %6.1f TF | dgrad %7.1f us %6.1f TF | wgrad %7.1f us %6.1f TF" % (
             name, flops / 1e9, t_f * 1e6, flops / t_f / 1e12, t_d * 1e6, flops / t_d / 1e12, t_w * 1e6,
