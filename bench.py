@@ -154,7 +154,10 @@ def gpu_leg(a):
                                "frac_of_peak": round(sum(x[1] for x in agg.values()) / tot_sec / 1e12 / peak_tf, 4)},
                 "conv_time_share": {k: round(v[2] / tot_sec, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:8]},
                 "step_necessary_gflop": round(nec_gf, 1),
-                "step_frac_of_mfma_peak": round(nec_gf * 1e9 / (dt / a.steps) / 1e12 / peak_tf, 4)}
+                "step_frac_of_mfma_peak": round(nec_gf * 1e9 / (dt / a.steps) / 1e12 / peak_tf, 4),
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, committed under profiles/ "
+                                  "(counters cannot be read from inside the timed process)",
+                "membound": membound_leg(dev)}
     if world > 1:
         dist.barrier()
     return rank, world, dt, args, losses, roof
@@ -195,35 +198,106 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("ITG_CPU_THREADS", 16))))
 
 
-def cpu_leg():
-    """The oracle (CPU restatement of the reference path) timed on the host cores: one full train
-    step at the same config with the vectorised LocalPadder ('port')."""
-    from oracle import nets, step as ostep
+def cpu_leg(workload="config1"):
+    """The oracle (CPU restatement of the reference path) timed on the host cores: full train steps at the same
+    config with the vectorised LocalPadder ('port'), plus - config 1 - ONE step with the reference-faithful Python-loop
+    LocalPadder / merge / crop ('port-loops': what the reference's own CPU path spends ~60 % of its time in,
+    SURVEY.md F6 / BASELINE.md section 4)."""
+    from oracle import step as ostep
     from oracle.nets import GCfg, DCfg
     from infinite_texture_gans_amd import utils as U
     ncores = host_cores()
     torch.set_num_threads(ncores)
-    args = U.prepare_parser().parse_args(FLAGS)
+    cfg3, band = workload == "config3", workload == "config4"
+    flags = [f for f in FLAGS3 if f != "--bf16"] if cfg3 else FLAGS + (["--num_patches_height", "4", "--num_patches_width", "4"] if band else [])
+    args = U.prepare_parser().parse_args(flags)
     torch.manual_seed(1234)
     netG, netD = U.prepare_models(args, "cpu")          # parameter containers only (no forward on CPU)
     gsd = ostep.as_leaf_params({k: v.clone() for k, v in netG.state_dict().items()})
     dsd = ostep.as_leaf_params({k: v.clone() for k, v in netD.state_dict().items()})
-    gcfg = GCfg(z_dim=128, G_ch=52, base_res=4, n_layers_G=6, attention=False, leak=0.02, type_norm="BN")
+    gcfg = GCfg(z_dim=128, G_ch=52, base_res=4, n_layers_G=args.n_layers_G, attention=args.attention, leak=0.02, type_norm="BN",
+                num_patches_h=args.num_patches_height, num_patches_w=args.num_patches_width)
     dcfg = DCfg(img_ch=3, base_ch=64, n_layers_D=4, SN=True)
     optD = ostep.Adam([dsd[k] for k in ostep.trainable(dsd)])
     optG = ostep.Adam([gsd[k] for k in ostep.trainable(gsd)])
     g = torch.Generator().manual_seed(7)
-    real = torch.rand(8, 3, 192, 192, generator=g) * 2 - 1
-    z = torch.randn(8, 128, 14, 14, generator=g)
+    crop = args.random_crop
+    zs = args.num_patches_height * 4 + 2
+    real = torch.rand(8, 3, crop, crop, generator=g) * 2 - 1
+    z = torch.randn(8, 128, zs, zs, generator=g)
     ostep.train_step(gsd, dsd, gcfg, dcfg, optG, optD, real, z, None, smooth=True)      # warm-up (thread pools, oneDNN)
     nsteps, t0 = 0, time.perf_counter()
     while nsteps < 3 or (time.perf_counter() - t0 < 10.0 and nsteps < 8):
         ostep.train_step(gsd, dsd, gcfg, dcfg, optG, optD, real, z, None, smooth=True)
         nsteps += 1
     dt = (time.perf_counter() - t0) / nsteps
-    return {"value": round(8.0 / dt, 4), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d full G+D train steps after 1 warm-up, batch 8 / 8 images (72 G-patches), vectorised "
-                      "LocalPadder, torch-CPU fp32 (%.2f s/step)" % (nsteps, dt)}
+    out = {"value": round(8.0 / dt, 4), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
+           "cpu_model": cpu_model(),
+           "sample": "%d full G+D train steps of %s after 1 warm-up, batch 8 / 8 images (%d G-patches), vectorised "
+                     "LocalPadder, torch-CPU fp32 (%.2f s/step)" % (nsteps, workload, 8 * args.num_patches_height ** 2, dt)}
+    if workload == "config1":
+        t0 = time.perf_counter()
+        ostep.train_step(gsd, dsd, gcfg, dcfg, optG, optD, real, z, None, smooth=True, loops=True)
+        dl = time.perf_counter() - t0
+        out["loops"] = {"value": round(8.0 / dl, 4), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port-loops",
+                        "sample": "1 full G+D train step with the reference-faithful per-patch torch.cat / slice loops of "
+                                  "LocalPadder, merge_patches_into_image and crop_images (%.2f s/step)" % dl}
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def membound_leg(dev):
+    """Achieved HBM GB/s (algorithmic bytes / HIP-event time, SURVEY.md section 8d's byte counts) of the memory-bound
+    operators of the generator at config-1 tensor sizes, standalone launches: LocalPadder (NHWC operator), BatchNorm
+    train forward (+LeakyReLU) and backward, LeakyReLU, nearest x2 upsample.  -> list for roofline["membound"]."""
+    from infinite_texture_gans_amd import ops
+    rows = []
+
+    def timeit(fn, iters=10):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e-3
+
+    def row(name, nbytes, t):
+        rows.append({"op": name, "mbytes": round(nbytes / 1e6, 1), "us": round(t * 1e6, 1), "gbps": round(nbytes / t / 1e9, 1),
+                     "frac_of_8tbps": round(nbytes / t / 8e12, 3)})
+
+    for c, p in ((26, 128), (104, 32)):
+        g = ops.GT(torch.randn(8, 3, 3, p, p, ops.ld_for(c), device=dev), c)
+        row("LocalPadder halo gather C=%d P=%d" % (c, p), 4 * 72 * g.ld * (p * p + (p + 2) ** 2),
+            timeit(lambda: ops.local_pad_grid(g, ops.PAD_REPLICATE)))
+    c, p = 13, 128
+    xg = ops.GT(torch.randn(8, 3, 3, p, p, ops.ld_for(c), device=dev), c)
+    numel = xg.t.numel()
+    gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+    rm, rv, nbt = torch.zeros(c, device=dev), torch.ones(c, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
+    row("BatchNorm train fwd + LeakyReLU C=13 P=128", 4 * numel * 3,
+        timeit(lambda: ops.bn_act(xg, gamma, beta, rm, rv, nbt, True, 1e-5, 0.1, ops.ACT_LRELU, 0.02, False)))
+    xr = ops.GT(xg.t.clone().requires_grad_(True), c)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = ops.bn_act(xr, gr, br, rm, rv, nbt, True, 1e-5, 0.1, ops.ACT_LRELU, 0.02, False)
+    dy = torch.randn_like(y.t)
+    row("BatchNorm train bwd C=13 P=128", 4 * numel * 5,
+        timeit(lambda: torch.autograd.grad(y.t, (xr.t, gr, br), dy, retain_graph=True)))
+    row("LeakyReLU C=13 P=128", 8 * numel, timeit(lambda: ops.act(xg, ops.ACT_LRELU, 0.2)))
+    xs = ops.GT(torch.randn(8, 3, 3, 64, 64, 28, device=dev), 26)
+    row("nearest x2 upsample C=26 P=64", 4 * xs.t.numel() * 5, timeit(lambda: ops.upsample2x(xs)))
+    return rows
 
 
 def relaunch(n):
@@ -266,6 +340,7 @@ def main():
     if rank != 0:
         return
     ms = dt / a.steps * 1e3
+    ranks = {"ranks": world, "backend": os.environ.get("ITG_DIST_BACKEND", "nccl (RCCL)") if world > 1 else "none"}
     if a.workload == "config3":
         out = {"metric": "G+D train-step real 128x128x3 crops/sec (batch 8 per GPU, bf16 MFMA path)",
                "value": round(args.batch_size * world * a.steps / dt, 3), "unit": "crops/s", "n_gpus": world, "steps": a.steps,
@@ -279,6 +354,9 @@ def main():
                           world, "all-reduced" if os.environ.get("ITG_SYNC_BN", "0") == "1" else "per-rank"), "last_losses": losses,
                           "launch": "hipGraph replay" if graph_mode() else "eager"},
                "roofline": roof}
+        out["config"].update(ranks)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_leg("config3")
         print(json.dumps(out), flush=True)
         return
     if a.workload == "config4":
@@ -294,6 +372,9 @@ def main():
                           "last_losses": losses,
                           "launch": "hipGraph replay" if graph_mode() else "eager"},
                "roofline": roof}
+        out["config"].update(ranks)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_leg("config4")
         print(json.dumps(out), flush=True)
         return
     out = {"metric": "G+D train-step real 192x192x3 crops/sec (batch 8 per GPU)", "value": round(args.batch_size * world * a.steps / dt, 3),
@@ -307,8 +388,9 @@ def main():
                           world, "all-reduced" if os.environ.get("ITG_SYNC_BN", "0") == "1" else "per-rank"), "last_losses": losses,
                       "launch": "hipGraph replay" if graph_mode() else "eager"},
            "roofline": roof}
+    out["config"].update(ranks)
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_leg()
+        out["cpu_baseline"] = cpu_leg("config1")
     print(json.dumps(out), flush=True)
 
 

@@ -141,9 +141,10 @@ class Trainer:
         # overlap, against 10.86 ms without the collectives).  The two gradient all-reduces come after the joins.
         self.overlap = os.environ.get("ITG_OVERLAP", "0" if self.sync_bn else "1") == "1"
         self.side, self._wstream, self.wstream, self.sc_stream = None, None, None, None
-        # D(real)'s weight gradients may leave their branch stream for the weight-gradient streams (a fork of a fork)
+        # D(real)'s weight gradients may leave their branch stream for the weight-gradient streams (a fork of a fork;
+        # also under hipGraph capture - what used to crash there was a wait for an idle forked stream, see
+        # ops.wgrad_streams_join)
         self.nested_fork = os.environ.get("ITG_NESTED_FORK", "1") == "1"
-        self.nested_fork_in_capture = os.environ.get("ITG_NESTED_FORK_CAPTURE", "0") == "1"
         self.set_overlap(self.overlap)
 
     def set_overlap(self, on):
@@ -225,7 +226,10 @@ class Trainer:
         """One discriminator update (reference train.py:126-153): D(real) fwd+bwd, G forward (graph kept for the
         generator update), D(fake.detach()) fwd+bwd, Adam(D).  -> (d_loss_real, d_loss_fake, fake)."""
         netG, netD = self.netG, self.netD
-        if self.wstream is not None:
+        if self.wstream is not None and not torch.cuda.is_current_stream_capturing():
+            # not needed for ordering (every fork waits for a fresh event) but measured worth 4-7 % of the eager step:
+            # it keeps the weight-gradient queues from running ahead into the next step's allocations.  Never under
+            # capture: an idle forked stream that something later waits for is the EndCapture crash (ops.wgrad_streams_join)
             for ws in self.wstream:
                 ws.wait_stream(torch.cuda.current_stream())
         self.flatD.zero_grad()
@@ -235,7 +239,7 @@ class Trainer:
             main = torch.cuda.current_stream()
             self.side.wait_stream(main)
             keep = ops.WGRAD_STREAM
-            if not self.nested_fork or (torch.cuda.is_current_stream_capturing() and not self.nested_fork_in_capture):
+            if not self.nested_fork:
                 ops.WGRAD_STREAM = None                        # D(real)'s weight gradients stay on the branch stream
             with torch.cuda.stream(self.side):
                 d_real = self._d_loss(self._d_real_logits(real_x), True)
@@ -276,10 +280,9 @@ class Trainer:
         return g_loss.detach()
 
     def _join(self):
-        """The weight-gradient stream has to drain before gradients are exchanged / consumed by Adam."""
+        """The weight-gradient streams have to drain before gradients are exchanged / consumed by Adam."""
         if self.wstream is not None:
-            for ws in self.wstream:
-                torch.cuda.current_stream().wait_stream(ws)
+            ops.wgrad_streams_join()
             ops.WGRAD_KEEPALIVE.clear()
 
     # ---- hipGraph: the whole iteration (~600 launches) as one graph replay

@@ -324,6 +324,8 @@ class _Conv(torch.autograd.Function):
                 # memory to a later main-stream kernel while the weight-gradient still reads it
                 WGRAD_KEEPALIVE.append((x, dy, inv_sigma))
                 side.wait_event(ev)
+                if side not in _wgrad_dirty:
+                    _wgrad_dirty.append(side)
             with (torch.cuda.stream(side) if side is not None else _NullCtx()):
                 st = _stream()
                 dxd = _desc(x, ci)
@@ -403,14 +405,23 @@ def wgrad_stream_for(sink_key):
     return w
 
 
+_wgrad_dirty = []          # weight-gradient streams that carry forked work nobody has waited for yet
+
+
 def wgrad_streams_join():
-    """The current stream waits for every weight-gradient stream."""
-    w = WGRAD_STREAM
-    if w is None:
+    """The current stream waits for every weight-gradient stream that carries un-joined work (and only for those).
+
+    Waiting for an IDLE forked stream is not just useless: under hipGraph capture it is what crashed
+    hipStreamEndCapture on ROCm 7.2 (tools/capture_nested_fork.py: a stream that entered the capture by waiting for the
+    origin and holds no node yet, waited for by a second forked stream which then forks kernels back onto it -
+    reproducible with plain torch ops).  A stream is therefore only ever waited for after work was forked onto it, and
+    it enters a capture only through the event of the kernel that forks onto it."""
+    if not _wgrad_dirty:
         return
     cur = torch.cuda.current_stream()
-    for s_ in (w if isinstance(w, (list, tuple)) else (w,)):
+    for s_ in _wgrad_dirty:
         cur.wait_stream(s_)
+    del _wgrad_dirty[:]
 
 
 class _NullCtx:

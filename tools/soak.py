@@ -1,8 +1,18 @@
 #!/usr/bin/env python3
-"""Soak test: N graph-replayed train steps of config 1 on synthetic data; losses must stay finite and the
-graph-replayed run must track an eager run of the same seeds (usage: python tools/soak.py [steps])."""
+"""Soak test of the config-1 train step on synthetic data (usage, GPU box: python tools/soak.py [seconds]).
+
+Asserts exactly this:
+  1. sustained throughput: eager (stream-overlapped) steps run back to back for >= `seconds` (default 6 s, ~600 steps);
+     crops/s is reported per 1-second window and the slowest window must reach >= 90 % of the fastest one (no thermal /
+     clock / allocator drift over seconds - the driver's 20-step bench only sees 0.2 s);
+  2. every loss of the run is finite;
+  3. a hipGraph-replayed run tracks an eager run of the same seeds over the first 10 steps (losses within 1e-3
+     relative).  Beyond a few dozen steps the two runs diverge like any two arithmetic orders of a GAN do (the
+     mathematically-zero bias gradients are rounding noise that Adam(beta1=0) turns into +-lr steps), so
+     nothing is claimed there."""
 import os
 import sys
+import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
@@ -10,38 +20,65 @@ import bench  # noqa: E402
 from infinite_texture_gans_amd import utils as U  # noqa: E402
 from infinite_texture_gans_amd.engine import Trainer  # noqa: E402
 
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 6.0
 dev = torch.device("cuda")
 args = U.prepare_parser().parse_args(bench.FLAGS)
 args.beta1 = float(args.beta1)
 
 
-def run(graph):
+def make():
     torch.manual_seed(3)
     G, D = U.prepare_models(args, dev)
     G.train(), D.train()
-    tr = Trainer(G, D, args, dev)
-    g = torch.Generator().manual_seed(5)
-    tex = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
-    out = []
+    return Trainer(G, D, args, dev), torch.Generator().manual_seed(5)
+
+
+def batch(g):
+    real = (torch.rand(8, 3, 192, 192, generator=g) * 2 - 1).to(dev)
+    z = torch.randn(8, 128, 14, 14, generator=g).to(dev)
+    return real, z
+
+
+# ---- 1 + 2: sustained eager throughput
+tr, g = make()
+pool = [batch(g) for _ in range(16)]
+for i in range(5):
+    tr.step(*pool[i])
+torch.cuda.synchronize()
+losses = []
+blocks = []
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+t_prev = t0
+while time.perf_counter() - t0 < seconds:
+    for i in range(25):
+        l = tr.step(*pool[i % 16])
+    losses.append(l)
+    torch.cuda.synchronize()
+    now = time.perf_counter()
+    blocks.append(8 * 25 / (now - t_prev))
+    t_prev = now
+vals = [float(v) for l_ in losses for v in l_]
+assert all(v == v and abs(v) < 1e3 for v in vals), "non-finite loss"
+# 1-second windows = means over consecutive blocks
+per_win = max(1, int(round(len(blocks) / seconds)))
+wins = [sum(blocks[i:i + per_win]) / len(blocks[i:i + per_win]) for i in range(0, len(blocks), per_win)]
+print("sustained: %d steps in %.1f s, crops/s per ~1 s window: min %.1f mean %.1f max %.1f" % (
+    25 * len(blocks), time.perf_counter() - t0, min(wins), sum(wins) / len(wins), max(wins)))
+assert min(wins) >= 0.9 * max(wins), wins
+
+# ---- 3: graph replay tracks eager over the first steps
+res = []
+for graph in (True, False):
+    tr, g = make()
+    data = [batch(g) for _ in range(10)]
     if graph:
         tr.capture(torch.zeros(8, 3, 192, 192, device=dev), torch.zeros(8, 128, 14, 14, device=dev), warmup=0)
-    for i in range(steps):
-        ys = torch.randint(0, 512 - 192, (8,), generator=g)
-        xs = torch.randint(0, 512 - 192, (8,), generator=g)
-        real = torch.stack([tex[0, :, y:y + 192, x:x + 192] for y, x in zip(ys, xs)]).to(dev)
-        z = torch.randn(8, 128, 14, 14, generator=g).to(dev)
-        l = (tr.step_graphed if graph else tr.step)(real, z)
-        if i % 20 == 0 or i == steps - 1:
-            out.append([float(v) for v in l])
-    return out, G
-
-
-a, Ga = run(True)
-b, Gb = run(False)
-for i, (x, y) in enumerate(zip(a, b)):
-    print(i, ["%.4f" % v for v in x], ["%.4f" % v for v in y])
-assert all(all(v == v and abs(v) < 1e3 for v in x) for x in a + b), "non-finite loss"
-d = max(float((p - q).abs().max()) for p, q in zip(Ga.parameters(), Gb.parameters()))
-print("max |param(graph) - param(eager)| after %d steps: %.3e" % (steps, d))
+    out = []
+    for real, z in data:
+        out.append([float(v) for v in (tr.step_graphed if graph else tr.step)(real, z)])
+    res.append(out)
+worst = max(abs(a - b) / max(abs(b), 1e-6) for x, y in zip(*res) for a, b in zip(x, y))
+print("graph replay vs eager, first 10 steps: worst relative loss difference %.2e" % worst)
+assert worst < 1e-3, worst
 print("soak ok")
