@@ -4,6 +4,7 @@
 // convolutions around it run through the implicit-GEMM conv kernels; the 2x2 pools through
 // itg_maxpool2_*.  Keys/values of a patch live in LDS; each thread owns one query row, the
 // softmax is a two-pass (max/sum, then normalise) sweep over LDS-broadcast keys.
+#include <cstdlib>
 #include "itg_common.h"
 
 namespace {
@@ -114,6 +115,165 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttBP p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------- LDS-tiled kernels (J <= 64 keys)
+// The kernels above keep score rows in global memory and give one thread a whole query (forward) or a whole
+// (key, channel) reduction over all queries (backward): 0.28 ms / 1.05 ms per call at BASELINE config 3's shape
+// (72 patches, 256 queries x 64 keys, 13 / 52 channels) - a fifth of that configuration's step.  Here a workgroup
+// stages keys, values and a chunk of 64 queries in LDS, the 64 x J score tile lives in LDS (pitch J + 1: conflict-free
+// by row and by column) and every phase is spread over all 256 threads.  Forward: one workgroup per (patch, 64-query
+// chunk); backward: one workgroup per patch walking its chunks in order, dK / dV accumulated in registers - a fixed
+// summation order, so the result is deterministic.
+constexpr int QC = 64;
+
+__device__ __forceinline__ void stage_rows(float* dst, const float* src, int rows, int ld, int c) {
+  const int q4 = ld >> 2;
+  for (int e = threadIdx.x; e < rows * q4; e += blockDim.x) {
+    const int c4 = e % q4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)e * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (c4 * 4 + k >= c) v[k] = 0.f;                   // pad lanes never carry data
+    *reinterpret_cast<f32x4*>(dst + e * 4) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void attention_fwd_tiled_kernel(AttP p, int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int J = p.J, SP = J + 1;
+  float* sphi = lds;                       // [J][ld8]
+  float* sg = sphi + J * p.ld8;            // [J][ld2]
+  float* sth = sg + J * p.ld2;             // [QC][ld8]
+  float* sS = sth + QC * p.ld8;            // [QC][J + 1]
+  const int b = blockIdx.x / nchunk, q0 = (blockIdx.x - b * nchunk) * QC;
+  const int nq = min(QC, p.HW - q0);
+  const int tid = threadIdx.x;
+  stage_rows(sphi, p.phi + (size_t)b * J * p.ld8, J, p.ld8, p.c8);
+  stage_rows(sg, p.g + (size_t)b * J * p.ld2, J, p.ld2, p.c2);
+  stage_rows(sth, p.theta + ((size_t)b * p.HW + q0) * p.ld8, nq, p.ld8, p.c8);
+  __syncthreads();
+  const int q8 = p.ld8 >> 2;
+  for (int e = tid; e < nq * J; e += 256) {              // scores
+    const int q = e / J, j = e - q * J;
+    float s = 0.f;
+    for (int c4 = 0; c4 < q8; ++c4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(sth + q * p.ld8 + c4 * 4);
+      const f32x4 k = *reinterpret_cast<const f32x4*>(sphi + j * p.ld8 + c4 * 4);
+      s = fmaf(a[0], k[0], s); s = fmaf(a[1], k[1], s); s = fmaf(a[2], k[2], s); s = fmaf(a[3], k[3], s);
+    }
+    sS[q * SP + j] = s;
+  }
+  __syncthreads();
+  if (tid < nq) {                                          // softmax of one row per thread (rows are conflict-free)
+    float* row = sS + tid * SP;
+    float mx = -INFINITY;
+    for (int j = 0; j < J; ++j) mx = fmaxf(mx, row[j]);
+    float sum = 0.f;
+    for (int j = 0; j < J; ++j) { const float e_ = expf(row[j] - mx); row[j] = e_; sum += e_; }
+    const float inv = 1.f / sum;
+    for (int j = 0; j < J; ++j) row[j] *= inv;
+  }
+  __syncthreads();
+  float* bout = p.beta + ((size_t)b * p.HW + q0) * J;     // saved for the backward pass (coalesced rows)
+  for (int e = tid; e < nq * J; e += 256) bout[e] = sS[(e / J) * SP + (e % J)];
+  const int q2 = p.ld2 >> 2;
+  for (int e = tid; e < nq * q2; e += 256) {              // O = beta . g
+    const int q = e / q2, c4 = e - q * q2;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* row = sS + q * SP;
+    for (int j = 0; j < J; ++j) acc += row[j] * *reinterpret_cast<const f32x4*>(sg + j * p.ld2 + c4 * 4);
+    *reinterpret_cast<f32x4*>(p.o + ((size_t)b * p.HW + q0 + q) * p.ld2 + c4 * 4) = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void attention_bwd_tiled_kernel(AttBP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int J = p.J, SP = J + 1;
+  float* sphi = lds;                       // [J][ld8]
+  float* sg = sphi + J * p.ld8;            // [J][ld2]
+  float* sth = sg + J * p.ld2;             // [QC][ld8]
+  float* sdo = sth + QC * p.ld8;           // [QC][ld2]
+  float* sB = sdo + QC * p.ld2;            // [QC][J + 1]  beta
+  float* sD = sB + QC * SP;                // [QC][J + 1]  d beta, then dS
+  const int b = blockIdx.x, tid = threadIdx.x;
+  stage_rows(sphi, p.phi + (size_t)b * J * p.ld8, J, p.ld8, p.c8);
+  stage_rows(sg, p.g + (size_t)b * J * p.ld2, J, p.ld2, p.c2);
+  const int q8 = p.ld8 >> 2, q2 = p.ld2 >> 2;
+  constexpr int NG = 4;                                    // d_g items (key, 4 channels) per thread: J * ld2 / 4 <= 1024
+  f32x4 dgacc[NG], dphiacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NG; ++i) dgacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int q0 = 0; q0 < p.HW; q0 += QC) {
+    const int nq = min(QC, p.HW - q0);
+    __syncthreads();                                       // the previous chunk's readers are done
+    stage_rows(sth, p.theta + ((size_t)b * p.HW + q0) * p.ld8, nq, p.ld8, p.c8);
+    stage_rows(sdo, p.d_o + ((size_t)b * p.HW + q0) * p.ld2, nq, p.ld2, p.c2);
+    const float* bin = p.beta + ((size_t)b * p.HW + q0) * J;
+    for (int e = tid; e < nq * J; e += 256) sB[(e / J) * SP + (e % J)] = bin[e];
+    __syncthreads();
+    // d_g[j][c] += sum_q beta[q][j] dO[q][c]
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int e = tid + i * 256;
+      if (e < J * q2) {
+        const int j = e / q2, c4 = e - j * q2;
+        f32x4 a = dgacc[i];
+        for (int q = 0; q < nq; ++q) a += sB[q * SP + j] * *reinterpret_cast<const f32x4*>(sdo + q * p.ld2 + c4 * 4);
+        dgacc[i] = a;
+      }
+    }
+    // d beta[q][j] = dO[q] . g[j]
+    for (int e = tid; e < nq * J; e += 256) {
+      const int q = e / J, j = e - q * J;
+      float s = 0.f;
+      for (int c4 = 0; c4 < q2; ++c4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(sdo + q * p.ld2 + c4 * 4);
+        const f32x4 k = *reinterpret_cast<const f32x4*>(sg + j * p.ld2 + c4 * 4);
+        s = fmaf(a[0], k[0], s); s = fmaf(a[1], k[1], s); s = fmaf(a[2], k[2], s); s = fmaf(a[3], k[3], s);
+      }
+      sD[q * SP + j] = s;
+    }
+    __syncthreads();
+    if (tid < nq) {                                        // dS = beta (d beta - sum_j beta d beta), one row per thread
+      float* dr = sD + tid * SP;
+      const float* br = sB + tid * SP;
+      float delta = 0.f;
+      for (int j = 0; j < J; ++j) delta = fmaf(br[j], dr[j], delta);
+      for (int j = 0; j < J; ++j) dr[j] = br[j] * (dr[j] - delta);
+    }
+    __syncthreads();
+    // d_theta[q][c] = sum_j dS[q][j] phi[j][c]
+    for (int e = tid; e < nq * q8; e += 256) {
+      const int q = e / q8, c4 = e - q * q8;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* dr = sD + q * SP;
+      for (int j = 0; j < J; ++j) acc += dr[j] * *reinterpret_cast<const f32x4*>(sphi + j * p.ld8 + c4 * 4);
+      *reinterpret_cast<f32x4*>(p.d_theta + ((size_t)b * p.HW + q0 + q) * p.ld8 + c4 * 4) = acc;
+    }
+    // d_phi[j][c] += sum_q dS[q][j] theta[q][c]
+    if (tid < J * q8) {
+      const int j = tid / q8, c4 = tid - j * q8;
+      f32x4 a = dphiacc;
+      for (int q = 0; q < nq; ++q) a += sD[q * SP + j] * *reinterpret_cast<const f32x4*>(sth + q * p.ld8 + c4 * 4);
+      dphiacc = a;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const int e = tid + i * 256;
+    if (e < J * q2) *reinterpret_cast<f32x4*>(p.d_g + (size_t)b * J * p.ld2 + (size_t)e * 4) = dgacc[i];
+  }
+  if (tid < J * q8) *reinterpret_cast<f32x4*>(p.d_phi + (size_t)b * J * p.ld8 + (size_t)tid * 4) = dphiacc;
+}
+
+// shapes the tiled kernels cover (everything the generator produces with base_res <= 4): the backward kernel keeps
+// J * ld2 / 4 <= 1024 d_g items and J * ld8 / 4 <= 256 d_phi items in registers
+inline bool att_tiled_ok(int J, int ld8, int ld2) {
+  static const char* off = getenv("ITG_ATT_TILED");
+  if (off && off[0] == '0') return false;
+  return J <= 64 && J * (ld2 >> 2) <= 1024 && J * (ld8 >> 2) <= 256;
+}
+
 }  // namespace
 
 extern "C" {
@@ -141,6 +301,13 @@ int itg_attention_fwd(const itg_tensor* theta, const itg_tensor* phi_pooled, con
   p.o = (float*)o_mid->ptr; p.beta = beta_save;
   p.NB = theta->n * theta->gh * theta->gw; p.HW = theta->ph * theta->pw; p.J = phi_pooled->ph * phi_pooled->pw;
   p.c8 = theta->c; p.ld8 = theta->ld; p.c2 = g_pooled->c; p.ld2 = g_pooled->ld;
+  if (att_tiled_ok(p.J, p.ld8, p.ld2)) {
+    const int nchunk = (p.HW + QC - 1) / QC;
+    size_t lt = ((size_t)p.J * (p.ld8 + p.ld2) + (size_t)QC * p.ld8 + (size_t)QC * (p.J + 1)) * sizeof(float);
+    hipLaunchKernelGGL(attention_fwd_tiled_kernel, dim3(p.NB * nchunk), dim3(256), lt, (hipStream_t)stream, p, nchunk);
+    ITG_CHECK_LAUNCH();
+    return ITG_OK;
+  }
   size_t lds = (size_t)p.J * (p.ld8 + p.ld2) * sizeof(float);
   hipLaunchKernelGGL(attention_fwd_kernel, dim3(p.NB), dim3(256), lds, (hipStream_t)stream, p);
   ITG_CHECK_LAUNCH();
@@ -164,6 +331,18 @@ int itg_attention_bwd(const itg_tensor* theta, const itg_tensor* phi_pooled, con
   p.d_o = (const float*)d_o_mid->ptr; p.d_theta = (float*)d_theta->ptr; p.d_phi = (float*)d_phi_pooled->ptr;
   p.d_g = (float*)d_g_pooled->ptr;
   p.c8 = theta->c; p.ld8 = theta->ld; p.c2 = g_pooled->c; p.ld2 = g_pooled->ld;
+  if (att_tiled_ok(p.J, p.ld8, p.ld2)) {
+    size_t lt = ((size_t)p.J * (p.ld8 + p.ld2) + (size_t)QC * (p.ld8 + p.ld2) + (size_t)2 * QC * (p.J + 1)) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_tiled_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(attention_bwd_tiled_kernel, dim3(p.NB), dim3(256), lt, (hipStream_t)stream, p);
+    ITG_CHECK_LAUNCH();
+    return ITG_OK;
+  }
   size_t lds = (size_t)p.J * (p.ld8 + p.ld2) * sizeof(float);
   hipLaunchKernelGGL(attention_bwd_kernel, dim3(p.NB), dim3(256), lds, (hipStream_t)stream, p);
   ITG_CHECK_LAUNCH();
