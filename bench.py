@@ -135,17 +135,21 @@ def gpu_leg(a):
     torch.cuda.synchronize()
     if rank == 0:
         agg = {}
-        for tag, launches, flops, e0, e1 in ops.PROFILE:
-            d = agg.setdefault(tag, [0, 0.0, 0.0])
+        for tag, launches, flops, e0, e1, nbytes in ops.PROFILE:
+            d = agg.setdefault(tag, [0, 0.0, 0.0, 0.0])
             d[0] += launches
             d[1] += flops
             d[2] += e0.elapsed_time(e1) * 1e-3
+            d[3] += nbytes
         ops.PROFILE = None
-        tag, (nl, fl, sec) = max(agg.items(), key=lambda kv: kv[1][2])
+        tag, (nl, fl, sec, nby) = max(agg.items(), key=lambda kv: kv[1][2])
         ach = fl / sec / 1e12
+        traffic = hbm_traffic(tag)
         tot_sec = sum(x[2] for x in agg.values())
         roof = {"bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": peak_tf,
-                "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4), "traffic": hbm_traffic(tag),
+                "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(nby / nl),
+                "traffic_over_algorithmic": None if traffic is None else round(traffic / (nby / nl), 2),
                 "launches_per_step": nl, "avg_launch_us": round(sec / nl * 1e6, 1),
                 "flops_per_launch": round(fl / nl / 1e9, 3),
                 "timing": "HIP events around each conv call of one un-overlapped iteration (a split-K call includes its "

@@ -185,19 +185,27 @@ __global__ __launch_bounds__(1024) void snb_norm_v_kernel(SnBatch b) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = dst[i] / nrm;
 }
 
-// t = W v : one wave per row, blockIdx.x flattened over layers x ceil(rows/4)
+// t = W v : one workgroup per row (blockIdx.x flattened over layers x rows), 16-byte loads, fp64 accumulation, fixed
+// reduction tree.  (One wave per row with scalar loads left 961 rows on 240 workgroups: 35 us per call, 3 calls a step.)
 __global__ __launch_bounds__(256) void snb_w_v_kernel(SnBatch b) {
   const int l = sn_find_layer(b, blockIdx.x);
-  const int rows = b.rows[l], cols = b.cols[l];
-  const float* w = b.w[l]; const float* v = b.v[l];
+  const int cols = b.cols[l];
+  const int row = blockIdx.x - b.blk0[l];
+  const float* w = b.w[l] + (size_t)row * cols; const float* v = b.v[l];
   float* t = b.work[l] + (size_t)SN_RS * cols;
-  const int row = (blockIdx.x - b.blk0[l]) * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= rows) return;
   double s = 0.0;
-  for (int j = lane; j < cols; j += 64) s += (double)w[(size_t)row * cols + j] * (double)v[j];
-  s = wave_sum_d(s);
-  if (lane == 0) t[row] = (float)s;
+  if ((cols & 3) == 0) {
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
+    const f32x4* v4 = reinterpret_cast<const f32x4*>(v);
+    for (int j = threadIdx.x; j < (cols >> 2); j += 256) {
+      const f32x4 a = w4[j], c = v4[j];
+      s += (double)a[0] * (double)c[0] + (double)a[1] * (double)c[1] + (double)a[2] * (double)c[2] + (double)a[3] * (double)c[3];
+    }
+  } else {
+    for (int j = threadIdx.x; j < cols; j += 256) s += (double)w[j] * (double)v[j];
+  }
+  s = block_sum_d(s);
+  if (threadIdx.x == 0) t[row] = (float)s;
 }
 
 // u = normalize(t) (training), sigma = <u, t>, inv = 1/sigma : one workgroup per layer
@@ -358,7 +366,7 @@ int itg_spectral_norm_power_iter_multi(int n, const float* const* w, float* cons
     ITG_CHECK_LAUNCH();
   }
   b.blk0[0] = 0;
-  for (int l = 0; l < n; ++l) b.blk0[l + 1] = b.blk0[l] + (rows[l] + 3) / 4;
+  for (int l = 0; l < n; ++l) b.blk0[l + 1] = b.blk0[l] + rows[l];
   hipLaunchKernelGGL(snb_w_v_kernel, dim3(b.blk0[n]), dim3(256), 0, s, b);
   ITG_CHECK_LAUNCH();
   hipLaunchKernelGGL(snb_norm_u_sigma_kernel, dim3(n), dim3(1024), 0, s, b, do_iter);

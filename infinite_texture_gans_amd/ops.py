@@ -57,10 +57,11 @@ def _nt_tag(rows):
 
 
 class _Prof:
-    def __init__(self, tag, launches, flops):
+    def __init__(self, tag, launches, flops, nbytes=0):
+        """``nbytes``: algorithmic HBM bytes of the call (operands read once + result written once)."""
         self.rec = PROFILE is not None
         if self.rec:
-            self.item = [tag, launches, flops, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+            self.item = [tag, launches, flops, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), nbytes]
 
     def __enter__(self):
         if self.rec:
@@ -257,7 +258,7 @@ class _Conv(torch.autograd.Function):
         g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec)
         nws = _lib.fn("itg_conv2d_fwd_workspace")(C.byref(dx_), C.byref(do_), C.byref(g))
         ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
-        with _Prof(_nt_tag(co), 1, 2.0 * n * Ho * Wo * co * ci * kh * kw):
+        with _Prof(_nt_tag(co), 1, 2.0 * n * Ho * Wo * co * ci * kh * kw, 4 * (x.numel() + out.numel() + wp.numel())):
             _lib.call("itg_conv2d_fwd", C.byref(dx_), _ptr(wp), _ptr(bias), _ptr(out_scale), C.byref(dr_), C.byref(do_),
                       C.byref(g), act, float(slope), _ptr(ws), nws, st)
         ctx.geom, ctx.act, ctx.slope, ctx.c_in, ctx.co = geom, act, slope, c_in, co
@@ -301,7 +302,7 @@ class _Conv(torch.autograd.Function):
             npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
             nws = _lib.fn("itg_conv2d_dgrad_workspace")(C.byref(ddy), C.byref(ddx), C.byref(g))
             ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
-            with _Prof(_nt_tag(ci), 1, 2.0 * npix_out * co * ci * kh * kw):
+            with _Prof(_nt_tag(ci), 1, 2.0 * npix_out * co * ci * kh * kw, 4 * (dy.numel() + gx.numel() + wp.numel())):
                 ia = ctx.in_act
                 dact = _desc(x, ci) if ia is not None else _null_desc()
                 _lib.call("itg_conv2d_dgrad", C.byref(ddy), _ptr(wp), _ptr(out_scale), C.byref(ddx), C.byref(dact),
@@ -337,7 +338,8 @@ class _Conv(torch.autograd.Function):
                 gw_ = wsink if direct_w else fresh(w)
                 gb = bsink if direct_b else (fresh(w[:, 0, 0, 0]) if need_b else None)
                 npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
-                with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1, 2.0 * npix_out * co * ci * kh * kw):
+                with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1, 2.0 * npix_out * co * ci * kh * kw,
+                           4 * (x.numel() + dy.numel() + w.numel())):
                     # one accumulate flag covers dw and db: a sink for one of them implies sinks for both
                     _lib.call("itg_conv2d_wgrad", C.byref(dxd), C.byref(ddy), _ptr(gw_), _ptr(gb), C.byref(g),
                               int(direct_w or direct_b), _ptr(ws), nws, st)

@@ -15,8 +15,13 @@ def _bench():
     return m
 
 
+def _latest(pattern):
+    import glob
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))[-1]
+
+
 def test_committed_bench_line_follows_the_contract():
-    line = json.load(open(os.path.join(ROOT, "profiles", "bench_r01_config1.json")))
+    line = json.load(open(_latest("bench_r*_config1.json")))
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                  ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                  ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
@@ -29,6 +34,10 @@ def test_committed_bench_line_follows_the_contract():
     assert r["traffic"] is None or r["traffic"] > 0
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    if "loops" in c:        # round 2 on: the reference-faithful Python-loop LocalPadder variant beside the vectorised port
+        assert c["loops"]["kind"] == "port-loops" and 0 < c["loops"]["value"] <= c["value"]
+    if "membound" in r:     # achieved GB/s of the memory-bound operators against 8 TB/s
+        assert all(0 < m["frac_of_8tbps"] < 1 and abs(m["gbps"] - m["mbytes"] / m["us"] * 1e3) / m["gbps"] < 2e-2 for m in r["membound"])
     # value is consistent with the step time: batch 8 per GPU
     assert abs(line["value"] - 8 * line["n_gpus"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
 
@@ -37,8 +46,8 @@ def test_bench_helpers():
     b = _bench()
     assert b.NECESSARY_GF_PER_STEP == 855.5 and b.FP32_MFMA_PEAK_TF == 157.3
     assert 1 <= b.host_cores() <= 16
-    t = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-    k = json.load(open(os.path.join(ROOT, "profiles", "bench_r01_config1.json")))["roofline"]["kernel"]
+    t = json.load(open(_latest("r*_hbm_traffic.json")))
+    k = json.load(open(_latest("bench_r*_config1.json")))["roofline"]["kernel"]
     assert k in t and b.hbm_traffic(k) == int(t[k]["fetch_bytes"] + t[k]["write_bytes"])
     assert b.hbm_traffic("no_such_kernel") is None
     a = b.U_FLAGS if hasattr(b, "U_FLAGS") else b.FLAGS

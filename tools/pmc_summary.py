@@ -76,7 +76,7 @@ def main():
             f.write("| `%s` | %.1f | %.1f | %.2f | %.1f | %.1f | %.1f | %.1f | %.2f | %s | %.1f |\n" % (
                 k[:64], x["launches"] / a.steps, ns / x["launches"] / 1e3, clock, mfma,
                 100 * x["SQ_ACTIVE_INST_ANY"] / wc, 100 * x["SQ_WAIT_INST_ANY"] / wc, 100 * x["SQ_WAIT_ANY"] / wc,
-                4.0 * wc * 4 / (cyc * 1024) if cyc else 0.0,
+                wc * 4 / (cyc * 1024) if cyc else 0.0,
                 ("%.1f" % (y["SQ_INSTS_VALU"] / y["SQ_INSTS_MFMA"])) if y.get("SQ_INSTS_MFMA") else
                 ("%.1f" % (y["SQ_INSTS_VALU"] / x["SQ_INSTS_MFMA"]) if x.get("SQ_INSTS_MFMA") else "-"),
                 100.0 * y["SQ_LDS_BANK_CONFLICT"] / y["SQ_LDS_IDX_ACTIVE"] if y.get("SQ_LDS_IDX_ACTIVE") else 0.0))

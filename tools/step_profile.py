@@ -41,7 +41,7 @@ def main():
     prof, ops.PROFILE = ops.PROFILE, None
     tot_t = tot_f = 0.0
     print("%3s %-52s %9s %9s %8s" % ("#", "kernel", "GFLOP", "us", "TF"))
-    for i, (tag, nl, fl, a, b) in enumerate(prof):
+    for i, (tag, nl, fl, a, b, _nb) in enumerate(prof):
         us = a.elapsed_time(b) * 1e3
         tot_t += us
         tot_f += fl
