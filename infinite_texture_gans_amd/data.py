@@ -28,7 +28,7 @@ def _to_normalised(im):
     a = np.asarray(im)
     if a.ndim == 2:
         a = a[:, :, None]
-    t = torch.from_numpy(np.ascontiguousarray(a)).permute(2, 0, 1)
+    t = torch.from_numpy(np.array(a)).permute(2, 0, 1)       # np.array: a writable copy of PIL's read-only buffer
     t = t.float() / 255.0 if a.dtype == np.uint8 else t.float()
     return (t - 0.5) / 0.5
 

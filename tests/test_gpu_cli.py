@@ -55,3 +55,53 @@ def test_train_cli_bf16_flag(tmp_path):
         ops.MFMA_PRECISION = prev
     ck = torch.load(out / "1_1.pth", map_location="cpu", weights_only=False)
     assert all(np.isfinite(ck["Gloss"])) and all(np.isfinite(ck["Dloss"]))
+
+
+def test_reference_style_caller_runs_on_the_drop_in_module_names():
+    """A training loop written the way the reference's train.py is (top-level `utils` / `models` imports, prepare_models,
+    torch.optim.Adam over module.parameters(), nn.BCEWithLogitsLoss, utils.sample_from_gen_PatchByPatch_train drawing its
+    latents from the global CPU generator) runs on this build's modules and reproduces the reference's own losses and
+    post-step parameters (golden train_bn_nl4_sn, 2 steps)."""
+    import torch.nn as nn
+    import torch.optim as optim
+    import utils                                     # the reference's module names (repo root shims)
+    from models import generators, discriminators    # noqa: F401
+    from helpers import load, state, rel_l2
+    fx = load("train_bn_nl4_sn")
+    dev = torch.device("cuda")
+    args = utils.prepare_parser().parse_args([str(x) for x in fx["argv"]] + [
+        "--padding_mode", "local", "--G_ch", "4", "--D_ch", "4", "--z_dim", "8", "--leak_G", "0.02", "--batch_size", "2",
+        "--num_images", "2", "--beta1", "0.0"])
+    netG, netD = utils.prepare_models(args, dev)
+    assert type(netG).__name__ == "ResidualPatchGenerator" and isinstance(netG, generators.ResidualPatchGenerator)
+    netG.load_state_dict(state(fx, "G0/")), netD.load_state_dict(state(fx, "D0/"))
+    netG.train(), netD.train()
+    optD = optim.Adam(netD.parameters(), lr=args.lr_D, betas=(float(args.beta1), args.beta2))
+    optG = optim.Adam(netG.parameters(), lr=args.lr_G, betas=(float(args.beta1), args.beta2))
+    crit = nn.BCEWithLogitsLoss().to(dev)
+    label_t = 0.9 if args.smooth else 1
+    for s in range(int(fx["steps"])):
+        real_x = torch.from_numpy(fx["real_x%d" % s]).to(dev)
+        netD.zero_grad()
+        real_logit = netD(real_x)
+        d_real = crit(real_logit, torch.full_like(real_logit, label_t))
+        d_real.backward()
+        torch.manual_seed(201 + 100 + s)             # the seed the fixture's sampler call ran under
+        fake_x = utils.sample_from_gen_PatchByPatch_train(netG, args.z_dim, args.base_res, args.map_dim,
+                                                          num_images=args.num_images,
+                                                          num_patches_height=args.num_patches_height,
+                                                          num_patches_width=args.num_patches_width, device=dev)
+        fake_logit = netD(fake_x.detach())
+        d_fake = crit(fake_logit, torch.zeros_like(fake_logit))
+        d_fake.backward()
+        optD.step()
+        netG.zero_grad()
+        fake_logit = netD(fake_x)
+        g_loss = crit(fake_logit, torch.full_like(fake_logit, label_t))
+        g_loss.backward()
+        optG.step()
+        got = [float(d_real), float(d_fake), float(g_loss)]
+        assert np.allclose(got, fx["loss%d" % s], rtol=1e-4, atol=1e-6), (s, got, fx["loss%d" % s])
+    sd = netD.state_dict()
+    for k, v in state(fx, "D1/").items():
+        assert rel_l2(sd[k].double().cpu(), v.double()) < 2e-3, k
