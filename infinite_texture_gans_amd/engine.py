@@ -182,6 +182,13 @@ class Trainer:
         return self.netG.forward_grid(z, maps, "1st_row_1st_col")
 
     record = None       # a list: every logit map the loss heads see is appended to it (parity tests)
+    marks = None        # a list: (name, event) pairs recorded on the main stream at the phase boundaries (tools/region_times.py)
+
+    def _mark(self, name):
+        if self.marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.marks.append((name, ev))
 
     def _d_logits(self, fake):
         """D on the generator's output: a patch grid (consumed in place, no merge copy) or whole NCHW images."""
@@ -196,10 +203,15 @@ class Trainer:
             self.record.append(logit.detach())
         return logit
 
-    def step(self, real_x, z, maps=None):
+    def step(self, real_x, z, maps=None, next_real=None):
         """real_x: (B,3,crop,crop) on the device; z/maps: latents (see utils.sample_latents_train), or LISTS of
         them: ``--disc_iters`` = len(z) discriminator updates on the same real batch with fresh latents each, then
         ONE generator update on the last fake batch (reference train.py:124-169).
+        ``next_real``: the NEXT iteration's real batch, if the caller already has it.  D(real) forward+backward of the
+        next iteration only depends on D's weights after this iteration's Adam(D): it is then issued on the side stream
+        beside this iteration's generator backward (a chain of small latency-bound launches) instead of beside the next
+        generator forward; the next ``step`` must be called with that very tensor as ``real_x``.  Same arithmetic, same
+        spectral-norm power-iteration order (it is issued after the G step's D forward).
         Returns (d_loss_real, d_loss_fake, g_loss) of the last D iteration as 0-dim device tensors (no host sync);
         ``self.d_losses`` holds the (real, fake) pair of every D iteration."""
         self.arena.reset()                                      # BatchNorm statistics scratch of this iteration
@@ -213,7 +225,7 @@ class Trainer:
             for zi, mi in zip(zs, ms):
                 d_real, d_fake, fake = self.d_step(real_x, zi, mi)
                 self.d_losses.append((d_real, d_fake))
-            g_loss = self.g_step(fake)
+            g_loss = self.g_step(fake, next_real)
             return d_real, d_fake, g_loss
         finally:                                                # never leave the process-wide hooks set behind an exception
             ops.ARENA = None
@@ -232,8 +244,21 @@ class Trainer:
             # capture: an idle forked stream that something later waits for is the EndCapture crash (ops.wgrad_streams_join)
             for ws in self.wstream:
                 ws.wait_stream(torch.cuda.current_stream())
-        self.flatD.zero_grad()
-        if self.overlap:
+        self._mark("start")
+        pending, self._pending = self._pending, None
+        if pending is not None and pending[0] is not real_x:
+            raise RuntimeError("step(next_real=...) of the previous iteration announced another real batch than this one")
+        if pending is not None:
+            # D(real) of this batch already ran (or is running) on the side stream, gradients zeroed ahead of it
+            d_real = pending[1]
+            fake = self.sample_fake(z, maps)
+            self._mark("G forward (beside D(real) fwd+bwd)")
+            torch.cuda.current_stream().wait_stream(self.side)
+        else:
+            self.flatD.zero_grad()
+        if pending is not None:
+            pass
+        elif self.overlap:
             # D(real) forward+backward and the generator forward are independent and neither fills the chip
             # on its own (small grids, latency-bound normalisation kernels): run them on two HIP streams
             main = torch.cuda.current_stream()
@@ -246,20 +271,24 @@ class Trainer:
                 d_real.backward()
             ops.WGRAD_STREAM = keep
             fake = self.sample_fake(z, maps)
+            self._mark("G forward (beside D(real) fwd+bwd)")
             main.wait_stream(self.side)                        # D(fake) continues D's spectral-norm state and .grad
         else:
             d_real = self._d_loss(self._d_real_logits(real_x), True)
             d_real.backward()
             fake = self.sample_fake(z, maps)                   # GT patches, graph kept for the G step
         d_fake = self._d_loss(self._d_logits(fake.detach()), False)
+        self._mark("D(fake) forward")
         d_fake.backward()
+        self._mark("D(fake) backward: dgrad chain (wgrads on side streams)")
         self._join()
         self._allreduce(self.flatD)
         self.optD.step()
         self.packD.repack()
+        self._mark("join wgrads + Adam(D) + repack")
         return d_real.detach(), d_fake.detach(), fake
 
-    def g_step(self, fake):
+    def g_step(self, fake, next_real=None):
         """The generator update on ``fake`` (reference train.py:161-169, + EMA :176-180).  D's weight gradients of
         this pass are never read (zeroed at the next D step), so they are not computed."""
         self.flatG.zero_grad()
@@ -267,17 +296,43 @@ class Trainer:
             p.requires_grad_(False)
         try:
             g_loss = self._g_loss(self._d_logits(fake))
-            g_loss.backward()
+            self._mark("G step: D forward")
         finally:
             for p in self.flatD.params:
                 p.requires_grad_(True)
+        if next_real is not None and self._can_prefetch():
+            self._prefetch_d_real(next_real)
+        g_loss.backward()
+        self._mark("G step: backward through D and G (G wgrads on side streams)")
         self._join()
         self._allreduce(self.flatG)
         self.optG.step()                                        # + EMA of the parameters (train.py:176-180)
         self.packG.repack()
         if self.netG_ema is not None:
             self._ema_buffers()
+        self._mark("join wgrads + Adam(G) + repack")
         return g_loss.detach()
+
+    def _can_prefetch(self):
+        """D(real) of the next iteration may run ahead: only with the stream overlap, outside hipGraph capture, and for a
+        discriminator without BatchNorm (its statistics scratch is reset at the start of every step)."""
+        return (self.overlap and not torch.cuda.is_current_stream_capturing()
+                and not any(isinstance(m, _BNParams) for m in self.netD.modules()))
+
+    def _prefetch_d_real(self, next_real):
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)                      # after Adam(D), the repack and the G step's D forward
+        keep, ops.WGRAD_STREAM = ops.WGRAD_STREAM, None  # its weight gradients stay on the branch stream
+        try:
+            with torch.cuda.stream(self.side):
+                self.flatD.zero_grad()                   # the gradients Adam(D) of this iteration consumed
+                d_real = self._d_loss(self._d_real_logits(next_real), True)
+                d_real.backward()
+        finally:
+            ops.WGRAD_STREAM = keep
+        self._pending = (next_real, d_real.detach())
+
+    _pending = None
 
     def _join(self):
         """The weight-gradient streams have to drain before gradients are exchanged / consumed by Adam."""

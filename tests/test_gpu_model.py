@@ -630,3 +630,30 @@ def test_one_rank_rccl_collectives_leave_the_step_unchanged(tmp_path):
                 assert (got - v.double()).abs().max() <= 2 * 2e-4 * steps + 1e-7, k
             else:
                 assert rel_l2(got, v.double()) < 2e-3, (k, rel_l2(got, v.double()))
+
+
+def test_lookahead_d_real_schedule_equals_the_plain_step():
+    """step(..., next_real=batch_{k+1}) runs D(real) of the next iteration beside this iteration's generator backward;
+    three iterations that way must equal three plain iterations (same losses, same parameters) and the reference golden."""
+    fx, a, G0, D0, tr0, losses0 = _train("bn_nl4_sn")
+    from infinite_texture_gans_amd.engine import Trainer
+    from infinite_texture_gans_amd import utils as U
+    G, D = build(a, state(fx, "G0/"), state(fx, "D0/"))
+    G.train(), D.train()
+    args = U.prepare_parser().parse_args([])
+    args.smooth, args.beta1 = a["smooth"], 0.0
+    tr = Trainer(G, D, args, cuda)
+    assert tr.overlap
+    steps = int(fx["steps"])
+    reals = [torch.from_numpy(fx["real_x%d" % s]).to(cuda) for s in range(steps)]
+    zs = [torch.from_numpy(fx["z%d" % s]).to(cuda) for s in range(steps)]
+    losses = []
+    for s in range(steps):
+        l = tr.step(reals[s], zs[s], None, reals[s + 1] if s + 1 < steps else None)
+        losses.append([float(v) for v in l])
+        assert (tr._pending is not None) == (s + 1 < steps)
+    for s in range(steps):
+        assert np.allclose(losses[s], fx["loss%d" % s], rtol=1e-4, atol=1e-6), (s, losses[s], fx["loss%d" % s])
+        assert np.allclose(losses[s], losses0[s], rtol=1e-5), (s, losses[s], losses0[s])
+    for (k, p), (_, q) in zip(D.state_dict().items(), D0.state_dict().items()):
+        assert rel_l2(p.double().cpu(), q.double().cpu()) < 1e-5, k
