@@ -210,9 +210,10 @@ int itg_axpby(const float* x, const float* y, float* out, float a, const float* 
 int itg_dot(const float* x, const float* y, int64_t n, double* out, void* stream);
 int itg_colsum(const itg_tensor* x, float* out /*c*/, double* acc /*ld scratch*/, void* stream); /* bias grad */
 
-/* ---- attention (reference models/layers.py:246-258), one workgroup per patch -----------
- * beta_save: 2 * NB * HW * (HW/4) floats; fwd stores the softmax in the first half, bwd uses
- * the second half as scratch for dS.                                                       */
+/* ---- attention (reference models/layers.py:246-258), per patch ---------------------------
+ * beta_save: itg_attention_scratch_floats() floats; fwd stores the softmax in the first
+ * NB * HW * (HW/4) of them, bwd uses the rest as scratch (dS, or the per-chunk dK / dV shares). */
+int64_t itg_attention_scratch_floats(const itg_tensor* theta, const itg_tensor* phi_pooled, const itg_tensor* g_pooled);
 int itg_attention_fwd(const itg_tensor* theta, const itg_tensor* phi_pooled, const itg_tensor* g_pooled,
                       const itg_tensor* o_mid, float* beta_save, void* stream);
 int itg_attention_bwd(const itg_tensor* theta, const itg_tensor* phi_pooled, const itg_tensor* g_pooled,

@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttBP p) {
 // (72 patches, 256 queries x 64 keys, 13 / 52 channels) - a fifth of that configuration's step.  Here a workgroup
 // stages keys, values and a chunk of 64 queries in LDS, the 64 x J score tile lives in LDS (pitch J + 1: conflict-free
 // by row and by column) and every phase is spread over all 256 threads.  Forward: one workgroup per (patch, 64-query
-// chunk); backward: one workgroup per patch walking its chunks in order, dK / dV accumulated in registers - a fixed
-// summation order, so the result is deterministic.
+// chunk) in both directions; the backward workgroups write their chunk's share of dK / dV to a scratch slab and a small
+// second launch adds the shares in chunk order - a fixed summation order, so the result is deterministic.
 constexpr int QC = 64;
 
 __device__ __forceinline__ void stage_rows(float* dst, const float* src, int rows, int ld, int c) {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void attention_fwd_tiled_kernel(AttP p, int nc
   }
 }
 
-__global__ __launch_bounds__(256) void attention_bwd_tiled_kernel(AttBP p) {
+__global__ __launch_bounds__(256) void attention_bwd_tiled_kernel(AttBP p, int nchunk, float* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int J = p.J, SP = J + 1;
   float* sphi = lds;                       // [J][ld8]
@@ -195,83 +195,81 @@ __global__ __launch_bounds__(256) void attention_bwd_tiled_kernel(AttBP p) {
   float* sdo = sth + QC * p.ld8;           // [QC][ld2]
   float* sB = sdo + QC * p.ld2;            // [QC][J + 1]  beta
   float* sD = sB + QC * SP;                // [QC][J + 1]  d beta, then dS
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x / nchunk, chunk = blockIdx.x - b * nchunk, tid = threadIdx.x;
+  const int q0 = chunk * QC, nq = min(QC, p.HW - q0);
+  const int q8 = p.ld8 >> 2, q2 = p.ld2 >> 2;
   stage_rows(sphi, p.phi + (size_t)b * J * p.ld8, J, p.ld8, p.c8);
   stage_rows(sg, p.g + (size_t)b * J * p.ld2, J, p.ld2, p.c2);
-  const int q8 = p.ld8 >> 2, q2 = p.ld2 >> 2;
-  constexpr int NG = 4;                                    // d_g items (key, 4 channels) per thread: J * ld2 / 4 <= 1024
-  f32x4 dgacc[NG], dphiacc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < NG; ++i) dgacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int q0 = 0; q0 < p.HW; q0 += QC) {
-    const int nq = min(QC, p.HW - q0);
-    __syncthreads();                                       // the previous chunk's readers are done
-    stage_rows(sth, p.theta + ((size_t)b * p.HW + q0) * p.ld8, nq, p.ld8, p.c8);
-    stage_rows(sdo, p.d_o + ((size_t)b * p.HW + q0) * p.ld2, nq, p.ld2, p.c2);
-    const float* bin = p.beta + ((size_t)b * p.HW + q0) * J;
-    for (int e = tid; e < nq * J; e += 256) sB[(e / J) * SP + (e % J)] = bin[e];
-    __syncthreads();
-    // d_g[j][c] += sum_q beta[q][j] dO[q][c]
-#pragma unroll
-    for (int i = 0; i < NG; ++i) {
-      const int e = tid + i * 256;
-      if (e < J * q2) {
-        const int j = e / q2, c4 = e - j * q2;
-        f32x4 a = dgacc[i];
-        for (int q = 0; q < nq; ++q) a += sB[q * SP + j] * *reinterpret_cast<const f32x4*>(sdo + q * p.ld2 + c4 * 4);
-        dgacc[i] = a;
-      }
-    }
-    // d beta[q][j] = dO[q] . g[j]
-    for (int e = tid; e < nq * J; e += 256) {
-      const int q = e / J, j = e - q * J;
-      float s = 0.f;
-      for (int c4 = 0; c4 < q2; ++c4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(sdo + q * p.ld2 + c4 * 4);
-        const f32x4 k = *reinterpret_cast<const f32x4*>(sg + j * p.ld2 + c4 * 4);
-        s = fmaf(a[0], k[0], s); s = fmaf(a[1], k[1], s); s = fmaf(a[2], k[2], s); s = fmaf(a[3], k[3], s);
-      }
-      sD[q * SP + j] = s;
-    }
-    __syncthreads();
-    if (tid < nq) {                                        // dS = beta (d beta - sum_j beta d beta), one row per thread
-      float* dr = sD + tid * SP;
-      const float* br = sB + tid * SP;
-      float delta = 0.f;
-      for (int j = 0; j < J; ++j) delta = fmaf(br[j], dr[j], delta);
-      for (int j = 0; j < J; ++j) dr[j] = br[j] * (dr[j] - delta);
-    }
-    __syncthreads();
-    // d_theta[q][c] = sum_j dS[q][j] phi[j][c]
-    for (int e = tid; e < nq * q8; e += 256) {
-      const int q = e / q8, c4 = e - q * q8;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const float* dr = sD + q * SP;
-      for (int j = 0; j < J; ++j) acc += dr[j] * *reinterpret_cast<const f32x4*>(sphi + j * p.ld8 + c4 * 4);
-      *reinterpret_cast<f32x4*>(p.d_theta + ((size_t)b * p.HW + q0 + q) * p.ld8 + c4 * 4) = acc;
-    }
-    // d_phi[j][c] += sum_q dS[q][j] theta[q][c]
-    if (tid < J * q8) {
-      const int j = tid / q8, c4 = tid - j * q8;
-      f32x4 a = dphiacc;
-      for (int q = 0; q < nq; ++q) a += sD[q * SP + j] * *reinterpret_cast<const f32x4*>(sth + q * p.ld8 + c4 * 4);
-      dphiacc = a;
-    }
+  stage_rows(sth, p.theta + ((size_t)b * p.HW + q0) * p.ld8, nq, p.ld8, p.c8);
+  stage_rows(sdo, p.d_o + ((size_t)b * p.HW + q0) * p.ld2, nq, p.ld2, p.c2);
+  const float* bin = p.beta + ((size_t)b * p.HW + q0) * J;
+  for (int e = tid; e < nq * J; e += 256) sB[(e / J) * SP + (e % J)] = bin[e];
+  __syncthreads();
+  // this chunk's share of d_g[j][c] = sum_q beta[q][j] dO[q][c] and (below) of d_phi -> slab[b][chunk][J*ld2 | J*ld8]
+  float* myslab = slab + (size_t)blockIdx.x * J * (p.ld2 + p.ld8);
+  for (int e = tid; e < J * q2; e += 256) {
+    const int j = e / q2, c4 = e - j * q2;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < nq; ++q) a += sB[q * SP + j] * *reinterpret_cast<const f32x4*>(sdo + q * p.ld2 + c4 * 4);
+    *reinterpret_cast<f32x4*>(myslab + (size_t)e * 4) = a;
   }
-#pragma unroll
-  for (int i = 0; i < NG; ++i) {
-    const int e = tid + i * 256;
-    if (e < J * q2) *reinterpret_cast<f32x4*>(p.d_g + (size_t)b * J * p.ld2 + (size_t)e * 4) = dgacc[i];
+  // d beta[q][j] = dO[q] . g[j]
+  for (int e = tid; e < nq * J; e += 256) {
+    const int q = e / J, j = e - q * J;
+    float s = 0.f;
+    for (int c4 = 0; c4 < q2; ++c4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(sdo + q * p.ld2 + c4 * 4);
+      const f32x4 k = *reinterpret_cast<const f32x4*>(sg + j * p.ld2 + c4 * 4);
+      s = fmaf(a[0], k[0], s); s = fmaf(a[1], k[1], s); s = fmaf(a[2], k[2], s); s = fmaf(a[3], k[3], s);
+    }
+    sD[q * SP + j] = s;
   }
-  if (tid < J * q8) *reinterpret_cast<f32x4*>(p.d_phi + (size_t)b * J * p.ld8 + (size_t)tid * 4) = dphiacc;
+  __syncthreads();
+  if (tid < nq) {                                          // dS = beta (d beta - sum_j beta d beta), one row per thread
+    float* dr = sD + tid * SP;
+    const float* br = sB + tid * SP;
+    float delta = 0.f;
+    for (int j = 0; j < J; ++j) delta = fmaf(br[j], dr[j], delta);
+    for (int j = 0; j < J; ++j) dr[j] = br[j] * (dr[j] - delta);
+  }
+  __syncthreads();
+  // d_theta[q][c] = sum_j dS[q][j] phi[j][c]
+  for (int e = tid; e < nq * q8; e += 256) {
+    const int q = e / q8, c4 = e - q * q8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* dr = sD + q * SP;
+    for (int j = 0; j < J; ++j) acc += dr[j] * *reinterpret_cast<const f32x4*>(sphi + j * p.ld8 + c4 * 4);
+    *reinterpret_cast<f32x4*>(p.d_theta + ((size_t)b * p.HW + q0 + q) * p.ld8 + c4 * 4) = acc;
+  }
+  // this chunk's share of d_phi[j][c] = sum_q dS[q][j] theta[q][c]
+  float* pslab = myslab + (size_t)J * p.ld2;
+  for (int e = tid; e < J * q8; e += 256) {
+    const int j = e / q8, c4 = e - j * q8;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < nq; ++q) a += sD[q * SP + j] * *reinterpret_cast<const f32x4*>(sth + q * p.ld8 + c4 * 4);
+    *reinterpret_cast<f32x4*>(pslab + (size_t)e * 4) = a;
+  }
 }
 
-// shapes the tiled kernels cover (everything the generator produces with base_res <= 4): the backward kernel keeps
-// J * ld2 / 4 <= 1024 d_g items and J * ld8 / 4 <= 256 d_phi items in registers
+// d_g / d_phi = the chunks' partial sums added in chunk order (deterministic)
+__global__ void attention_bwd_reduce_kernel(const float* __restrict__ slab, float* __restrict__ d_g, float* __restrict__ d_phi,
+                                            int NB, int nchunk, int n2, int n8) {
+  const int per = n2 + n8;
+  const int64_t total = (int64_t)NB * (per >> 2);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / (per >> 2)), e = (int)(i - (int64_t)b * (per >> 2)) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nchunk; ++c) v += *reinterpret_cast<const f32x4*>(slab + ((size_t)b * nchunk + c) * per + e);
+    float* dst = e < n2 ? d_g + (size_t)b * n2 + e : d_phi + (size_t)b * n8 + (e - n2);
+    *reinterpret_cast<f32x4*>(dst) = v;
+  }
+}
+
+// shapes the tiled kernels cover (everything the generator produces with base_res <= 4)
 inline bool att_tiled_ok(int J, int ld8, int ld2) {
   static const char* off = getenv("ITG_ATT_TILED");
   if (off && off[0] == '0') return false;
-  return J <= 64 && J * (ld2 >> 2) <= 1024 && J * (ld8 >> 2) <= 256;
+  return J <= 64 && ld2 <= 128 && ld8 <= 32;
 }
 
 }  // namespace
@@ -289,6 +287,16 @@ static int att_check(const itg_tensor* theta, const itg_tensor* phi, const itg_t
   size_t lds = (size_t)phi->ph * phi->pw * (phi->ld + g->ld) * sizeof(float);
   if (lds > 64 * 1024) return ITG_ERR_ARG;
   return ITG_OK;
+}
+
+int64_t itg_attention_scratch_floats(const itg_tensor* theta, const itg_tensor* phi_pooled, const itg_tensor* g_pooled) {
+  if (!theta || !phi_pooled || !g_pooled) return ITG_ERR_ARG;
+  const int64_t nb = (int64_t)theta->n * theta->gh * theta->gw, hw = (int64_t)theta->ph * theta->pw;
+  const int64_t j = (int64_t)phi_pooled->ph * phi_pooled->pw;
+  const int64_t beta = nb * hw * j;                                        // the saved softmax
+  const int64_t ds = nb * hw * j;                                          // generic backward: dS
+  const int64_t slabs = nb * ((hw + QC - 1) / QC) * j * (phi_pooled->ld + g_pooled->ld);   // tiled backward: dK / dV shares
+  return beta + (ds > slabs ? ds : slabs);
 }
 
 int itg_attention_fwd(const itg_tensor* theta, const itg_tensor* phi_pooled, const itg_tensor* g_pooled,
@@ -332,14 +340,21 @@ int itg_attention_bwd(const itg_tensor* theta, const itg_tensor* phi_pooled, con
   p.d_g = (float*)d_g_pooled->ptr;
   p.c8 = theta->c; p.ld8 = theta->ld; p.c2 = g_pooled->c; p.ld2 = g_pooled->ld;
   if (att_tiled_ok(p.J, p.ld8, p.ld2)) {
+    const int nchunk = (p.HW + QC - 1) / QC;
     size_t lt = ((size_t)p.J * (p.ld8 + p.ld2) + (size_t)QC * (p.ld8 + p.ld2) + (size_t)2 * QC * (p.J + 1)) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_tiled_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
       attr_done = true;
     }
-    hipLaunchKernelGGL(attention_bwd_tiled_kernel, dim3(p.NB), dim3(256), lt, (hipStream_t)stream, p);
+    float* slab = p.dS;                                    // second part of beta_save (itg_attention_scratch_floats)
+    hipLaunchKernelGGL(attention_bwd_tiled_kernel, dim3(p.NB * nchunk), dim3(256), lt, (hipStream_t)stream, p, nchunk, slab);
+    ITG_CHECK_LAUNCH();
+    const int n2 = p.J * p.ld2, n8 = p.J * p.ld8;
+    const int64_t tot = (int64_t)p.NB * ((n2 + n8) >> 2);
+    hipLaunchKernelGGL(attention_bwd_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)slab, p.d_g, p.d_phi, p.NB, nchunk, n2, n8);
     ITG_CHECK_LAUNCH();
     return ITG_OK;
   }

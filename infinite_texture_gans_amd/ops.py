@@ -720,8 +720,9 @@ class _Att(torch.autograd.Function):
         n, gh, gw, ph, pw, _ = theta.shape
         nb, hw, j = n * gh * gw, ph * pw, phi.shape[3] * phi.shape[4]
         o = torch.empty((n, gh, gw, ph, pw, g.shape[5]), device=theta.device, dtype=torch.float32)
-        beta = torch.empty(2 * nb * hw * j, device=theta.device, dtype=torch.float32)
         a, b, c_, d = _desc(theta, c8), _desc(phi, c8), _desc(g, c2), _desc(o, c2)
+        beta = torch.empty(_lib.fn("itg_attention_scratch_floats")(C.byref(a), C.byref(b), C.byref(c_)), device=theta.device,
+                           dtype=torch.float32)
         _lib.call("itg_attention_fwd", C.byref(a), C.byref(b), C.byref(c_), C.byref(d), _ptr(beta), _stream())
         ctx.meta = (c8, c2)
         ctx.save_for_backward(theta, phi, g, beta)
