@@ -1531,8 +1531,6 @@ int launch_tn(WgP p, int splits, int prec, hipStream_t s) {
   p.ncol_tiles = (p.Kpad + BCOL - 1) / BCOL;
   p.nco_tiles = (p.co_rows + BCO - 1) / BCO;
   dim3 grid((unsigned)(p.ncol_tiles * p.nco_tiles), 1, (unsigned)splits);
-  snprintf(g_last_launch, sizeof(g_last_launch), "conv_tn_kernel<%d, %d, %d, %d, %s>", BCOL, BCO, WCOL, WCO,
-           prec == ITG_PREC_BF16 ? "true" : "false");
   // offset-table pitch: the taps one column tile can touch (+ the dY slot)
   int taps_tile = (BCOL + p.cin_ld - 1) / p.cin_ld + 1;
   if (taps_tile > p.ntaps) taps_tile = p.ntaps;
@@ -1542,6 +1540,8 @@ int launch_tn(WgP p, int splits, int prec, hipStream_t s) {
   static const int depth_env = env_int("ITG_TN_DEPTH", 0);
   const int depth = depth_env ? depth_env : (p.chunks_per_split >= 128 ? 1 : 2);
   const int kp = prec == ITG_PREC_BF16 ? 32 : BKP;
+  snprintf(g_last_launch, sizeof(g_last_launch), "conv_tn_kernel<%d, %d, %d, %d, %s, %d>", BCOL, BCO, WCOL, WCO,
+           prec == ITG_PREC_BF16 ? "true" : "false", prec == ITG_PREC_BF16 ? 1 : depth);
   if (prec == ITG_PREC_BF16)
     hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, true, 1>), grid, dim3(256), (size_t)2 * kp * otp * 4, s, p, otp);
   else if (depth == 2)
