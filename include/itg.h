@@ -50,6 +50,11 @@ typedef struct {
   int32_t pad_mode; /* ITG_PAD_*: how reads outside the merged image resolve */
   int32_t pad_h;    /* vertical padding when it differs from `pad` (row-sharded grids: 0); < 0 = same as pad */
   int32_t precision; /* ITG_PREC_*: MFMA operand type of the contraction (tensors are fp32 in memory either way) */
+  int32_t reserved;  /* 0 */
+  double* out_stats; /* itg_conv2d_fwd only, or NULL: 2 * out.ld doubles (sum | sum of squares per channel over every
+                      * output pixel), ACCUMULATED into by the conv's epilogue - the BatchNorm statistics of the
+                      * layer that consumes this output (nn.BatchNorm2d after every generator conv, reference
+                      * models/layers.py:279-280,301-322) without a second pass over the tensor (out.ld <= 512) */
 } itg_conv_geom;
 
 /* ITG_PREC_F32: v_mfma_f32_16x16x4_f32, the reference's arithmetic (BASELINE configs 1, 2, 4, 5).

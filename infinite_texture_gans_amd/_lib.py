@@ -23,10 +23,11 @@ PREC_F32, PREC_BF16 = 0, 1      # itg.h ITG_PREC_*
 
 class ConvGeom(C.Structure):
     _fields_ = [("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
-                ("pad_mode", C.c_int32), ("pad_h", C.c_int32), ("precision", C.c_int32)]
+                ("pad_mode", C.c_int32), ("pad_h", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32),
+                ("out_stats", C.c_void_p)]
 
-    def __init__(self, kh, kw, stride, pad, pad_mode, pad_h=-1, precision=0):
-        super().__init__(kh, kw, stride, pad, pad_mode, pad_h, precision)
+    def __init__(self, kh, kw, stride, pad, pad_mode, pad_h=-1, precision=0, out_stats=None):
+        super().__init__(kh, kw, stride, pad, pad_mode, pad_h, precision, 0, out_stats)
 
 
 PACK_MAX_JOBS = 48

@@ -67,14 +67,16 @@ class ResidualPatchGenerator(nn.Module):
             maps = [None] * self.n_layers_G
         A, s = ops.ACT_LRELU, float(self.leak)
         gh, gw = self.num_patches_h, self.num_patches_w
-        if self.padding_mode == 'local':
-            h = self.start.forward_grid(ops.to_grid(z, 1, 1, merged=True), image_location)
-        else:
-            h = self.start.forward_grid(ops.to_grid(z, 1, 1, merged=True), image_location)
+        # every conv whose output goes straight into a training-mode BatchNorm takes that BatchNorm's statistics in its
+        # own epilogue (the block after an attention layer normalises the attention output instead: no fusion there)
+        bn = self.type_norm == 'BN' and self.training
+        h = self.start.forward_grid(ops.to_grid(z, 1, 1, merged=True), image_location, out_stats=bn)
+        if self.padding_mode != 'local':
             gh, gw = 1, 1
-        h = self.block1.forward_grid(h, maps[0], image_location)
+        h = self.block1.forward_grid(h, maps[0], image_location, out_stats=bn)
         for i in range(2, self.n_layers_G + 1):
-            h = getattr(self, "block%d" % i).forward_grid(h, maps[i - 1], image_location, upsample_input=True)
+            h = getattr(self, "block%d" % i).forward_grid(h, maps[i - 1], image_location, upsample_input=True,
+                                                          out_stats=bn and not (i == 3 and self.attention))
             if i == 3 and self.attention:
                 h = self.attention.run(h)
         if self.type_norm == 'BN':

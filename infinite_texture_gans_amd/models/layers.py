@@ -6,6 +6,8 @@ module boundary) or the internal patch-grid NHWC form (:class:`ops.GT`), in whic
 result stays in that form - this is how the generator keeps its whole forward/backward in
 NHWC without per-layer conversions.  There is no CPU path.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -81,11 +83,11 @@ class _ConvParams(nn.Module):
         return (w.grad, b.grad if (b is not None and b.grad is not None) else None)
 
     def run(self, x, pad=None, pad_mode=ops.PAD_ZERO, act=ops.ACT_NONE, slope=0.0, residual=None, out_grid=None,
-            pad_h=-1, in_act=None, defer_act_bwd=False):
+            pad_h=-1, in_act=None, defer_act_bwd=False, out_stats=False):
         w, sn = self.weight_and_sn()
         return ops.conv(x, w, self.bias, self.k, self.k, self.stride, self.padding if pad is None else pad,
                         pad_mode, act, slope, residual, sn, out_grid, self._sinks(w), pad_h, packed=self._packed,
-                        in_act=in_act, defer_act_bwd=defer_act_bwd)
+                        in_act=in_act, defer_act_bwd=defer_act_bwd, out_stats=out_stats)
 
     def forward(self, x):
         """Plain conv on an NCHW image batch (zero padding), as the reference's nn.Conv2d."""
@@ -225,8 +227,9 @@ class conv2d_lp(nn.Module):
         else:
             self.conv = conv3x3(ch_in, ch_out, SN, 1, 1)
 
-    def forward_grid(self, x, image_location="1st_row_1st_col", act=ops.ACT_NONE, slope=0.0, residual=None):
-        """x: GT patches (or, for the generator's ``start`` layer, the merged latent as a 1x1-grid GT)."""
+    def forward_grid(self, x, image_location="1st_row_1st_col", act=ops.ACT_NONE, slope=0.0, residual=None, out_stats=False):
+        """x: GT patches (or, for the generator's ``start`` layer, the merged latent as a 1x1-grid GT).
+        ``out_stats``: the output feeds a training-mode BatchNorm - its statistics are taken in this conv's epilogue."""
         if self.padding_mode != "local":
             # per-patch zero padding: every patch is an independent image
             n, gh, gw, ph, pw, ld = x.t.shape
@@ -238,14 +241,15 @@ class conv2d_lp(nn.Module):
         gh, gw, outer = lp.cfg()
         if not lp.merge_patches_into_image:
             # valid conv over the pre-padded merged latent == crop(b+2, stride b) + valid conv per patch
-            return self.conv.run(x, pad=0, act=act, slope=slope, residual=residual, out_grid=(gh, gw))
+            return self.conv.run(x, pad=0, act=act, slope=slope, residual=residual, out_grid=(gh, gw), out_stats=out_stats)
         if lp.halo is not None:
             if lp.training:
                 return self._forward_band_train(x, lp, outer, act, slope, residual)
             return self._forward_row_sharded(x, lp, outer, act, slope, residual)
         if lp.training:
             # halo + outer padding are resolved inside the conv's tile loader
-            return self.conv.run(x, pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope, residual=residual)
+            return self.conv.run(x, pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope, residual=residual,
+                                 out_stats=out_stats)
         left, top = lp.halo_sources(x, image_location)
         if left is None and top is None and "1st_row" in image_location and "1st_col" in image_location:
             return self.conv.run(x, pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope, residual=residual)
@@ -460,9 +464,11 @@ class ResBlockGenerator(nn.Module):
         # nn.LeakyReLU(leak) if leak > 0 else nn.ReLU(): both are ACT_LRELU with slope = leak
         self.activation = nn.LeakyReLU(self.leak) if self.leak > 0 else nn.ReLU()
 
-    def forward_grid(self, x, map=None, image_location="1st_row_1st_col", upsample_input=False):
+    def forward_grid(self, x, map=None, image_location="1st_row_1st_col", upsample_input=False, out_stats=False):
         """x: GT.  ``upsample_input``: x is the block input BEFORE the generator's nearest x2
-        upsample; the upsample is then folded into bn1 (BN mode) and moved behind the 1x1 shortcut."""
+        upsample; the upsample is then folded into bn1 (BN mode) and moved behind the 1x1 shortcut.
+        ``out_stats``: the block output goes straight into a training-mode BatchNorm (next block's bn1 / the final bn)."""
+        fuse = self.type_norm == "BN" and self.training and os.environ.get("ITG_BN_FUSE", "1") == "1"
         A, s = ops.ACT_LRELU, float(self.leak)
         if self.type_norm == "SSM":
             if upsample_input:
@@ -482,7 +488,7 @@ class ResBlockGenerator(nn.Module):
             out = self.bn1.run(x, map, act=A, slope=s)
         else:
             out = self.bn1.run(x, act=A, slope=s, upsample=upsample_input)
-        out = self.conv1.forward_grid(out, image_location)
+        out = self.conv1.forward_grid(out, image_location, out_stats=fuse)
         if self.type_norm == "SSM":
             out = self.bn2.run(out, map, act=A, slope=s)
         else:
@@ -494,7 +500,7 @@ class ResBlockGenerator(nn.Module):
             sc = self._shortcut(x, map, upsample_input)
         else:
             sc = ops.upsample2x(x) if upsample_input else x
-        return self.conv2.forward_grid(out, image_location, residual=sc)
+        return self.conv2.forward_grid(out, image_location, residual=sc, out_stats=fuse and out_stats)
 
     def _shortcut(self, x, map, upsample_input):
         sc = x

@@ -102,10 +102,12 @@ def _req_cuda(t, what):
 
 class GT:
     """Patch-grid NHWC activation: ``t`` is (n, gh, gw, ph, pw, ld), ``c`` logical channels."""
-    __slots__ = ("t", "c")
+    __slots__ = ("t", "c", "stats")
 
-    def __init__(self, t, c):
-        self.t, self.c = t, int(c)
+    def __init__(self, t, c, stats=None):
+        # stats: fp64 [2 * ld] per-channel (sum, sum of squares) of ``t`` when the conv that produced it accumulated
+        # them in its epilogue (conv(..., out_stats=True)); the BatchNorm that consumes ``t`` then skips its stats pass
+        self.t, self.c, self.stats = t, int(c), stats
 
     n = property(lambda s: s.t.shape[0])
     gh = property(lambda s: s.t.shape[1])
@@ -232,7 +234,8 @@ class _Conv(torch.autograd.Function):
     coordinates).  ``sn`` = (inv_sigma, u, v) makes ``w`` the spectral-norm ``weight_orig``."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, sn, c_in, geom, act, slope, out_grid, sinks=None, packed=None, fuse=(None, False)):
+    def forward(ctx, x, w, bias, residual, sn, c_in, geom, act, slope, out_grid, sinks=None, packed=None, fuse=(None, False),
+                stats=None):
         kh, kw, stride, pad, pad_mode, pad_h, prec = geom
         pv = pad_h if pad_h >= 0 else pad
         n, gh, gw, ph, pw, ld = x.shape
@@ -255,7 +258,7 @@ class _Conv(torch.autograd.Function):
         out = torch.empty((n, ogh, ogw, Ho // ogh, Wo // ogw, ld_for(co)), device=x.device, dtype=torch.float32)
         dx_, do_ = _desc(x, c_in), _desc(out, co)
         dr_ = _desc(residual, co) if residual is not None else _null_desc()
-        g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec)
+        g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, stats.data_ptr() if stats is not None else None)
         nws = _lib.fn("itg_conv2d_fwd_workspace")(C.byref(dx_), C.byref(do_), C.byref(g))
         ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
         with _Prof(_nt_tag(co), 1, 2.0 * n * Ho * Wo * co * ci * kh * kw, 4 * (x.numel() + out.numel() + wp.numel())):
@@ -358,20 +361,26 @@ class _Conv(torch.autograd.Function):
                 if not need_w:
                     gw_ = None
         gres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
-        return gx, gw_, gb, gres, None, None, None, None, None, None, None, None, None
+        return gx, gw_, gb, gres, None, None, None, None, None, None, None, None, None, None
 
 
 def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, residual=None,
-         sn=None, out_grid=None, sinks=None, pad_h=-1, precision=None, packed=None, in_act=None, defer_act_bwd=False):
+         sn=None, out_grid=None, sinks=None, pad_h=-1, precision=None, packed=None, in_act=None, defer_act_bwd=False,
+         out_stats=False):
     """x: GT.  Returns GT with ``out_grid`` (default: the input grid).  ``sinks`` = (weight.grad, bias.grad)
     buffers: the backward then accumulates the parameter gradients straight into them (and reports no
     gradient to autograd), which removes one AccumulateGrad add kernel per parameter."""
     og = out_grid if out_grid is not None else (x.gh, x.gw)
     r = residual.t if residual is not None else None
     prec = MFMA_PRECISION if precision is None else precision
+    # out_stats: the epilogue also accumulates the per-channel (sum, sum of squares) of the output - the statistics pass
+    # of the BatchNorm that consumes it (at most 512 padded channels; single-output-channel taps-as-rows convs excluded)
+    stats = None
+    if out_stats and ld_for(w.shape[0]) <= 512 and w.shape[0] > 1:
+        stats = _zeros_f64(2 * ld_for(w.shape[0]), x.t.device)
     t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode, pad_h, prec), act, slope, og, sinks, packed,
-                    (in_act, bool(defer_act_bwd)))
-    return GT(t, w.shape[0])
+                    (in_act, bool(defer_act_bwd)), stats)
+    return GT(t, w.shape[0], stats)
 
 
 # ------------------------------------------------------------------------------- batch norm (+act, +upsample)
@@ -465,7 +474,7 @@ def _zeros_f64(n, device):
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, rm, rv, nbt, c, training, eps, momentum, act, slope, ups, sync, sinks=None):
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, c, training, eps, momentum, act, slope, ups, sync, sinks=None, pre_sums=None):
         x = x.contiguous()
         n, gh, gw, ph, pw, ld = x.shape
         dev = x.device
@@ -474,8 +483,11 @@ class _BNAct(torch.autograd.Function):
         count = float(x.numel() // ld)
         sums = None
         if training:
-            sums = _zeros_f64(2 * ld, dev)
-            _lib.call("itg_bn_stats", C.byref(dx_), _ptr(sums), st)
+            if pre_sums is not None:      # accumulated by the epilogue of the conv that produced x
+                sums = pre_sums
+            else:
+                sums = _zeros_f64(2 * ld, dev)
+                _lib.call("itg_bn_stats", C.byref(dx_), _ptr(sums), st)
             if sync is not None and _active(sync):
                 sync.all_reduce(sums)
                 count = sync.global_count(count)
@@ -533,14 +545,15 @@ class _BNAct(torch.autograd.Function):
                   count, act, float(slope), C.byref(dgx), _ptr(dg), _ptr(db), acc, st)
         if acc:
             dg = db = None
-        return gx, dg, db, None, None, None, None, None, None, None, None, None, None, None, None
+        return gx, dg, db, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def bn_act(x, gamma, beta, rm, rv, nbt, training=True, eps=1e-5, momentum=0.1, act=ACT_NONE, slope=0.0,
            upsample=False, sync=None, sinks=None):
     """y = act(BatchNorm(x)) [nearest-upsampled x2 when ``upsample``]: statistics are taken on x
     (identical to those of the upsampled tensor), the unbiased running_var uses the x4 count."""
-    t = _BNAct.apply(x.t, gamma, beta, rm, rv, nbt, x.c, training, eps, momentum, act, slope, upsample, sync, sinks)
+    t = _BNAct.apply(x.t, gamma, beta, rm, rv, nbt, x.c, training, eps, momentum, act, slope, upsample, sync, sinks,
+                     x.stats if training else None)
     return GT(t, x.c)
 
 

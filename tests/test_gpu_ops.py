@@ -462,3 +462,39 @@ def test_attention_module_backward_matches_oracle_autograd():
             assert float(a.abs().max()) < 1e-5 and float(b.abs().max()) < 1e-5
             continue
         assert rel_l2(a.cpu(), b) < 1e-5, (n_, rel_l2(a.cpu(), b))
+
+
+# ------------------------------------------------------------------------------- BatchNorm statistics in the conv epilogue
+@pytest.mark.parametrize("name,n,grid,p,ci,co,residual", [
+    ("generic_kernel", 2, (3, 3), 8, 26, 13, False),
+    ("split_k_second_stage", 2, (3, 3), 4, 208, 104, True),
+    ("halo_tile_kernel", 1, (2, 2), 64, 13, 13, True),
+    ("halo_tile_kernel_2_row_tiles", 1, (2, 2), 64, 13, 26, False),
+])
+def test_conv_epilogue_accumulates_batchnorm_statistics(name, n, grid, p, ci, co, residual):
+    """conv(..., out_stats=True): the per-channel (sum, sum of squares) of the stored output, as the consumer BatchNorm's
+    statistics pass would compute them (fp64), from the three epilogues that can produce them; and BatchNorm fed with
+    them equals BatchNorm with its own pass."""
+    ops = _ops()
+    g = _gen(60 + co)
+    gh, gw = grid
+    x = torch.randn(n * gh * gw, ci, p, p, generator=g)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)
+    b = torch.randn(co, generator=g) * 0.1
+    r = torch.randn(n * gh * gw, co, p, p, generator=g) if residual else None
+    xg = ops.to_grid(x.to(cuda), gh, gw, merged=False)
+    rg = ops.to_grid(r.to(cuda), gh, gw, merged=False) if residual else None
+    y = ops.conv(xg, w.to(cuda), b.to(cuda), 3, 3, 1, 1, ops.PAD_REPLICATE, residual=rg, out_stats=True)
+    y0 = ops.conv(xg, w.to(cuda), b.to(cuda), 3, 3, 1, 1, ops.PAD_REPLICATE, residual=rg)
+    assert y.stats is not None and y0.stats is None and torch.equal(y.t, y0.t)
+    ld = y.t.shape[-1]
+    t = y.t.double().reshape(-1, ld)
+    want = torch.cat((t.sum(0), (t * t).sum(0)))
+    assert rel_l2(y.stats.cpu(), want.cpu()) < 1e-6, rel_l2(y.stats.cpu(), want.cpu())
+    gamma, beta = (1 + 0.1 * torch.randn(co, generator=g)).to(cuda), (0.1 * torch.randn(co, generator=g)).to(cuda)
+    outs = []
+    for src in (y, y0):
+        rm, rv, nbt = torch.zeros(co, device=cuda), torch.ones(co, device=cuda), torch.zeros((), dtype=torch.int64, device=cuda)
+        outs.append((ops.bn_act(src, gamma, beta, rm, rv, nbt, True, 1e-5, 0.1, ops.ACT_LRELU, 0.02).t, rm, rv))
+    assert rel_l2(outs[0][0].cpu(), outs[1][0].cpu()) < 1e-6
+    assert rel_l2(outs[0][1].cpu(), outs[1][1].cpu()) < 1e-6 and rel_l2(outs[0][2].cpu(), outs[1][2].cpu()) < 1e-6
