@@ -186,7 +186,9 @@ def hbm_traffic(kernel):
     """HBM bytes per launch of ``kernel`` from the committed PMC summary (separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes, gfx950 corrections applied by tools/prof_summary.py), or None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    wl = _WORKLOAD[0]
+    pat = "r[0-9][0-9]_hbm_traffic.json" if wl == "config1" else "r[0-9][0-9]_%s_hbm_traffic.json" % wl
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
     if not files:
         return None
     try:

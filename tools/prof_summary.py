@@ -54,11 +54,12 @@ def main():
     ap.add_argument("--round", default="r01")
     ap.add_argument("--cmd", default="")
     ap.add_argument("--note", default="")
+    ap.add_argument("--suffix", default="", help="e.g. _config3: files profiles/<round><suffix>_bench_kernel_stats.md / _hbm_traffic.json")
     a = ap.parse_args()
     stats = find(a.stats, "*kernel_stats.csv")
     rows = list(csv.DictReader(open(stats)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    out = os.path.join(ROOT, "profiles", "%s_bench_kernel_stats" % a.round)
+    out = os.path.join(ROOT, "profiles", "%s%s_bench_kernel_stats" % (a.round, a.suffix))
     shutil.copy(stats, out + ".csv")
     with open(out + ".md", "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats -- %s  (MI355X)\n" % a.cmd)
@@ -84,7 +85,7 @@ def main():
                 traffic[k] = {"fetch_bytes": fb, "write_bytes": wb, "launches": fe[k][1]}
                 if fb * fe[k][1] > 50e6:
                     f.write("| `%s` | %d | %.1f | %.1f |\n" % (k[:70], fe[k][1], fb / 1e6, wb / 1e6))
-            json.dump(traffic, open(os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % a.round), "w"), indent=0)
+            json.dump(traffic, open(os.path.join(ROOT, "profiles", "%s%s_hbm_traffic.json" % (a.round, a.suffix)), "w"), indent=0)
     print("wrote", out + ".md")
 
 
