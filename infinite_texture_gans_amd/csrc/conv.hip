@@ -553,7 +553,9 @@ __device__ __forceinline__ f32x4 store_out(const ConvP& p, int n, int oy, int ox
 // K index k = 16 q + 4 g + e maps to (tap, c) = divmod(k, cin_ld); cin_ld % 4 == 0 keeps the four e of a lane
 // in one tap, so lane group g of chunk q reads 16 B at pixel * cpt + koff[q][g].
 // NLD = b128 loads per thread and tile = ceil(340 * (cin_ld / 4) / 256): 6 up to cin_ld 16, 11 up to 32
-template <int FI, int NLD>
+// STATS: also accumulate the consumer BatchNorm's statistics (p.stats) - its own instantiation, so that the input-gradient
+// and plain forward launches keep the register budget they were tuned to
+template <int FI, int NLD, bool STATS>
 __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(const ConvP p, int tiles_x, int tiles_y, int ntiles, int cpt, int nch) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int co_rows = 16 * FI;
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(cons
   // per-workgroup constants of the epilogue
   const float osc = p.scale ? *p.scale : 1.f;
   if (tid < 32) biasl[tid] = (p.bias && tid < p.out.c) ? p.bias[tid] : 0.f;
-  if (tid < 64) lstat[tid] = 0.0;
+  if (STATS && tid < 64) lstat[tid] = 0.0;
   const bool has_res = p.res.p != nullptr;
   int tile = blockIdx.x;
   if (tile < ntiles) load_tile(tile);
@@ -677,9 +679,11 @@ __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(cons
     const int ty_i = b % tiles_y;
     const int n = b / tiles_y;
     const int t0 = ty_i * TT_H, u0 = tx_i * TT_W;
-    f32x4 ts1[FI], ts2[FI];                          // this tile's BatchNorm partial sums (p.stats)
+    f32x4 ts1[STATS ? FI : 1], ts2[STATS ? FI : 1];   // this tile's BatchNorm partial sums (p.stats)
+    if constexpr (STATS) {
 #pragma unroll
-    for (int i = 0; i < FI; ++i) { ts1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ts2[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int i = 0; i < FI; ++i) { ts1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ts2[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       int t = t0 + 2 * wave + (f >> 1), u = u0 + 16 * (f & 1) + fj;
@@ -698,10 +702,10 @@ __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(cons
         }
         const f32x4 v = store_out(p, n, t * p.osy + p.ooy, u * p.osx + p.oox, co, acc[i][f], osc,
                                   *reinterpret_cast<const f32x4*>(biasl + co), has_res, r);
-        ts1[i] += v; ts2[i] += v * v;
+        if constexpr (STATS) { ts1[i] += v; ts2[i] += v * v; }
       }
     }
-    if (p.stats) {      // grid-uniform: pixel lanes -> one lane per channel group -> fp64 in LDS
+    if constexpr (STATS) {      // pixel lanes -> one lane per channel group -> fp64 in LDS
 #pragma unroll
       for (int i = 0; i < FI; ++i)
 #pragma unroll
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(cons
     }
     __syncthreads();                                  // every wave is done reading Xt
   }
-  if (p.stats) {
+  if constexpr (STATS) {
     __syncthreads();
     if (tid < 32 && tid < p.out.ld) {
       atomicAdd(&p.stats[tid], lstat[tid]);
@@ -729,12 +733,14 @@ __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(cons
 }
 
 // eligibility + launch of the halo-tile kernel; returns 1 when it handled the call
-int try_conv_tile(const ConvP& p, hipStream_t s, int* rc) {
+int try_conv_tile(ConvP& p, hipStream_t s, int* rc) {
   static const int enable = env_int("ITG_CONV_TILE", 1);
   if (!enable || p.ncls > 1 || p.ntaps != 9 || p.kw != 3 || p.isy != 1 || p.isx != 1 || p.osy != 1 || p.osx != 1)
     return 0;
   if (p.prec != ITG_PREC_F32 || p.cin_ld > 32 || p.co_rows > 32) return 0;
   if ((int64_t)p.MT * p.MU < 64 * 64) return 0;          // tiny images: the gather kernel with split-K wins
+  const int FI = p.co_rows / 16;
+  if (FI == 2) p.stats = nullptr;      // two row tiles + statistics spill (17-24 VGPRs): the caller runs the separate pass
   ConvP q = p;
   int64_t ib = (int64_t)p.in.n * p.in.gh * p.in.gw * p.in.ph * p.in.pw * p.in.ld * 4;
   if (ib >= 0xFFFF0000LL) return 0;
@@ -742,19 +748,26 @@ int try_conv_tile(const ConvP& p, hipStream_t s, int* rc) {
   q.scale = p.scale;
   const int cpt = (p.cin_ld % 8 == 4) ? p.cin_ld : p.cin_ld + 4;     // conflict-free b128 fragment reads
   const int nch = (9 * p.cin_ld + 15) / 16;
-  const int FI = p.co_rows / 16;
   const int tiles_x = (p.MU + TT_W - 1) / TT_W, tiles_y = (p.MT + TT_H - 1) / TT_H;
   const int64_t ntiles = (int64_t)p.in.n * tiles_x * tiles_y;
   const size_t lds = ((size_t)nch * 16 * FI * 20 + ((nch * 4 + 3) & ~3) + 32 + 128 + (size_t)TT_PIX * cpt) * sizeof(float);
   const int nld = (TT_PIX * (p.cin_ld >> 2) + 255) / 256;
   if (ntiles > 0x7fffffff || lds > 64 * 1024 || nld > 11) return 0;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<1, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<2, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<1, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<2, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    attr_done = true;
+  const bool st = p.stats != nullptr;
+  const void* kern;
+  if (FI == 1 && nld <= 6) kern = st ? (const void*)&conv_tile_kernel<1, 6, true> : (const void*)&conv_tile_kernel<1, 6, false>;
+  else if (FI == 1) kern = st ? (const void*)&conv_tile_kernel<1, 11, true> : (const void*)&conv_tile_kernel<1, 11, false>;
+  else if (nld <= 6) kern = st ? (const void*)&conv_tile_kernel<2, 6, true> : (const void*)&conv_tile_kernel<2, 6, false>;
+  else kern = st ? (const void*)&conv_tile_kernel<2, 11, true> : (const void*)&conv_tile_kernel<2, 11, false>;
+  static const void* attr_set[8] = {nullptr};
+  {
+    bool seen = false;
+    int slot = 0;
+    for (; slot < 8 && attr_set[slot]; ++slot) seen = seen || attr_set[slot] == kern;
+    if (!seen && slot < 8) {
+      (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      attr_set[slot] = kern;
+    }
   }
   // persistent grid = what is resident at once (register budget: 4 workgroups per CU with 6 loads, 3 with 11)
   int per_cu = (int)((160 * 1024) / lds);
@@ -764,15 +777,10 @@ int try_conv_tile(const ConvP& p, hipStream_t s, int* rc) {
   if (per_cu < 1) per_cu = 1;
   const int64_t want = 256 * (int64_t)per_cu;
   const unsigned blocks = (unsigned)(ntiles < want ? ntiles : want);
-  snprintf(g_last_launch, sizeof(g_last_launch), "conv_tile_kernel<%d, %d>", FI, nld <= 6 ? 6 : 11);
-  if (FI == 1 && nld <= 6)
-    hipLaunchKernelGGL((conv_tile_kernel<1, 6>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles, cpt, nch);
-  else if (FI == 1)
-    hipLaunchKernelGGL((conv_tile_kernel<1, 11>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles, cpt, nch);
-  else if (nld <= 6)
-    hipLaunchKernelGGL((conv_tile_kernel<2, 6>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles, cpt, nch);
-  else
-    hipLaunchKernelGGL((conv_tile_kernel<2, 11>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles, cpt, nch);
+  snprintf(g_last_launch, sizeof(g_last_launch), "conv_tile_kernel<%d, %d, %s>", FI, nld <= 6 ? 6 : 11, st ? "true" : "false");
+  int a_tx = tiles_x, a_ty = tiles_y, a_nt = (int)ntiles, a_cpt = cpt, a_nch = nch;
+  void* args[] = {(void*)&q, &a_tx, &a_ty, &a_nt, &a_cpt, &a_nch};
+  (void)hipLaunchKernel(kern, dim3(blocks), dim3(256), args, lds, s);
   *rc = hipGetLastError() == hipSuccess ? ITG_OK : ITG_ERR_LAUNCH;
   return 1;
 }
