@@ -812,12 +812,12 @@ NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = 
   //   fill          < 2 workgroups per CU leaves the MFMA pipe idle between phases
   //   split cost    the second stage's slab round trip ~ ks * 100 / K of the kernel's own time
   //   tile penalty  narrower tiles re-read the weight panel more often and carry more issue overhead
-  static const double split_cost = (double)env_int("ITG_SPLIT_COST", 100);
+  static const double split_cost = (double)env_int("ITG_SPLIT_COST", 200);
   pl.bpix = 128; pl.ksplit = 1;
   double best_eff = 0.0;
   const int cands_big[4] = {256, 128, 96, 64};
   const int cand_ks[13] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16};
-  static const double fill_min = env_int("ITG_FILL_MIN", 200) / 100.0;
+  static const double fill_min = env_int("ITG_FILL_MIN", 300) / 100.0;
   static const int allow96 = env_int("ITG_NT_96", 1);
   static const double pen96 = env_int("ITG_PEN96", 104) / 100.0;
   for (int ci = 0; ci < 4; ++ci) {
