@@ -732,6 +732,124 @@ __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(cons
   }
 }
 
+// ------------------------------------------------------------------------------- thin 3x3 convs on the vector ALU
+// Stride-1 3x3 convolutions whose (padded input channels) x (padded output channels) is at most 64: the generator's
+// `final` layer (13 -> 3, tanh; reference models/generators.py:83,119-121) and its input gradient (3 -> 13).  On the
+// MFMA kernels such a layer fills 3 of 16 rows (or 4 of 16 K lanes): 67 us / 44 us for 94 MB of traffic.  Here a
+// workgroup stages one (8+2) x (32+2) halo tile in LDS, every thread owns ONE output pixel and all its output
+// channels, reads its 9 neighbours as 16-byte LDS vectors and takes the filter taps through the scalar cache
+// (wave-uniform addresses -> s_load), i.e. <= 576 v_fma per pixel and nothing else in the loop: HBM-bound.
+template <int CI4, int CO4>
+__global__ __launch_bounds__(256, 5) void conv_valu_kernel(const ConvP p, int tiles_x, int tiles_y, int cpt) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Xt = lds;
+  constexpr int NLD = (TT_PIX * CI4 + 255) / 256;
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  const int tx_i = b % tiles_x; b /= tiles_x;
+  const int ty_i = b % tiles_y;
+  const int n = b / tiles_y;
+  const int t0 = ty_i * TT_H, u0 = tx_i * TT_W;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in.p, 0, p.in_bytes, 0x00020000);
+  const int y0 = t0 + p.ioy, x0 = u0 + p.iox;
+  f32x4 rt[NLD];                                           // every load of the tile in flight before the first LDS store
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int e = min(tid + i * 256, TT_PIX * CI4 - 1);
+    const int pix = e / CI4, c4 = e - pix * CI4;
+    const int r = pix / (TT_W + 2), c = pix - r * (TT_W + 2);
+    int iy = y0 + r, ix = x0 + c;
+    bool ok = true;
+    if (p.pad_mode != ITG_PAD_REPLICATE) ok = (unsigned)iy < (unsigned)p.in.H && (unsigned)ix < (unsigned)p.in.W;
+    iy = min(max(iy, 0), p.in.H - 1); ix = min(max(ix, 0), p.in.W - 1);
+    const unsigned o = (unsigned)grid_off(p.in, n, iy, ix) * 4u + (unsigned)c4 * 16u;
+    rt[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? o : p.in_bytes, 0, 0));
+  }
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int e = tid + i * 256;
+    if (e < TT_PIX * CI4) {
+      const int pix = e / CI4, c4 = e - pix * CI4;
+      *reinterpret_cast<f32x4*>(Xt + pix * cpt + c4 * 4) = rt[i];
+    }
+  }
+  __syncthreads();
+  const int ty = tid >> 5, tx = tid & 31;
+  f32x4 acc[CO4];
+#pragma unroll
+  for (int o = 0; o < CO4; ++o) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* __restrict__ w = p.w;                      // [16 rows (co)][Kpad], k = tap * cin_ld + c
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const float* xp = Xt + ((ty + ky) * (TT_W + 2) + tx + kx) * cpt;
+    f32x4 xv[CI4];
+#pragma unroll
+    for (int c4 = 0; c4 < CI4; ++c4) xv[c4] = *reinterpret_cast<const f32x4*>(xp + c4 * 4);
+#pragma unroll
+    for (int co = 0; co < CO4 * 4; ++co) {
+      const float* wr = w + co * p.Kpad + tap * (CI4 * 4);  // wave-uniform: scalar loads
+      float a = acc[co >> 2][co & 3];
+#pragma unroll
+      for (int c4 = 0; c4 < CI4; ++c4) {
+        a = fmaf(xv[c4][0], wr[c4 * 4 + 0], a);
+        a = fmaf(xv[c4][1], wr[c4 * 4 + 1], a);
+        a = fmaf(xv[c4][2], wr[c4 * 4 + 2], a);
+        a = fmaf(xv[c4][3], wr[c4 * 4 + 3], a);
+      }
+      acc[co >> 2][co & 3] = a;
+    }
+  }
+  const int t = t0 + ty, u = u0 + tx;
+  if (t >= p.MT || u >= p.MU) return;
+  const float osc = p.scale ? *p.scale : 1.f;
+  const bool has_res = p.res.p != nullptr;
+  int oy = t * p.osy + p.ooy, ox = u * p.osx + p.oox;
+  int ry = oy, rx = ox;
+  if (p.out_mode == 1) { ry = min(max(oy, 0), p.out.H - 1); rx = min(max(ox, 0), p.out.W - 1); }
+#pragma unroll
+  for (int o = 0; o < CO4; ++o) {
+    if (o * 4 >= p.out.ld) continue;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (o * 4 + e < p.out.c) bv[e] = p.bias[o * 4 + e];
+    }
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    if (has_res) r = *reinterpret_cast<const f32x4*>(p.res.p + grid_off(p.res, n, ry, rx) + o * 4);
+    store_out(p, n, oy, ox, o * 4, acc[o], osc, bv, has_res, r);
+  }
+}
+
+// eligibility + launch of the vector-ALU kernel; returns 1 when it handled the call
+int try_conv_valu(const ConvP& p, hipStream_t s, int* rc) {
+  static const int enable = env_int("ITG_CONV_VALU", 1);
+  if (!enable || p.ncls > 1 || p.ntaps != 9 || p.kw != 3 || p.isy != 1 || p.isx != 1 || p.osy != 1 || p.osx != 1) return 0;
+  if (p.prec != ITG_PREC_F32 || p.stats || p.co_rows != 16) return 0;
+  const int ci4 = p.cin_ld >> 2, co4 = p.out.ld >> 2;
+  // (4 input groups, 1 output group) = the forward of `final`: 44 us against 68 us on the halo-tile MFMA kernel; its
+  // input gradient (1, 4) measured slower here (61 vs 41 us) and stays on the tile kernel
+  static const int dgrad_too = env_int("ITG_CONV_VALU_DGRAD", 0);
+  if (!((ci4 == 4 && co4 == 1) || (dgrad_too && ci4 == 1 && (co4 == 4 || co4 == 1)))) return 0;
+  if ((int64_t)p.MT * p.MU < 64 * 64) return 0;
+  ConvP q = p;
+  int64_t ib = (int64_t)p.in.n * p.in.gh * p.in.gw * p.in.ph * p.in.pw * p.in.ld * 4;
+  if (ib >= 0xFFFF0000LL) return 0;
+  q.in_bytes = (unsigned)ib;
+  const int cpt = (p.cin_ld % 8 == 4) ? p.cin_ld : p.cin_ld + 4;
+  const int tiles_x = (p.MU + TT_W - 1) / TT_W, tiles_y = (p.MT + TT_H - 1) / TT_H;
+  const int64_t ntiles = (int64_t)p.in.n * tiles_x * tiles_y;
+  if (ntiles > 0x7fffffff) return 0;
+  const size_t lds = (size_t)TT_PIX * cpt * sizeof(float);
+  snprintf(g_last_launch, sizeof(g_last_launch), "conv_valu_kernel<%d, %d>", ci4, co4);
+  if (ci4 == 4) hipLaunchKernelGGL((conv_valu_kernel<4, 1>), dim3((unsigned)ntiles), dim3(256), lds, s, q, tiles_x, tiles_y, cpt);
+  else if (co4 == 4) hipLaunchKernelGGL((conv_valu_kernel<1, 4>), dim3((unsigned)ntiles), dim3(256), lds, s, q, tiles_x, tiles_y, cpt);
+  else hipLaunchKernelGGL((conv_valu_kernel<1, 1>), dim3((unsigned)ntiles), dim3(256), lds, s, q, tiles_x, tiles_y, cpt);
+  *rc = hipGetLastError() == hipSuccess ? ITG_OK : ITG_ERR_LAUNCH;
+  return 1;
+}
+
 // eligibility + launch of the halo-tile kernel; returns 1 when it handled the call
 int try_conv_tile(ConvP& p, hipStream_t s, int* rc) {
   static const int enable = env_int("ITG_CONV_TILE", 1);
@@ -886,6 +1004,10 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
   // it removes 8 of the 13 statistics launches of a generator forward.)
   static const int stats_paths = env_int("ITG_STATS_PATHS", 3);
   double* const want_stats = p.stats;
+  {
+    int rc_v = ITG_OK;
+    if (try_conv_valu(p, s, &rc_v)) return rc_v;
+  }
   {
     int rc_tile = ITG_OK;
     ConvP pt = p;
