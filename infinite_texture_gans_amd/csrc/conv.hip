@@ -1635,7 +1635,160 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgP p, int til
   }
 }
 
-struct TileWgPlan { int ok, mf, nld, cpt, tiles_x, tiles_y, blocks; int64_t ntiles; size_t lds; };
+// ------------------------------------------------------------------------ thin 3x3 weight gradient (<= 4 output channels)
+// `final` (13 -> 3 channels on the full 192 x 192 crops): with 16-row MFMA tiles 13 of the 16 dY columns are padding.
+// v_mfma_f32_4x4x1_16b_f32 is 16 independent 4 x 4 outer products: block b (lanes 4 b .. 4 b + 3) computes
+// D_b[i][j] += A[lane 4 b + i] * B[lane 4 b + j], lane 4 b + j holding column j in its 4 registers (measured,
+// tools/probes/mfma4x4_probe.hip).  Here i = output channel (A = dY[pixel][lane % 4], the same in every block) and
+// block b = one (tap, 4-channel group) of X, j = the channel in the group: one instruction per pixel contracts 16
+// (tap, c4) groups with no padding, and a lane's registers are dW[co = 0..3][(tap, c)] of its own (tap, c).
+// Same persistent halo tiles, slabs and reduction as wgrad_tile_kernel.  The (tap, c4) groups are dealt GPP per
+// pass so that, with 16 channels, the three taps of a pass fall in different LDS banks (the pixel is shared).
+template <int NP, int NLD>
+__global__ __launch_bounds__(256, 2) void wgrad_thin_kernel(const WgP p, int tiles_x, int tiles_y, int ntiles, int gpp) {
+  constexpr int cpt = 16;                                  // X tile pitch: compile-time, so that every LDS read below has an immediate offset
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int YP = TT_H * TT_W + 4;                      // dY tile is channel-major: [4][YP]
+  float* Xt = lds;                                         // [TT_PIX][cpt]
+  float* Yt = lds + TT_PIX * cpt;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = p.cin_ld >> 2;
+  const __amdgpu_buffer_rsrc_t rxr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x.p, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ryr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy.p, 0, p.dy_bytes, 0x00020000);
+  int e_r[NLD], e_c[NLD], e_lds[NLD];
+  unsigned e_cb[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    int e = tid + i * 256;
+    bool live = e < TT_PIX * q4;
+    int pix = live ? e / q4 : 0, c4 = live ? e - pix * q4 : 0;
+    e_r[i] = live ? pix / (TT_W + 2) : -1;
+    e_c[i] = pix - (pix / (TT_W + 2)) * (TT_W + 2);
+    e_lds[i] = pix * cpt + c4 * 4;
+    e_cb[i] = (unsigned)c4 * 16u;
+  }
+  const int y_r = tid / TT_W, y_c = tid % TT_W;            // one dY pixel (4 channels) per thread
+  f32x4 rtA[NLD], rtB[NLD], ryA, ryB;                    // two tiles in flight: a tile's MFMA work is shorter than a load
+  auto load_tile = [&](int tile, f32x4 (&rt)[NLD], f32x4& ry) {
+    int b = tile;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+    const int t0 = ty_i * TT_H, u0 = tx_i * TT_W;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      int iy = t0 - p.pad_h + e_r[i], ix = u0 - p.pad + e_c[i];
+      bool ok = e_r[i] >= 0;
+      if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.x.H && (unsigned)ix < (unsigned)p.x.W;
+      iy = min(max(iy, 0), p.x.H - 1); ix = min(max(ix, 0), p.x.W - 1);
+      unsigned o = (unsigned)grid_off(p.x, n, iy, ix) * 4u + e_cb[i];
+      rt[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxr, ok ? o : p.x_bytes, 0, 0));
+    }
+    int t = t0 + y_r, u = u0 + y_c;
+    bool ok = t < p.MT && u < p.MU;
+    unsigned o = (unsigned)grid_off(p.dy, n, ok ? t : 0, ok ? u : 0) * 4u;
+    ry = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ryr, ok ? o : p.dy_bytes, 0, 0));
+  };
+  f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
+  auto store_tile = [&](const f32x4 (&rt)[NLD], const f32x4& ry) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      if (e_r[i] >= 0) *reinterpret_cast<f32x4*>(Xt + e_lds[i]) = rt[i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Yt[c * YP + tid] = ry[c];
+    dbacc += ry;
+  };
+  const int ch = lane & 3, blk = lane >> 2;
+  const int nq = 9 * q4;
+  int xoff[NP], mrow[NP];                                  // this lane's (tap, c) per pass: LDS offset and dW row
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    int q = gpp * i + blk;
+    bool live = blk < gpp && q < nq;
+    q = live ? q : min(gpp * i, nq - 1);                   // idle blocks repeat the pass's first group (same address: a broadcast)
+    int tap = q / q4, c4 = q - tap * q4;
+    int ky = tap / 3, kx = tap - ky * 3;
+    xoff[i] = (ky * (TT_W + 2) + kx) * cpt + 4 * c4 + ch;
+    mrow[i] = live ? tap * p.cin_ld + 4 * c4 + ch : -1;
+  }
+  f32x4 acc[NP];
+  const float* xp[NP];                                     // this wave's two pixel rows, at the lane's (tap, c)
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    xp[i] = Xt + 2 * wave * (TT_W + 2) * cpt + xoff[i];
+  }
+
+  auto contract = [&]() {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const float* yrow = Yt + ch * YP + (2 * wave + rr) * TT_W;
+#pragma unroll
+      for (int s4 = 0; s4 < TT_W / 4; ++s4) {
+        const f32x4 ya = *reinterpret_cast<const f32x4*>(yrow + 4 * s4);
+        float xb[4][NP];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < NP; ++i) xb[k][i] = xp[i][(rr * (TT_W + 2) + 4 * s4 + k) * cpt];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < NP; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(ya[k], xb[k][i], acc[i], 0, 0, 0);
+      }
+    }
+  };
+  int tile = blockIdx.x;
+  const int step = gridDim.x;
+  if (tile < ntiles) load_tile(tile, rtA, ryA);
+  if (tile + step < ntiles) load_tile(tile + step, rtB, ryB);
+  for (; tile < ntiles; tile += 2 * step) {
+    store_tile(rtA, ryA);
+    __syncthreads();
+    if (tile + 2 * step < ntiles) load_tile(tile + 2 * step, rtA, ryA);
+    contract();
+    __syncthreads();
+    if (tile + step >= ntiles) break;
+    store_tile(rtB, ryB);
+    __syncthreads();
+    if (tile + 3 * step < ntiles) load_tile(tile + 3 * step, rtB, ryB);
+    contract();
+    __syncthreads();
+  }
+  // ---- sum the 4 waves' accumulators in wave order through LDS: R[m = tap * cin_ld + c][4]
+  float* R = lds;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        if (mrow[i] < 0) continue;
+        f32x4* dst = reinterpret_cast<f32x4*>(R) + mrow[i];
+        *dst = w == 0 ? acc[i] : *dst + acc[i];
+      }
+    }
+    __syncthreads();
+  }
+  float* slab = p.slab + (size_t)blockIdx.x * p.co_rows * p.Kpad;
+  const int mrows = 9 * p.cin_ld;
+  for (int idx = tid; idx < p.co_rows * p.Kpad; idx += 256) {
+    int co = idx / p.Kpad, m = idx - co * p.Kpad;
+    slab[idx] = (m < mrows && co < 4) ? R[m * 4 + co] : 0.f;
+  }
+  if (p.dbslab) {       // bias gradient: per-thread sums of the staged dY pixels -> fixed-order sum per channel
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(lds) + 9 * 32;
+    red[tid] = dbacc;
+    __syncthreads();
+    if (tid < 16) {
+      float sdb = 0.f;
+      if (tid < 4)
+        for (int r = 0; r < 256; ++r) sdb += red[r][tid];
+      p.dbslab[(size_t)blockIdx.x * p.co_rows + tid] = sdb;
+    }
+  }
+}
+
+struct TileWgPlan { int ok, mf, nld, cpt, tiles_x, tiles_y, blocks, thin, gpp; int64_t ntiles; size_t lds; };
 
 TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g) {
   TileWgPlan t;
@@ -1653,6 +1806,10 @@ TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_
   t.nld = t.nld <= 6 ? 6 : 11;
   if ((TT_PIX * (x->ld >> 2) + 255) / 256 > 11) return t;
   t.cpt = (x->ld % 8 == 4) ? x->ld : x->ld + 4;
+  static const int thin_en = env_int("ITG_WGRAD_THIN", 1);
+  t.thin = thin_en && dy->ld == 4 && x->ld <= 16;         // <= 36 (tap, c4) groups: three passes of 12 or 16
+  t.gpp = 16;
+  if (t.thin) { t.cpt = 16; t.gpp = x->ld == 16 ? 12 : 16; }   // 16 channels: three taps per pass, bank-conflict free at pitch 16
   t.tiles_x = (W + TT_W - 1) / TT_W; t.tiles_y = (H + TT_H - 1) / TT_H;
   t.ntiles = (int64_t)dy->n * t.tiles_x * t.tiles_y;
   size_t fl = (size_t)TT_PIX * t.cpt + (size_t)TT_H * TT_W * 16;
@@ -1663,8 +1820,9 @@ TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_
   // one persistent workgroup per CU: alone the kernel is 13 % faster with two, but it runs beside the input-gradient chain
   // of the same backward pass and two would crowd that out of LDS (step: 780 vs 774 crops/s)
   static const int wtile_cu = env_int("ITG_WTILE_CU", 1);
+  static const int wthin_cu = env_int("ITG_WTHIN_CU", 1);
   int per_cu = (int)((160 * 1024) / t.lds);
-  if (per_cu > wtile_cu) per_cu = wtile_cu;
+  if (per_cu > (t.thin ? wthin_cu : wtile_cu)) per_cu = t.thin ? wthin_cu : wtile_cu;
   int64_t want = 256 * (int64_t)(per_cu < 1 ? 1 : per_cu);
   t.blocks = (int)(t.ntiles < want ? t.ntiles : want);
   t.ok = 1;
@@ -1681,6 +1839,12 @@ void launch_wgrad_tile(const WgP& p, const TileWgPlan& t, hipStream_t s) {
   snprintf(g_last_launch, sizeof(g_last_launch), "wgrad_tile_kernel<%d, %d>", NJ, NLD);
   hipLaunchKernelGGL((wgrad_tile_kernel<NJ, NLD>), dim3((unsigned)t.blocks), dim3(256), t.lds, s, p, t.tiles_x, t.tiles_y,
                      (int)t.ntiles, t.cpt);
+}
+
+void launch_wgrad_thin(const WgP& p, const TileWgPlan& t, hipStream_t s) {
+  snprintf(g_last_launch, sizeof(g_last_launch), "wgrad_thin_kernel<3, 6>");
+  hipLaunchKernelGGL((wgrad_thin_kernel<3, 6>), dim3((unsigned)t.blocks), dim3(256), t.lds, s, p, t.tiles_x, t.tiles_y,
+                     (int)t.ntiles, t.gpp);
 }
 
 // dW[co][ci][ky][kx] (+)= sum_z slab[z][co][(ky*kw+kx)*ci_ld + ci]
@@ -2283,7 +2447,8 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
   if (tw.ok) {
     rc = ITG_OK;
     const bool small = tw.nld <= 6;
-    if (tw.mf == 1) launch_wgrad_tile<1, 6>(p, tw, s);
+    if (tw.thin) launch_wgrad_thin(p, tw, s);
+    else if (tw.mf == 1) launch_wgrad_tile<1, 6>(p, tw, s);
     else if (tw.mf == 2) launch_wgrad_tile<2, 6>(p, tw, s);
     else if (tw.mf == 3 && small) launch_wgrad_tile<3, 6>(p, tw, s);
     else if (tw.mf == 3) launch_wgrad_tile<3, 11>(p, tw, s);

@@ -87,6 +87,8 @@ CONV_CASES = [
     ("tile3x3_rep_26_13", 1, (3, 3), 24, 26, 13, 3, 1, 1, "replicate"),              # 72x72: partial tiles, cin_ld 28
     ("tile3x3_zero_13_26", 1, (2, 3), 40, 13, 26, 3, 1, 1, "constant"),              # 80x120, 32 filter rows
     ("tile3x3_rep_3_13", 1, (3, 3), 32, 3, 13, 3, 1, 1, "replicate"),                # cin_ld 4: four taps per K chunk
+    ("tile3x3_zero_7_2_thin", 2, (2, 3), 36, 7, 2, 3, 1, 1, "constant"),             # <= 4 outputs: 4x4x1-MFMA weight gradient, 16 groups / pass
+    ("tile3x3_rep_16_4_thin", 1, (2, 2), 40, 16, 4, 3, 1, 1, "replicate"),           # all four output rows live
 ]
 
 
