@@ -65,6 +65,8 @@ def gpu_leg(a):
         else:
             dist.init_process_group(backend)
         group = dist.group.WORLD
+        if os.environ.get("ITG_RT_INIT_ONLY") == "1":       # rehearsal: RCCL present (its streams exist), no collective in the step
+            group = None
     band = a.workload == "config4"
     cfg3 = a.workload == "config3"
     _WORKLOAD[0] = a.workload
@@ -114,7 +116,8 @@ def gpu_leg(a):
         step = tr.step
     # ITG_LOOKAHEAD=1: hand the step the NEXT real batch as well, so that D(real) of iteration k+1 runs beside the generator
     # backward of iteration k (engine.Trainer.step(next_real=...)).  Measured neutral on one MI355X (772 vs 770 crops/s): the
-    # step is bound by the sum of the kernels' work, not by idle gaps - off by default.
+    # step is bound by the sum of the kernels' work, not by idle gaps - off by default (768 vs 785 with the measured
+    # stream placement of round 2; issued AFTER the backward, beside the head bucket's all-reduce, it costs 5 %).
     ahead = not use_graph and os.environ.get("ITG_LOOKAHEAD", "0") == "1" and not band
     sync()
     t0 = time.perf_counter()

@@ -152,6 +152,15 @@ int itg_local_pad_nhwc_fwd(const itg_tensor* x, const itg_tensor* y, int pad_mod
 int itg_local_pad_stream_fwd(const itg_tensor* x, const float* left, const float* top, const float* bottom,
                              const itg_tensor* y, int pad_mode, void* stream);
 
+/* ---- stream placement probe ---------------------------------------------------------------
+ * One wave that occupies `stream`'s hardware queue for `microseconds` (<= 100000) and exits.  No reference counterpart
+ * (the reference runs one CUDA stream, train.py:122-171); the step engine overlaps D(real) with the generator forward
+ * and the weight gradients with the input-gradient chain on HIP streams, and HIP multiplexes streams onto at most
+ * GPU_MAX_HW_QUEUES (4) hardware queues in creation order: two streams that share a queue run in order, and more than
+ * four busy queues cost a third of the step.  engine.Trainer launches this on candidate streams in pairs and keeps
+ * streams that ran concurrently.                                                           */
+int itg_stream_spin(int microseconds, void* stream);
+
 /* ---- layout conversion at the NCHW boundary -------------------------------------------- */
 int itg_nchw_to_grid(const float* src, const itg_tensor* dst, int merged_src, void* stream);
 int itg_grid_to_nchw(const itg_tensor* src, float* dst, int merged_dst, void* stream);

@@ -74,6 +74,7 @@ SIGNATURES = {
     "itg_colsum": (_i, [_TP, _P, _P, _P]),
     "itg_axpby": (_i, [_P, _P, _P, _f, _P, _f, _l, _P]),
     "itg_dot": (_i, [_P, _P, _l, _P, _P]),
+    "itg_stream_spin": (_i, [_i, _P]),
     "itg_attention_scratch_floats": (_l, [_TP, _TP, _TP]),
     "itg_attention_fwd": (_i, [_TP, _TP, _TP, _TP, _P, _P]),
     "itg_attention_bwd": (_i, [_TP, _TP, _TP, _P, _TP, _TP, _TP, _TP, _P]),

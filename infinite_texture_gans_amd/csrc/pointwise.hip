@@ -433,6 +433,16 @@ __global__ void local_pad_nhwc_kernel(GridT s, GridT d, const float* __restrict_
 
 }  // namespace
 
+// One wave that keeps its hardware queue busy for `ticks` of the 100 MHz constant clock and then exits (a time bound
+// every wave reaches): the step engine launches it on two streams at once to learn whether they were mapped to
+// different hardware queues (see itg_stream_spin in itg.h).
+__global__ void stream_spin_kernel(long long ticks, unsigned* sink) {
+  const long long t0 = wall_clock64();
+  unsigned n = 0;
+  while (wall_clock64() - t0 < ticks && n < 0x40000000u) { __builtin_amdgcn_s_sleep(8); ++n; }
+  if (sink && threadIdx.x == 0) *sink = n;
+}
+
 extern "C" {
 
 static int flat_check(const itg_tensor* a, const itg_tensor* b) {
@@ -599,6 +609,13 @@ int itg_local_pad_stream_fwd(const itg_tensor* x, const float* left, const float
   int64_t total = grid_pixels(y) * (y->ld >> 2);
   hipLaunchKernelGGL(local_pad_nhwc_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, s, d, left, top,
                      bottom, pad_mode);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_stream_spin(int microseconds, void* stream) {
+  if (microseconds < 0 || microseconds > 100000) return ITG_ERR_ARG;
+  hipLaunchKernelGGL(stream_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100, (unsigned*)nullptr);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }

@@ -73,6 +73,86 @@ class FlatAdam:
                           self.betas[1], self.eps, self.t, self.ema_decay, step_dev=self.t_dev)
 
 
+class GradExchange:
+    """Data-parallel exchange of one model's flat gradient buffer in TWO buckets, the first one under the backward pass.
+
+    Parameters sit in the flat buffer in module order and the backward pass runs through the modules in reverse, so
+    the TAIL of the buffer is final first.  The buffer is split at a unit boundary (a top-level block; a layer of an
+    nn.Sequential) such that the head holds >= ITG_BUCKET_HEAD (20 %) of the parameters: D = [D0 D1 D2 | D3 logit]
+    (24 % | 76 %), G = [start block1 | block2.. final] (68 % | 32 %).  When the first conv of the head ENTERS its
+    backward, every autograd node of the tail has been enqueued (its output gradient depends on all of them): the
+    tail's all-reduce is then issued on a communication stream that waits for the backward stream and for the
+    weight-gradient streams as they are at that moment, and runs beside the rest of the backward.  The head follows
+    after the weight-gradient streams were joined.  RCCL over xGMI is ring / link bound (MI355X_MICROARCH.md): two
+    collectives of several MB each, not one per layer.
+
+    Only for models whose parameters are all written on the backward's own path (convs, BatchNorm, attention):
+    the SSM generator's shared MLP collects gradients from every layer until the end and keeps the single bucket."""
+
+    def __init__(self, flat, net, sync, device, two_buckets=True, issue_stream=None):
+        """``issue_stream``: the stream the early bucket is exchanged on - one that is IDLE during the backward pass and
+        has a hardware queue of its own (the step's D(real) branch stream); a fifth busy queue would cost more than the
+        overlap gains (ops.concurrent_streams), and a collective parked in a queue that other kernels share holds them up
+        until its inputs are ready.  The collective is a blocking (async_op=False) call made under that stream: torch's
+        ProcessGroupNCCL then launches the RCCL kernel on the stream itself."""
+        self.flat, self.sync = flat, sync
+        self.world = sync.world
+        self.split = self._split_point(net, flat.numel) if two_buckets else 0
+        self.comm = (issue_stream or torch.cuda.Stream(device=device)) if self.split else None
+        self.early = False
+        self._armed = False
+
+    @staticmethod
+    def _split_point(net, total):
+        frac = float(os.environ.get("ITG_BUCKET_HEAD", "0.2"))
+        if frac <= 0 or any(True for _ in net.parameters(recurse=False)):
+            return 0
+        units = []
+        for c in net.children():
+            units.extend(c.children() if isinstance(c, nn.Sequential) else [c])
+        seen = 0
+        for u in units:
+            seen += sum(p.numel() for p in u.parameters())
+            if seen >= frac * total:
+                return seen if seen < total else 0
+        return 0
+
+    def arm(self):
+        """Call right before the backward pass whose gradients are exchanged (the LAST pass that accumulates into them)."""
+        if self.split:
+            self._armed = True
+            ops.BACKWARD_ENTRY_HOOK = self._on_conv_backward
+
+    def _on_conv_backward(self, sinks):
+        if not self._armed:
+            return
+        sink = sinks[0] if sinks[0] is not None else sinks[1]
+        off = (sink.data_ptr() - self.flat.grad.data_ptr()) // 4
+        if not 0 <= off < self.split:
+            return                                       # a layer of the tail, or of the other model
+        self._armed = False
+        cur = torch.cuda.current_stream()
+        self.comm.wait_stream(cur)
+        for s_ in ops._wgrad_dirty:                      # the tail's weight gradients (and whatever else is queued there)
+            self.comm.wait_stream(s_)
+        with torch.cuda.stream(self.comm):
+            self.sync.all_reduce(self.flat.grad[self.split:])
+        self.early = True
+
+    def finish(self):
+        """After the weight-gradient streams were joined: exchange what is left, wait for the early bucket, average."""
+        ops.BACKWARD_ENTRY_HOOK = None
+        self._armed = False
+        g = self.flat.grad
+        if self.early:
+            self.sync.all_reduce(g[:self.split])
+            torch.cuda.current_stream().wait_stream(self.comm)
+            self.early = False
+        else:
+            self.sync.all_reduce(g)
+        g.mul_(1.0 / self.world)
+
+
 class PackSet:
     """The packed filter panels of every conv of a model, refreshed with ONE launch whenever the
     optimizer has changed the weights (instead of two pack launches per conv call).  Layers find their
@@ -146,17 +226,28 @@ class Trainer:
         # ops.wgrad_streams_join)
         self.nested_fork = os.environ.get("ITG_NESTED_FORK", "1") == "1"
         self.set_overlap(self.overlap)
+        from .dist import _active
+        if self.sync is not None and _active(self.sync) and os.environ.get("ITG_BUCKETS", "1") == "1":
+            # the early buckets travel on the D(real) branch stream: idle during both backward passes that are exchanged
+            issue = self.side if self.overlap else None
+            self._exchange = {
+                id(self.flatD): GradExchange(self.flatD, netD, self.sync, device, issue_stream=issue),
+                id(self.flatG): GradExchange(self.flatG, netG, self.sync, device, issue_stream=issue,
+                                             two_buckets=getattr(netG, "type_norm", "BN") == "BN"),
+            }
 
     def set_overlap(self, on):
-        """Two-stream overlap on / off (off: every kernel runs alone on the current stream, e.g. to time it)."""
+        """Stream overlap on / off (off: every kernel runs alone on the current stream, e.g. to time it).  The branch
+        stream and the weight-gradient streams are chosen by measurement so that each sits on its own hardware queue
+        (ops.concurrent_streams): four busy queues in all, which is what the chip runs well."""
         self.overlap = bool(on)
         if on and self.side is None:
-            self.side = torch.cuda.Stream(device=self.device)
-            self.sc_stream = (torch.cuda.Stream(device=self.device)
-                              if os.environ.get("ITG_SC_STREAM", "1") == "1" else None)
-        if on and getattr(self, "_wstream", None) is None:
-            nws = int(os.environ.get("ITG_WGRAD_STREAMS", "2"))
-            self._wstream = [torch.cuda.Stream(device=self.device) for _ in range(max(1, nws))]
+            nws = max(1, min(2, int(os.environ.get("ITG_WGRAD_STREAMS", "2"))))
+            picked = ops.concurrent_streams(self.device, 1 + nws)
+            self.side, self._wstream = picked[0], picked[1:]
+            # the generator blocks' 1x1 shortcut on a stream of its own is worth nothing measurable (784 vs 785 crops/s);
+            # ITG_SC_STREAM=1 runs it on the second weight-gradient stream, which is idle during the forward pass
+            self.sc_stream = self._wstream[-1] if os.environ.get("ITG_SC_STREAM", "0") == "1" else None
         self.wstream = self._wstream if on else None
 
     def repack(self):
@@ -174,9 +265,20 @@ class Trainer:
         return ops.hinge(logit, "g") if self.hinge else ops.bce_with_logits(logit, self.label_t)
 
     def _allreduce(self, flat):
-        """Data-parallel gradient exchange: one collective per model.  Losses are per-rank means over
-        per-rank batches, so the global-batch gradient is the average over ranks."""
-        average_flat_gradient(flat.grad, self.sync)
+        """Data-parallel gradient exchange (losses are per-rank means over per-rank batches, so the global-batch
+        gradient is the average over ranks): two buckets per model, the first under the backward (GradExchange)."""
+        ex = self._exchange.get(id(flat)) if self._exchange else None
+        if ex is not None:
+            ex.finish()
+        else:
+            average_flat_gradient(flat.grad, self.sync)
+
+    def _arm_exchange(self, flat):
+        ex = self._exchange.get(id(flat)) if self._exchange else None
+        if ex is not None:
+            ex.arm()
+
+    _exchange = None
 
     def sample_fake(self, z, maps):
         return self.netG.forward_grid(z, maps, "1st_row_1st_col")
@@ -279,6 +381,7 @@ class Trainer:
             fake = self.sample_fake(z, maps)                   # GT patches, graph kept for the G step
         d_fake = self._d_loss(self._d_logits(fake.detach()), False)
         self._mark("D(fake) forward")
+        self._arm_exchange(self.flatD)                   # D(real)'s pass has accumulated (or is ordered before this one per layer)
         d_fake.backward()
         self._mark("D(fake) backward: dgrad chain (wgrads on side streams)")
         self._join()
@@ -300,8 +403,11 @@ class Trainer:
         finally:
             for p in self.flatD.params:
                 p.requires_grad_(True)
+        # D(real) of the next iteration beside the generator backward.  (Issuing it after the backward instead, so that it
+        # would run beside the all-reduce of G's head bucket, costs 5 % on one rank: 744 vs 778 crops/s - not done.)
         if next_real is not None and self._can_prefetch():
             self._prefetch_d_real(next_real)
+        self._arm_exchange(self.flatG)
         g_loss.backward()
         self._mark("G step: backward through D and G (G wgrads on side streams)")
         self._join()

@@ -281,6 +281,8 @@ class _Conv(torch.autograd.Function):
         x, w, out = ctx.saved_tensors
         kh, kw, stride, pad, pad_mode, pad_h, prec = ctx.geom
         co, ci = ctx.co, ctx.c_in
+        if BACKWARD_ENTRY_HOOK is not None and ctx.sinks is not None:
+            BACKWARD_ENTRY_HOOK(ctx.sinks)
         st = _stream()
         dout = dout.contiguous()
         if ctx.act != ACT_NONE and not ctx.defer_act:
@@ -390,6 +392,9 @@ from .dist import SyncGroup, _active  # noqa: E402,F401  (sync-BN statistics exc
 # Side stream for weight-gradient kernels (set by engine.Trainer for the duration of a step).  The power
 # iteration of a spectrally normalised layer rewrites u / v in place, which a still-running weight-gradient of
 # the previous pass reads: sn_power_iter* therefore waits for this stream first.
+BACKWARD_ENTRY_HOOK = None   # callable((weight.grad, bias.grad)) at the entry of every conv backward that owns gradient sinks
+                             # (engine.GradExchange: the first layer of the model's head starting its backward means the
+                             # gradients of everything behind it are enqueued)
 SHORTCUT_STREAM = None       # stream of the generator blocks' 1x1 shortcut branch (set by engine.Trainer for a step), or None
 WGRAD_STREAM = None          # one stream or a list of streams used round-robin (consecutive layers overlap each other too)
 WGRAD_KEEPALIVE = []
@@ -414,6 +419,62 @@ def wgrad_stream_for(sink_key):
             slot = _wgrad_slot[sink_key] = _wgrad_rr[0]
         return w[slot % len(w)]
     return w
+
+
+_STREAM_DEBUG = os.environ.get("ITG_STREAM_DEBUG", "0") == "1"
+
+
+def concurrent_streams(device, want, spin_us=150, candidates=12):
+    """``want`` streams from torch's pool that run CONCURRENTLY with the current stream and with each other.
+
+    HIP multiplexes streams onto at most GPU_MAX_HW_QUEUES (default 4) hardware queues, dealt in creation order, and a
+    hardware queue executes in order: two streams that landed on one queue do not overlap at all, and a cross-queue
+    wait parked in a shared queue blocks the other stream's kernels behind it.  Which pool stream sits on which queue
+    depends on every stream created before (torch's pools, RCCL's internal streams: with a process group initialised
+    first the same code lost the D(real) || G-forward overlap, 785 -> 709 crops/s).  So the mapping is measured: a
+    one-wave spin kernel (itg_stream_spin) on the already chosen streams and on a candidate at once; the candidate is
+    kept when the whole thing takes one spin, not two.  At most three are kept beside the current stream: more than four
+    busy hardware queues is the one configuration that is far worse than no overlap (533 crops/s, measured with
+    GPU_MAX_HW_QUEUES=5..12).  If fewer than ``want`` concurrent streams exist the last ones repeat (correct, just
+    in order)."""
+    cur = torch.cuda.current_stream(device)
+
+    def spin(st):
+        _lib.call("itg_stream_spin", int(spin_us), C.c_void_p(st.cuda_stream))
+
+    def together(streams):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        for st in streams:
+            st.wait_event(e0)
+        spin(cur)
+        for st in streams:
+            spin(st)
+        for st in streams:
+            cur.wait_stream(st)
+        e1.record(cur)
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3
+        if _STREAM_DEBUG:
+            print("[streams] %d spins of %d us on %d streams at once: %.0f us" % (1 + len(streams), spin_us, 1 + len(streams), us),
+                  flush=True)
+        return us < 1.6 * spin_us
+
+    spin(cur)
+    torch.cuda.synchronize(device)
+    chosen = []
+    for _ in range(candidates):
+        if len(chosen) >= min(want, 3):
+            break
+        cand = torch.cuda.Stream(device=device)
+        together([cand])                                 # first use of a stream: its queue is set up now, not timed
+        if together(chosen + [cand]):
+            chosen.append(cand)
+    if not chosen:
+        chosen = [torch.cuda.Stream(device=device)]
+    while len(chosen) < want:
+        chosen.append(chosen[-1])
+    return chosen
 
 
 _wgrad_dirty = []          # weight-gradient streams that carry forked work nobody has waited for yet

@@ -31,10 +31,17 @@ def main(out_path):
         G.train(), D.train()
         args = U.prepare_parser().parse_args(["--smooth"])
         args.beta1 = 0.0
-        tr = Trainer(G, D, args, dev, dist_group=dist.group.WORLD, sync_bn=True)
+        # ITG_TEST_SYNC_BN=0: per-rank statistics, so the stream overlap stays on, the tail buckets are all-reduced on
+        # the communication stream under the backward and D(real) of the next iteration runs beside G's head bucket
+        sync_bn = os.environ.get("ITG_TEST_SYNC_BN", "1") == "1"
+        tr = Trainer(G, D, args, dev, dist_group=dist.group.WORLD, sync_bn=sync_bn)
+        assert tr._exchange and all(e.split > 0 for e in tr._exchange.values()), "two-bucket exchange not active"
         losses = []
-        for s in range(int(fx["steps"])):
-            l = tr.step(torch.from_numpy(fx["real_x%d" % s]).to(dev), torch.from_numpy(fx["z%d" % s]).to(dev))
+        steps = int(fx["steps"])
+        reals = [torch.from_numpy(fx["real_x%d" % s]).to(dev) for s in range(steps)]
+        for s in range(steps):
+            nxt = reals[s + 1] if not sync_bn and s + 1 < steps else None
+            l = tr.step(reals[s], torch.from_numpy(fx["z%d" % s]).to(dev), None, nxt)
             losses.append([float(v) for v in l])
         torch.save({"G": {k: v.cpu() for k, v in G.state_dict().items()},
                     "D": {k: v.cpu() for k, v in D.state_dict().items()}}, out_path)

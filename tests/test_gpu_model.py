@@ -494,10 +494,11 @@ def test_bf16_mfma_path_tracks_reference_golden():
             assert np.allclose([float(v) for v in l], fx["loss%d" % s_], rtol=3e-2, atol=1e-3), (s_, l, fx["loss%d" % s_])
 
 
-def _dp_worker(rank, world, port, tag, out_path):
+def _dp_worker(rank, world, port, tag, out_path, sync_bn=True, env=None, ahead=False):
     import os
     import sys
     sys.path.insert(0, os.path.dirname(__file__))
+    os.environ.update(env or {})
     import torch.distributed as dist
     from infinite_texture_gans_amd.engine import Trainer
     from infinite_texture_gans_amd import utils as U
@@ -510,13 +511,19 @@ def _dp_worker(rank, world, port, tag, out_path):
         G.train(), D.train()
         args = U.prepare_parser().parse_args([])
         args.smooth, args.beta1 = a["smooth"], 0.0
-        tr = Trainer(G, D, args, cuda, dist_group=dist.group.WORLD, sync_bn=True)
+        tr = Trainer(G, D, args, cuda, dist_group=dist.group.WORLD, sync_bn=sync_bn)
         losses = []
-        for s in range(int(fx["steps"])):
-            real, z = torch.from_numpy(fx["real_x%d" % s]), torch.from_numpy(fx["z%d" % s])
-            k, kz = real.shape[0] // world, z.shape[0] // world
-            l = tr.step(real[rank * k:(rank + 1) * k].to(cuda), z[rank * kz:(rank + 1) * kz].to(cuda))
+        steps = int(fx["steps"])
+        reals = [torch.from_numpy(fx["real_x%d" % s]) for s in range(steps)]
+        reals = [r[rank * (r.shape[0] // world):(rank + 1) * (r.shape[0] // world)].to(cuda) for r in reals]
+        for s in range(steps):
+            z = torch.from_numpy(fx["z%d" % s])
+            kz = z.shape[0] // world
+            nxt = reals[s + 1] if ahead and s + 1 < steps else None
+            l = tr.step(reals[s], z[rank * kz:(rank + 1) * kz].to(cuda), None, nxt)
             losses.append([float(v) for v in l])
+        if env and env.get("ITG_BUCKETS") == "1":
+            assert tr._exchange and all(e.split > 0 for e in tr._exchange.values()), "two-bucket exchange not active"
         torch.save({"losses": losses, "G": {k: v.cpu() for k, v in G.state_dict().items()},
                     "D": {k: v.cpu() for k, v in D.state_dict().items()}}, "%s.%d" % (out_path, rank))
     finally:
@@ -550,6 +557,36 @@ def test_data_parallel_sync_bn_train_step_matches_reference_golden(tmp_path):
                 continue        # each rank's power iteration sees its own call sequence; sigma is compared through the weights
             else:
                 assert rel_l2(got, v.double()) < 2e-3, (k, rel_l2(got, v.double()))
+
+
+def test_bucketed_gradient_exchange_with_lookahead_equals_the_plain_exchange(tmp_path):
+    """Two data-parallel ranks with per-rank BatchNorm statistics (the reference's DataParallel semantics), three
+    iterations: (a) one all-reduce per model after the backward, kernels on one stream, against (b) the production
+    schedule - stream overlap, the tail bucket all-reduced on the communication stream under the backward, D(real) of
+    the next iteration issued beside the head bucket's all-reduce.  Same arithmetic, so the same losses and parameters
+    (up to the summation order of the atomics in the BatchNorm statistics)."""
+    import torch.multiprocessing as mp
+    tag, world = "bn_nl4_sn", 2
+    res = {}
+    for name, env, ahead in (("plain", {"ITG_BUCKETS": "0", "ITG_OVERLAP": "0"}, False),
+                             ("bucketed", {"ITG_BUCKETS": "1", "ITG_OVERLAP": "1"}, True)):
+        out = str(tmp_path / name)
+        mp.spawn(_dp_worker, args=(world, free_port(), tag, out, False, env, ahead), nprocs=world, join=True)
+        res[name] = [torch.load("%s.%d" % (out, r)) for r in range(world)]
+    for r in range(world):
+        a, b = res["plain"][r], res["bucketed"][r]
+        assert np.allclose(a["losses"], b["losses"], rtol=1e-5, atol=1e-7), (a["losses"], b["losses"])
+        for key in ("G", "D"):
+            for k, v in a[key].items():
+                if v.dtype.is_floating_point:
+                    if key == "G" and zero_grad_bias(k):
+                        assert (v - b[key][k]).abs().max() <= 2 * 2e-4 * len(a["losses"]) + 1e-7, k
+                    else:
+                        assert rel_l2(b[key][k].double(), v.double()) < 1e-4, (key, k, rel_l2(b[key][k].double(), v.double()))
+    # both ranks hold the same weights after the exchange
+    for k, v in res["bucketed"][0]["D"].items():
+        if "weight_u" not in k and "weight_v" not in k:
+            assert torch.equal(v, res["bucketed"][1]["D"][k]), k
 
 
 def test_midsize_train_step_with_tile_and_thin_kernels_matches_oracle():
@@ -602,16 +639,19 @@ def test_midsize_train_step_with_tile_and_thin_kernels_matches_oracle():
             assert e < 3e-3, (k, e)
 
 
-def test_one_rank_rccl_collectives_leave_the_step_unchanged(tmp_path):
+@pytest.mark.parametrize("sync_bn", ["1", "0"], ids=["sync_bn", "overlapped_buckets_lookahead"])
+def test_one_rank_rccl_collectives_leave_the_step_unchanged(tmp_path, sync_bn):
     """The data-parallel step with all of its collectives issued on the real RCCL library (one-rank `nccl` group,
-    ITG_FORCE_COLLECTIVES=1: sync-BN all-reduces in forward and backward + one flat gradient all-reduce per model) must
-    reproduce the reference golden exactly like the plain step does."""
+    ITG_FORCE_COLLECTIVES=1) must reproduce the reference golden exactly like the plain step does.  sync_bn: sync-BN
+    all-reduces in forward and backward + the two-bucket gradient exchange on one stream; overlapped: the production
+    schedule of a data-parallel rank - stream overlap, the tail bucket's asynchronous all-reduce on the communication
+    stream under the backward, D(real) of the next iteration beside G's head bucket."""
     import json
     import os
     import subprocess
     import sys
     env = dict(os.environ, ITG_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", ITG_TEST_SYNC_BN=sync_bn)
     out = str(tmp_path / "nccl1.pt")
     p = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "one_rank_nccl.py"), out], env=env,
                        capture_output=True, text=True, timeout=600)

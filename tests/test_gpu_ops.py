@@ -500,3 +500,35 @@ def test_conv_epilogue_accumulates_batchnorm_statistics(name, n, grid, p, ci, co
         outs.append((ops.bn_act(src, gamma, beta, rm, rv, nbt, True, 1e-5, 0.1, ops.ACT_LRELU, 0.02).t, rm, rv))
     assert rel_l2(outs[0][0].cpu(), outs[1][0].cpu()) < 1e-6
     assert rel_l2(outs[0][1].cpu(), outs[1][1].cpu()) < 1e-6 and rel_l2(outs[0][2].cpu(), outs[1][2].cpu()) < 1e-6
+
+
+def test_stream_placement_probe_picks_streams_that_overlap():
+    """ops.concurrent_streams returns streams whose spin kernels run beside the current stream's and beside each other
+    (HIP deals streams onto 4 hardware queues in creation order; two streams on one queue run in order)."""
+    import ctypes as C
+    ops = _ops()
+    from infinite_texture_gans_amd import _lib
+    picked = ops.concurrent_streams(cuda, 3)
+    assert len(picked) == 3
+    cur = torch.cuda.current_stream()
+    us = 300
+
+    def run(streams):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        for st in streams:
+            st.wait_event(e0)
+        for st in [cur] + streams:
+            _lib.call("itg_stream_spin", us, C.c_void_p(st.cuda_stream))
+        for st in streams:
+            cur.wait_stream(st)
+        e1.record(cur)
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e3
+    run(picked)
+    alone, together = run([]), run(picked)
+    assert 0.9 * us < alone < 1.5 * us, alone                   # the spin kernel keeps its time
+    if len({s.cuda_stream for s in picked}) == 3:                # four queues available (the default)
+        assert together < 1.6 * us, (alone, together)
+    with pytest.raises(Exception):
+        _lib.call("itg_stream_spin", -1, C.c_void_p(cur.cuda_stream))

@@ -22,7 +22,17 @@ def main():
     torch.manual_seed(args.seed)
     netG, netD = U.prepare_models(args, dev)
     netG.train(), netD.train()
-    tr = Trainer(netG, netD, args, dev)
+    group = None
+    if os.environ.get("ITG_FORCE_COLLECTIVES", "0") == "1":     # one-rank RCCL rehearsal: the data-parallel step's collectives
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29547")
+        print("affinity before init", len(os.sched_getaffinity(0)), "threads", len(os.listdir("/proc/self/task")))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        torch.zeros(1, device=dev); dist.barrier()
+        print("affinity after init", len(os.sched_getaffinity(0)), "threads", len(os.listdir("/proc/self/task")))
+        group = None if os.environ.get("ITG_RT_INIT_ONLY") == "1" else dist.group.WORLD   # init only: RCCL present, no collective in the step
+    tr = Trainer(netG, netD, args, dev, dist_group=group)
     g = torch.Generator().manual_seed(1)
     crop = args.random_crop
     real = (torch.rand(8, 3, crop, crop, generator=g) * 2 - 1).to(dev)
@@ -34,11 +44,16 @@ def main():
     acc = {}
     order = []
     runs = []
+    import time
+    t0 = time.perf_counter()
     for _ in range(n):                      # no sync inside: the host runs ahead of the GPU as in the bench
         tr.marks = []
         tr.step(real, z)
         runs.append(tr.marks)
+    t1 = time.perf_counter()
     torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print("wall: host issue %.3f ms / step, host + drain %.3f ms / step" % ((t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3))
     for m in runs[2:]:
         for (a, ea), (b, eb) in zip(m[:-1], m[1:]):
             if b not in acc:
