@@ -56,7 +56,8 @@ def main():
     ap.add_argument("--note", default="")
     a = ap.parse_args()
     A, B = load(a.prefix + "_A"), load(a.prefix + "_B")
-    names = sorted(A, key=lambda k: -A[k]["ns"])[:a.top]
+    # stream_spin_kernel: the start-up stream placement probe (ops.concurrent_streams), not part of a step
+    names = [k for k in sorted(A, key=lambda k: -A[k]["ns"]) if "stream_spin" not in k][:a.top]
     out = os.path.join(ROOT, "profiles", "%s_pmc_summary.md" % a.round)
     with open(out, "w") as f:
         f.write("# rocprofv3 --pmc passes over tools/step_profile.py (one un-overlapped train step x %g, MI355X)\n" % a.steps)

@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--suffix", default="", help="e.g. _config3: files profiles/<round><suffix>_bench_kernel_stats.md / _hbm_traffic.json")
     a = ap.parse_args()
     stats = find(a.stats, "*kernel_stats.csv")
-    rows = list(csv.DictReader(open(stats)))
+    rows = [r for r in csv.DictReader(open(stats)) if "stream_spin_kernel" not in r["Name"]]   # start-up stream placement probe
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     out = os.path.join(ROOT, "profiles", "%s%s_bench_kernel_stats" % (a.round, a.suffix))
     shutil.copy(stats, out + ".csv")
