@@ -366,7 +366,7 @@ def main():
                                       "padding_mode=local, 3x3 patch grid of 64^2 (fake 192^2), conv operands bf16 / fp32 "
                                       "accumulate, everything else fp32, batch 8 + 8 generated images per GPU",
                           "global_batch": args.batch_size * world, "g_patches_per_sec": round(72 * world * a.steps / dt, 1),
-                          "parallelism": "dp%d (%s BatchNorm statistics, one flat gradient all-reduce per model)" % (
+                          "parallelism": "dp%d (%s BatchNorm statistics, flat gradient exchange in two buckets per model)" % (
                           world, "all-reduced" if os.environ.get("ITG_SYNC_BN", "0") == "1" else "per-rank"), "last_losses": losses,
                           "launch": "hipGraph replay" if graph_mode() else "eager"},
                "roofline": roof}
@@ -400,7 +400,7 @@ def main():
                                   "padding_mode=local (replicate), G_ch=52 D_ch=64, 3x3 patch grid of 128^2, "
                                   "spec_norm_D, smooth, batch 8 + 8 generated images per GPU",
                       "global_batch": args.batch_size * world, "g_patches_per_sec": round(72 * world * a.steps / dt, 1),
-                      "parallelism": "dp%d (%s BatchNorm statistics, one flat gradient all-reduce per model)" % (
+                      "parallelism": "dp%d (%s BatchNorm statistics, flat gradient exchange in two buckets per model)" % (
                           world, "all-reduced" if os.environ.get("ITG_SYNC_BN", "0") == "1" else "per-rank"), "last_losses": losses,
                       "launch": "hipGraph replay" if graph_mode() else "eager"},
            "roofline": roof}

@@ -29,6 +29,13 @@ SHAPES = [
     ("G b6c2 13->13 P128", 8, (3, 3), 128, 13, 13, 3, 1, 1, "rep"),
     ("G final 13->3 P128", 8, (3, 3), 128, 13, 3, 3, 1, 1, "rep"),
 ]
+# what-if shapes (only with a filter that names them): stride / K length / width of D's layers varied one at a time
+EXTRA = [
+    ("X D1 as stride 1 (97^2 in)", 8, (1, 1), 97, 64, 128, 4, 1, 1, "zero"),
+    ("X D1 K=4096 (256->128 s2)", 8, (1, 1), 192, 256, 128, 4, 2, 1, "zero"),
+    ("X D3 K=1024 (64->512 s1)", 8, (1, 1), 48, 64, 512, 4, 1, 1, "zero"),
+    ("X D1 co=512 (64->512 s2)", 8, (1, 1), 192, 64, 512, 4, 2, 1, "zero"),
+]
 
 
 def timeit(fn, iters=10):
@@ -57,6 +64,8 @@ def timeit(fn, iters=10):
 
 def main():
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
+    if flt.startswith("X"):
+        SHAPES.extend(EXTRA)
     tot = [0.0, 0.0, 0.0]
     for name, n, (gh, gw), p, ci, co, k, s, pad, mode in SHAPES:
         if flt and flt not in name:
