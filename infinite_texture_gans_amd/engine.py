@@ -98,7 +98,8 @@ class GradExchange:
         self.flat, self.sync = flat, sync
         self.world = sync.world
         self.split = self._split_point(net, flat.numel) if two_buckets else 0
-        self.comm = (issue_stream or torch.cuda.Stream(device=device)) if self.split else None
+        self.cuda = torch.device(device).type == "cuda"          # CPU tensors (gloo protocol tests): same buckets, no streams
+        self.comm = (issue_stream or torch.cuda.Stream(device=device)) if self.split and self.cuda else None
         self.early = False
         self._armed = False
 
@@ -131,11 +132,14 @@ class GradExchange:
         if not 0 <= off < self.split:
             return                                       # a layer of the tail, or of the other model
         self._armed = False
-        cur = torch.cuda.current_stream()
-        self.comm.wait_stream(cur)
-        for s_ in ops._wgrad_dirty:                      # the tail's weight gradients (and whatever else is queued there)
-            self.comm.wait_stream(s_)
-        with torch.cuda.stream(self.comm):
+        if self.cuda:
+            cur = torch.cuda.current_stream()
+            self.comm.wait_stream(cur)
+            for s_ in ops._wgrad_dirty:                  # the tail's weight gradients (and whatever else is queued there)
+                self.comm.wait_stream(s_)
+            with torch.cuda.stream(self.comm):
+                self.sync.all_reduce(self.flat.grad[self.split:])
+        else:
             self.sync.all_reduce(self.flat.grad[self.split:])
         self.early = True
 
@@ -146,7 +150,8 @@ class GradExchange:
         g = self.flat.grad
         if self.early:
             self.sync.all_reduce(g[:self.split])
-            torch.cuda.current_stream().wait_stream(self.comm)
+            if self.cuda:
+                torch.cuda.current_stream().wait_stream(self.comm)
             self.early = False
         else:
             self.sync.all_reduce(g)

@@ -192,3 +192,82 @@ def test_band_sharded_forward_backward_matches_single_process(tmp_path):
     flat = torch.cat([t.reshape(-1) for t in torch.autograd.grad(loss, (w1, w2))])
     err = float((got["flat"] - flat).norm() / flat.norm())
     assert err < 1e-5, err
+
+
+# ------------------------------------------------------------------------------- two-bucket gradient exchange
+class _Flat:
+    """What engine.GradExchange needs of engine.FlatParams: the flat gradient buffer."""
+
+    def __init__(self, net_):
+        self.numel = sum(p.numel() for p in net_.parameters())
+        self.grad = torch.zeros(self.numel)
+        o = 0
+        self.views = []
+        for p in net_.parameters():
+            self.views.append(self.grad[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+
+
+def _toy_d():
+    import torch.nn as nn
+    return nn.Sequential(nn.Sequential(nn.Conv2d(3, 4, 3), nn.LeakyReLU(0.2), nn.Conv2d(4, 8, 3), nn.LeakyReLU(0.2),
+                                       nn.Conv2d(8, 16, 3), nn.LeakyReLU(0.2), nn.Conv2d(16, 1, 3)))
+
+
+def test_bucket_split_points_follow_module_boundaries():
+    """The head bucket ends at a unit boundary (a layer of an nn.Sequential / a top-level block) and holds >= 20 % of the
+    parameters; config 1's models split as DESIGN.md section 5 says."""
+    from infinite_texture_gans_amd.engine import GradExchange
+    d = _toy_d()
+    total = sum(p.numel() for p in d.parameters())
+    sizes = [sum(p.numel() for p in m.parameters()) for m in d[0] if any(True for _ in m.parameters())]
+    split = GradExchange._split_point(d, total)
+    assert split in [sum(sizes[:k]) for k in range(1, len(sizes))] and split >= 0.2 * total
+    assert split - sizes[[sum(sizes[:k]) for k in range(1, len(sizes))].index(split)] < 0.2 * total      # the first such boundary
+    import bench
+    from infinite_texture_gans_amd import utils as U
+    args = U.prepare_parser().parse_args(bench.FLAGS)
+    G, D = U.prepare_models(args, torch.device("cpu"))
+    nG, nD = sum(p.numel() for p in G.parameters()), sum(p.numel() for p in D.parameters())
+    sG, sD = GradExchange._split_point(G, nG), GradExchange._split_point(D, nD)
+    assert sG == sum(p.numel() for p in G.start.parameters()) + sum(p.numel() for p in G.block1.parameters())
+    assert 0.67 < sG / nG < 0.69 and 0.23 < sD / nD < 0.25
+
+
+def exchange_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from infinite_texture_gans_amd.engine import GradExchange
+        d = _toy_d()
+        flat = _Flat(d)
+        ex = GradExchange(flat, d, SyncGroup(dist.group.WORLD), "cpu")
+        assert 0 < ex.split < flat.numel
+        g = torch.Generator().manual_seed(100 + rank)
+        res = []
+        for it in range(2):
+            flat.grad.copy_(torch.randn(flat.numel, generator=g))
+            mine = flat.grad.clone()
+            ex.arm()
+            # backward order: last layer first; a tail layer's hook must not trigger, the first head layer's must
+            ex._on_conv_backward((flat.views[-2], flat.views[-1]))
+            assert not ex.early
+            tail_before = flat.grad[ex.split:].clone()
+            ex._on_conv_backward((flat.views[2], flat.views[3]))          # second conv: inside the head
+            assert ex.early and not torch.equal(flat.grad[ex.split:], tail_before)
+            assert torch.equal(flat.grad[:ex.split], mine[:ex.split])    # the head is still local
+            ex._on_conv_backward((flat.views[0], flat.views[1]))          # later head layers: nothing more happens
+            ex.finish()
+            res.append((mine, flat.grad.clone()))
+        torch.save(res, "%s.%d" % (out, rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_bucket_gradient_exchange_over_gloo_equals_the_average(tmp_path):
+    out = str(tmp_path / "ex")
+    mp.spawn(exchange_worker, args=(2, free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    for it in range(2):
+        want = (r0[it][0] + r1[it][0]) / 2
+        assert torch.allclose(r0[it][1], want, rtol=0, atol=1e-7) and torch.equal(r0[it][1], r1[it][1])
