@@ -33,6 +33,9 @@ def run(norm, out, streamed):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                       # e.g. `infer_bench.py SSM 4096` under rocprofv3: one configuration only
+        run(sys.argv[1], int(sys.argv[2]), False)
+        sys.exit(0)
     for norm in ("BN", "SSM"):
         for out in (1024, 4096):
             run(norm, out, False)
