@@ -338,6 +338,7 @@ class Trainer:
             ops.ARENA = None
             ops.WGRAD_STREAM = None
             ops.SHORTCUT_STREAM = None
+            ops.BACKWARD_ENTRY_HOOK = None
             if self.wstream is not None and not torch.cuda.is_current_stream_capturing():
                 ops.WGRAD_KEEPALIVE.clear()
 
