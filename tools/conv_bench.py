@@ -35,6 +35,9 @@ EXTRA = [
     ("X D1 K=4096 (256->128 s2)", 8, (1, 1), 192, 256, 128, 4, 2, 1, "zero"),
     ("X D3 K=1024 (64->512 s1)", 8, (1, 1), 48, 64, 512, 4, 1, 1, "zero"),
     ("X D1 co=512 (64->512 s2)", 8, (1, 1), 192, 64, 512, 4, 2, 1, "zero"),
+    ("X D1 K=64 (4->128 s2): fixed cost", 8, (1, 1), 192, 4, 128, 4, 2, 1, "zero"),
+    ("X D1 K=256 (16->128 s2)", 8, (1, 1), 192, 16, 128, 4, 2, 1, "zero"),
+    ("X D1 K=512 (32->128 s2)", 8, (1, 1), 192, 32, 128, 4, 2, 1, "zero"),
 ]
 
 
