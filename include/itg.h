@@ -123,8 +123,13 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
                      const itg_tensor* dx, const itg_tensor* act_out, int act, float slope,
                      const itg_conv_geom* g, float* workspace, int64_t workspace_floats, void* stream);
 
-/* dW (OIHW, accumulated into dw when accumulate != 0) and optional db (length co).
+/* dW (OIHW) and optional db (length co).  accumulate: ITG_ACC_DW adds into dw instead of overwriting it, ITG_ACC_DB
+ * likewise for db (gradient sinks: the flat .grad buffer of the step engine; a spectrally normalised layer sinks its
+ * bias but takes dW into a temporary for itg_spectral_norm_bwd).
  * workspace: itg_conv2d_wgrad_workspace() floats (split-K slabs + fp64 bias scratch). */
+#define ITG_ACC_DW 1
+#define ITG_ACC_DB 2
+#define ITG_WS_ZEROED 4   /* itg_spectral_norm_bwd: the caller hands over an accumulator that is already zero */
 int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g);
 int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw_oihw, float* db,
                      const itg_conv_geom* g, int accumulate, float* workspace, int64_t workspace_floats,
@@ -259,7 +264,8 @@ int itg_spectral_norm_power_iter(const float* w, float* u, float* v, int rows, i
 int itg_spectral_norm_power_iter_multi(int n, const float* const* w, float* const* u, float* const* v,
                                        const int* rows, const int* cols, int do_iter, float eps,
                                        float* const* inv_sigma_out, float* const* workspace, void* stream);
-/* dW_orig = (G - <G, W/sigma> u v^T) / sigma  */
+/* dW_orig = (G - <G, W/sigma> u v^T) / sigma.  accumulate: ITG_ACC_DW adds into d_w_orig; ITG_WS_ZEROED = the fp64
+ * accumulator in workspace is zero already (no memset launch).  */
 int itg_spectral_norm_bwd(const float* g_w, const float* w_orig, const float* u, const float* v,
                           const float* inv_sigma, int rows, int cols, float* d_w_orig, int accumulate,
                           float* workspace, void* stream);

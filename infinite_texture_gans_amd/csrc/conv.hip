@@ -1872,7 +1872,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
       __syncthreads();
     }
-    if (threadIdx.x == 0) db[o] = accumulate ? db[o] + part[0] : part[0];
+    if (threadIdx.x == 0) db[o] = (accumulate & ITG_ACC_DB) ? db[o] + part[0] : part[0];
     __syncthreads();
   }
   for (int idx = threadIdx.x; idx < 64 * taps; idx += 256) {
@@ -1895,7 +1895,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
   __syncthreads();
   float* dst = dw + ((size_t)o * ci + c0) * taps;
-  for (int idx = threadIdx.x; idx < cn * taps; idx += 256) dst[idx] = accumulate ? dst[idx] + tile[idx] : tile[idx];
+  for (int idx = threadIdx.x; idx < cn * taps; idx += 256) dst[idx] = (accumulate & ITG_ACC_DW) ? dst[idx] + tile[idx] : tile[idx];
 }
 
 // out[zo][e] = sum over the zo-th group of `group` slabs
@@ -2027,9 +2027,9 @@ __global__ void tap_wgrad_finish_kernel(const float* __restrict__ tmp, const flo
   if (i < ci * ntaps) {
     int c = i / ntaps, t = i - c * ntaps;
     float v = tmp[(size_t)t * ci + c];
-    dw[i] = accumulate ? dw[i] + v : v;
+    dw[i] = (accumulate & ITG_ACC_DW) ? dw[i] + v : v;
   }
-  if (i == 0 && db) db[0] = accumulate ? db[0] + dbtmp[tdb] : dbtmp[tdb];
+  if (i == 0 && db) db[0] = (accumulate & ITG_ACC_DB) ? db[0] + dbtmp[tdb] : dbtmp[tdb];
 }
 
 

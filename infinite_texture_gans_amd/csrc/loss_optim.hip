@@ -382,12 +382,12 @@ int itg_spectral_norm_bwd(const float* g_w, const float* w_orig, const float* u,
     return ITG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   double* acc = reinterpret_cast<double*>(workspace);
-  if (hipMemsetAsync(acc, 0, sizeof(double), s) != hipSuccess) return ITG_ERR_LAUNCH;
+  if (!(accumulate & ITG_WS_ZEROED) && hipMemsetAsync(acc, 0, sizeof(double), s) != hipSuccess) return ITG_ERR_LAUNCH;
   int64_t n = (int64_t)rows * cols;
   hipLaunchKernelGGL(dot_kernel, dim3(nblocks(n, 512)), dim3(256), 0, s, g_w, w_orig, n, acc);
   ITG_CHECK_LAUNCH();
   hipLaunchKernelGGL(sn_bwd_kernel, dim3(nblocks(n)), dim3(256), 0, s, g_w, u, v, inv_sigma, (const double*)acc, rows,
-                     cols, d_w_orig, accumulate);
+                     cols, d_w_orig, accumulate & ITG_ACC_DW);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }

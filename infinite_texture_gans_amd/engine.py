@@ -435,6 +435,7 @@ class Trainer:
         main = torch.cuda.current_stream()
         self.side.wait_stream(main)                      # after Adam(D), the repack and the G step's D forward
         keep, ops.WGRAD_STREAM = ops.WGRAD_STREAM, None  # its weight gradients stay on the branch stream
+        arena, ops.ARENA = ops.ARENA, None               # it outlives this step: no scratch from the arena the next step zeroes
         try:
             with torch.cuda.stream(self.side):
                 self.flatD.zero_grad()                   # the gradients Adam(D) of this iteration consumed
@@ -442,6 +443,7 @@ class Trainer:
                 d_real.backward()
         finally:
             ops.WGRAD_STREAM = keep
+            ops.ARENA = arena
         self._pending = (next_real, d_real.detach())
 
     _pending = None

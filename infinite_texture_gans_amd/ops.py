@@ -339,22 +339,26 @@ class _Conv(torch.autograd.Function):
                 ws = torch.empty(nws, device=x.device, dtype=torch.float32)
                 direct_w = wsink is not None and ctx.sn is None and need_w
                 direct_b = bsink is not None and need_b
-                fresh = torch.zeros_like if (direct_w or direct_b) else torch.empty_like   # accumulate flag is shared
-                gw_ = wsink if direct_w else fresh(w)
-                gb = bsink if direct_b else (fresh(w[:, 0, 0, 0]) if need_b else None)
+                gw_ = wsink if direct_w else torch.empty_like(w)
+                gb = bsink if direct_b else (torch.empty_like(w[:, 0, 0, 0]) if need_b else None)
                 npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
                 with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1, 2.0 * npix_out * co * ci * kh * kw,
                            4 * (x.numel() + dy.numel() + w.numel())):
-                    # one accumulate flag covers dw and db: a sink for one of them implies sinks for both
+                    # separate accumulate flags: a spectrally normalised layer sinks its bias gradient but takes dW into a
+                    # temporary (no zero-fill launch for it)
                     _lib.call("itg_conv2d_wgrad", C.byref(dxd), C.byref(ddy), _ptr(gw_), _ptr(gb), C.byref(g),
-                              int(direct_w or direct_b), _ptr(ws), nws, st)
+                              (ACC_DW if direct_w else 0) | (ACC_DB if direct_b else 0), _ptr(ws), nws, st)
                 if ctx.sn is not None and need_w:
                     _, u, v = ctx.sn
                     rows, cols = co, w.numel() // co
                     d_orig = wsink if wsink is not None else torch.empty_like(w)
-                    ws2 = torch.empty(2, device=x.device, dtype=torch.float64)
+                    # the <G, W> accumulator: a slice of the step's zeroed arena when there is one (no memset launch)
+                    ws2 = ARENA.take(1) if ARENA is not None and ARENA.buf.device == x.device else None
+                    zeroed = ws2 is not None
+                    if ws2 is None:
+                        ws2 = torch.empty(2, device=x.device, dtype=torch.float64)
                     _lib.call("itg_spectral_norm_bwd", _ptr(gw_), _ptr(w), _ptr(u), _ptr(v), _ptr(inv_sigma), rows, cols,
-                              _ptr(d_orig), int(wsink is not None), _ptr(ws2), st)
+                              _ptr(d_orig), (ACC_DW if wsink is not None else 0) | (WS_ZEROED if zeroed else 0), _ptr(ws2), st)
                     gw_ = None if wsink is not None else d_orig
                 elif direct_w:
                     gw_ = None
@@ -395,6 +399,7 @@ from .dist import SyncGroup, _active  # noqa: E402,F401  (sync-BN statistics exc
 BACKWARD_ENTRY_HOOK = None   # callable((weight.grad, bias.grad)) at the entry of every conv backward that owns gradient sinks
                              # (engine.GradExchange: the first layer of the model's head starting its backward means the
                              # gradients of everything behind it are enqueued)
+ACC_DW, ACC_DB, WS_ZEROED = 1, 2, 4      # include/itg.h: ITG_ACC_DW, ITG_ACC_DB, ITG_WS_ZEROED
 SHORTCUT_STREAM = None       # stream of the generator blocks' 1x1 shortcut branch (set by engine.Trainer for a step), or None
 WGRAD_STREAM = None          # one stream or a list of streams used round-robin (consecutive layers overlap each other too)
 WGRAD_KEEPALIVE = []
