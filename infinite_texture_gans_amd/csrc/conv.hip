@@ -935,7 +935,8 @@ NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = 
   double best_eff = 0.0;
   const int cands_big[4] = {256, 128, 96, 64};
   const int cand_ks[13] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16};
-  static const double fill_min = env_int("ITG_FILL_MIN", 300) / 100.0;
+  static const int fill_env = env_int("ITG_FILL_MIN", 0);      // workgroups per CU below which a launch counts as under-filled
+  const double fill_min = (fill_env ? fill_env : (prec == ITG_PREC_BF16 ? 200 : 300)) / 100.0;   // bf16 stages are short: 2 (config 3 +1 %)
   static const int allow96 = env_int("ITG_NT_96", 1);
   static const double pen96 = env_int("ITG_PEN96", 104) / 100.0;
   for (int ci = 0; ci < 4; ++ci) {
@@ -1953,8 +1954,11 @@ TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec = ITG_PREC_F32) {
   else { t.bco = 128; t.bcol = 128; }
   int tiles = ((t.Kpad + t.bcol - 1) / t.bcol) * ((t.co_rows + t.bco - 1) / t.bco);
   t.nchunks = (int)((M + kp - 1) / kp);
-  static const int want_blocks = env_int("ITG_TN_BLOCKS", 768);
-  int want = (want_blocks + tiles - 1) / tiles;      // ~4 workgroups per CU overall
+  // workgroup target: ~3 per CU; with bf16 operands a split's MFMA work is a quarter as long and the slab round trip
+  // weighs more: 2 per CU (config 3: 1996 -> 2026 crops/s; config 1 loses 1 % with it)
+  static const int want_env = env_int("ITG_TN_BLOCKS", 0);
+  const int want_blocks = want_env ? want_env : (prec == ITG_PREC_BF16 ? 512 : 768);
+  int want = (want_blocks + tiles - 1) / tiles;
   int max_splits = (t.nchunks + 7) / 8;             // at least 8 chunks per split
   int splits = want < max_splits ? want : max_splits;
   if (splits < 1) splits = 1;
