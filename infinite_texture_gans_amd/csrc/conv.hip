@@ -1939,7 +1939,7 @@ int launch_tn(WgP p, int splits, int prec, hipStream_t s) {
   return ITG_OK;
 }
 
-constexpr int RED_GROUP = 16;   // slabs summed per thread in either reduce stage
+static const int RED_GROUP = env_int("ITG_RED_GROUP", 16);   // slabs summed per thread in either reduce stage
 struct TnPlan { int bcol, bco, splits, chunks_per_split, nchunks, co_rows, Kpad, ngroups; int64_t slab_floats, ws_floats; };
 
 TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec = ITG_PREC_F32) {
