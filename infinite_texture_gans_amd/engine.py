@@ -216,6 +216,7 @@ class Trainer:
         self.optG = FlatAdam(self.flatG, args.lr_G, (b1, b2), ema=self.flatE.data if self.flatE else None,
                              ema_decay=args.ema_decay)
         self.label_t = 0.9 if args.smooth else 1.0
+        self._one = torch.ones((), device=device)               # the seed of every backward pass (no ones_like fill per pass)
         self.hinge = getattr(args, "loss", "standard") == "hinge"
         self.packG, self.packD = PackSet(netG), PackSet(netD)
         self.repack()
@@ -376,19 +377,19 @@ class Trainer:
                 ops.WGRAD_STREAM = None                        # D(real)'s weight gradients stay on the branch stream
             with torch.cuda.stream(self.side):
                 d_real = self._d_loss(self._d_real_logits(real_x), True)
-                d_real.backward()
+                d_real.backward(self._one)
             ops.WGRAD_STREAM = keep
             fake = self.sample_fake(z, maps)
             self._mark("G forward (beside D(real) fwd+bwd)")
             main.wait_stream(self.side)                        # D(fake) continues D's spectral-norm state and .grad
         else:
             d_real = self._d_loss(self._d_real_logits(real_x), True)
-            d_real.backward()
+            d_real.backward(self._one)
             fake = self.sample_fake(z, maps)                   # GT patches, graph kept for the G step
         d_fake = self._d_loss(self._d_logits(fake.detach()), False)
         self._mark("D(fake) forward")
         self._arm_exchange(self.flatD)                   # D(real)'s pass has accumulated (or is ordered before this one per layer)
-        d_fake.backward()
+        d_fake.backward(self._one)
         self._mark("D(fake) backward: dgrad chain (wgrads on side streams)")
         self._join()
         self._allreduce(self.flatD)
@@ -414,7 +415,7 @@ class Trainer:
         if next_real is not None and self._can_prefetch():
             self._prefetch_d_real(next_real)
         self._arm_exchange(self.flatG)
-        g_loss.backward()
+        g_loss.backward(self._one)
         self._mark("G step: backward through D and G (G wgrads on side streams)")
         self._join()
         self._allreduce(self.flatG)
@@ -440,7 +441,7 @@ class Trainer:
             with torch.cuda.stream(self.side):
                 self.flatD.zero_grad()                   # the gradients Adam(D) of this iteration consumed
                 d_real = self._d_loss(self._d_real_logits(next_real), True)
-                d_real.backward()
+                d_real.backward(self._one)
         finally:
             ops.WGRAD_STREAM = keep
             ops.ARENA = arena
