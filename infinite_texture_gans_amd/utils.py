@@ -186,11 +186,22 @@ def crop_image(img, cropping_size_h=256, cropping_size_w=256, stride=256, device
 
 
 # ------------------------------------------------------------------------------- latents
+def _randn_on(device, *shape):
+    """torch.randn on the CPU generator (the reference's RNG stream, utils.py:503-519), delivered to ``device``.  For a GPU
+    the draw lands in page-locked memory and the copy is asynchronous: a pageable host -> device copy blocks the host
+    until the stream has drained, which stops the host from issuing the next train step ahead of the GPU (train.py
+    end to end: 745 -> see DESIGN.md section 7)."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return torch.randn(*shape).to(dev)
+    return torch.randn(*shape, pin_memory=True).to(dev, non_blocking=True)
+
+
 def build_z(num_images=1, z_dim=128, base_res=4, num_patches_height=3, num_patches_width=3,
             total_num_patches_height=3, total_num_patches_width=3, device="cpu"):
     """Full-grid latent cut into overlapping sub-image latents.  reference utils.py:221-234."""
-    z_full = torch.randn(num_images, z_dim, total_num_patches_height * base_res + 2,
-                         total_num_patches_width * base_res + 2).to(device)
+    z_full = _randn_on(device, num_images, z_dim, total_num_patches_height * base_res + 2,
+                       total_num_patches_width * base_res + 2)
     return crop_images(z_full, num_patches_height * base_res + 2, num_patches_width * base_res + 2,
                        (num_patches_width - 1) * base_res, device=device)
 
@@ -201,8 +212,7 @@ def build_maps(num_images=1, map_dim=1, n_layers_G=4, base_res=4, num_patches_he
     out = []
     for i in range(n_layers_G):
         r = (2 ** i) * base_res
-        full = torch.randn(num_images, map_dim, total_num_patches_height * r + 4,
-                           total_num_patches_width * r + 4).to(device)
+        full = _randn_on(device, num_images, map_dim, total_num_patches_height * r + 4, total_num_patches_width * r + 4)
         out.append(crop_images(full, num_patches_height * r + 4, num_patches_width * r + 4,
                                (num_patches_width - 1) * r, device=device))
     return out
@@ -217,13 +227,13 @@ def sample_latents_train(netG, z_dim=128, base_res=4, map_dim=1, num_images=1, n
     """z then SSM maps 0..nl-1, drawn on the CPU generator and moved to ``device``
     (the reference's RNG order, utils.py:503-519)."""
     g = _unwrap(netG)
-    z = torch.randn(num_images, z_dim, num_patches_height * base_res + 2, num_patches_width * base_res + 2).to(device)
+    z = _randn_on(device, num_images, z_dim, num_patches_height * base_res + 2, num_patches_width * base_res + 2)
     maps = [None] * g.n_layers_G
     if g.type_norm == "SSM":
         maps = []
         for i in range(g.n_layers_G):
             r = (2 ** i) * base_res
-            m = torch.randn(num_images, map_dim, num_patches_height * r + 4, num_patches_width * r + 4).to(device)
+            m = _randn_on(device, num_images, map_dim, num_patches_height * r + 4, num_patches_width * r + 4)
             maps.append(crop_images(m, r + 4, r + 4, r, device=device))
     return z, maps
 
@@ -232,10 +242,10 @@ def sample_latents_zeros(netG, z_dim=128, base_res=4, map_dim=1, num_images=1, d
     """Latents of the non-local baseline (padding_mode='zeros'): z (N, z_dim, b, b), then the SSM maps
     (N, map_dim, r, r) of layer 0..nl-1 (reference utils.py:556-566)."""
     g = _unwrap(netG)
-    z = torch.randn(num_images, z_dim, base_res, base_res).to(device)
+    z = _randn_on(device, num_images, z_dim, base_res, base_res)
     maps = [None] * g.n_layers_G
     if g.type_norm == "SSM":
-        maps = [torch.randn(num_images, map_dim, (2 ** i) * base_res, (2 ** i) * base_res).to(device)
+        maps = [_randn_on(device, num_images, map_dim, (2 ** i) * base_res, (2 ** i) * base_res)
                 for i in range(g.n_layers_G)]
     return z, maps
 
@@ -335,12 +345,15 @@ def sample_from_gen_PatchByPatch_test(netG, z_dim=128, base_res=4, map_dim=1, nu
     steps_h, steps_w, t_h, t_w, p = tiling_plan(g.n_layers_G, base_res, nph, npw, output_resolution_height,
                                                 output_resolution_width)
     ssm = g.type_norm == "SSM"
-    if z_full is None:
-        z_full = torch.randn(num_images, z_dim, t_h * base_res + 2, t_w * base_res + 2)
-        maps_full = [torch.randn(num_images, map_dim, t_h * (2 ** i) * base_res + 4, t_w * (2 ** i) * base_res + 4)
-                     for i in range(g.n_layers_G)] if ssm else None
     if one_shot is None:
         one_shot = not g.attention
+    if z_full is None:
+        # page-locked for the one-shot forward (its up to 72 MB copies then run at PCIe rate); the streamed schedule cuts
+        # the latents into sub-image windows on the CPU first, which is slower on page-locked memory (SSM 1024^2: 1.2 vs 0.6 s)
+        pin = torch.device(device).type == "cuda" and one_shot and halo is None
+        z_full = torch.randn(num_images, z_dim, t_h * base_res + 2, t_w * base_res + 2, pin_memory=pin)
+        maps_full = [torch.randn(num_images, map_dim, t_h * (2 ** i) * base_res + 4, t_w * (2 ** i) * base_res + 4,
+                                 pin_memory=pin) for i in range(g.n_layers_G)] if ssm else None
     with torch.no_grad():
         if halo is not None:
             # patch grid sharded by patch rows over halo.world ranks; returns THIS rank's strip of rows
