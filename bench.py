@@ -65,6 +65,13 @@ def gpu_leg(a):
         else:
             dist.init_process_group(backend)
         group = dist.group.WORLD
+        if dist.get_world_size() != world:
+            raise SystemExit("process group has %d ranks, WORLD_SIZE says %d" % (dist.get_world_size(), world))
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else ""
+        except Exception:      # noqa: BLE001
+            ver = "?"
+        _RANKS.update(ranks=dist.get_world_size(), backend=("nccl (RCCL %s)" % ver) if backend == "nccl" else backend)
         if os.environ.get("ITG_RT_INIT_ONLY") == "1":       # rehearsal: RCCL present (its streams exist), no collective in the step
             group = None
     band = a.workload == "config4"
@@ -154,7 +161,7 @@ def gpu_leg(a):
         ops.PROFILE = None
         tag, (nl, fl, sec, nby) = max(agg.items(), key=lambda kv: kv[1][2])
         ach = fl / sec / 1e12
-        traffic = hbm_traffic(tag)
+        traffic, traffic_note = hbm_traffic(tag)
         tot_sec = sum(x[2] for x in agg.values())
         roof = {"bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": peak_tf,
                 "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4), "traffic": traffic,
@@ -167,14 +174,39 @@ def gpu_leg(a):
                 "conv_stack": {"time_ms": round(tot_sec * 1e3, 3), "tflops": round(sum(x[1] for x in agg.values()) / tot_sec / 1e12, 2),
                                "frac_of_peak": round(sum(x[1] for x in agg.values()) / tot_sec / 1e12 / peak_tf, 4)},
                 "conv_time_share": {k: round(v[2] / tot_sec, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:8]},
+                # every conv kernel instantiation with >= 1.5 % of the conv time: its own rate against the same peak, so
+                # that the below-roofline tail (weight gradients, the generator's narrow layers) is in the line itself
+                "kernels": [{"kernel": k, "launches": v[0], "avg_us": round(v[2] / v[0] * 1e6, 1),
+                             "tflops": round(v[1] / v[2] / 1e12, 1), "frac": round(v[1] / v[2] / 1e12 / peak_tf, 3),
+                             "time_share": round(v[2] / tot_sec, 3)}
+                            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2]) if v[2] / tot_sec >= 0.015],
                 "step_necessary_gflop": round(nec_gf, 1),
                 "step_frac_of_mfma_peak": round(nec_gf * 1e9 / (dt / a.steps) / 1e12 / peak_tf, 4),
-                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, committed under profiles/ "
-                                  "(counters cannot be read from inside the timed process)",
+                "traffic_source": traffic_note,
+                "streams": dict(ops.STREAM_PLACEMENT),
                 "membound": membound_leg(dev)}
     if world > 1:
         dist.barrier()
+    _PAR[0] = exchange_desc(tr)
     return rank, world, dt, args, losses, roof
+
+
+_PAR = [""]
+_RANKS = {"ranks": 1, "backend": "none"}      # what the process group reports once initialised (not the environment)
+
+
+def exchange_desc(tr):
+    """How this trainer exchanges gradients, from the objects it actually built (not from the environment)."""
+    if getattr(tr, "sync", None) is None or tr.world == 1 and not tr._exchange:
+        return "no gradient exchange (one rank)"
+    if tr._exchange:
+        parts = []
+        for name, flat in (("D", tr.flatD), ("G", tr.flatG)):
+            ex = tr._exchange.get(id(flat))
+            parts.append("%s: %s" % (name, "two buckets, split at %d of %d floats" % (ex.split, flat.numel) if ex is not None and ex.split
+                                     else "single all-reduce"))
+        return "flat gradient exchange per model (" + "; ".join(parts) + ")"
+    return "flat gradient exchange, single all-reduce per model"
 
 
 GRAPH_DEFAULT = {"config1": "0", "config3": "1", "config4": "0"}   # config 3's 5.5 ms step is shorter than its host time
@@ -185,20 +217,46 @@ def graph_mode():
     return os.environ.get("ITG_GRAPH", GRAPH_DEFAULT[_WORKLOAD[0]]) == "1" and int(os.environ.get("WORLD_SIZE", 1)) == 1
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources and the ABI header: identifies the build a profile was taken from (the .so itself is
+    rebuilt by the driver and need not be byte-identical)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "infinite_texture_gans_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(ROOT, "include", "itg.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def hbm_traffic(kernel):
-    """HBM bytes per launch of ``kernel`` from the committed PMC summary (separate rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE passes, gfx950 corrections applied by tools/prof_summary.py), or None."""
+    """(HBM bytes per launch of ``kernel``, provenance note) from the committed PMC summary (separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied by tools/prof_summary.py).  The summary carries the hash
+    of the kernel sources it was measured on: when that is not the build that is running, traffic is None."""
     import glob
     wl = _WORKLOAD[0]
     pat = "r[0-9][0-9]_hbm_traffic.json" if wl == "config1" else "r[0-9][0-9]_%s_hbm_traffic.json" % wl
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
     if not files:
-        return None
+        return None, "no committed PMC summary under profiles/"
+    name = os.path.basename(files[-1])
     try:
-        t = json.load(open(files[-1])).get(kernel)
-        return None if t is None else int(t["fetch_bytes"] + t["write_bytes"])
-    except Exception:
-        return None
+        js = json.load(open(files[-1]))
+        meta = js.get("_meta", {})
+        here = kernel_source_hash()
+        if meta.get("kernel_source_sha16") != here:
+            return None, ("profiles/%s was measured on kernel sources %s (git %s), this build is %s: traffic withheld; "
+                          "re-run tools/profile_all.sh" % (name, meta.get("kernel_source_sha16", "unrecorded"),
+                                                           meta.get("git_head", "?"), here))
+        t = js.get(kernel)
+        if t is None:
+            return None, "profiles/%s has no entry for this kernel" % name
+        return int(t["fetch_bytes"] + t["write_bytes"]), (
+            "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of kernel sources %s = this build (git %s); "
+            "counters cannot be read from inside the timed process" % (name, here, meta.get("git_head", "?")))
+    except Exception as e:      # noqa: BLE001
+        return None, "profiles/%s unreadable: %s" % (name, e)
 
 
 def host_cores():
@@ -356,7 +414,7 @@ def main():
     if rank != 0:
         return
     ms = dt / a.steps * 1e3
-    ranks = {"ranks": world, "backend": os.environ.get("ITG_DIST_BACKEND", "nccl (RCCL)") if world > 1 else "none"}
+    ranks = dict(_RANKS)
     if a.workload == "config3":
         out = {"metric": "G+D train-step real 128x128x3 crops/sec (batch 8 per GPU, bf16 MFMA path)",
                "value": round(args.batch_size * world * a.steps / dt, 3), "unit": "crops/s", "n_gpus": world, "steps": a.steps,
@@ -366,8 +424,8 @@ def main():
                                       "padding_mode=local, 3x3 patch grid of 64^2 (fake 192^2), conv operands bf16 / fp32 "
                                       "accumulate, everything else fp32, batch 8 + 8 generated images per GPU",
                           "global_batch": args.batch_size * world, "g_patches_per_sec": round(72 * world * a.steps / dt, 1),
-                          "parallelism": "dp%d (%s BatchNorm statistics, flat gradient exchange in two buckets per model)" % (
-                          world, "all-reduced" if os.environ.get("ITG_SYNC_BN", "0") == "1" else "per-rank"), "last_losses": losses,
+                          "parallelism": "dp%d (%s BatchNorm statistics, %s)" % (
+                          world, "all-reduced" if os.environ.get("ITG_SYNC_BN", "0") == "1" else "per-rank", _PAR[0]), "last_losses": losses,
                           "launch": "hipGraph replay" if graph_mode() else "eager"},
                "roofline": roof}
         out["config"].update(ranks)
@@ -400,8 +458,8 @@ def main():
                                   "padding_mode=local (replicate), G_ch=52 D_ch=64, 3x3 patch grid of 128^2, "
                                   "spec_norm_D, smooth, batch 8 + 8 generated images per GPU",
                       "global_batch": args.batch_size * world, "g_patches_per_sec": round(72 * world * a.steps / dt, 1),
-                      "parallelism": "dp%d (%s BatchNorm statistics, flat gradient exchange in two buckets per model)" % (
-                          world, "all-reduced" if os.environ.get("ITG_SYNC_BN", "0") == "1" else "per-rank"), "last_losses": losses,
+                      "parallelism": "dp%d (%s BatchNorm statistics, %s)" % (
+                          world, "all-reduced" if os.environ.get("ITG_SYNC_BN", "0") == "1" else "per-rank", _PAR[0]), "last_losses": losses,
                       "launch": "hipGraph replay" if graph_mode() else "eager"},
            "roofline": roof}
     out["config"].update(ranks)

@@ -1194,8 +1194,14 @@ constexpr int BKP = 16;  // pixels per pipeline stage (fp32 operands; 32 with bf
 //             column-major, i.e. as the K-contiguous MFMA operand) and contracted 32 pixels at a time by
 //             v_mfma_f32_16x16x32_bf16 with fp32 accumulation.
 // DEPTH = pixel stages whose global loads are in flight while one stage is computed (1 or 2).
+// register budget: 3 workgroups per CU with two stages in flight, 4 with one - except the 256 x 64 tile, whose 16 row x column
+// fragments per wave plus 5 prefetch vectors need the 168-register budget in either form
+constexpr int tn_min_blocks(int bcol, int wcol, int wco, bool bf, int depth) {
+  return depth == 2 ? 3 : (bf ? 2 : ((wcol / 16) * (wco / 16) >= 16 && bcol >= 256 ? 3 : 4));
+}
+
 template <int BCOL, int BCO, int WCOL, int WCO, bool BF, int DEPTH>
-__global__ __launch_bounds__(256, (DEPTH == 2 ? 3 : (BF ? 2 : 4))) void conv_tn_kernel(WgP p, int otp) {
+__global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) void conv_tn_kernel(WgP p, int otp) {
   constexpr int FI = WCOL / 16, FJ = WCO / 16;
   constexpr int WAVES_COL = BCOL / WCOL;
   static_assert(WAVES_COL * (BCO / WCO) == 4, "4 waves per workgroup");
@@ -1939,7 +1945,7 @@ int launch_tn(WgP p, int splits, int prec, hipStream_t s) {
   return ITG_OK;
 }
 
-static const int RED_GROUP = env_int("ITG_RED_GROUP", 16);   // slabs summed per thread in either reduce stage
+static const int RED_GROUP = env_int("ITG_RED_GROUP", 16) < 2 ? 2 : env_int("ITG_RED_GROUP", 16);   // slabs summed per thread in either reduce stage (>= 2: it is a divisor)
 struct TnPlan { int bcol, bco, splits, chunks_per_split, nchunks, co_rows, Kpad, ngroups; int64_t slab_floats, ws_floats; };
 
 TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec = ITG_PREC_F32) {
@@ -2209,6 +2215,7 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   if ((rc = check_tensor(in)) || (rc = check_tensor(out))) return rc;
   if (!w_packed || !g || g->kh <= 0 || g->kw <= 0 || g->stride <= 0 || g->pad < 0) return ITG_ERR_ARG;
   if (thin_out_conv(in, out, g) && !(residual && residual->ptr)) {
+    if (g->out_stats) return ITG_ERR_ARG;       // single-output-channel layers have no BatchNorm consumer on this path
     // taps-as-rows path (see tap_gather_fwd_kernel): a 1x1 conv into P[pixel][16], then the tap gather
     const int H = in->gh * in->ph, W = in->gw * in->pw;
     if (in->n != out->n || conv_out_dim(H, g->kh, 1, pad_v(g)) != out->gh * out->ph ||
@@ -2396,6 +2403,7 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
   if ((rc = check_tensor(x)) || (rc = check_tensor(dy))) return rc;
   if (!dw || !g || !workspace) return ITG_ERR_ARG;
   if (x->n != dy->n) return ITG_ERR_ARG;
+  if (accumulate & ~(ITG_ACC_DW | ITG_ACC_DB)) return ITG_ERR_ARG;     // a bit set, not a boolean (ABI note)
   hipStream_t s = (hipStream_t)stream;
   if (thin_out_conv(x, dy, g)) {
     const int H = x->gh * x->ph, W = x->gw * x->pw;

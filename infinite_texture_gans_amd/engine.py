@@ -93,8 +93,13 @@ class GradExchange:
         """``issue_stream``: the stream the early bucket is exchanged on - one that is IDLE during the backward pass and
         has a hardware queue of its own (the step's D(real) branch stream); a fifth busy queue would cost more than the
         overlap gains (ops.concurrent_streams), and a collective parked in a queue that other kernels share holds them up
-        until its inputs are ready.  The collective is a blocking (async_op=False) call made under that stream: torch's
-        ProcessGroupNCCL then launches the RCCL kernel on the stream itself."""
+        until its inputs are ready.  The collective is a blocking (async_op=False) call made under that stream.  On which
+        stream the RCCL kernel then runs depends on the torch build (2.10: the current stream, tools/probes/nccl_stream.py;
+        older builds: the group's internal stream, ordered by events) - ordering is correct either way: the issuing stream
+        has waited for the backward stream and the dirty weight-gradient streams, and finish() waits for the issuing
+        stream.  UNVERIFIED on more than one RCCL rank (no multi-GPU box in this build's pool): the bucketed schedule is
+        therefore opt-in (ITG_BUCKETS=1) for real multi-rank RCCL groups and the default there is one all-reduce per model
+        after the joins."""
         self.flat, self.sync = flat, sync
         self.world = sync.world
         self.split = self._split_point(net, flat.numel) if two_buckets else 0
@@ -109,10 +114,29 @@ class GradExchange:
         if frac <= 0 or any(True for _ in net.parameters(recurse=False)):
             return 0
         units = []
-        for c in net.children():
-            units.extend(c.children() if isinstance(c, nn.Sequential) else [c])
+        for name, c in net.named_children():
+            if isinstance(c, nn.Sequential):
+                units.extend((name, u) for u in c.children())
+            else:
+                units.append((name, c))
+        # The hook fires when the first conv of the head enters its backward, which only proves that the tail is complete
+        # if every unit behind the split also EXECUTES behind it.  The generator registers `bn` and `attention` after all
+        # blocks although attention runs between block3 and block4: a split that would put such an out-of-order unit in
+        # the tail (or the blocks it precedes in the head) is refused - the scan stops at the last block that executes
+        # before the first out-of-order unit.
+        order = getattr(net, "execution_order", None)
+        limit = len(units)
+        if order is not None:
+            rank_of = {n: i for i, n in enumerate(order)}
+            pos = [rank_of.get(n, len(order)) for n, _ in units]
+            for i in range(len(units)):
+                if any(pos[j] < pos[i] for j in range(i + 1, len(units))):      # a later-registered unit runs earlier
+                    limit = i
+                    break
         seen = 0
-        for u in units:
+        for i, (_, u) in enumerate(units):
+            if i >= limit:
+                return 0
             seen += sum(p.numel() for p in u.parameters())
             if seen >= frac * total:
                 return seen if seen < total else 0
@@ -233,7 +257,11 @@ class Trainer:
         self.nested_fork = os.environ.get("ITG_NESTED_FORK", "1") == "1"
         self.set_overlap(self.overlap)
         from .dist import _active
-        if self.sync is not None and _active(self.sync) and os.environ.get("ITG_BUCKETS", "1") == "1":
+        # two-bucket exchange: default on for the rehearsal backends (gloo / one-rank RCCL, where it is tested), opt-in on a
+        # real multi-rank RCCL group until it has run there once
+        multi_rccl = (dist_group is not None and self.world > 1 and torch.device(device).type == "cuda"
+                      and os.environ.get("ITG_DIST_BACKEND", "nccl") == "nccl")
+        if self.sync is not None and _active(self.sync) and os.environ.get("ITG_BUCKETS", "0" if multi_rccl else "1") == "1":
             # the early buckets travel on the D(real) branch stream: idle during both backward passes that are exchanged
             issue = self.side if self.overlap else None
             self._exchange = {
@@ -328,7 +356,9 @@ class Trainer:
         ops.SHORTCUT_STREAM = self.sc_stream if self.overlap else None
         try:
             zs = list(z) if isinstance(z, (list, tuple)) else [z]
-            ms = list(maps) if isinstance(z, (list, tuple)) else [maps]
+            ms = list(maps) if isinstance(maps, (list, tuple)) and isinstance(z, (list, tuple)) else [maps] * len(zs)
+            if len(ms) != len(zs):
+                raise ValueError("step(): %d latents but %d map sets" % (len(zs), len(ms)))
             self.d_losses = []
             for zi, mi in zip(zs, ms):
                 d_real, d_fake, fake = self.d_step(real_x, zi, mi)

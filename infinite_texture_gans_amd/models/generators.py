@@ -50,6 +50,20 @@ class ResidualPatchGenerator(nn.Module):
             if isinstance(m, LocalPadder):
                 m.pin(num_patches_h, num_patches_w, outer_padding)
 
+    @property
+    def execution_order(self):
+        """Names of the parameter-carrying children in the order forward() runs them (registration order differs:
+        `bn` and `attention` are registered behind the blocks as in the reference, generators.py:76-83); the bucketed
+        gradient exchange only splits the flat gradient where both orders agree (engine.GradExchange)."""
+        names = ["start"]
+        for i in range(1, self.n_layers_G + 1):
+            names.append("block%d" % i)
+            if i == 3 and self.attention:
+                names.append("attention")
+        if self.type_norm == 'BN':
+            names.append("bn")
+        return names + ["final"]
+
     def set_sync(self, sync):
         """Make every BatchNorm (incl. SSM's inner one) take its statistics over ``sync``'s ranks."""
         for m in self.modules():

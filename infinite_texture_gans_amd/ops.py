@@ -475,11 +475,22 @@ def concurrent_streams(device, want, spin_us=150, candidates=12):
         together([cand])                                 # first use of a stream: its queue is set up now, not timed
         if together(chosen + [cand]):
             chosen.append(cand)
+    found = len(chosen)
     if not chosen:
         chosen = [torch.cuda.Stream(device=device)]
     while len(chosen) < want:
         chosen.append(chosen[-1])
+    STREAM_PLACEMENT.update(want=min(want, 3), concurrent=found, probed=True)
+    if found < min(want, 3):
+        # a loaded host or a tracing profiler stretches the spin timings and makes every candidate fail: the step is then
+        # correct but partly serialised - say so once instead of silently benchmarking another schedule
+        import sys
+        print("[itg] stream placement: only %d of %d side streams run concurrently with the main stream "
+              "(ITG_STREAM_DEBUG=1 prints the probe timings)" % (found, min(want, 3)), file=sys.stderr, flush=True)
     return chosen
+
+
+STREAM_PLACEMENT = {"want": 0, "concurrent": 0, "probed": False}    # what the last probe found (bench.py reports it)
 
 
 _wgrad_dirty = []          # weight-gradient streams that carry forked work nobody has waited for yet

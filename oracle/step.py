@@ -142,12 +142,15 @@ def train_step(gsd, dsd, gcfg, dcfg, optG, optD, real_x, z, maps, smooth=True, l
     for zi, mi in zip(zs, ms):
         d_real, d_fake, fake, real_logit, fake_logit = d_step(gsd, dsd, gcfg, dcfg, optD, real_x, zi, mi, label_t, loops)
         d_losses += [float(d_real.detach()), float(d_fake.detach())]
+    # D's gradients of the D step as Adam(D) consumed them (the G step's backward accumulates into the same .grad
+    # afterwards, as in the reference, train.py:161-166)
+    grad_d = {k: dsd[k].grad.detach().clone() for k in trainable(dsd) if dsd[k].grad is not None}
     g_loss, fake_logit2 = g_step(gsd, dsd, dcfg, optG, fake, label_t)
     if ema_sd is not None:
         ema_update(ema_sd, gsd, ema_decay)
     return dict(d_loss_real=float(d_real.detach()), d_loss_fake=float(d_fake.detach()), g_loss=float(g_loss.detach()),
                 fake=fake.detach(), real_logit=real_logit.detach(), fake_logit=fake_logit.detach(),
-                fake_logit2=fake_logit2.detach(), d_losses=d_losses)
+                fake_logit2=fake_logit2.detach(), d_losses=d_losses, gradD=grad_d)
 
 
 @torch.no_grad()

@@ -48,7 +48,14 @@ def test_bench_helpers():
     assert 1 <= b.host_cores() <= 16
     t = json.load(open(_latest("r*_hbm_traffic.json")))
     k = json.load(open(_latest("bench_r*_config1.json")))["roofline"]["kernel"]
-    assert k in t and b.hbm_traffic(k) == int(t[k]["fetch_bytes"] + t[k]["write_bytes"])
-    assert b.hbm_traffic("no_such_kernel") is None
+    # the traffic summary is only used when it was measured on the kernel sources that are checked out (its _meta hash):
+    # a summary of another build yields None plus a reason, never a stale number
+    val, note = b.hbm_traffic(k)
+    if t.get("_meta", {}).get("kernel_source_sha16") == b.kernel_source_hash():
+        assert k in t and val == int(t[k]["fetch_bytes"] + t[k]["write_bytes"]) and b.kernel_source_hash() in note
+    else:
+        assert val is None and "withheld" in note
+    assert b.hbm_traffic("no_such_kernel")[0] is None
+    assert len(b.kernel_source_hash()) == 16
     a = b.U_FLAGS if hasattr(b, "U_FLAGS") else b.FLAGS
     assert "--n_layers_G" in a and a[a.index("--n_layers_G") + 1] == "6" and a[a.index("--random_crop") + 1] == "192"

@@ -168,6 +168,7 @@ def _fullsize_step(flags, nl_G, attention, crop, prec, fp64_truth=False):
     # D's first-step gradients (the D step's, before the G step touches them): the oracle's .grad of the D step were
     # overwritten by its G step (it accumulates D weight gradients there like the reference), so recompute them
     out["gradD"] = gradD
+    out["gradD_ref"] = r["gradD"]
     out["oracle"] = (gsd, dsd, gcfg, dcfg, real, z)
     out["gradG"] = {k: p.grad.clone() for k, p in netG.named_parameters()}
     out["gradG_ref"] = {k: gsd[k].grad for k in ostep.trainable(gsd)}
@@ -208,6 +209,13 @@ def test_config2_full_size_train_step_matches_cpu_oracle_within_1e3():
     for k, e_hip, e_cpu, e_rel in rows:
         assert e_hip <= 2 * e_cpu + 1e-4, (k, e_hip, e_cpu)
         assert e_rel < 1e-2, (k, e_rel)
+    # D's first-step gradients (real + fake passes accumulated, as Adam(D) consumed them) against the oracle's: D has
+    # one LeakyReLU per layer on far fewer, larger activations than G's backward chain, measured ~1e-5; bar 1e-3
+    errs = {k: _rel(o["gradD"][k], ref) for k, ref in o["gradD_ref"].items()}
+    print("config2 full-size: D gradients, %d tensors: max rel-L2 %.2e" % (len(errs), max(errs.values())))
+    assert set(errs) == set(o["gradD"]), (sorted(errs), sorted(o["gradD"]))
+    for k, e in errs.items():
+        assert e < 1e-3, (k, e)
 
 
 def test_config3_full_size_bf16_train_step_tracks_cpu_oracle():

@@ -85,6 +85,14 @@ def main():
                 traffic[k] = {"fetch_bytes": fb, "write_bytes": wb, "launches": fe[k][1]}
                 if fb * fe[k][1] > 50e6:
                     f.write("| `%s` | %d | %.1f | %.1f |\n" % (k[:70], fe[k][1], fb / 1e6, wb / 1e6))
+            import subprocess, sys
+            sys.path.insert(0, ROOT)
+            import bench
+            try:
+                head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+            except Exception:      # noqa: BLE001  (the GPU box has no .git)
+                head = os.environ.get("ITG_GIT_HEAD", "unknown")
+            traffic["_meta"] = {"kernel_source_sha16": bench.kernel_source_hash(), "git_head": head}
             json.dump(traffic, open(os.path.join(ROOT, "profiles", "%s%s_hbm_traffic.json" % (a.round, a.suffix)), "w"), indent=0)
     print("wrote", out + ".md")
 
