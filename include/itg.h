@@ -28,6 +28,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef enum {
   ITG_OK = 0,
@@ -277,6 +281,9 @@ int itg_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, 
                       float beta1, float beta2, float eps, int step, const int32_t* step_dev, float ema_decay,
                       void* stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,160 @@
+// Shared declarations of the convolution translation units (conv_nt.hip: implicit-GEMM forward / input gradient,
+// conv_tile.hip: halo-tile kernels of the narrow 3x3 layers, conv_wgrad.hip: weight gradients, conv.hip: packing,
+// taps-as-rows paths and the C ABI).  Internal: not part of include/itg.h.
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include "itg_common.h"
+
+extern "C" int itg_bn_stats(const itg_tensor* x, double* sums, void* stream);
+
+namespace itgk {
+
+constexpr int BK = 16;    // K elements per pipeline stage
+constexpr int LDK = 20;   // LDS row pitch (floats): BK + 4 keeps rows 16-B aligned
+
+// name of the GEMM kernel instantiation launched by this thread's last conv call, exactly as a profiler prints it
+extern thread_local char g_last_launch[96];
+
+inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+struct ConvP {
+  GridT in, out, res;
+  const float* w;
+  const float* bias;
+  const float* scale;           // one device float multiplied into the contraction (1/sigma), or null
+  int ntaps, kw, cin_ld, Kpad;
+  int MT, MU, M;
+  int isy, ioy, isx, iox;
+  int osy, ooy, osx, oox;
+  int pad_mode, out_mode, act;
+  float slope;
+  int res_mode;                 // 0: out += res;  ITG_ACT_*: out *= act'(res), res = the activation's OUTPUT (fused act backward)
+  float res_slope;
+  int co_rows, nco_tiles;
+  unsigned in_bytes, w_bytes;   // buffer-resource extents of the pixel operand / packed weights
+  int use_tab;                  // per-row tap-offset table in LDS (narrow layers)
+  int xcd_remap;                // deal contiguous runs of tiles to each XCD (its L2 then sees 1/8 of the pixel tiles)
+  double* stats;                // fwd only, or null: [2][out.ld] per-channel sum / sum of squares of the stored output
+  int prec;                     // ITG_PREC_F32 | ITG_PREC_BF16
+  float* partial;      // split-K slabs [ksplit][M][co_rows] (ksplit > 1)
+  int ksplit, kchunks; // K chunks (of BK) per split
+  // stride-2 input-gradient: the 4 output-parity classes run as ONE grid (blockIdx.y = class)
+  int ncls;
+  int cMT[4], cMU[4], cM[4], cioy[4], ciox[4], cooy[4], coox[4];
+  unsigned cwoff[4];   // float offset of the class's packed sub-kernel
+  unsigned cpoff[4];   // float offset of the class's split-K slabs
+};
+
+// derivative of an activation expressed through its OUTPUT o (as itg_act_bwd does)
+__device__ __forceinline__ f32x4 act_deriv(f32x4 o, int act, float slope) {
+  f32x4 d;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) d[e] = act == ITG_ACT_LRELU ? (o[e] > 0.f ? 1.f : slope) : (act == ITG_ACT_TANH ? 1.f - o[e] * o[e] : 1.f);
+  return d;
+}
+
+__device__ __forceinline__ void decode_m(int m, int MT, int MU, int& n, int& t, int& u) {
+  int per = MT * MU;
+  n = m / per;
+  int r = m - n * per;
+  t = r / MU;
+  u = r - t * MU;
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint2 pack_bf16x4(f32x4 v) {
+  bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  return __builtin_bit_cast(uint2, h);
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+__device__ __forceinline__ int round_up_d(int x, int m) { return (x + m - 1) / m * m; }
+
+// Stride-1 3x3 convolutions with <= 32 input and <= 32 output channels (the generator's last blocks
+// and `final`, forward and input-gradient).  The implicit-GEMM kernel above re-gathers every input
+// pixel 9 times through L2; here a workgroup stages one (8+2) x (32+2) pixel halo tile ONCE into LDS
+// (coalesced NHWC rows, raw buffer loads with hardware zero-fill / clamped replicate coordinates), keeps
+// the whole filter bank in LDS, and every wave runs its 64 pixels x 9 taps on MFMA from there.
+constexpr int TT_H = 8, TT_W = 32;
+constexpr int TT_PIX = (TT_H + 2) * (TT_W + 2);
+
+// Epilogue of the persistent tile kernels.  Bias and 1/sigma are loaded ONCE per workgroup and the residual tile is
+// fetched BEFORE the next tile's prefetch is issued: an epilogue that loads anything would wait vmcnt(0) and with it
+// drain the prefetch that is meant to stay in flight across the tile boundary.
+__device__ __forceinline__ f32x4 store_out(const ConvP& p, int n, int oy, int ox, int co, f32x4 v, float osc, f32x4 biasv,
+                                           bool has_res, f32x4 r) {
+  bool border = false;
+  if (p.out_mode == 1) {
+    int ty = min(max(oy, 0), p.out.H - 1), tx = min(max(ox, 0), p.out.W - 1);
+    border = (ty == 0) | (ty == p.out.H - 1) | (tx == 0) | (tx == p.out.W - 1);
+    oy = ty; ox = tx;
+  }
+  const int off = grid_off(p.out, n, oy, ox);
+  v = v * osc + biasv;
+  if (has_res) {
+    if (p.res_mode == 0) v += r;
+    else v *= act_deriv(r, p.res_mode, p.res_slope);
+  }
+  if (p.act != ITG_ACT_NONE) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act, p.slope);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (co + e >= p.out.c) v[e] = 0.f;
+  float* dst = p.out.p + off + co;
+  if (border) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(dst + e, v[e]);
+  } else {
+    *reinterpret_cast<f32x4*>(dst) = v;
+  }
+  return v;
+}
+
+// ---- plans (host)
+struct NtPlan { int bco, bpix, tbk, ksplit, kchunks; int64_t ws_floats; };
+struct WgP {
+  GridT x, dy;
+  float* slab;       // [splits][co_pad][Kpad]
+  float* dbslab;     // [splits][co_pad] bias-gradient partials, or null
+  int ntaps, kw, cin_ld, Kpad, Ktot;
+  int MT, MU, M;     // output-pixel domain of the conv
+  int stride, pad, pad_h, pad_mode;
+  int co_rows, ncol_tiles, nco_tiles;
+  int chunks_per_split, nchunks;
+  unsigned x_bytes, dy_bytes;
+};
+
+constexpr int BKP = 16;  // pixels per pipeline stage (fp32 operands; 32 with bf16 operands)
+struct TileWgPlan { int ok, mf, nld, cpt, tiles_x, tiles_y, blocks, thin, gpp; int64_t ntiles; size_t lds; };
+struct TnPlan { int bcol, bco, splits, chunks_per_split, nchunks, co_rows, Kpad, ngroups; int64_t slab_floats, ws_floats; };
+
+inline int red_group() {       // slabs summed per thread in either weight-gradient reduce stage (>= 2: it is a divisor)
+  static const int v = env_int("ITG_RED_GROUP", 16) < 2 ? 2 : env_int("ITG_RED_GROUP", 16);
+  return v;
+}
+
+// conv_tile.hip
+int try_conv_valu(const ConvP& p, hipStream_t s, int* rc);
+int try_conv_tile(ConvP& p, hipStream_t s, int* rc);
+// conv_nt.hip
+NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = ITG_PREC_F32);
+int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s);
+int launch_zero_border(const GridT& g, hipStream_t s);
+// conv_wgrad.hip
+TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g);
+TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec = ITG_PREC_F32);
+TnPlan tn_plan_for_tiles(const TileWgPlan& tw, int co_ld, int Ktot);
+int run_wgrad(WgP& p, const TnPlan& t, const TileWgPlan& tw, int prec, const itg_tensor* x, const itg_tensor* dy,
+              const itg_conv_geom* g, float* dw, float* db, int accumulate, float* workspace, hipStream_t s);
+
+}  // namespace itgk

@@ -124,6 +124,7 @@ class GradExchange:
         # blocks although attention runs between block3 and block4: a split that would put such an out-of-order unit in
         # the tail (or the blocks it precedes in the head) is refused - the scan stops at the last block that executes
         # before the first out-of-order unit.
+        units = [(n, u) for n, u in units if any(True for _ in u.parameters())]
         order = getattr(net, "execution_order", None)
         limit = len(units)
         if order is not None:

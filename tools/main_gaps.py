@@ -11,7 +11,7 @@ import sys
 
 
 def short(n):
-    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    n = n.replace("(anonymous namespace)::", "").replace("itgk::", "").replace("void ", "")
     return re.sub(r"\(.*$", "", n).replace("at::native::", "")[:56]
 
 

@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    name = name.replace("(anonymous namespace)::", "").replace("itgk::", "").replace("void ", "")
     return re.sub(r"\(.*$", "", name)
 
 
