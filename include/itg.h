@@ -49,6 +49,28 @@ typedef struct {
 enum { ITG_PAD_ZERO = 0, ITG_PAD_REPLICATE = 1 };
 enum { ITG_ACT_NONE = 0, ITG_ACT_LRELU = 1, ITG_ACT_TANH = 2 };
 
+/* Input transform of a convolution (optional, itg_conv_geom.in_norm): the conv does not see the tensor `in` it is
+ * handed but  u = up2x?( act( alpha * in + beta' ) ),  i.e. the BatchNorm-apply + LeakyReLU (+ nearest x2 upsample)
+ * that precedes every generator conv (reference models/layers.py:301-311, generators.py:95-117) runs inside the
+ * conv's tile loader and u is never written to memory; padding positions stay zero / replicate u.
+ *   itg_conv2d_fwd / itg_conv2d_wgrad : `in` / `x` is the BatchNorm's INPUT (half the conv's input extent when
+ *       upsample = 1); ab = alpha | beta' (2 * in.ld floats, itg_bn_finalize).
+ *   itg_conv2d_dgrad : `dx` is the gradient w.r.t. u (u's extent).  With bwd_sums != NULL the epilogue also
+ *       accumulates the BatchNorm backward sums over every element g of dx:  ge = g * act'(alpha x + beta'),
+ *       bwd_sums[c] += ge, bwd_sums[ld + c] += ge * xhat  (x, mean_rstd: the BatchNorm's input and statistics;
+ *       2 * ld zeroed doubles) - what itg_bn_bwd_reduce computes in a pass of its own; itg_bn_bwd_apply(x, dx, ...)
+ *       then finishes the BatchNorm backward.  Kernel paths that cannot take the sums run that pass themselves.  */
+typedef struct {
+  const float* ab;          /* alpha | beta', 2 * ld floats */
+  int32_t act;              /* ITG_ACT_NONE | ITG_ACT_LRELU (0 <= slope <= 1) */
+  float slope;
+  int32_t upsample;         /* 0 | 1 */
+  int32_t reserved;
+  const itg_tensor* x;      /* dgrad + bwd_sums only: the BatchNorm's input */
+  const float* mean_rstd;   /* dgrad + bwd_sums only: mean | rstd, 2 * ld floats */
+  double* bwd_sums;         /* dgrad only, or NULL */
+} itg_in_norm;
+
 typedef struct {
   int32_t kh, kw, stride, pad;
   int32_t pad_mode; /* ITG_PAD_*: how reads outside the merged image resolve */
@@ -59,6 +81,7 @@ typedef struct {
                       * output pixel), ACCUMULATED into by the conv's epilogue - the BatchNorm statistics of the
                       * layer that consumes this output (nn.BatchNorm2d after every generator conv, reference
                       * models/layers.py:279-280,301-322) without a second pass over the tensor (out.ld <= 512) */
+  const itg_in_norm* in_norm; /* NULL, or the input transform described above */
 } itg_conv_geom;
 
 /* ITG_PREC_F32: v_mfma_f32_16x16x4_f32, the reference's arithmetic (BASELINE configs 1, 2, 4, 5).

@@ -237,6 +237,22 @@ int conv_out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1;
 inline int pad_v(const itg_conv_geom* g) { return g->pad_h >= 0 ? g->pad_h : g->pad; }
 inline int prec_of(const itg_conv_geom* g) { return g->precision == ITG_PREC_BF16 ? ITG_PREC_BF16 : ITG_PREC_F32; }
 
+// itg_in_norm of a call (or none): validated against the tensor it transforms
+inline int in_norm_of(const itg_conv_geom* g, const itg_tensor* in, const itg_in_norm** out) {
+  *out = nullptr;
+  const itg_in_norm* n = g->in_norm;
+  if (!n) return ITG_OK;
+  if (!n->ab || (n->act != ITG_ACT_NONE && n->act != ITG_ACT_LRELU) || n->slope < 0.f || n->slope > 1.f) return ITG_ERR_ARG;
+  if ((n->upsample != 0 && n->upsample != 1) || (((uintptr_t)n->ab) & 15) || !in) return ITG_ERR_ARG;
+  *out = n;
+  return ITG_OK;
+}
+inline void clear_xf(ConvP& p) {
+  p.in_ab = nullptr; p.in_act = ITG_ACT_NONE; p.in_slope = 0.f; p.in_ups = 0;
+  p.bnx = null_grid(); p.bn_ab = nullptr; p.bn_mr = nullptr; p.bn_act = ITG_ACT_NONE; p.bn_slope = 0.f; p.bn_ups = 0;
+  p.bn_sums = nullptr;
+}
+
 
 }  // namespace
 
@@ -329,7 +345,10 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   int rc;
   if ((rc = check_tensor(in)) || (rc = check_tensor(out))) return rc;
   if (!w_packed || !g || g->kh <= 0 || g->kw <= 0 || g->stride <= 0 || g->pad < 0) return ITG_ERR_ARG;
-  if (thin_out_conv(in, out, g) && !(residual && residual->ptr)) {
+  const itg_in_norm* nin;
+  if (!w_packed || !g) return ITG_ERR_ARG;
+  if ((rc = in_norm_of(g, in, &nin))) return rc;
+  if (thin_out_conv(in, out, g) && !(residual && residual->ptr) && !nin) {
     if (g->out_stats) return ITG_ERR_ARG;       // single-output-channel layers have no BatchNorm consumer on this path
     // taps-as-rows path (see tap_gather_fwd_kernel): a 1x1 conv into P[pixel][16], then the tap gather
     const int H = in->gh * in->ph, W = in->gw * in->pw;
@@ -351,18 +370,21 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
     return ITG_OK;
   }
   ConvP p;
+  clear_xf(p);
   p.ncls = 1;
   p.prec = prec_of(g);
   p.in = make_grid(in);
   p.out = make_grid(out);
   p.res = null_grid();
+  const int ups = nin ? nin->upsample : 0;
+  if (nin) { p.in_ab = nin->ab; p.in_act = nin->act; p.in_slope = nin->slope; p.in_ups = ups; }
   if (residual && residual->ptr) {
     if ((rc = check_tensor(residual))) return rc;
     if (!same_shape(residual, out)) return ITG_ERR_ARG;
     p.res = make_grid(residual);
   }
   if (in->n != out->n) return ITG_ERR_ARG;
-  int Ho = conv_out_dim(p.in.H, g->kh, g->stride, pad_v(g)), Wo = conv_out_dim(p.in.W, g->kw, g->stride, g->pad);
+  int Ho = conv_out_dim(p.in.H << ups, g->kh, g->stride, pad_v(g)), Wo = conv_out_dim(p.in.W << ups, g->kw, g->stride, g->pad);
   if (Ho != p.out.H || Wo != p.out.W) return ITG_ERR_ARG;
   if (g->pad_mode == ITG_PAD_REPLICATE && g->stride != 1) return ITG_ERR_ARG;
   p.w = w_packed; p.bias = bias; p.scale = out_scale; p.res_mode = 0; p.res_slope = 0.f;
@@ -389,7 +411,7 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
   if (!w_packed_dgrad || !g) return ITG_ERR_ARG;
   if (dy->n != dx->n) return ITG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (thin_in_conv(dy, dx, g)) {
+  if (thin_in_conv(dy, dx, g) && !g->in_norm) {
     const int Ho = dy->gh * dy->ph, Wo = dy->gw * dy->pw, H = dx->gh * dx->ph, W = dx->gw * dx->pw;
     if (conv_out_dim(H, 4, 2, 1) != Ho || conv_out_dim(W, 4, 2, 1) != Wo) return ITG_ERR_ARG;
     const int rows = 64;     // 4 parity classes x 4 taps x 4 (padded) input channels
@@ -422,11 +444,26 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
     return ITG_OK;
   }
   ConvP p;
+  clear_xf(p);
   p.stats = nullptr;
   p.ncls = 1;
   p.prec = prec_of(g);
   p.in = make_grid(dy);
   p.out = make_grid(dx);
+  {
+    const itg_in_norm* nin;
+    if ((rc = in_norm_of(g, dx, &nin))) return rc;
+    if (nin && nin->bwd_sums) {
+      if (!nin->x || !nin->mean_rstd || (rc = check_tensor(nin->x))) return rc ? rc : ITG_ERR_ARG;
+      const itg_tensor* x = nin->x;
+      const int u = nin->upsample;
+      if (x->n != dx->n || x->gh != dx->gh || x->gw != dx->gw || (x->ph << u) != dx->ph || (x->pw << u) != dx->pw ||
+          x->c != dx->c || x->ld != dx->ld || dx->ld > 512)
+        return ITG_ERR_ARG;
+      p.bnx = make_grid(x); p.bn_ab = nin->ab; p.bn_mr = nin->mean_rstd; p.bn_act = nin->act; p.bn_slope = nin->slope;
+      p.bn_ups = u; p.bn_sums = nin->bwd_sums;
+    }
+  }
   p.res = null_grid();
   p.res_mode = 0; p.res_slope = 0.f;
   if (act_out && act_out->ptr && act != ITG_ACT_NONE) {
@@ -497,7 +534,7 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
 
 int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g) {
   if (!x || !dy || !g) return 0;
-  if (thin_out_conv(x, dy, g)) {
+  if (thin_out_conv(x, dy, g) && !g->in_norm) {
     int64_t Min = grid_pixels(x);
     TnPlan t = plan_tn(Min, 16, x->ld, prec_of(g));
     return Min * 16 + 16 * (int64_t)x->c + 16 + t.ws_floats + (int64_t)t.splits * t.co_rows;
@@ -516,7 +553,7 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
   if (x->n != dy->n) return ITG_ERR_ARG;
   if (accumulate & ~(ITG_ACC_DW | ITG_ACC_DB)) return ITG_ERR_ARG;     // a bit set, not a boolean (ABI note)
   hipStream_t s = (hipStream_t)stream;
-  if (thin_out_conv(x, dy, g)) {
+  if (thin_out_conv(x, dy, g) && !g->in_norm) {
     const int H = x->gh * x->ph, W = x->gw * x->pw;
     if (conv_out_dim(H, g->kh, 1, pad_v(g)) != dy->gh * dy->ph || conv_out_dim(W, g->kw, 1, g->pad) != dy->gw * dy->pw)
       return ITG_ERR_ARG;
@@ -541,7 +578,11 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
   WgP p;
   p.x = make_grid(x);
   p.dy = make_grid(dy);
-  int Ho = conv_out_dim(p.x.H, g->kh, g->stride, pad_v(g)), Wo = conv_out_dim(p.x.W, g->kw, g->stride, g->pad);
+  const itg_in_norm* nin;
+  if ((rc = in_norm_of(g, x, &nin))) return rc;
+  const int ups = nin ? nin->upsample : 0;
+  p.in_ab = nin ? nin->ab : nullptr; p.in_act = nin ? nin->act : ITG_ACT_NONE; p.in_slope = nin ? nin->slope : 0.f; p.in_ups = ups;
+  int Ho = conv_out_dim(p.x.H << ups, g->kh, g->stride, pad_v(g)), Wo = conv_out_dim(p.x.W << ups, g->kw, g->stride, g->pad);
   if (Ho != p.dy.H || Wo != p.dy.W) return ITG_ERR_ARG;
   if (g->pad_mode == ITG_PAD_REPLICATE && g->stride != 1) return ITG_ERR_ARG;
   int64_t M = (int64_t)x->n * Ho * Wo;

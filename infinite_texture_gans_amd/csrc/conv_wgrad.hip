@@ -17,7 +17,9 @@ constexpr int tn_min_blocks(int bcol, int wcol, int wco, bool bf, int depth) {
   return depth == 2 ? 3 : (bf ? 2 : ((wcol / 16) * (wco / 16) >= 16 && bcol >= 256 ? 3 : 4));
 }
 
-template <int BCOL, int BCO, int WCOL, int WCO, bool BF, int DEPTH>
+// XF: the input transform of WgP (BatchNorm-apply + activation + upsample of x in the loader); its own instantiation so that
+// the plain kernel is exactly the round-2 code
+template <int BCOL, int BCO, int WCOL, int WCO, bool BF, int DEPTH, bool XF>
 __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) void conv_tn_kernel(WgP p, int otp) {
   constexpr int FI = WCOL / 16, FJ = WCO / 16;
   constexpr int WAVES_COL = BCOL / WCOL;
@@ -119,8 +121,10 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
       } else {
         int iy = pt_ * p.stride - p.pad_h + pky[i], ix = pu * p.stride - p.pad + pkx[i];
         bool ok = live;
-        if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.x.H && (unsigned)ix < (unsigned)p.x.W;
-        iy = min(max(iy, 0), p.x.H - 1); ix = min(max(ix, 0), p.x.W - 1);
+        const int ups = XF ? p.in_ups : 0;
+        const int Hv = p.x.H << ups, Wv = p.x.W << ups;      // conv coordinates: those of the (x2 upsampled) input
+        if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+        iy = min(max(iy, 0), Hv - 1) >> ups; ix = min(max(ix, 0), Wv - 1) >> ups;
         o = ok ? (unsigned)grid_off(p.x, live ? pn : 0, iy, ix) * 4u : p.x_bytes;
       }
       otab[(buf * KP + prow) * OTP + (pe0 + i * 256) / KP] = o;
@@ -130,11 +134,31 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
   };
 
   f32x4 rxs[DEPTH][XL], rys[DEPTH][YL];
-  auto load_tiles = [&](int slot, f32x4 (&rx)[XL], f32x4 (&ry)[YL]) {
+  // input transform (p.in_ab, see ConvP): alpha | beta' in LDS behind the offset table; a thread's column groups - hence its
+  // coefficients - never change, but XL x 8 registers for them would cost a workgroup per CU: two ds_read_b128 per store
+  constexpr bool xf = XF;
+  float* const abt = reinterpret_cast<float*>(otab + (DEPTH + 1) * KP * OTP);
+  if constexpr (xf) {
+    for (int t = tid; t < 2 * p.cin_ld; t += 256) abt[t] = p.in_ab[t];
+  }
+  unsigned sokx[DEPTH];          // xf: which X loads of the stage held by a register set carry data (the others stay zero)
+  auto load_tiles = [&](int slot, int set, f32x4 (&rx)[XL], f32x4 (&ry)[YL]) {
+    if constexpr (xf) {
+      unsigned m = 0;
 #pragma unroll
-    for (int i = 0; i < XL; ++i) {
-      unsigned o = xok[i] ? otab[(slot * KP + xr[i]) * OTP + xj[i]] + xcb[i] : p.x_bytes;
-      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxr, o, 0, 0));
+      for (int i = 0; i < XL; ++i) {
+        const unsigned ot = xok[i] ? otab[(slot * KP + xr[i]) * OTP + xj[i]] : p.x_bytes;
+        m |= (ot != p.x_bytes ? 1u : 0u) << i;
+        unsigned o = ot != p.x_bytes ? ot + xcb[i] : p.x_bytes;
+        rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxr, o, 0, 0));
+      }
+      sokx[set] = m;
+    } else {
+#pragma unroll
+      for (int i = 0; i < XL; ++i) {
+        unsigned o = xok[i] ? otab[(slot * KP + xr[i]) * OTP + xj[i]] + xcb[i] : p.x_bytes;
+        rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxr, o, 0, 0));
+      }
     }
 #pragma unroll
     for (int i = 0; i < YL; ++i) {
@@ -144,12 +168,24 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
   };
   f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
   const bool do_db = p.dbslab != nullptr && col_tile == 0;
-  auto store_tiles = [&](int buf, const f32x4 (&rx)[XL], const f32x4 (&ry)[YL]) {
+  auto store_tiles = [&](int buf, int set, const f32x4 (&rx)[XL], const f32x4 (&ry)[YL]) {
 #pragma unroll
     for (int i = 0; i < XL; ++i)
       if (xr[i] < KP) {
-        if constexpr (BF) *reinterpret_cast<uint2*>(Xh + (buf * KP + xr[i]) * LHX + xcol[i]) = pack_bf16x4(rx[i]);
-        else *reinterpret_cast<f32x4*>(Xs + (buf * KP + xr[i]) * LDX + xcol[i]) = rx[i];
+        f32x4 v = rx[i];
+        if constexpr (xf) {
+          const int c = (int)(xcb[i] >> 2);
+          const f32x4 xa = *reinterpret_cast<const f32x4*>(abt + c), xb = *reinterpret_cast<const f32x4*>(abt + p.cin_ld + c);
+          const bool live = (sokx[set] >> i) & 1u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = fmaf(v[e], xa[e], xb[e]);
+            if (p.in_act == ITG_ACT_LRELU) t = fmaxf(t, t * p.in_slope);
+            v[e] = live ? t : 0.f;
+          }
+        }
+        if constexpr (BF) *reinterpret_cast<uint2*>(Xh + (buf * KP + xr[i]) * LHX + xcol[i]) = pack_bf16x4(v);
+        else *reinterpret_cast<f32x4*>(Xs + (buf * KP + xr[i]) * LDX + xcol[i]) = v;
       }
 #pragma unroll
     for (int i = 0; i < YL; ++i) {
@@ -219,15 +255,15 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
       produce(0);
       if (nk > 1) produce(1);
       __syncthreads();
-      load_tiles(0, rxs[0], rys[0]);
-      store_tiles(0, rxs[0], rys[0]);
+      load_tiles(0, 0, rxs[0], rys[0]);
+      store_tiles(0, 0, rxs[0], rys[0]);
       __syncthreads();
       for (int kk = 0; kk < nk; ++kk) {
         const int buf = kk & 1;
-        if (kk + 1 < nk) load_tiles(buf ^ 1, rxs[0], rys[0]);   // table of stage kk + 1: written one barrier ago
+        if (kk + 1 < nk) load_tiles(buf ^ 1, 0, rxs[0], rys[0]);   // table of stage kk + 1: written one barrier ago
         if (kk + 2 < nk) produce(buf);                           // stage kk + 2 -> the slot stage kk's loads have finished with
         compute(buf);
-        if (kk + 1 < nk) store_tiles(buf ^ 1, rxs[0], rys[0]);
+        if (kk + 1 < nk) store_tiles(buf ^ 1, 0, rxs[0], rys[0]);
         __syncthreads();
       }
     } else {
@@ -237,23 +273,23 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
       if (nk > 1) produce(1);
       if (nk > 2) produce(2);
       __syncthreads();
-      load_tiles(0, rxs[0], rys[0]);
-      if (nk > 1) load_tiles(1, rxs[DEPTH - 1], rys[DEPTH - 1]);
-      store_tiles(0, rxs[0], rys[0]);
+      load_tiles(0, 0, rxs[0], rys[0]);
+      if (nk > 1) load_tiles(1, DEPTH - 1, rxs[DEPTH - 1], rys[DEPTH - 1]);
+      store_tiles(0, 0, rxs[0], rys[0]);
       __syncthreads();
       int s0 = 0;                                                // kk % 3
       for (int kk = 0; kk < nk; kk += 2) {
         const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
-        if (kk + 2 < nk) load_tiles(s2, rxs[0], rys[0]);
+        if (kk + 2 < nk) load_tiles(s2, 0, rxs[0], rys[0]);
         if (kk + 3 < nk) produce(s0);                            // stage kk + 3
         compute(0);
-        if (kk + 1 < nk) store_tiles(1, rxs[DEPTH - 1], rys[DEPTH - 1]);
+        if (kk + 1 < nk) store_tiles(1, DEPTH - 1, rxs[DEPTH - 1], rys[DEPTH - 1]);
         __syncthreads();
         if (kk + 1 >= nk) break;
-        if (kk + 3 < nk) load_tiles(s0, rxs[DEPTH - 1], rys[DEPTH - 1]);
+        if (kk + 3 < nk) load_tiles(s0, DEPTH - 1, rxs[DEPTH - 1], rys[DEPTH - 1]);
         if (kk + 4 < nk) produce(s1);                            // stage kk + 4
         compute(1);
-        if (kk + 2 < nk) store_tiles(0, rxs[0], rys[0]);
+        if (kk + 2 < nk) store_tiles(0, 0, rxs[0], rys[0]);
         __syncthreads();
         s0 = s2;                                                 // (kk + 2) % 3
       }
@@ -297,8 +333,9 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
 // against ALL 9 * cin_ld (tap, c) rows: per 4 pixels MF ds_read_b32 + 1 and MF MFMAs, no address arithmetic.
 // The 4 waves' accumulators are summed in a fixed order through LDS; one slab per workgroup, reduced by the
 // same two-stage reduction as the generic path.
-template <int NJ, int NLD>
-__global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgP p, int tiles_x, int tiles_y, int ntiles, int cpt) {
+// XF: the input transform of WgP (BatchNorm-apply + activation + upsample of x while its halo tile is written to LDS)
+template <int NJ, int NLD, bool XF>
+__global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgP p, int tiles_x, int tiles_y, int ntiles, int cpt, int coef_off) {
   constexpr int MF = 4 * NJ;                               // 16-row MFMA tiles of the (tap, c) dimension
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CPD = 16;                                  // dY tile pitch (co_rows = 16)
@@ -334,6 +371,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgP p, int til
     y_lds[i] = pix * CPD + (e % yq4) * 4;
   }
   for (int e = tid; e < TT_H * TT_W * CPD; e += 256) Yt[e] = 0.f;     // channel groups >= dy.ld stay zero
+  float* const coef = lds + coef_off;                                 // XF: alpha | beta' [2][32]
+  if constexpr (XF) {
+    if (tid < 64) coef[tid] = (tid & 31) < p.cin_ld ? p.in_ab[(tid >> 5) * p.cin_ld + (tid & 31)] : 0.f;
+  }
+  const int ups = XF ? p.in_ups : 0;
+  unsigned okmask = 0;
   f32x4 rt[NLD], ry[YLD];
   auto load_tile = [&](int tile) {
     int b = tile;
@@ -341,15 +384,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgP p, int til
     const int ty_i = b % tiles_y;
     const int n = b / tiles_y;
     const int t0 = ty_i * TT_H, u0 = tx_i * TT_W;
+    unsigned m = 0;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       int iy = t0 - p.pad_h + e_r[i], ix = u0 - p.pad + e_c[i];
       bool ok = e_r[i] >= 0;
-      if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.x.H && (unsigned)ix < (unsigned)p.x.W;
-      iy = min(max(iy, 0), p.x.H - 1); ix = min(max(ix, 0), p.x.W - 1);
+      const int Hv = p.x.H << ups, Wv = p.x.W << ups;
+      if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+      iy = min(max(iy, 0), Hv - 1) >> ups; ix = min(max(ix, 0), Wv - 1) >> ups;
       unsigned o = (unsigned)grid_off(p.x, n, iy, ix) * 4u + e_cb[i];
       rt[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxr, ok ? o : p.x_bytes, 0, 0));
+      if constexpr (XF) m |= (ok ? 1u : 0u) << i;
     }
+    if constexpr (XF) okmask = m;
 #pragma unroll
     for (int i = 0; i < YLD; ++i) {
       int t = t0 + y_r[i], u = u0 + y_c[i];
@@ -361,8 +408,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgP p, int til
   f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
   auto store_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < NLD; ++i)
-      if (e_r[i] >= 0) *reinterpret_cast<f32x4*>(Xt + e_lds[i]) = rt[i];
+    for (int i = 0; i < NLD; ++i) {
+      if (e_r[i] < 0) continue;
+      f32x4 v = rt[i];
+      if constexpr (XF) {
+        const f32x4 xa = *reinterpret_cast<const f32x4*>(coef + (e_cb[i] >> 2)), xb = *reinterpret_cast<const f32x4*>(coef + 32 + (e_cb[i] >> 2));
+        const bool live = (okmask >> i) & 1u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = fmaf(v[e], xa[e], xb[e]);
+          if (p.in_act == ITG_ACT_LRELU) t = fmaxf(t, t * p.in_slope);
+          v[e] = live ? t : 0.f;
+        }
+      }
+      *reinterpret_cast<f32x4*>(Xt + e_lds[i]) = v;
+    }
 #pragma unroll
     for (int i = 0; i < YLD; ++i)
       if (y_r[i] >= 0) { *reinterpret_cast<f32x4*>(Yt + y_lds[i]) = ry[i]; dbacc += ry[i]; }
@@ -468,8 +528,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgP p, int til
 // (tap, c4) groups with no padding, and a lane's registers are dW[co = 0..3][(tap, c)] of its own (tap, c).
 // Same persistent halo tiles, slabs and reduction as wgrad_tile_kernel.  The (tap, c4) groups are dealt GPP per
 // pass so that, with 16 channels, the three taps of a pass fall in different LDS banks (the pixel is shared).
-template <int NP, int NLD>
-__global__ __launch_bounds__(256, 2) void wgrad_thin_kernel(const WgP p, int tiles_x, int tiles_y, int ntiles, int gpp) {
+template <int NP, int NLD, bool XF>
+__global__ __launch_bounds__(256, 2) void wgrad_thin_kernel(const WgP p, int tiles_x, int tiles_y, int ntiles, int gpp, int coef_off) {
   constexpr int cpt = 16;                                  // X tile pitch: compile-time, so that every LDS read below has an immediate offset
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int YP = TT_H * TT_W + 4;                      // dY tile is channel-major: [4][YP]
@@ -492,32 +552,56 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_kernel(const WgP p, int til
     e_cb[i] = (unsigned)c4 * 16u;
   }
   const int y_r = tid / TT_W, y_c = tid % TT_W;            // one dY pixel (4 channels) per thread
+  float* const coef = lds + coef_off;                      // XF: alpha | beta' [2][16]
+  if constexpr (XF) {
+    if (tid < 32) coef[tid] = (tid & 15) < p.cin_ld ? p.in_ab[(tid >> 4) * p.cin_ld + (tid & 15)] : 0.f;
+    __syncthreads();
+  }
+  const int ups = XF ? p.in_ups : 0;
   f32x4 rtA[NLD], rtB[NLD], ryA, ryB;                    // two tiles in flight: a tile's MFMA work is shorter than a load
-  auto load_tile = [&](int tile, f32x4 (&rt)[NLD], f32x4& ry) {
+  unsigned okA = 0, okB = 0;
+  auto load_tile = [&](int tile, f32x4 (&rt)[NLD], f32x4& ry, unsigned& okm) {
     int b = tile;
     const int tx_i = b % tiles_x; b /= tiles_x;
     const int ty_i = b % tiles_y;
     const int n = b / tiles_y;
     const int t0 = ty_i * TT_H, u0 = tx_i * TT_W;
+    unsigned m = 0;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       int iy = t0 - p.pad_h + e_r[i], ix = u0 - p.pad + e_c[i];
       bool ok = e_r[i] >= 0;
-      if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.x.H && (unsigned)ix < (unsigned)p.x.W;
-      iy = min(max(iy, 0), p.x.H - 1); ix = min(max(ix, 0), p.x.W - 1);
+      const int Hv = p.x.H << ups, Wv = p.x.W << ups;
+      if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+      iy = min(max(iy, 0), Hv - 1) >> ups; ix = min(max(ix, 0), Wv - 1) >> ups;
       unsigned o = (unsigned)grid_off(p.x, n, iy, ix) * 4u + e_cb[i];
       rt[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxr, ok ? o : p.x_bytes, 0, 0));
+      if constexpr (XF) m |= (ok ? 1u : 0u) << i;
     }
+    if constexpr (XF) okm = m;
     int t = t0 + y_r, u = u0 + y_c;
     bool ok = t < p.MT && u < p.MU;
     unsigned o = (unsigned)grid_off(p.dy, n, ok ? t : 0, ok ? u : 0) * 4u;
     ry = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ryr, ok ? o : p.dy_bytes, 0, 0));
   };
   f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
-  auto store_tile = [&](const f32x4 (&rt)[NLD], const f32x4& ry) {
+  auto store_tile = [&](const f32x4 (&rt)[NLD], const f32x4& ry, unsigned okm) {
 #pragma unroll
-    for (int i = 0; i < NLD; ++i)
-      if (e_r[i] >= 0) *reinterpret_cast<f32x4*>(Xt + e_lds[i]) = rt[i];
+    for (int i = 0; i < NLD; ++i) {
+      if (e_r[i] < 0) continue;
+      f32x4 v = rt[i];
+      if constexpr (XF) {
+        const f32x4 xa = *reinterpret_cast<const f32x4*>(coef + (e_cb[i] >> 2)), xb = *reinterpret_cast<const f32x4*>(coef + 16 + (e_cb[i] >> 2));
+        const bool live = (okm >> i) & 1u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = fmaf(v[e], xa[e], xb[e]);
+          if (p.in_act == ITG_ACT_LRELU) t = fmaxf(t, t * p.in_slope);
+          v[e] = live ? t : 0.f;
+        }
+      }
+      *reinterpret_cast<f32x4*>(Xt + e_lds[i]) = v;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) Yt[c * YP + tid] = ry[c];
     dbacc += ry;
@@ -564,18 +648,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_kernel(const WgP p, int til
   };
   int tile = blockIdx.x;
   const int step = gridDim.x;
-  if (tile < ntiles) load_tile(tile, rtA, ryA);
-  if (tile + step < ntiles) load_tile(tile + step, rtB, ryB);
+  if (tile < ntiles) load_tile(tile, rtA, ryA, okA);
+  if (tile + step < ntiles) load_tile(tile + step, rtB, ryB, okB);
   for (; tile < ntiles; tile += 2 * step) {
-    store_tile(rtA, ryA);
+    store_tile(rtA, ryA, okA);
     __syncthreads();
-    if (tile + 2 * step < ntiles) load_tile(tile + 2 * step, rtA, ryA);
+    if (tile + 2 * step < ntiles) load_tile(tile + 2 * step, rtA, ryA, okA);
     contract();
     __syncthreads();
     if (tile + step >= ntiles) break;
-    store_tile(rtB, ryB);
+    store_tile(rtB, ryB, okB);
     __syncthreads();
-    if (tile + 3 * step < ntiles) load_tile(tile + 3 * step, rtB, ryB);
+    if (tile + 3 * step < ntiles) load_tile(tile + 3 * step, rtB, ryB, okB);
     contract();
     __syncthreads();
   }
@@ -638,6 +722,9 @@ TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_
   size_t fl = (size_t)TT_PIX * t.cpt + (size_t)TT_H * TT_W * 16;
   size_t red = (size_t)9 * 32 * 16 + 4 + 256 * 4;               // reduction buffer + bias partials reuse the tiles' space
   if (red > fl) fl = red;
+  fl = (fl + 3) & ~(size_t)3;
+  t.coef_off = (int)fl;                                         // alpha | beta' of the input transform behind everything else
+  fl += 64;
   t.lds = fl * sizeof(float);
   if (t.lds > 64 * 1024 || t.ntiles > 0x7fffffff) return t;
   // one persistent workgroup per CU: alone the kernel is 13 % faster with two, but it runs beside the input-gradient chain
@@ -656,18 +743,27 @@ template <int NJ, int NLD>
 void launch_wgrad_tile(const WgP& p, const TileWgPlan& t, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<NJ, NLD>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<NJ, NLD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<NJ, NLD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     attr_done = true;
   }
-  snprintf(g_last_launch, sizeof(g_last_launch), "wgrad_tile_kernel<%d, %d>", NJ, NLD);
-  hipLaunchKernelGGL((wgrad_tile_kernel<NJ, NLD>), dim3((unsigned)t.blocks), dim3(256), t.lds, s, p, t.tiles_x, t.tiles_y,
-                     (int)t.ntiles, t.cpt);
+  snprintf(g_last_launch, sizeof(g_last_launch), "wgrad_tile_kernel<%d, %d, %s>", NJ, NLD, p.in_ab ? "true" : "false");
+  if (p.in_ab)
+    hipLaunchKernelGGL((wgrad_tile_kernel<NJ, NLD, true>), dim3((unsigned)t.blocks), dim3(256), t.lds, s, p, t.tiles_x, t.tiles_y,
+                       (int)t.ntiles, t.cpt, t.coef_off);
+  else
+    hipLaunchKernelGGL((wgrad_tile_kernel<NJ, NLD, false>), dim3((unsigned)t.blocks), dim3(256), t.lds, s, p, t.tiles_x, t.tiles_y,
+                       (int)t.ntiles, t.cpt, t.coef_off);
 }
 
 void launch_wgrad_thin(const WgP& p, const TileWgPlan& t, hipStream_t s) {
-  snprintf(g_last_launch, sizeof(g_last_launch), "wgrad_thin_kernel<3, 6>");
-  hipLaunchKernelGGL((wgrad_thin_kernel<3, 6>), dim3((unsigned)t.blocks), dim3(256), t.lds, s, p, t.tiles_x, t.tiles_y,
-                     (int)t.ntiles, t.gpp);
+  snprintf(g_last_launch, sizeof(g_last_launch), "wgrad_thin_kernel<3, 6, %s>", p.in_ab ? "true" : "false");
+  if (p.in_ab)
+    hipLaunchKernelGGL((wgrad_thin_kernel<3, 6, true>), dim3((unsigned)t.blocks), dim3(256), t.lds, s, p, t.tiles_x, t.tiles_y,
+                       (int)t.ntiles, t.gpp, t.coef_off);
+  else
+    hipLaunchKernelGGL((wgrad_thin_kernel<3, 6, false>), dim3((unsigned)t.blocks), dim3(256), t.lds, s, p, t.tiles_x, t.tiles_y,
+                       (int)t.ntiles, t.gpp, t.coef_off);
 }
 
 // dW[co][ci][ky][kx] (+)= sum_z slab[z][co][(ky*kw+kx)*ci_ld + ci]
@@ -749,14 +845,21 @@ int launch_tn(WgP p, int splits, int prec, hipStream_t s) {
   static const int depth_env = env_int("ITG_TN_DEPTH", 0);
   const int depth = depth_env ? depth_env : (p.chunks_per_split >= 128 ? 1 : 2);
   const int kp = prec == ITG_PREC_BF16 ? 32 : BKP;
-  snprintf(g_last_launch, sizeof(g_last_launch), "conv_tn_kernel<%d, %d, %d, %d, %s, %d>", BCOL, BCO, WCOL, WCO,
-           prec == ITG_PREC_BF16 ? "true" : "false", prec == ITG_PREC_BF16 ? 1 : depth);
-  if (prec == ITG_PREC_BF16)
-    hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, true, 1>), grid, dim3(256), (size_t)2 * kp * otp * 4, s, p, otp);
+  snprintf(g_last_launch, sizeof(g_last_launch), "conv_tn_kernel<%d, %d, %d, %d, %s, %d, %s>", BCOL, BCO, WCOL, WCO,
+           prec == ITG_PREC_BF16 ? "true" : "false", prec == ITG_PREC_BF16 ? 1 : depth, p.in_ab ? "true" : "false");
+  const size_t abb = p.in_ab ? (size_t)2 * p.cin_ld * 4 : 0;      // alpha | beta' of the input transform behind the offset table
+  if (p.in_ab) {
+    if (prec == ITG_PREC_BF16) return ITG_ERR_ARG;                 // the loader transform exists for fp32 operands
+    if (depth == 2)
+      hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 2, true>), grid, dim3(256), (size_t)3 * kp * otp * 4 + abb, s, p, otp);
+    else
+      hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 1, true>), grid, dim3(256), (size_t)2 * kp * otp * 4 + abb, s, p, otp);
+  } else if (prec == ITG_PREC_BF16)
+    hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, true, 1, false>), grid, dim3(256), (size_t)2 * kp * otp * 4, s, p, otp);
   else if (depth == 2)
-    hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 2>), grid, dim3(256), (size_t)3 * kp * otp * 4, s, p, otp);
+    hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 2, false>), grid, dim3(256), (size_t)3 * kp * otp * 4, s, p, otp);
   else
-    hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 1>), grid, dim3(256), (size_t)2 * kp * otp * 4, s, p, otp);
+    hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 1, false>), grid, dim3(256), (size_t)2 * kp * otp * 4, s, p, otp);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }

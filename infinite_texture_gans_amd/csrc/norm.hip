@@ -6,6 +6,7 @@
 // workgroup); the fp64 (sum, sumsq) pair is what ranks all-reduce for sync-BN.
 // Replaces nn.BatchNorm2d at reference models/layers.py:218,279-280 and generators.py:78,115,
 // and the modulation arithmetic of StochasticSpatialModulation.forward (layers.py:228-234).
+#include <cstdlib>
 #include "itg_common.h"
 
 namespace {
@@ -13,6 +14,7 @@ namespace {
 constexpr int MAX_LD = 2048;
 
 inline int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+inline int env_i(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 // number of 256-thread workgroups: multiple of q4/gcd(256,q4), about `total/(256*per_thread)`
 inline int sweep_blocks(int64_t total_f4, int q4, int per_thread, int cap) {
@@ -46,7 +48,17 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   const int cg = (int)(gt % q4);
   const int64_t step = T / q4;
   double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
-  for (int64_t pix = gt / q4; pix < npix; pix += step) {
+  int64_t pix = gt / q4;
+  for (; pix + 3 * step < npix; pix += 4 * step) {          // four loads in flight per thread (the sweep is latency-bound otherwise)
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (pix + u * step) * ld + cg * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { double d = v[u][e]; s[e] += d; ss[e] += d * d; }
+  }
+  for (; pix < npix; pix += step) {
     f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * ld + cg * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { double d = v[e]; s[e] += d; ss[e] += d * d; }
@@ -223,7 +235,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   const f32x4 mu = *reinterpret_cast<const f32x4*>(mean_rstd + cg * 4);
   const f32x4 rs = *reinterpret_cast<const f32x4*>(mean_rstd + ld + cg * 4);
   double s[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0};
-  for (int64_t pix = gt / q4; pix < npix; pix += step) {
+  int64_t pix = gt / q4;
+  constexpr int UN = UPS ? 2 : 4;                            // pixels in flight per thread (an upsampled dy is 4 loads per pixel)
+  for (; pix + (UN - 1) * step < npix; pix += UN * step) {
+    f32x4 v[UN], g[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      v[u] = *reinterpret_cast<const f32x4*>(x + (pix + u * step) * ld + cg * 4);
+      g[u] = load_dy<UPS>(dy, pix + u * step, ld, cg, ph, pw);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float ge = g[u][e] * act_grad(fmaf(v[u][e], a[e], b[e]), act, slope);
+        float xh = (v[u][e] - mu[e]) * rs[e];
+        s[e] += (double)ge;
+        sx[e] += (double)ge * (double)xh;
+      }
+  }
+  for (; pix < npix; pix += step) {
     f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * ld + cg * 4);
     f32x4 g = load_dy<UPS>(dy, pix, ld, cg, ph, pw);
 #pragma unroll
@@ -355,7 +386,8 @@ int itg_bn_stats(const itg_tensor* x, double* sums, void* stream) {
   if (!sums || x->ld > MAX_LD) return ITG_ERR_ARG;
   int64_t npix = grid_pixels(x);
   int q4 = x->ld >> 2;
-  int blocks = sweep_blocks(npix * q4, q4, 8, 512);
+  static const int cap = env_i("ITG_BN_RED_BLOCKS", 1024);
+  int blocks = sweep_blocks(npix * q4, q4, 8, cap);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, npix,
                      x->ld, sums);
   ITG_CHECK_LAUNCH();
@@ -435,7 +467,8 @@ int itg_bn_bwd_reduce(const itg_tensor* x, const itg_tensor* dy, const float* ab
   if ((rc = ups_mode(x, dy, &ups))) return rc;
   int64_t npix = grid_pixels(x);
   int q4 = x->ld >> 2;
-  int blocks = sweep_blocks(npix * q4, q4, 8, 512);
+  static const int cap = env_i("ITG_BN_RED_BLOCKS", 1024);
+  int blocks = sweep_blocks(npix * q4, q4, 8, cap);
   if (ups)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        (const float*)x->ptr, (const float*)dy->ptr, ab, mean_rstd, npix, x->ld, x->ph, x->pw, act,

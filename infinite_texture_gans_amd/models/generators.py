@@ -94,9 +94,8 @@ class ResidualPatchGenerator(nn.Module):
             if i == 3 and self.attention:
                 h = self.attention.run(h)
         if self.type_norm == 'BN':
-            h = self.bn.run(h, act=A, slope=s)
-        else:
-            h = ops.act(h, A, s)
+            return self.final.forward_grid(h, image_location, act=ops.ACT_TANH, bn=self.bn, bn_act=(A, s))
+        h = ops.act(h, A, s)
         return self.final.forward_grid(h, image_location, act=ops.ACT_TANH)
 
     def forward(self, z, maps=None, image_location='1st_row_1st_col'):

@@ -23,6 +23,18 @@ def _pad_mode(outer_padding):
     raise ValueError("outer_padding must be 'replicate' or 'constant', got %r" % (outer_padding,))
 
 
+def loader_norm_enabled():
+    """ITG_BN_LOADER=1: BatchNorm-apply + activation + upsample inside the conv kernels' tile loaders and the BatchNorm
+    backward sums in the input-gradient epilogues (itg_in_norm).  Off by default: measured on MI355X it removes 0.32 ms of
+    normalisation passes per step and adds 0.40 ms to the convolutions whose loaders / epilogues carry them (config 1:
+    765 vs 778 crops/s, profiles/r03_bn_loader_ab.txt)."""
+    return os.environ.get("ITG_BN_LOADER", "0") == "1"
+
+
+def _whole_image(image_location):
+    return all(k in image_location for k in ("1st_row", "1st_col", "last_row", "last_col"))
+
+
 # ------------------------------------------------------------------------------- parameters
 class _ConvParams(nn.Module):
     """Holds a conv's parameters under the reference's names: ``weight``/``bias`` or, with
@@ -88,6 +100,16 @@ class _ConvParams(nn.Module):
         return ops.conv(x, w, self.bias, self.k, self.k, self.stride, self.padding if pad is None else pad,
                         pad_mode, act, slope, residual, sn, out_grid, self._sinks(w), pad_h, packed=self._packed,
                         in_act=in_act, defer_act_bwd=defer_act_bwd, out_stats=out_stats)
+
+    def run_bn(self, x, bn, in_act, in_slope, upsample=False, pad=None, pad_mode=ops.PAD_ZERO, act=ops.ACT_NONE, slope=0.0,
+               residual=None, out_grid=None, pad_h=-1, out_stats=False):
+        """conv(up2x?(in_act(bn(x)))): the BatchNorm ``bn`` (a _BNParams) is applied by the conv kernels' loaders."""
+        if self.SN:
+            raise ValueError("the loader-side BatchNorm is not combined with spectral norm")
+        w = self.weight
+        return ops.bn_conv(x, bn.as_tuple(), w, self.bias, self.k, self.k, self.stride, self.padding if pad is None else pad,
+                           pad_mode, act, slope, residual, out_grid, self._sinks(w), pad_h, packed=self._packed,
+                           out_stats=out_stats, in_act=in_act, in_slope=in_slope, upsample=upsample)
 
     def forward(self, x):
         """Plain conv on an NCHW image batch (zero padding), as the reference's nn.Conv2d."""
@@ -227,16 +249,30 @@ class conv2d_lp(nn.Module):
         else:
             self.conv = conv3x3(ch_in, ch_out, SN, 1, 1)
 
-    def forward_grid(self, x, image_location="1st_row_1st_col", act=ops.ACT_NONE, slope=0.0, residual=None, out_stats=False):
+    def forward_grid(self, x, image_location="1st_row_1st_col", act=ops.ACT_NONE, slope=0.0, residual=None, out_stats=False,
+                     bn=None, bn_act=(ops.ACT_NONE, 0.0), upsample=False):
         """x: GT patches (or, for the generator's ``start`` layer, the merged latent as a 1x1-grid GT).
-        ``out_stats``: the output feeds a training-mode BatchNorm - its statistics are taken in this conv's epilogue."""
+        ``out_stats``: the output feeds a training-mode BatchNorm - its statistics are taken in this conv's epilogue.
+        ``bn`` (a _BNParams) + ``bn_act`` = (activation, slope) + ``upsample``: the conv's input is
+        up2x?(act(bn(x))) (reference models/layers.py:301-311); on the paths that gather the halo inside the conv kernel the
+        normalisation runs in the kernel's tile loader, on the others (streamed / row-sharded halos) as its own pass."""
+        fused = (bn is not None and not self.conv.SN and loader_norm_enabled() and ops.MFMA_PRECISION == ops.PREC_F32
+                 and (self.padding_mode != "local" or (self.local_padder.halo is None and self.local_padder.merge_patches_into_image
+                                                       and (self.training or _whole_image(image_location)))))
+        if bn is not None and not fused:
+            x = bn.run(x, act=bn_act[0], slope=bn_act[1], upsample=upsample)
         if self.padding_mode != "local":
             # per-patch zero padding: every patch is an independent image
             n, gh, gw, ph, pw, ld = x.t.shape
-            flat = GT(x.t.reshape(n * gh * gw, 1, 1, ph, pw, ld), x.c)
-            r = None if residual is None else GT(residual.t.reshape(n * gh * gw, 1, 1, ph, pw, -1), residual.c)
-            y = self.conv.run(flat, pad=1, pad_mode=ops.PAD_ZERO, act=act, slope=slope, residual=r)
-            return GT(y.t.reshape(n, gh, gw, ph, pw, -1), y.c)
+            flat = GT(x.t.reshape(n * gh * gw, 1, 1, ph, pw, ld), x.c, x.stats)
+            s_ = 2 if (fused and upsample) else 1
+            r = None if residual is None else GT(residual.t.reshape(n * gh * gw, 1, 1, ph * s_, pw * s_, -1), residual.c)
+            if fused:
+                y = self.conv.run_bn(flat, bn, bn_act[0], bn_act[1], upsample, pad=1, pad_mode=ops.PAD_ZERO, act=act, slope=slope,
+                                     residual=r)
+            else:
+                y = self.conv.run(flat, pad=1, pad_mode=ops.PAD_ZERO, act=act, slope=slope, residual=r)
+            return GT(y.t.reshape(n, gh, gw, ph * s_, pw * s_, -1), y.c)
         lp = self.local_padder
         gh, gw, outer = lp.cfg()
         if not lp.merge_patches_into_image:
@@ -246,6 +282,9 @@ class conv2d_lp(nn.Module):
             if lp.training:
                 return self._forward_band_train(x, lp, outer, act, slope, residual)
             return self._forward_row_sharded(x, lp, outer, act, slope, residual)
+        if fused:      # training, or ONE sub-image that is the whole picture (one-shot generation: no state is carried on)
+            return self.conv.run_bn(x, bn, bn_act[0], bn_act[1], upsample, pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope,
+                                    residual=residual, out_stats=out_stats)
         if lp.training:
             # halo + outer padding are resolved inside the conv's tile loader
             return self.conv.run(x, pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope, residual=residual,
@@ -323,10 +362,18 @@ class _BNParams(nn.BatchNorm2d):
     sync = None
     grad_sinks = False
 
-    def run(self, x, act=ops.ACT_NONE, slope=0.0, upsample=False):
-        sinks = None
+    def _sinks(self):
         if self.grad_sinks and self.weight is not None and self.weight.requires_grad and self.weight.grad is not None:
-            sinks = (self.weight.grad, self.bias.grad)
+            return (self.weight.grad, self.bias.grad)
+        return None
+
+    def as_tuple(self):
+        """What ops.bn_conv needs of this BatchNorm (parameters, buffers, mode, gradient sinks)."""
+        return (self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked, self.training,
+                self.eps, self.momentum, self.sync, self._sinks())
+
+    def run(self, x, act=ops.ACT_NONE, slope=0.0, upsample=False):
+        sinks = self._sinks()
         return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked,
                           training=self.training, eps=self.eps, momentum=self.momentum, act=act, slope=slope,
                           upsample=upsample, sync=self.sync, sinks=sinks)
@@ -486,13 +533,12 @@ class ResBlockGenerator(nn.Module):
                 sc = self._shortcut(x, map, upsample_input)
         if self.type_norm == "SSM":
             out = self.bn1.run(x, map, act=A, slope=s)
-        else:
-            out = self.bn1.run(x, act=A, slope=s, upsample=upsample_input)
-        out = self.conv1.forward_grid(out, image_location, out_stats=fuse)
-        if self.type_norm == "SSM":
+            out = self.conv1.forward_grid(out, image_location, out_stats=fuse)
             out = self.bn2.run(out, map, act=A, slope=s)
         else:
-            out = self.bn2.run(out, act=A, slope=s)
+            # BatchNorm-apply + LeakyReLU (+ the x2 upsample) happen in conv1's / conv2's tile loaders where the conv path
+            # gathers its halo itself (conv2d_lp.forward_grid); otherwise as their own pass
+            out = self.conv1.forward_grid(x, image_location, out_stats=fuse, bn=self.bn1, bn_act=(A, s), upsample=upsample_input)
         if forked:
             main.wait_stream(side)
             sc.t.record_stream(main)                 # allocated on the side stream, read by conv2's epilogue on this one
@@ -500,7 +546,9 @@ class ResBlockGenerator(nn.Module):
             sc = self._shortcut(x, map, upsample_input)
         else:
             sc = ops.upsample2x(x) if upsample_input else x
-        return self.conv2.forward_grid(out, image_location, residual=sc, out_stats=fuse and out_stats)
+        if self.type_norm == "SSM":
+            return self.conv2.forward_grid(out, image_location, residual=sc, out_stats=fuse and out_stats)
+        return self.conv2.forward_grid(out, image_location, residual=sc, out_stats=fuse and out_stats, bn=self.bn2, bn_act=(A, s))
 
     def _shortcut(self, x, map, upsample_input):
         sc = x
