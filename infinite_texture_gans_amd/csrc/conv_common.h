@@ -54,6 +54,7 @@ struct ConvP {
   GridT bnx; const float* bn_ab; const float* bn_mr; int bn_act; float bn_slope; int bn_ups; double* bn_sums;
   int prec;                     // ITG_PREC_F32 | ITG_PREC_BF16
   float* partial;      // split-K slabs [ksplit][M][co_rows] (ksplit > 1)
+  unsigned* tickets;   // split-K, in-launch combine: one zeroed word per (class, workgroup of a split), or null = second-stage launch
   int ksplit, kchunks; // K chunks (of BK) per split
   // stride-2 input-gradient: the 4 output-parity classes run as ONE grid (blockIdx.y = class)
   int ncls;

@@ -7,6 +7,7 @@
 // The pixel operand is gathered in merged-image coordinates from a patch-grid NHWC tensor, so the LocalPadder halo
 // (reference models/layers.py:145-173) is a neighbour-patch read and the outer replicate / zero padding (layers.py:82)
 // a clamp / predicate; nothing is materialised.
+#include <atomic>
 #include "conv_nt_kernel.h"
 
 namespace itgk {
@@ -96,6 +97,21 @@ __global__ void splitk_epilogue_kernel(ConvP p) {
       *reinterpret_cast<f32x4*>(dst) = v;
     }
   }
+}
+
+// ---- split-K ticket words (in-launch combine)
+constexpr int TICKET_SLOT = 1024, TICKET_SLOTS = 256;
+__device__ unsigned g_ticket_words[TICKET_SLOT * TICKET_SLOTS];      // zero at load; every use leaves its words zero again
+
+unsigned* next_ticket_slot() {
+  static unsigned* base = nullptr;
+  static std::atomic<unsigned> next{0};
+  if (!base) {
+    void* ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_ticket_words)) != hipSuccess) return nullptr;
+    base = static_cast<unsigned*>(ptr);
+  }
+  return base + (size_t)(next.fetch_add(1) % TICKET_SLOTS) * TICKET_SLOT;
 }
 
 int launch_zero_border(const GridT& gx, hipStream_t s) {
@@ -206,8 +222,18 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
   NtPlan pl = plan_nt((int64_t)p.M * ncls_, p.co_rows, p.Kpad, ncls_, p.prec);
   if (pl.ws_floats > workspace_floats || (pl.ws_floats && !workspace)) return ITG_ERR_WORKSPACE;
   p.ksplit = pl.ksplit; p.kchunks = pl.kchunks; p.partial = workspace;
-  if (pl.ksplit > 1 || !(stats_paths & 2)) p.stats = nullptr;
-  if (pl.ksplit > 1) p.bn_sums = nullptr;                    // the second stage does not take them: separate reduce launch
+  p.tickets = nullptr;
+  if (pl.ksplit > 1) {
+    // in-launch combine: ticket words from a static device array, handed out in slots of TICKET_SLOT words round-robin
+    // per launch (a slot is reused TICKET_SLOTS split-K launches later - streams are joined every train step, far fewer
+    // launches apart - and every word is reset to zero by the workgroup that draws the last ticket)
+    static const int inl = env_int("ITG_SPLITK_INLAUNCH", 0);   // measured: b1 forward 59 -> 93 us, step 778 -> 736 crops/s (229 KB of slabs per tile: the release / acquire pair costs more than the second-stage launch)
+    const int64_t words = (((int64_t)p.M + pl.bpix - 1) / pl.bpix) * ((p.co_rows + pl.bco - 1) / pl.bco) * ncls_;
+    if (inl && words <= TICKET_SLOT) p.tickets = next_ticket_slot();
+  }
+  const bool second_stage = pl.ksplit > 1 && !p.tickets;
+  if (second_stage || !(stats_paths & 2)) p.stats = nullptr;
+  if (second_stage) p.bn_sums = nullptr;                     // the second stage does not take them: separate reduce launch
   for (int c = 0; c < 4; ++c) p.cpoff[c] = (unsigned)((size_t)c * pl.ksplit * p.M * p.co_rows);
   {
     int64_t ib = (int64_t)p.in.n * p.in.gh * p.in.gw * p.in.ph * p.in.pw * p.in.ld * 4;
@@ -225,7 +251,7 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
   const int mode = p.in_ab ? NT_XF : (p.bn_sums ? NT_BNS : NT_PLAIN);
   int rc = mode == NT_PLAIN ? launch_nt_shape<NT_PLAIN>(pl.bco, pl.bpix, p, k, s) : launch_nt_fused(mode, pl.bco, pl.bpix, p, k, s);
   if (rc) return rc;
-  if (pl.ksplit == 1) return (want_stats && !p.stats) ? stats_after(p, want_stats, s) : ITG_OK;   // (bn_sums: taken by the epilogue)
+  if (!second_stage) return (want_stats && !p.stats) ? stats_after(p, want_stats, s) : ITG_OK;   // (bn_sums: taken by the epilogue)
   const int ncls = p.ncls > 1 ? p.ncls : 1;
   for (int c = 0; c < ncls; ++c) {
     ConvP q = p;

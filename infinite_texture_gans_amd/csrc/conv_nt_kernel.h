@@ -273,13 +273,6 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
 
   // ---- epilogue: lane holds 4 consecutive output channels of one pixel per fragment
   const int cq = (lane >> 4) * 4;
-  if (p.scale && p.ksplit <= 1) {          // 1/sigma of an unscaled panel (split-K: applied by the second stage)
-    const float osc = *p.scale;
-#pragma unroll
-    for (int i = 0; i < FI; ++i)
-#pragma unroll
-      for (int j = 0; j < FJ; ++j) acc[i][j] *= osc;
-  }
   if (p.ksplit > 1) {
     float* slab = cpartial + (size_t)blockIdx.z * cM * p.co_rows;
 #pragma unroll
@@ -292,7 +285,51 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
         if (co < p.co_rows) *reinterpret_cast<f32x4*>(slab + (size_t)m * p.co_rows + co) = acc[i][j];
       }
     }
-    return;
+    if (!p.tickets) return;                 // two-launch form: splitk_epilogue_kernel sums the slabs
+    // In-launch combine (MI355X guide, split-K recipe): every wave drains its slab stores, the workgroup meets, one lane
+    // releases at agent scope and draws a ticket; the workgroup whose ticket is the last of its tile acquires and sums ALL
+    // slabs of the tile in slab order (fixed order: deterministic, whichever split arrives last) and runs the ordinary
+    // epilogue.  Correct for any placement of a tile's splits over XCDs.  The ticket word is reset by the last arriver.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* const flag = reinterpret_cast<int*>(smem);          // the K loop ended with a barrier: its buffers are free
+    if (tid == 0) {
+      unsigned* const tk = p.tickets + (blockIdx.y * gridDim.x + blockIdx.x);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool last = t == (unsigned)(gridDim.z - 1);
+      if (last) {
+        __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      flag[0] = last ? 1 : 0;
+    }
+    __syncthreads();
+    if (!flag[0]) return;
+    const size_t zs = (size_t)cM * p.co_rows;
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) {
+      const int m = m0 + wpix0 + 16 * j + (lane & 15);
+#pragma unroll
+      for (int i = 0; i < FI; ++i) {
+        const int co = co0 + wco0 + 16 * i + cq;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < cM && co < p.co_rows) {
+          const float* q = cpartial + (size_t)m * p.co_rows + co;
+          for (int z = 0; z < (int)gridDim.z; ++z) v += *reinterpret_cast<const f32x4*>(q + (size_t)z * zs);
+        }
+        acc[i][j] = v;
+      }
+    }
+  }
+  if (p.scale) {          // 1/sigma of an unscaled panel (two-launch split-K: applied by the second stage)
+    const float osc = *p.scale;
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) acc[i][j] *= osc;
   }
   // BatchNorm statistics of the consumer layer, taken from the values as they are stored (p.stats)
   f32x4 st1[FI], st2[FI];
