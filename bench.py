@@ -209,7 +209,7 @@ def exchange_desc(tr):
     return "flat gradient exchange, single all-reduce per model"
 
 
-GRAPH_DEFAULT = {"config1": "0", "config3": "1", "config4": "0"}   # config 3's 5.5 ms step is shorter than its host time
+GRAPH_DEFAULT = {"config1": "0", "config3": "1", "config4": "0", "config5": "0"}   # config 3's 5.5 ms step is shorter than its host time
 _WORKLOAD = ["config1"]
 
 
@@ -394,22 +394,179 @@ def relaunch(n):
     return subprocess.call(cmd, env=env)
 
 
+SSM_GF_PER_PATCH = 10.66            # SSM generator forward, one 128^2 patch (n_layers_G 6, G_ch 52)
+FLAGS5 = ["--n_layers_G", "6", "--type_norm", "SSM", "--padding_mode", "local", "--outer_padding", "replicate", "--leak_G", "0.02",
+          "--seed", "1234"]
+
+
+def infer_leg(a):
+    """BASELINE config 5: inference tiling (reference test_sample.py -> utils.py:258-397) of one ``--out``^2 image per step as
+    ONE forward over the T x T patch grid, the patch rows sharded over the ranks (dist.RowHalo: one pixel row
+    per conv and neighbour over RCCL).  The band's latents are resident in HBM before the timed region and the image stays on
+    the device (the PCIe-inclusive figure is in DESIGN.md)."""
+    import torch.distributed as dist
+    from infinite_texture_gans_amd import ops, utils as U
+    from infinite_texture_gans_amd.dist import RowHalo
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("ITG_FORCE_DEVICE", os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    group = None
+    if world > 1:
+        backend = os.environ.get("ITG_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        group = dist.group.WORLD
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else ""
+        except Exception:      # noqa: BLE001
+            ver = "?"
+        _RANKS.update(ranks=dist.get_world_size(), backend=("nccl (RCCL %s)" % ver) if backend == "nccl" else backend)
+    _WORKLOAD[0] = "config5"
+    args = U.prepare_parser().parse_args(FLAGS5)
+    torch.manual_seed(args.seed)               # identical weights on every rank
+    netG, _ = U.prepare_models(args, dev)
+    netG.eval()
+    out = a.out
+    sh, sw, t_h, t_w, p = U.tiling_plan(args.n_layers_G, args.base_res, 3, 3, out, out)
+    halo = RowHalo(rank, world, group)
+    zf = mf = None
+    if a.reference_rng:
+        g = torch.Generator().manual_seed(args.seed + 1)
+        zf = torch.randn(1, args.z_dim, t_h * args.base_res + 2, t_w * args.base_res + 2, generator=g)
+        mf = [torch.randn(1, args.map_dim, t_h * (2 ** i) * args.base_res + 4, t_w * (2 ** i) * args.base_res + 4, generator=g)
+              for i in range(args.n_layers_G)]
+    lat = [U.band_latents(netG, t_h, t_w, args.base_res, halo, dev, args.z_dim, args.map_dim, seed=args.seed + 1 + i,
+                          z_full=zf, maps_full=mf) for i in range(2)]
+
+    def step(i):
+        z, m = lat[i % 2]
+        return U.generate_band(netG, z, m, t_w, args.base_res, halo)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        img = step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        img = step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+    finite = bool(torch.isfinite(img).all())
+    rows_mine = halo.band(t_h)
+    # per-kernel HIP events of one more forward (rank 0): the dominant conv instantiation against the fp32 MFMA peak
+    roof = None
+    if rank == 0:
+        ops.PROFILE = []
+    step(0)
+    torch.cuda.synchronize()
+    if rank == 0:
+        agg = {}
+        for tag, launches, flops, e0, e1, nbytes in ops.PROFILE:
+            d = agg.setdefault(tag, [0, 0.0, 0.0, 0.0])
+            d[0] += launches; d[1] += flops; d[2] += e0.elapsed_time(e1) * 1e-3; d[3] += nbytes
+        ops.PROFILE = None
+        tag, (nl, fl, sec, nby) = max(agg.items(), key=lambda kv: kv[1][2])
+        tot_sec, tot_fl = sum(x[2] for x in agg.values()), sum(x[1] for x in agg.values())
+        traffic, note = hbm_traffic(tag)
+        roof = {"bound": "mfma", "kernel": tag, "achieved": round(fl / sec / 1e12, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(fl / sec / 1e12 / FP32_MFMA_PEAK_TF, 4), "traffic": traffic, "traffic_source": note,
+                "launches_per_step": nl, "avg_launch_us": round(sec / nl * 1e6, 1),
+                "conv_stack": {"time_ms": round(tot_sec * 1e3, 3), "tflops": round(tot_fl / tot_sec / 1e12, 2),
+                               "frac_of_peak": round(tot_fl / tot_sec / 1e12 / FP32_MFMA_PEAK_TF, 4),
+                               "gflop_this_rank": round(tot_fl / 1e9, 1)},
+                "grid_gflop": round(SSM_GF_PER_PATCH * t_h * t_w, 1),
+                "step_frac_of_mfma_peak": round(SSM_GF_PER_PATCH * t_h * t_w * 1e9 / (dt / a.steps) / 1e12 / (FP32_MFMA_PEAK_TF * world), 4),
+                "kernels": [{"kernel": k, "launches": v[0], "avg_us": round(v[2] / v[0] * 1e6, 1), "tflops": round(v[1] / v[2] / 1e12, 1),
+                             "frac": round(v[1] / v[2] / 1e12 / FP32_MFMA_PEAK_TF, 3), "time_share": round(v[2] / tot_sec, 3)}
+                            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2]) if v[2] / tot_sec >= 0.015]}
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        return
+    ms = dt / a.steps * 1e3
+    line = {"metric": "inference tiling: output megapixels/sec of one-shot patch-grid generation (SSM generator, %dx%d image)" % (out, out),
+            "value": round(out * out * a.steps / dt / 1e6, 3), "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "config 5: type_norm=SSM, n_layers_G=6, G_ch=52, random-init weights, eval-mode norm; one %dx%d image "
+                                   "per step = ONE forward over the %dx%d patch grid of 128^2 patches (test_sample.py path, one-shot "
+                                   "instead of %d streamed 3x3 sub-images)" % (out, out, t_h, t_w, sh * sw),
+                       "patches_per_sec": round(t_h * t_w * a.steps / dt, 1),
+                       "parallelism": "patch rows over %d rank(s) (rank 0: rows %d-%d of %d), one halo pixel row per 3x3 conv and "
+                                      "neighbour%s" % (world, rows_mine[0], rows_mine[1] - 1, t_h, "" if world == 1 else " over RCCL send/recv"),
+                       "latents": "reference full-grid CPU draw, cut per band" if a.reference_rng else "each rank draws its band's rows on the device (per-patch-row seeds)",
+                       "finite": finite, "launch": "eager"},
+            "roofline": roof}
+    line["config"].update(_RANKS)
+    if world == 1 and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_infer_leg()
+    print(json.dumps(line), flush=True)
+
+
+def cpu_infer_leg():
+    """The oracle's one-shot generation (CPU restatement of reference utils.py:258-397 + models/generators.py:86-124) of a
+    384 x 384 image (3 x 3 patch grid, same SSM generator) on the host cores: a bounded sample of the same workload."""
+    from oracle import step as ostep
+    from oracle.nets import GCfg
+    from infinite_texture_gans_amd import utils as U
+    ncores = host_cores()
+    torch.set_num_threads(ncores)
+    args = U.prepare_parser().parse_args(FLAGS5)
+    torch.manual_seed(1234)
+    netG, _ = U.prepare_models(args, "cpu")
+    sd = {k: v.clone() for k, v in netG.state_dict().items()}
+    cfg = GCfg(z_dim=128, G_ch=52, base_res=4, n_layers_G=6, attention=False, leak=0.02, type_norm="SSM")
+    sh, sw, t_h, t_w, p = ostep.grid_size(384, 384, cfg)
+    zf, maps = ostep.full_latents(cfg, t_h, t_w, torch.Generator().manual_seed(7))
+    ostep.infer_oneshot(sd, cfg, zf, maps, 384, 384)
+    n, t0 = 0, time.perf_counter()
+    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 20):
+        ostep.infer_oneshot(sd, cfg, zf, maps, 384, 384)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(384 * 384 / dt / 1e6, 4), "unit": "Mpix/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model(),
+            "sample": "%d one-shot generations of a 384x384 image (3x3 patch grid, %d patches, same SSM generator) after 1 warm-up, "
+                      "torch-CPU fp32 (%.2f s each)" % (n, t_h * t_w, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["config1", "config3", "config4"], default="config1",
+    ap.add_argument("--reference_rng", action="store_true",
+                    help="config5: every rank draws the reference's FULL-grid CPU latents (seed-identical images) instead of only "
+                         "the rows of its own band on the device")
+    ap.add_argument("--out", type=int, default=4096, help="config5: output height = width in pixels")
+    ap.add_argument("--workload", choices=["config1", "config3", "config4", "config5"], default="config1",
                     help="config1 (default, the headline metric): batch 8 per GPU, data parallel.  config3: 128^2 crops, "
                          "n_layers_G=5 + attention, convolutions on bf16-operand MFMA.  config4: 4x4 patch "
-                         "grid of ONE batch sharded by patch rows over <= 4 GPUs with halo exchange (strong scaling)")
+                         "grid of ONE batch sharded by patch rows over <= 4 GPUs with halo exchange (strong scaling).  config5: "
+                         "inference tiling, ONE 4096^2 image (33 x 33 patch grid, SSM generator) per step, patch rows sharded "
+                         "over the ranks with halo-row exchange (strong scaling); value = output megapixels per second")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch(a.gpus))          # plain `python bench.py --gpus N`: start N ranks, relay rank 0's line
     world = int(os.environ.get("WORLD_SIZE", 1))
     if a.gpus != world:
         sys.exit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (a.gpus, world))
+    if a.workload == "config5":
+        return infer_leg(a)
     rank, world, dt, args, losses, roof = gpu_leg(a)
     if rank != 0:
         return

@@ -110,10 +110,35 @@ class RowHalo:
             bottom = torch.empty_like(last_row)
             ops += [dist.P2POp(dist.isend, last_row, self.rank + 1, self.group),
                     dist.P2POp(dist.irecv, bottom, self.rank + 1, self.group)]
-        if ops:
+        if not ops:
+            return top, bottom
+        if first_row.is_cuda:
+            # Device rows (RCCL): the four transfers are posted as one group on a communication stream of this object and
+            # the CONSUMER stream waits for that stream - the host never blocks (ProcessGroupNCCL's Work.wait() is a
+            # stream-level wait as well, but it is taken on whatever stream is current; an explicit communication stream
+            # keeps the transfers off the compute queue and lets whatever the caller issues before it needs the rows run
+            # beside them).  The rows are kept referenced until the consumer has waited.
+            cur = torch.cuda.current_stream(first_row.device)
+            comm = self._comm_stream(first_row.device)
+            comm.wait_stream(cur)                          # the rows to send are produced on the compute stream
+            with torch.cuda.stream(comm):
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()                             # stream-level: orders `comm` behind the transfer
+            cur.wait_stream(comm)
+            for t in (first_row, last_row, top, bottom):
+                if t is not None:
+                    t.record_stream(comm)
+        else:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         return top, bottom
+
+    _comm = None
+
+    def _comm_stream(self, device):
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=device)
+        return self._comm
 
 
 class ThreadRowHalo(RowHalo):
@@ -169,16 +194,22 @@ class BandComm(RowHalo):
         a, b = self.band(total_rows)
         return _BandSync(self, total_rows, b - a)
 
-    def all_gather(self, t):
-        """list of every rank's tensor (bands may have different heights: sizes are exchanged first)."""
+    def all_gather(self, t, heights=None):
+        """list of every rank's tensor.  ``heights``: the size of dim -2 on every rank when the caller knows it (the band
+        heights of a row-sharded grid are static: band() x patch height) - otherwise the sizes are exchanged first, which
+        costs a host synchronisation per call."""
         if self.world == 1:
             return [t]
         if t.is_cuda and self.dist.get_backend(self.group) == "gloo":      # one-GPU rehearsal, see exchange()
-            return [o.to(t.device) for o in self.all_gather(t.cpu())]
-        sizes = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(self.world)]
-        self.dist.all_gather(sizes, torch.tensor([t.shape[-2]], dtype=torch.int64, device=t.device), group=self.group)
-        outs = [torch.empty(t.shape[:-2] + (int(s), t.shape[-1]), dtype=t.dtype, device=t.device) for s in sizes]
-        if all(int(s) == t.shape[-2] for s in sizes):
+            return [o.to(t.device) for o in self.all_gather(t.cpu(), heights)]
+        if heights is None:
+            sizes = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(self.world)]
+            self.dist.all_gather(sizes, torch.tensor([t.shape[-2]], dtype=torch.int64, device=t.device), group=self.group)
+            heights = [int(s) for s in sizes]
+        if heights[self.rank] != t.shape[-2]:
+            raise ValueError("band of %d rows announced as %d" % (t.shape[-2], heights[self.rank]))
+        outs = [torch.empty(t.shape[:-2] + (h, t.shape[-1]), dtype=t.dtype, device=t.device) for h in heights]
+        if all(h == t.shape[-2] for h in heights):
             self.dist.all_gather(outs, t.contiguous(), group=self.group)
         else:
             for r in range(self.world):      # ragged bands: one broadcast per rank
@@ -186,6 +217,36 @@ class BandComm(RowHalo):
                     outs[r].copy_(t)
                 self.dist.broadcast(outs[r], src=r, group=self.group)
         return outs
+
+    def reduce_scatter_rows(self, g, heights):
+        """SUM over ranks of ``g`` (..., H, W), returning only this rank's band of rows: with equal bands one
+        reduce-scatter (each rank receives 1/world of the tensor instead of all of it), with ragged bands the all-reduce
+        followed by the slice."""
+        lo = sum(heights[:self.rank])
+        h = heights[self.rank]
+        if self.world == 1:
+            return g[..., lo:lo + h, :].contiguous()
+        if g.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            return self.reduce_scatter_rows(g.cpu(), heights).to(g.device)
+        if len(set(heights)) == 1 and self.dist.get_backend(self.group) != "gloo":
+            chunks, o = [], 0
+            for hr in heights:
+                chunks.append(g[..., o:o + hr, :].contiguous())
+                o += hr
+            out = torch.empty_like(chunks[self.rank])
+            self.dist.reduce_scatter(out, chunks, op=self.dist.ReduceOp.SUM, group=self.group)
+            return out
+        g = g.contiguous().clone()
+        self.dist.all_reduce(g, op=self.dist.ReduceOp.SUM, group=self.group)
+        return g[..., lo:lo + h, :].contiguous()
+
+    def band_heights(self, total_rows, patch):
+        """Pixel-row count of every rank's band: static for a model (no exchange needed)."""
+        out = []
+        for r in range(self.world):
+            base, extra = divmod(total_rows, self.world)
+            out.append((base + (1 if r < extra else 0)) * patch)
+        return out
 
 
 class _BandSync:

@@ -563,6 +563,8 @@ class BandTrainer(Trainer):
                 m.pin(1, 1, netG.outer_padding)
                 m.halo = comm if m.merge_patches_into_image else None
 
+    _heights = None
+
     def _mine(self, n):
         if n % self.world:
             raise ValueError("batch of %d images does not split evenly over %d ranks" % (n, self.world))
@@ -575,6 +577,8 @@ class BandTrainer(Trainer):
         r = self.netG.base_res
         band = ops.to_nchw(self.netG.forward_grid(z[:, :, a * r:b * r + 2, :].contiguous(), None, "1st_row_1st_col"),
                            merged=True)
-        full = ops.gather_rows(band, self.comm)
+        if self._heights is None:      # static for the model: rows per rank x patch height
+            self._heights = self.comm.band_heights(self.total_rows, band.shape[-2] // (b - a))
+        full = ops.gather_rows(band, self.comm, self._heights)
         return full[self._mine(full.shape[0])].contiguous()
 

@@ -1112,25 +1112,23 @@ def halo_exchange(first, last, comm):
 
 class _GatherRows(torch.autograd.Function):
     """Bands (n, c, h_r, W) of all ranks -> full images (n, c, H, W) on every rank.  Backward: the
-    gradient of this rank's band summed over ranks."""
+    gradient of this rank's band summed over ranks (a reduce-scatter when the bands are equal)."""
 
     @staticmethod
-    def forward(ctx, band, comm):
-        parts = comm.all_gather(band.contiguous())
+    def forward(ctx, band, comm, heights):
+        parts = comm.all_gather(band.contiguous(), heights)
         ctx.comm = comm
-        ctx.lo = sum(p.shape[-2] for p in parts[:comm.rank])
-        ctx.h = band.shape[-2]
+        ctx.heights = [p.shape[-2] for p in parts]
         return torch.cat(parts, -2)
 
     @staticmethod
     def backward(ctx, g):
-        g = g.contiguous().clone()
-        ctx.comm.all_reduce(g)
-        return g[..., ctx.lo:ctx.lo + ctx.h, :].contiguous(), None
+        return ctx.comm.reduce_scatter_rows(g.contiguous(), ctx.heights), None, None
 
 
-def gather_rows(band, comm):
-    return _GatherRows.apply(band, comm)
+def gather_rows(band, comm, heights=None):
+    """``heights``: every rank's band height when static (no size exchange / host sync per step)."""
+    return _GatherRows.apply(band, comm, heights)
 
 
 # ------------------------------------------------------------------------------- losses

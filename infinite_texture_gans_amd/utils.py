@@ -401,36 +401,77 @@ def _generate_one_shot(g, z_full, maps_full, t_h, t_w, base_res, device):
             m.reset_state()
 
 
-def _generate_row_sharded(g, z_full, maps_full, t_h, t_w, base_res, device, halo, p, out_h, out_w):
-    """One-shot generation with the T_h x T_w patch grid split by patch rows over the ranks of ``halo``
-    (dist.RowHalo): every 3x3 conv exchanges one pixel row with each neighbour.  Latents are the SAME
-    full-grid tensors on every rank (same seed); each rank cuts out its band (+ the latent's own halo)."""
-    from .models.layers import LocalPadder
+def band_latents(g, t_h, t_w, base_res, halo, device, z_dim=128, map_dim=1, seed=0, z_full=None, maps_full=None):
+    """The latents of THIS rank's band of patch rows: z (1, z_dim, rows*b + 2, T_w*b + 2) and, for SSM, one map per layer
+    (1, map_dim, rows*r + 4, T_w*r + 4), on ``device``.
+
+    With ``z_full`` / ``maps_full`` (the reference's full-grid CPU draw, utils.py:221-256: z first, then maps 0..nl-1 from
+    the global generator) the band is cut out of them - seed-identical images, but every rank draws the whole grid
+    (18 M values at the finest level of a 4096^2 image: ~55 ms that do not shrink with the rank count).  Without them each
+    rank draws only its own rows, on the device, from generators seeded per (seed, layer, patch row): the rows two
+    neighbouring bands share (2 of z, 4 of every map) come out identical on both ranks, so the sharded image is the one a
+    single rank would have drawn with the same seed."""
     a, b = halo.band(t_h)
+    if z_full is not None:
+        z = z_full[:, :, a * base_res:b * base_res + 2, :].to(device)
+        maps = None
+        if maps_full is not None:
+            maps = [maps_full[i][:, :, a * (2 ** i) * base_res:b * (2 ** i) * base_res + 4, :].to(device)
+                    for i in range(g.n_layers_G)]
+        return z, maps
+
+    def rows(layer, ch, r, extra, width):
+        gen = torch.Generator(device=device)
+        parts = []
+        for k in range(a, b + 1):                      # block k = the r latent rows of patch row k; block b only lends its first rows
+            gen.manual_seed((int(seed) * 1000003 + layer * 10007 + k) & 0x7fffffffffffffff)
+            blk = torch.randn(1, ch, r if k < t_h else extra, width, device=device, generator=gen)
+            parts.append(blk if k < b else blk[:, :, :extra])
+        return torch.cat(parts, 2)
+
+    z = rows(0, z_dim, base_res, 2, t_w * base_res + 2)
+    maps = None
+    if g.type_norm == "SSM":
+        maps = [rows(1 + i, map_dim, (2 ** i) * base_res, 4, t_w * (2 ** i) * base_res + 4) for i in range(g.n_layers_G)]
+    return z, maps
+
+
+def generate_band(g, z_loc, maps_loc, t_w, base_res, halo):
+    """One forward of this rank's band (latents from band_latents, on the device) -> the band's image (1, c, rows*P, T_w*P)
+    on the device; every 3x3 conv exchanges one pixel row with each neighbour rank."""
+    from .models.layers import LocalPadder
+    rows = (z_loc.shape[2] - 2) // base_res
     pads = [m for m in g.modules() if isinstance(m, LocalPadder)]
     saved = (g.num_patches_h, g.num_patches_w)
     try:
-        g.num_patches_h, g.num_patches_w = b - a, t_w
+        g.num_patches_h, g.num_patches_w = rows, t_w
         for m in pads:
-            m.pin(b - a, t_w, g.outer_padding)
+            m.pin(rows, t_w, g.outer_padding)
             m.reset_state()
             m.halo = halo if m.merge_patches_into_image else None
-        z_loc = z_full[:, :, a * base_res:b * base_res + 2, :].to(device)
         maps = None
-        if maps_full is not None:
-            maps = []
-            for i in range(g.n_layers_G):
-                r = (2 ** i) * base_res
-                maps.append(crop_images(maps_full[i][:, :, a * r:b * r + 4, :].to(device), r + 4, r + 4, r))
-        strip = _to_host(ops.to_nchw(g.forward_grid(z_loc, maps, "1st_row_1st_col"), merged=True))
-        lo, hi = a * p, min(b * p, out_h)
-        return strip[:, :, :max(0, hi - lo), :out_w]
+        if maps_loc is not None:
+            maps = [crop_images(maps_loc[i], (2 ** i) * base_res + 4, (2 ** i) * base_res + 4, (2 ** i) * base_res)
+                    for i in range(g.n_layers_G)]
+        with torch.no_grad():
+            return ops.to_nchw(g.forward_grid(z_loc, maps, "1st_row_1st_col"), merged=True)
     finally:
         g.num_patches_h, g.num_patches_w = saved
         for m in pads:
             m.pin(saved[0], saved[1], g.outer_padding)
             m.reset_state()
             m.halo = None
+
+
+def _generate_row_sharded(g, z_full, maps_full, t_h, t_w, base_res, device, halo, p, out_h, out_w):
+    """One-shot generation with the T_h x T_w patch grid split by patch rows over the ranks of ``halo``
+    (dist.RowHalo): every 3x3 conv exchanges one pixel row with each neighbour.  Latents are the SAME
+    full-grid tensors on every rank (same seed); each rank cuts out its band (+ the latent's own halo)."""
+    a, b = halo.band(t_h)
+    z_loc, maps_loc = band_latents(g, t_h, t_w, base_res, halo, device, z_full=z_full, maps_full=maps_full)
+    strip = _to_host(generate_band(g, z_loc, maps_loc, t_w, base_res, halo))
+    lo, hi = a * p, min(b * p, out_h)
+    return strip[:, :, :max(0, hi - lo), :out_w]
 
 
 def _generate_streamed(g, z_full, maps_full, steps_h, steps_w, p, base_res, nph, npw, device):

@@ -115,26 +115,28 @@ def _rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-def _fullsize_step(flags, nl_G, attention, crop, prec, fp64_truth=False):
+def _fullsize_step(flags, nl_G, attention, crop, prec, fp64_truth=False, grid=3, band=False):
     """One train iteration at a BASELINE configuration on identical seeded state / real_x / z: HIP Trainer vs the
     CPU oracle's train_step.  Returns the comparison numbers."""
     from oracle import step as ostep
     from oracle.nets import GCfg, DCfg
     from infinite_texture_gans_amd import ops, utils as U
-    from infinite_texture_gans_amd.engine import Trainer
+    from infinite_texture_gans_amd.engine import Trainer, BandTrainer
+    from infinite_texture_gans_amd.dist import BandComm
     args = U.prepare_parser().parse_args(flags)
     args.beta1 = float(args.beta1)
     torch.manual_seed(1234)
     netG, netD = U.prepare_models(args, "cpu")
     gsd = ostep.as_leaf_params({k: v.clone() for k, v in netG.state_dict().items()})
     dsd = ostep.as_leaf_params({k: v.clone() for k, v in netD.state_dict().items()})
-    gcfg = GCfg(z_dim=128, G_ch=52, base_res=4, n_layers_G=nl_G, attention=attention, leak=0.02, type_norm="BN")
+    gcfg = GCfg(z_dim=128, G_ch=52, base_res=4, n_layers_G=nl_G, attention=attention, leak=0.02, type_norm="BN",
+                num_patches_h=grid, num_patches_w=grid)
     dcfg = DCfg(img_ch=3, base_ch=64, n_layers_D=4, SN=True)
     optD = ostep.Adam([dsd[k] for k in ostep.trainable(dsd)])
     optG = ostep.Adam([gsd[k] for k in ostep.trainable(gsd)])
     g = torch.Generator().manual_seed(7)
     real = torch.rand(8, 3, crop, crop, generator=g) * 2 - 1
-    z = torch.randn(8, 128, 14, 14, generator=g)
+    z = torch.randn(8, 128, 4 * grid + 2, 4 * grid + 2, generator=g)
     torch.set_num_threads(16)
     truth = None
     if fp64_truth:      # the same step in fp64 on the same initial state: the yardstick for gradient errors (F10)
@@ -147,7 +149,7 @@ def _fullsize_step(flags, nl_G, attention, crop, prec, fp64_truth=False):
     r = ostep.train_step(gsd, dsd, gcfg, dcfg, optG, optD, real, z, None, smooth=True)
     netG, netD = netG.to(cuda).train(), netD.to(cuda).train()
     with ops.mfma_precision(prec):
-        tr = Trainer(netG, netD, args, cuda)
+        tr = BandTrainer(netG, netD, args, cuda, BandComm(0, 1, None)) if band else Trainer(netG, netD, args, cuda)
         tr.record = []
         ops.ARENA, ops.WGRAD_STREAM = tr.arena, tr.wstream
         tr.arena.reset()
@@ -159,7 +161,7 @@ def _fullsize_step(flags, nl_G, attention, crop, prec, fp64_truth=False):
             ops.ARENA = ops.WGRAD_STREAM = None
         torch.cuda.synchronize()
     out = {"losses": ([float(d_real), float(d_fake), float(g_loss)], [r["d_loss_real"], r["d_loss_fake"], r["g_loss"]]),
-           "fake": _rel(ops.to_nchw(fake, merged=True), r["fake"]),
+           "fake": _rel(fake if torch.is_tensor(fake) else ops.to_nchw(fake, merged=True), r["fake"]),
            "logits": [_rel(a, b) for a, b in zip(tr.record, (r["real_logit"], r["fake_logit"], r["fake_logit2"]))]}
     gs, ds = netG.state_dict(), netD.state_dict()
     out["bn"] = max(_rel(gs[k], gsd[k]) for k in gs if "running" in k)
@@ -230,3 +232,133 @@ def test_config3_full_size_bf16_train_step_tracks_cpu_oracle():
     assert o["fake"] < 2e-2, o["fake"]
     assert all(e < 2e-2 for e in o["logits"]), o["logits"]
     assert o["bn"] < 2e-2 and o["nbt"]
+
+
+def test_config4_full_size_band_train_step_matches_cpu_oracle_within_1e3():
+    """BASELINE config 4 at its real size on one rank: bench.py's FLAGS with the 4x4 patch grid (128 G-patches of 128^2,
+    8 fake images of 512^2, 192^2 reals, batch 8) through the row-sharded engine (engine.BandTrainer: image-layout bands,
+    halo rows concatenated per conv, band-wide BatchNorm sums, band gather in front of D) against the CPU oracle's
+    train_step on identical state / real_x / z.  Forward tensors, losses, BatchNorm running statistics, spectral-norm
+    vectors and D's first-step gradients at <= 1e-3 relative."""
+    import bench
+    flags = bench.FLAGS + ["--num_patches_height", "4", "--num_patches_width", "4"]
+    o = _fullsize_step(flags, 6, False, 192, "f32", grid=4, band=True)
+    got, want = o["losses"]
+    print("config4 full-size: losses", got, want, "fake %.2e logits %s bn %.2e sn %.2e" % (o["fake"], o["logits"], o["bn"], o["sn"]))
+    assert all(abs(a - b) <= 1e-3 * abs(b) for a, b in zip(got, want)), (got, want)
+    assert o["fake"] < 1e-3, o["fake"]
+    assert all(e < 1e-3 for e in o["logits"]), o["logits"]
+    assert o["bn"] < 1e-3 and o["nbt"] and o["sn"] < 1e-3, (o["bn"], o["sn"])
+    errs = {k: _rel(o["gradD"][k], ref) for k, ref in o["gradD_ref"].items()}
+    print("config4 full-size: D gradients max rel-L2 %.2e" % max(errs.values()))
+    assert max(errs.values()) < 1e-3, errs
+
+
+# ------------------------------------------------------------------------------- config 5: SSM inference tiling at size
+def _ssm_generator(nl=6, G_ch=52, seed=1234):
+    from oracle import step as ostep
+    from oracle.nets import GCfg
+    from infinite_texture_gans_amd import utils as U
+    import bench
+    flags = [f for f in bench.FLAGS] + ["--type_norm", "SSM"]
+    flags[flags.index("--n_layers_G") + 1] = str(nl)
+    args = U.prepare_parser().parse_args(flags)
+    args.G_ch = G_ch
+    torch.manual_seed(seed)
+    netG, _ = U.prepare_models(args, "cpu")
+    sd = {k: v.clone() for k, v in netG.state_dict().items()}
+    # running statistics as a trained checkpoint has them (not the 0 / 1 of a fresh module): the eval-mode normalisation matters
+    g = torch.Generator().manual_seed(seed + 1)
+    for k in sd:
+        if k.endswith("running_mean"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+        elif k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(sd[k].shape, generator=g)
+    netG.load_state_dict(sd)
+    cfg = GCfg(z_dim=128, G_ch=G_ch, base_res=4, n_layers_G=nl, attention=False, leak=0.02, type_norm="SSM")
+    return netG.to(cuda).eval(), sd, cfg, ostep
+
+
+def test_config5_ssm_one_shot_640x896_matches_cpu_oracle():
+    """BASELINE config 5's generator (SSM, n_layers_G 6, G_ch 52) at BASELINE.md's inference size 640 x 896 (a 5 x 7 patch
+    grid): the HIP one-shot forward against oracle.step.infer_oneshot on the same full-grid latents, <= 1e-3 relative
+    (reference utils.py:258-397; streamed == one-shot without attention)."""
+    from infinite_texture_gans_amd import utils as U
+    netG, sd, cfg, ostep = _ssm_generator()
+    sh, sw, t_h, t_w, p = ostep.grid_size(640, 896, cfg)
+    assert (t_h, t_w, p) == (5, 7, 128)
+    zf, maps = ostep.full_latents(cfg, t_h, t_w, torch.Generator().manual_seed(5))
+    torch.set_num_threads(16)
+    want = ostep.infer_oneshot(sd, cfg, zf, maps, 640, 896)
+    got = U.sample_from_gen_PatchByPatch_test(netG, z_dim=128, base_res=4, map_dim=1, num_images=1, device=cuda,
+                                              output_resolution_height=640, output_resolution_width=896, z_full=zf, maps_full=maps)
+    assert got.shape == want.shape == (1, 3, 640, 896)
+    e = _rel(got, want)
+    print("config5 SSM 640x896 one-shot vs CPU oracle: rel-L2 %.2e, max abs %.2e" % (e, float((got.cpu() - want).abs().max())))
+    assert e < 1e-3, e
+
+
+def test_config5_ssm_4096_output_is_local_in_the_latents():
+    """Size-independent property at config 5's FULL size (4096^2 = a 33 x 33 patch grid, one forward): patch-by-patch
+    generation is local (SURVEY F7 - replicate-pad contamination never crosses the outermost patch), so the top-left
+    896^2 of the 4096^2 image equals the same region generated from the top-left 9 x 9 block of the same latents."""
+    from infinite_texture_gans_amd import utils as U
+    netG, sd, cfg, ostep = _ssm_generator()
+    sh, sw, t_h, t_w, p = ostep.grid_size(4096, 4096, cfg)
+    assert (t_h, t_w) == (33, 33)
+    zf, maps = ostep.full_latents(cfg, t_h, t_w, torch.Generator().manual_seed(6))
+    kw = dict(z_dim=128, base_res=4, map_dim=1, num_images=1, device=cuda)
+    big = U.sample_from_gen_PatchByPatch_test(netG, output_resolution_height=4096, output_resolution_width=4096, z_full=zf,
+                                              maps_full=maps, **kw)
+    assert big.shape == (1, 3, 4096, 4096) and bool(torch.isfinite(big).all())
+    b = cfg.base_res
+    zs = zf[:, :, :9 * b + 2, :9 * b + 2].contiguous()
+    ms = [m[:, :, :9 * (2 ** i) * b + 4, :9 * (2 ** i) * b + 4].contiguous() for i, m in enumerate(maps)]
+    small = U.sample_from_gen_PatchByPatch_test(netG, output_resolution_height=1152, output_resolution_width=1152, z_full=zs,
+                                                maps_full=ms, **kw)
+    e = _rel(big[:, :, :896, :896], small[:, :, :896, :896])
+    print("config5 SSM 4096^2: top-left 896^2 vs the 9x9-grid run on the latent sub-block: rel-L2 %.2e" % e)
+    assert e < 1e-5, e
+    # and the far corner is not a copy of it (the image really is 4096^2 of distinct texture)
+    assert _rel(big[:, :, -896:, -896:], small[:, :, :896, :896]) > 0.1
+
+
+def test_row_sharded_generation_with_8_ranks_and_a_ragged_split_equals_unsharded():
+    """Config 5's sharding at its rank count: a 9-row patch grid over EIGHT ranks (bands of 2,1,1,1,1,1,1,1 patch rows: the
+    ragged split 33 rows over 8 GPUs also produces) with halo rows exchanged between neighbours == the single-device
+    one-shot forward, and both == the CPU oracle.  Ranks are threads of this process (dist.ThreadRowHalo)."""
+    import threading
+    from infinite_texture_gans_amd import utils as U
+    from infinite_texture_gans_amd.dist import ThreadRowHalo
+    netG, sd, cfg, ostep = _ssm_generator(nl=4, G_ch=16, seed=77)
+    out_h, out_w = 9 * 32, 5 * 32
+    sh, sw, t_h, t_w, p = ostep.grid_size(out_h, out_w, cfg)
+    assert (t_h, t_w, p) == (9, 5, 32)
+    zf, maps = ostep.full_latents(cfg, t_h, t_w, torch.Generator().manual_seed(8))
+    kw = dict(z_dim=128, base_res=4, map_dim=1, num_images=1, device=cuda, output_resolution_height=out_h,
+              output_resolution_width=out_w, z_full=zf, maps_full=maps)
+    one = U.sample_from_gen_PatchByPatch_test(netG, **kw)
+    want = ostep.infer_oneshot(sd, cfg, zf, maps, out_h, out_w)
+    assert _rel(one, want) < 1e-4, _rel(one, want)
+    world = 8
+    shared = ThreadRowHalo.Shared(world)
+    strips, errs = [None] * world, []
+
+    def work(r):
+        try:
+            import copy
+            G = copy.deepcopy(netG)
+            strips[r] = U.sample_from_gen_PatchByPatch_test(G, halo=ThreadRowHalo(r, shared), **kw)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+            shared.barrier.abort()
+
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    heights = [s_.shape[-2] for s_ in strips]
+    assert len(set(heights)) > 1, heights          # the split really is ragged
+    got = torch.cat(strips, -2)
+    assert got.shape == one.shape
+    assert _rel(got, one) < 1e-5, _rel(got, one)
