@@ -162,6 +162,32 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw_oihw, 
                      const itg_conv_geom* g, int accumulate, float* workspace, int64_t workspace_floats,
                      void* stream);
 
+/* Deferred form of the weight gradient (the train step's backward pass): itg_conv2d_wgrad_slabs runs only the contraction
+ * of ONE layer (split over pixel ranges into fp32 slabs in `workspace`, which must stay untouched until the reduce) and
+ * describes the rest of the work in *job; itg_wgrad_reduce_multi then finishes up to ITG_WGRAD_MAX_JOBS layers in ONE
+ * launch: fixed-order sum of every layer's slabs, OIHW transposition, bias gradients - instead of two or three small
+ * launches per layer (79 per train step before).  The caller fills job->dw / job->db / job->accumulate (ITG_ACC_* as in
+ * itg_conv2d_wgrad) and, for a spectrally normalised layer, job->w_orig and job->dot (one zeroed double): dw is then a
+ * temporary that receives G = dL/dW and <G, w_orig> is accumulated into *dot for itg_spectral_norm_bwd_multi.
+ * Two jobs of one launch must not share dw / db.  Returns ITG_ERR_ARG for layers that cannot be deferred (the
+ * single-output-channel taps-as-rows path): use itg_conv2d_wgrad for those.                                         */
+#define ITG_WGRAD_MAX_JOBS 24
+typedef struct {
+  const float* slab;    /* [splits][co_rows][Kpad]                      (filled by itg_conv2d_wgrad_slabs) */
+  const float* dbslab;  /* [dbsplits][co_rows] bias partials, or NULL   (filled) */
+  float* dw;            /* OIHW target                                   (caller) */
+  float* db;            /* bias-gradient target or NULL                  (caller) */
+  const float* w_orig;  /* spectral norm: OIHW weight_orig, else NULL    (caller) */
+  double* dot;          /* spectral norm: zeroed accumulator of <G, w_orig> (caller) */
+  int32_t splits, dbsplits, co, ci, ci_ld, kh, kw, co_rows, Kpad;      /* (filled) */
+  int32_t accumulate;   /* ITG_ACC_DW | ITG_ACC_DB                       (caller) */
+  float* stage;         /* [ngroups][co_rows][Kpad] scratch of the group stage inside `workspace`, or NULL (filled) */
+  int32_t ngroups, group;   /* layers with many slabs: slabs are first summed in groups of `group` (filled) */
+} itg_wgrad_job;
+int itg_conv2d_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g, float* workspace,
+                           int64_t workspace_floats, itg_wgrad_job* job, void* stream);
+int itg_wgrad_reduce_multi(const itg_wgrad_job* jobs, int n, void* stream);
+
 /* ---- LocalPadder as a standalone operator -----------------------------------------
  * reference models/layers.py:145-173 + utils.py:577-613,658-742 (training branch /
  * first sub-image): x (n*gh*gw patches of p x p) -> y (patches of (p+2) x (p+2)),
@@ -296,6 +322,13 @@ int itg_spectral_norm_power_iter_multi(int n, const float* const* w, float* cons
 int itg_spectral_norm_bwd(const float* g_w, const float* w_orig, const float* u, const float* v,
                           const float* inv_sigma, int rows, int cols, float* d_w_orig, int accumulate,
                           float* workspace, void* stream);
+/* the second half of itg_spectral_norm_bwd for up to ITG_WGRAD_MAX_JOBS layers in one launch: the dots <G, W> come from
+ * itg_wgrad_reduce_multi (job->dot).  accumulate: ITG_ACC_DW adds into d_w_orig.                                   */
+typedef struct {
+  const float* g_w; const float* u; const float* v; const float* inv_sigma; const double* dot; float* d_w_orig;
+  int32_t rows, cols, accumulate, reserved;
+} itg_sn_job;
+int itg_spectral_norm_bwd_multi(const itg_sn_job* jobs, int n, void* stream);
 
 /* ---- optimiser (train.py:57-58,153,169,176-180): Adam over a flat parameter buffer with
  * optional fused EMA (ema = decay*ema + (1-decay)*p); step >= 1, read from *step_dev (device int32)

@@ -43,6 +43,22 @@ class ConvGeom(C.Structure):
 
 
 PACK_MAX_JOBS = 48
+WGRAD_MAX_JOBS = 24
+
+
+class WgradJob(C.Structure):
+    """itg_wgrad_job: one layer's deferred weight-gradient reduce."""
+    _fields_ = [("slab", C.c_void_p), ("dbslab", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("w_orig", C.c_void_p),
+                ("dot", C.c_void_p), ("splits", C.c_int32), ("dbsplits", C.c_int32), ("co", C.c_int32), ("ci", C.c_int32),
+                ("ci_ld", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("co_rows", C.c_int32), ("Kpad", C.c_int32),
+                ("accumulate", C.c_int32), ("stage", C.c_void_p), ("ngroups", C.c_int32), ("group", C.c_int32)]
+
+
+class SnJob(C.Structure):
+    """itg_sn_job: the apply half of a spectral-norm backward."""
+    _fields_ = [("g_w", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("inv_sigma", C.c_void_p), ("dot", C.c_void_p),
+                ("d_w_orig", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("accumulate", C.c_int32),
+                ("reserved", C.c_int32)]
 
 _P = C.c_void_p
 _TP = C.POINTER(Tensor)
@@ -64,6 +80,9 @@ SIGNATURES = {
     "itg_conv2d_dgrad": (_i, [_TP, _P, _P, _TP, _TP, _i, _f, _GP, _P, _l, _P]),
     "itg_conv2d_wgrad_workspace": (_l, [_TP, _TP, _GP]),
     "itg_conv2d_wgrad": (_i, [_TP, _TP, _P, _P, _GP, _i, _P, _l, _P]),
+    "itg_conv2d_wgrad_slabs": (_i, [_TP, _TP, _GP, _P, _l, C.POINTER(WgradJob), _P]),
+    "itg_wgrad_reduce_multi": (_i, [C.POINTER(WgradJob), _i, _P]),
+    "itg_spectral_norm_bwd_multi": (_i, [C.POINTER(SnJob), _i, _P]),
     "itg_local_pad_fwd": (_i, [_P, _P, _i, _i, _i, _i, _i, _i, _i, _P]),
     "itg_local_pad_bwd": (_i, [_P, _P, _i, _i, _i, _i, _i, _i, _i, _P]),
     "itg_local_pad_nhwc_fwd": (_i, [_TP, _TP, _i, _P]),

@@ -545,6 +545,46 @@ int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, co
   return t.ws_floats + (int64_t)t.splits * t.co_rows;
 }
 
+// shared by itg_conv2d_wgrad / itg_conv2d_wgrad_slabs: geometry checks, plan, WgP
+static int wgrad_setup(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g, bool want_db, float* workspace,
+                       int64_t workspace_floats, WgP& p, TnPlan& t_out, TileWgPlan& tw_out, int& prec_out) {
+  int rc;
+  p.x = make_grid(x);
+  p.dy = make_grid(dy);
+  const itg_in_norm* nin;
+  if ((rc = in_norm_of(g, x, &nin))) return rc;
+  const int ups = nin ? nin->upsample : 0;
+  p.in_ab = nin ? nin->ab : nullptr; p.in_act = nin ? nin->act : ITG_ACT_NONE; p.in_slope = nin ? nin->slope : 0.f; p.in_ups = ups;
+  int Ho = conv_out_dim(p.x.H << ups, g->kh, g->stride, pad_v(g)), Wo = conv_out_dim(p.x.W << ups, g->kw, g->stride, g->pad);
+  if (Ho != p.dy.H || Wo != p.dy.W) return ITG_ERR_ARG;
+  if (g->pad_mode == ITG_PAD_REPLICATE && g->stride != 1) return ITG_ERR_ARG;
+  int64_t M = (int64_t)x->n * Ho * Wo;
+  if (M >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
+  p.ntaps = g->kh * g->kw; p.kw = g->kw; p.cin_ld = x->ld;
+  p.Ktot = p.ntaps * x->ld;
+  const int prec = prec_of(g);
+  const TileWgPlan tw = plan_wgrad_tile(x, dy, g);
+  TnPlan t = tw.ok ? tn_plan_for_tiles(tw, dy->ld, p.Ktot) : plan_tn(M, dy->ld, p.Ktot, prec);
+  if (t.ws_floats + (int64_t)t.splits * t.co_rows > workspace_floats) return ITG_ERR_WORKSPACE;
+  p.Kpad = t.Kpad; p.co_rows = t.co_rows;
+  p.slab = workspace;
+  p.dbslab = want_db ? workspace + t.ws_floats : nullptr;       // [splits][co_rows] after the slabs
+  p.MT = Ho; p.MU = Wo; p.M = (int)M;
+  p.stride = g->stride; p.pad = g->pad; p.pad_h = pad_v(g); p.pad_mode = g->pad_mode;
+  p.chunks_per_split = t.chunks_per_split; p.nchunks = t.nchunks;
+  {
+    int64_t xb = grid_pixels(x) * x->ld * 4, yb = grid_pixels(dy) * dy->ld * 4;
+    if (xb >= 0xFFFF0000LL || yb >= 0xFFFF0000LL) return ITG_ERR_ARG;
+    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
+  }
+  static const int plan_debug = env_int("ITG_PLAN_DEBUG", 0);
+  if (plan_debug)
+    fprintf(stderr, "[tn] M=%lld co_rows=%d Kpad=%d -> bcol=%d bco=%d splits=%d ngroups=%d tile=%d\n", (long long)M, t.co_rows,
+            t.Kpad, t.bcol, t.bco, t.splits, t.ngroups, tw.ok);
+  t_out = t; tw_out = tw; prec_out = prec;
+  return ITG_OK;
+}
+
 int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float* db, const itg_conv_geom* g,
                      int accumulate, float* workspace, int64_t workspace_floats, void* stream) {
   int rc;
@@ -576,39 +616,38 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
     return ITG_OK;
   }
   WgP p;
-  p.x = make_grid(x);
-  p.dy = make_grid(dy);
-  const itg_in_norm* nin;
-  if ((rc = in_norm_of(g, x, &nin))) return rc;
-  const int ups = nin ? nin->upsample : 0;
-  p.in_ab = nin ? nin->ab : nullptr; p.in_act = nin ? nin->act : ITG_ACT_NONE; p.in_slope = nin ? nin->slope : 0.f; p.in_ups = ups;
-  int Ho = conv_out_dim(p.x.H << ups, g->kh, g->stride, pad_v(g)), Wo = conv_out_dim(p.x.W << ups, g->kw, g->stride, g->pad);
-  if (Ho != p.dy.H || Wo != p.dy.W) return ITG_ERR_ARG;
-  if (g->pad_mode == ITG_PAD_REPLICATE && g->stride != 1) return ITG_ERR_ARG;
-  int64_t M = (int64_t)x->n * Ho * Wo;
-  if (M >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
-  p.ntaps = g->kh * g->kw; p.kw = g->kw; p.cin_ld = x->ld;
-  p.Ktot = p.ntaps * x->ld;
-  const int prec = prec_of(g);
-  const TileWgPlan tw = plan_wgrad_tile(x, dy, g);
-  TnPlan t = tw.ok ? tn_plan_for_tiles(tw, dy->ld, p.Ktot) : plan_tn(M, dy->ld, p.Ktot, prec);
-  if (t.ws_floats + (int64_t)t.splits * t.co_rows > workspace_floats) return ITG_ERR_WORKSPACE;
-  p.Kpad = t.Kpad; p.co_rows = t.co_rows;
-  p.slab = workspace;
-  p.dbslab = db ? workspace + t.ws_floats : nullptr;       // [splits][co_rows] after the slabs
-  p.MT = Ho; p.MU = Wo; p.M = (int)M;
-  p.stride = g->stride; p.pad = g->pad; p.pad_h = pad_v(g); p.pad_mode = g->pad_mode;
-  p.chunks_per_split = t.chunks_per_split; p.nchunks = t.nchunks;
-  {
-    int64_t xb = grid_pixels(x) * x->ld * 4, yb = grid_pixels(dy) * dy->ld * 4;
-    if (xb >= 0xFFFF0000LL || yb >= 0xFFFF0000LL) return ITG_ERR_ARG;
-    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
-  }
-  static const int plan_debug = env_int("ITG_PLAN_DEBUG", 0);
-  if (plan_debug)
-    fprintf(stderr, "[tn] M=%lld co_rows=%d Kpad=%d -> bcol=%d bco=%d splits=%d ngroups=%d tile=%d\n", (long long)M, t.co_rows,
-            t.Kpad, t.bcol, t.bco, t.splits, t.ngroups, tw.ok);
+  TnPlan t;
+  TileWgPlan tw;
+  int prec;
+  if ((rc = wgrad_setup(x, dy, g, db != nullptr, workspace, workspace_floats, p, t, tw, prec))) return rc;
   return run_wgrad(p, t, tw, prec, x, dy, g, dw, db, accumulate, workspace, s);
+}
+
+
+int itg_conv2d_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g, float* workspace,
+                           int64_t workspace_floats, itg_wgrad_job* job, void* stream) {
+  int rc;
+  if ((rc = check_tensor(x)) || (rc = check_tensor(dy))) return rc;
+  if (!g || !workspace || !job) return ITG_ERR_ARG;
+  if (x->n != dy->n || g->kh * g->kw > 49) return ITG_ERR_ARG;
+  if (thin_out_conv(x, dy, g) && !g->in_norm) return ITG_ERR_ARG;      // taps-as-rows path: not deferrable
+  WgP p;
+  TnPlan t;
+  TileWgPlan tw;
+  int prec;
+  if ((rc = wgrad_setup(x, dy, g, true, workspace, workspace_floats, p, t, tw, prec))) return rc;
+  if ((rc = run_wgrad_slabs(p, t, tw, prec, (hipStream_t)stream))) return rc;
+  job->slab = workspace; job->dbslab = p.dbslab;
+  job->splits = t.splits; job->dbsplits = t.splits;
+  job->co = dy->c; job->ci = x->c; job->ci_ld = x->ld; job->kh = g->kh; job->kw = g->kw;
+  job->co_rows = t.co_rows; job->Kpad = t.Kpad;
+  job->ngroups = t.ngroups; job->group = red_group();
+  job->stage = t.ngroups > 0 ? workspace + t.slab_floats : nullptr;
+  return ITG_OK;
+}
+
+int itg_wgrad_reduce_multi(const itg_wgrad_job* jobs, int n, void* stream) {
+  return launch_reduce_multi(jobs, n, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -173,5 +173,7 @@ TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec = ITG_PREC_F32);
 TnPlan tn_plan_for_tiles(const TileWgPlan& tw, int co_ld, int Ktot);
 int run_wgrad(WgP& p, const TnPlan& t, const TileWgPlan& tw, int prec, const itg_tensor* x, const itg_tensor* dy,
               const itg_conv_geom* g, float* dw, float* db, int accumulate, float* workspace, hipStream_t s);
+int run_wgrad_slabs(WgP& p, const TnPlan& t, const TileWgPlan& tw, int prec, hipStream_t s);
+int launch_reduce_multi(const itg_wgrad_job* jobs, int n, hipStream_t s);
 
 }  // namespace itgk

@@ -908,8 +908,8 @@ TnPlan tn_plan_for_tiles(const TileWgPlan& tw, int co_ld, int Ktot) {
 }
 
 
-int run_wgrad(WgP& p, const TnPlan& t, const TileWgPlan& tw, int prec, const itg_tensor* x, const itg_tensor* dy,
-              const itg_conv_geom* g, float* dw, float* db, int accumulate, float* workspace, hipStream_t s) {
+// the contraction of one layer into its slabs (no reduce stage)
+int run_wgrad_slabs(WgP& p, const TnPlan& t, const TileWgPlan& tw, int prec, hipStream_t s) {
   int rc;
   if (tw.ok) {
     rc = ITG_OK;
@@ -927,6 +927,12 @@ int run_wgrad(WgP& p, const TnPlan& t, const TileWgPlan& tw, int prec, const itg
   else if (t.bco == 32) rc = launch_tn<256, 32, 64, 32>(p, t.splits, prec, s);
   else if (t.bco == 64) rc = launch_tn<256, 64, 64, 64>(p, t.splits, prec, s);
   else rc = launch_tn<128, 128, 64, 64>(p, t.splits, prec, s);
+  return rc;
+}
+
+int run_wgrad(WgP& p, const TnPlan& t, const TileWgPlan& tw, int prec, const itg_tensor* x, const itg_tensor* dy,
+              const itg_conv_geom* g, float* dw, float* db, int accumulate, float* workspace, hipStream_t s) {
+  int rc = run_wgrad_slabs(p, t, tw, prec, s);
   if (rc) return rc;
   const float* red_src = workspace;
   int red_n = t.splits;
@@ -944,6 +950,157 @@ int run_wgrad(WgP& p, const TnPlan& t, const TileWgPlan& tw, int prec, const itg
   int blocks = dy->c * ((x->c + 63) / 64);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, red_src, dw, db, (const float*)p.dbslab,
                      t.splits, red_n, dy->c, x->c, x->ld, g->kh, g->kw, t.co_rows, t.Kpad, accumulate);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+// ------------------------------------------------------------------------------- every layer's reduce stage in one launch
+// One workgroup per (layer, output channel o, 64-input-channel chunk) as in wgrad_reduce_kernel, but the slab range is
+// also spread over the threads (zp slab phases per element, summed phase by phase in a fixed order: deterministic), so a
+// layer with hundreds of slabs needs no group stage, and the (ci, tap) tile is padded to an odd pitch (the 16-tap layers
+// were 16-way bank conflicted at pitch 16: 73 % of the LDS cycles).  Spectrally normalised layers also accumulate <G, W>.
+struct RedJobs {
+  itg_wgrad_job j[ITG_WGRAD_MAX_JOBS];
+  int start[ITG_WGRAD_MAX_JOBS + 1];       // first workgroup of each job
+  int n;
+};
+
+// first stage for the layers with many slabs: stage[zo][e] = sum of the zo-th group of slabs, every such layer in one launch
+struct GroupJobs {
+  const f32x4* in[ITG_WGRAD_MAX_JOBS];
+  f32x4* out[ITG_WGRAD_MAX_JOBS];
+  long long start[ITG_WGRAD_MAX_JOBS + 1];     // first flat float4 item of each job; items of a job = e4 * ngroups
+  long long e4[ITG_WGRAD_MAX_JOBS];
+  int splits[ITG_WGRAD_MAX_JOBS], group[ITG_WGRAD_MAX_JOBS];
+  int n;
+};
+
+__global__ void slab_group_reduce_multi_kernel(const GroupJobs gj) {
+  const long long total = gj.start[gj.n];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int ji = 0;
+    while (ji + 1 < gj.n && i >= gj.start[ji + 1]) ++ji;
+    const long long w = i - gj.start[ji];
+    const long long e = w % gj.e4[ji];
+    const int zo = (int)(w / gj.e4[ji]);
+    const int z1 = min(gj.splits[ji], (zo + 1) * gj.group[ji]);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int z = zo * gj.group[ji]; z < z1; ++z) v += gj.in[ji][(size_t)z * gj.e4[ji] + e];
+    gj.out[ji][w] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RedJobs jb) {
+  __shared__ float part[8192];
+  __shared__ float tile[64 * 50];
+  __shared__ double dpart[4];
+  int ji = 0;
+  while (ji + 1 < jb.n && (int)blockIdx.x >= jb.start[ji + 1]) ++ji;        // n <= 24: a short scalar scan
+  const itg_wgrad_job& J = jb.j[ji];
+  const int b = blockIdx.x - jb.start[ji];
+  const int taps = J.kh * J.kw;
+  const int nchunk = (J.ci + 63) / 64;
+  const int o = b / nchunk;
+  const int c0 = (b - o * nchunk) * 64;
+  const int cn = min(64, J.ci - c0);
+  const size_t zstride = (size_t)J.co_rows * J.Kpad;
+  const float* src = J.slab + (size_t)o * J.Kpad + c0;
+  const int tid = threadIdx.x;
+  if (J.db && c0 == 0) {      // bias gradient: fixed-order sum of the per-split partials
+    float sdb = 0.f;
+    for (int z = tid; z < J.dbsplits; z += 256) sdb += J.dbslab[(size_t)z * J.co_rows + o];
+    part[tid] = sdb;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (tid < w) part[tid] += part[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0) J.db[o] = (J.accumulate & ITG_ACC_DB) ? J.db[o] + part[0] : part[0];
+    __syncthreads();
+  }
+  const int nelem = 64 * taps;
+  int zp = J.splits / 8;
+  zp = max(1, min(zp, 8192 / nelem));
+  for (int w = tid; w < nelem * zp; w += 256) {
+    const int e = w % nelem, zi = w / nelem;
+    const int c = e & 63, t = e >> 6;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < cn) {
+      const float* q = src + (size_t)t * J.ci_ld + c;
+      int z = zi;
+      for (; z + 3 * zp < J.splits; z += 4 * zp) {       // four loads in flight, fixed order
+        s0 += q[(size_t)z * zstride];
+        s1 += q[(size_t)(z + zp) * zstride];
+        s2 += q[(size_t)(z + 2 * zp) * zstride];
+        s3 += q[(size_t)(z + 3 * zp) * zstride];
+      }
+      for (; z < J.splits; z += zp) s0 += q[(size_t)z * zstride];
+    }
+    part[w] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  const int pitch = taps | 1;
+  for (int e = tid; e < nelem; e += 256) {
+    float sum = 0.f;
+    for (int zi = 0; zi < zp; ++zi) sum += part[zi * nelem + e];
+    tile[(e & 63) * pitch + (e >> 6)] = sum;
+  }
+  __syncthreads();
+  float* dst = J.dw + ((size_t)o * J.ci + c0) * taps;
+  double dsum = 0.0;
+  for (int idx = tid; idx < cn * taps; idx += 256) {
+    const int c = idx / taps, t = idx - c * taps;
+    const float v = tile[c * pitch + t];
+    if (J.w_orig) dsum += (double)v * (double)J.w_orig[((size_t)o * J.ci + c0) * taps + idx];
+    dst[idx] = (J.accumulate & ITG_ACC_DW) ? dst[idx] + v : v;
+  }
+  if (J.w_orig) {             // workgroup-uniform
+    dsum = wave_sum_d(dsum);
+    if ((tid & 63) == 0) dpart[tid >> 6] = dsum;
+    __syncthreads();
+    if (tid == 0) atomicAdd(J.dot, (dpart[0] + dpart[1]) + (dpart[2] + dpart[3]));
+  }
+}
+
+int launch_reduce_multi(const itg_wgrad_job* jobs, int n, hipStream_t s) {
+  if (!jobs || n <= 0 || n > ITG_WGRAD_MAX_JOBS) return ITG_ERR_ARG;
+  RedJobs jb;
+  jb.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const itg_wgrad_job& J = jobs[i];
+    if (!J.slab || !J.dw || J.splits <= 0 || J.co <= 0 || J.ci <= 0 || J.kh * J.kw > 49 || (J.w_orig && !J.dot)) return ITG_ERR_ARG;
+    if (J.db && !J.dbslab) return ITG_ERR_ARG;
+    jb.j[i] = J;
+    jb.start[i] = total;
+    total += J.co * ((J.ci + 63) / 64);
+  }
+  jb.start[n] = total;
+  // layers with many slabs: group stage first (one launch for all of them); their final stage then sums the groups
+  GroupJobs gj;
+  gj.n = 0;
+  long long items = 0;
+  for (int i = 0; i < n; ++i) {
+    const itg_wgrad_job& J = jobs[i];
+    if (J.ngroups <= 0) continue;
+    if (!J.stage || J.group < 2) return ITG_ERR_ARG;
+    const int k = gj.n++;
+    gj.in[k] = reinterpret_cast<const f32x4*>(J.slab);
+    gj.out[k] = reinterpret_cast<f32x4*>(J.stage);
+    gj.e4[k] = (long long)J.co_rows * J.Kpad / 4;
+    gj.splits[k] = J.splits; gj.group[k] = J.group;
+    gj.start[k] = items;
+    items += gj.e4[k] * J.ngroups;
+    jb.j[i].slab = J.stage;
+    jb.j[i].splits = J.ngroups;
+  }
+  if (gj.n > 0) {
+    gj.start[gj.n] = items;
+    const int gb = (int)((items + 255) / 256 < 8192 ? (items + 255) / 256 : 8192);
+    hipLaunchKernelGGL(slab_group_reduce_multi_kernel, dim3(gb), dim3(256), 0, s, gj);
+    ITG_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)total), dim3(256), 0, s, jb);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }

@@ -283,6 +283,28 @@ inline int nblocks(int64_t n, int cap = 4096) {
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
+struct SnJobs {
+  itg_sn_job j[ITG_WGRAD_MAX_JOBS];
+  long long start[ITG_WGRAD_MAX_JOBS + 1];     // first flat element of each job
+  int n;
+};
+
+// dW_orig (+)= (G - <G, W> / sigma * u v^T) / sigma for every job; the dots were accumulated by itg_wgrad_reduce_multi
+__global__ void sn_bwd_multi_kernel(const SnJobs jb) {
+  const long long total = jb.start[jb.n];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int ji = 0;
+    while (ji + 1 < jb.n && i >= jb.start[ji + 1]) ++ji;
+    const itg_sn_job& J = jb.j[ji];
+    const long long e = i - jb.start[ji];
+    const float is = *J.inv_sigma;
+    const float coef = (float)(*J.dot) * is;
+    const int r = (int)(e / J.cols), c = (int)(e - (long long)r * J.cols);
+    const float val = (J.g_w[e] - coef * J.u[r] * J.v[c]) * is;
+    J.d_w_orig[e] = (J.accumulate & ITG_ACC_DW) ? J.d_w_orig[e] + val : val;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -375,6 +397,25 @@ int itg_spectral_norm_power_iter_multi(int n, const float* const* w, float* cons
 }
 
 // workspace: 2 floats (one fp64 accumulator, 8-byte aligned)
+int itg_spectral_norm_bwd_multi(const itg_sn_job* jobs, int n, void* stream) {
+  if (!jobs || n <= 0 || n > ITG_WGRAD_MAX_JOBS) return ITG_ERR_ARG;
+  SnJobs jb;
+  jb.n = n;
+  long long total = 0;
+  for (int i = 0; i < n; ++i) {
+    const itg_sn_job& J = jobs[i];
+    if (!J.g_w || !J.u || !J.v || !J.inv_sigma || !J.dot || !J.d_w_orig || J.rows <= 0 || J.cols <= 0) return ITG_ERR_ARG;
+    jb.j[i] = J;
+    jb.start[i] = total;
+    total += (long long)J.rows * J.cols;
+  }
+  jb.start[n] = total;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(sn_bwd_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, jb);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
 int itg_spectral_norm_bwd(const float* g_w, const float* w_orig, const float* u, const float* v,
                           const float* inv_sigma, int rows, int cols, float* d_w_orig, int accumulate, float* workspace,
                           void* stream) {

@@ -256,6 +256,14 @@ class Trainer:
         # also under hipGraph capture - what used to crash there was a wait for an idle forked stream, see
         # ops.wgrad_streams_join)
         self.nested_fork = os.environ.get("ITG_NESTED_FORK", "1") == "1"
+        # weight gradients in the deferred form: slabs per layer on the weight-gradient streams, ONE reduce launch per
+        # backward pass at the join (ops.flush_deferred)
+        # (ITG_DEFER_REDUCE=1; off by default.  Measured on MI355X, config 1: 353 -> 298 launches and 0.45 ms less kernel time per
+        # step, but 765 vs 780 crops/s: the per-layer reduce launches run on the weight-gradient streams in the shadow of the
+        # input-gradient chain, which is the critical path; the single reduce at the join - ~50 MB of slabs per wide layer,
+        # bandwidth-bound at ~150 us per pass - is ON that path.)
+        self.defer_reduce = os.environ.get("ITG_DEFER_REDUCE", "0") == "1"
+        self._defer = []
         self.set_overlap(self.overlap)
         from .dist import _active
         # two-bucket exchange: default on for the rehearsal backends (gloo / one-rank RCCL, where it is tested), opt-in on a
@@ -265,10 +273,11 @@ class Trainer:
         if self.sync is not None and _active(self.sync) and os.environ.get("ITG_BUCKETS", "0" if multi_rccl else "1") == "1":
             # the early buckets travel on the D(real) branch stream: idle during both backward passes that are exchanged
             issue = self.side if self.overlap else None
+            early = not self.defer_reduce      # deferred reduces finish the tail's gradients only at the join: single bucket
             self._exchange = {
-                id(self.flatD): GradExchange(self.flatD, netD, self.sync, device, issue_stream=issue),
+                id(self.flatD): GradExchange(self.flatD, netD, self.sync, device, issue_stream=issue, two_buckets=early),
                 id(self.flatG): GradExchange(self.flatG, netG, self.sync, device, issue_stream=issue,
-                                             two_buckets=getattr(netG, "type_norm", "BN") == "BN"),
+                                             two_buckets=early and getattr(netG, "type_norm", "BN") == "BN"),
             }
 
     def set_overlap(self, on):
@@ -354,6 +363,7 @@ class Trainer:
         self.arena.reset()                                      # BatchNorm statistics scratch of this iteration
         ops.ARENA = self.arena
         ops.WGRAD_STREAM = self.wstream
+        ops.WGRAD_DEFER = self._defer if self.defer_reduce else None
         ops.SHORTCUT_STREAM = self.sc_stream if self.overlap else None
         try:
             zs = list(z) if isinstance(z, (list, tuple)) else [z]
@@ -369,6 +379,7 @@ class Trainer:
         finally:                                                # never leave the process-wide hooks set behind an exception
             ops.ARENA = None
             ops.WGRAD_STREAM = None
+            ops.WGRAD_DEFER = None
             ops.SHORTCUT_STREAM = None
             ops.BACKWARD_ENTRY_HOOK = None
             if self.wstream is not None and not torch.cuda.is_current_stream_capturing():
@@ -404,11 +415,15 @@ class Trainer:
             main = torch.cuda.current_stream()
             self.side.wait_stream(main)
             keep = ops.WGRAD_STREAM
-            if not self.nested_fork:
-                ops.WGRAD_STREAM = None                        # D(real)'s weight gradients stay on the branch stream
+            if not self.nested_fork or (self.defer_reduce and torch.cuda.is_current_stream_capturing()):
+                # D(real)'s weight gradients stay on the branch stream (under hipGraph capture also when the reduces are
+                # deferred: joining the weight-gradient streams INTO the branch stream and forking onto them again later
+                # is another shape of the ROCm 7.2 hipStreamEndCapture crash, tools/capture_nested_fork.py)
+                ops.WGRAD_STREAM = None
             with torch.cuda.stream(self.side):
                 d_real = self._d_loss(self._d_real_logits(real_x), True)
                 d_real.backward(self._one)
+                self._finish_d_real()
             ops.WGRAD_STREAM = keep
             fake = self.sample_fake(z, maps)
             self._mark("G forward (beside D(real) fwd+bwd)")
@@ -416,6 +431,7 @@ class Trainer:
         else:
             d_real = self._d_loss(self._d_real_logits(real_x), True)
             d_real.backward(self._one)
+            self._finish_d_real()
             fake = self.sample_fake(z, maps)                   # GT patches, graph kept for the G step
         d_fake = self._d_loss(self._d_logits(fake.detach()), False)
         self._mark("D(fake) forward")
@@ -473,6 +489,7 @@ class Trainer:
                 self.flatD.zero_grad()                   # the gradients Adam(D) of this iteration consumed
                 d_real = self._d_loss(self._d_real_logits(next_real), True)
                 d_real.backward(self._one)
+                self._finish_d_real()
         finally:
             ops.WGRAD_STREAM = keep
             ops.ARENA = arena
@@ -481,10 +498,21 @@ class Trainer:
     _pending = None
 
     def _join(self):
-        """The weight-gradient streams have to drain before gradients are exchanged / consumed by Adam."""
+        """The weight-gradient streams have to drain before gradients are exchanged / consumed by Adam; the queued reduces of
+        this backward pass run behind them, in one launch."""
         if self.wstream is not None:
             ops.wgrad_streams_join()
+            ops.flush_deferred()
             ops.WGRAD_KEEPALIVE.clear()
+        else:
+            ops.flush_deferred()
+
+    def _finish_d_real(self):
+        """End of D(real)'s backward on whatever stream it ran: its queued weight gradients are reduced THERE (D(fake)'s
+        pass accumulates into the same .grad afterwards and is ordered behind this stream)."""
+        if ops.WGRAD_DEFER:
+            ops.wgrad_streams_join()
+            ops.flush_deferred()
 
     # ---- hipGraph: the whole iteration (~600 launches) as one graph replay
     def capture(self, real_x, z, maps=None, warmup=2):

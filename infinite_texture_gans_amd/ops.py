@@ -335,6 +335,11 @@ class _Conv(torch.autograd.Function):
             with (torch.cuda.stream(side) if side is not None else _NullCtx()):
                 st = _stream()
                 dxd = _desc(x, ci)
+                sinks_ok = not ((need_w and wsink is None) or (need_b and bsink is None))
+                if WGRAD_DEFER is not None and sinks_ok and _queue_wgrad(x, dxd, dy, ddy, g, w, wsink, bsink, need_w, need_b,
+                                                                         ctx.sn, st):
+                    gres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
+                    return gx, None, None, gres, None, None, None, None, None, None, None, None, None, None
                 nws = _lib.fn("itg_conv2d_wgrad_workspace")(C.byref(dxd), C.byref(ddy), C.byref(g))
                 ws = torch.empty(nws, device=x.device, dtype=torch.float32)
                 direct_w = wsink is not None and ctx.sn is None and need_w
@@ -407,6 +412,78 @@ _wgrad_rr = [0]
 
 
 _wgrad_slot = {}
+
+# Deferred weight-gradient reduce (engine.Trainer sets WGRAD_DEFER to a list for the duration of a step): a conv backward
+# then only runs the contraction into its slabs (itg_conv2d_wgrad_slabs, on the weight-gradient stream) and queues the rest;
+# flush_deferred() finishes every queued layer of the backward pass in ONE launch (itg_wgrad_reduce_multi: slab sums, OIHW
+# transposition, bias gradients, the <G, W> dots of spectrally normalised layers) plus one itg_spectral_norm_bwd_multi -
+# instead of 2-5 small launches per layer (79 second-stage + 20 spectral-norm launches per train step before).
+WGRAD_DEFER = None
+_WGRAD_WS = {}           # persistent slab workspaces / spectral-norm temporaries, keyed by layer and shape (never freed: the
+                         # slabs must outlive the conv call, and a captured hipGraph replays their addresses)
+
+
+def _persistent(key, numel, device, dtype=torch.float32):
+    t = _WGRAD_WS.get(key)
+    if t is None or t.numel() < numel or t.device != device:
+        t = _WGRAD_WS[key] = torch.empty(numel, device=device, dtype=dtype)
+    return t
+
+
+def _queue_wgrad(x, dxd, dy, ddy, gwg, w, wsink, bsink, need_w, need_b, sn, st):
+    """Deferred form of the weight gradient of one conv; False when the layer cannot be deferred."""
+    key = ((wsink if wsink is not None else bsink).data_ptr(), tuple(x.shape), tuple(dy.shape))
+    nws = _lib.fn("itg_conv2d_wgrad_workspace")(C.byref(dxd), C.byref(ddy), C.byref(gwg))
+    ws = _persistent(("ws",) + key, nws, x.device)
+    job = _lib.WgradJob()
+    co, ci, kh, kw = w.shape
+    with _Prof(_nt_tag(co).replace("nt", "tn"), 1, 2.0 * (dy.numel() // dy.shape[5]) * co * ci * kh * kw,
+               4 * (x.numel() + dy.numel() + w.numel())):
+        rc = _lib.fn("itg_conv2d_wgrad_slabs")(C.byref(dxd), C.byref(ddy), C.byref(gwg), _ptr(ws), nws, C.byref(job), st)
+    if rc == -1:                    # ITG_ERR_ARG: a path without slabs (single-output-channel taps-as-rows layer)
+        return False
+    if rc:
+        raise _lib.ItgError("itg_conv2d_wgrad_slabs failed with %d" % rc)
+    snjob = None
+    if sn is not None and need_w:
+        inv_sigma, u, v = sn
+        gtmp = _persistent(("g",) + key, w.numel(), x.device)
+        dot = ARENA.take(1) if ARENA is not None and ARENA.buf.device == x.device else None
+        if dot is None:
+            dot = torch.zeros(1, device=x.device, dtype=torch.float64)
+        job.dw, job.w_orig, job.dot = gtmp.data_ptr(), w.data_ptr(), dot.data_ptr()
+        job.accumulate = ACC_DB if (need_b and bsink is not None) else 0
+        snjob = _lib.SnJob(gtmp.data_ptr(), u.data_ptr(), v.data_ptr(), inv_sigma.data_ptr(), dot.data_ptr(), wsink.data_ptr(),
+                           w.shape[0], w.numel() // w.shape[0], ACC_DW, 0)
+        keep = (gtmp, dot, u, v, inv_sigma, w)
+    else:
+        job.dw = wsink.data_ptr() if need_w else _persistent(("g",) + key, w.numel(), x.device).data_ptr()
+        job.w_orig, job.dot = None, None
+        job.accumulate = (ACC_DW if need_w else 0) | (ACC_DB if need_b else 0)
+        keep = ()
+    job.db = bsink.data_ptr() if (need_b and bsink is not None) else None
+    WGRAD_DEFER.append((job, snjob, (ws, x, dy) + keep))
+    return True
+
+
+def flush_deferred():
+    """Finish every queued weight gradient on the CURRENT stream (which must have been ordered behind the streams the
+    slabs were computed on: wgrad_streams_join)."""
+    jobs = WGRAD_DEFER
+    if not jobs:
+        return
+    st = _stream()
+    n = _lib.WGRAD_MAX_JOBS
+    for i in range(0, len(jobs), n):
+        chunk = [j[0] for j in jobs[i:i + n]]
+        _lib.call("itg_wgrad_reduce_multi", (_lib.WgradJob * len(chunk))(*chunk), len(chunk), st)
+    sn = [j[1] for j in jobs if j[1] is not None]
+    for i in range(0, len(sn), n):
+        chunk = sn[i:i + n]
+        _lib.call("itg_spectral_norm_bwd_multi", (_lib.SnJob * len(chunk))(*chunk), len(chunk), st)
+    if not torch.cuda.is_current_stream_capturing():
+        WGRAD_KEEPALIVE.append(tuple(j[2] for j in jobs))       # operands stay referenced until the owner's join clears the list
+    del jobs[:]
 
 
 def wgrad_stream_for(sink_key):
@@ -775,20 +852,26 @@ class _BNConv(torch.autograd.Function):
                 st2 = _stream()
                 nin_w = _lib.InNorm(ab.data_ptr(), in_act, float(in_slope), ups)
                 gwg = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, None, nin_w)
-                nws = _lib.fn("itg_conv2d_wgrad_workspace")(C.byref(dxd), C.byref(ddy), C.byref(gwg))
-                ws2 = torch.empty(nws, device=dev, dtype=torch.float32)
+                sinks_ok = not ((need_w and wsink is None) or (need_b and bsink is None))
+                deferred = (WGRAD_DEFER is not None and sinks_ok and
+                            _queue_wgrad(x, dxd, dy, ddy, gwg, w, wsink, bsink, need_w, need_b, None, st2))
+                nws = 0 if deferred else _lib.fn("itg_conv2d_wgrad_workspace")(C.byref(dxd), C.byref(ddy), C.byref(gwg))
+                ws2 = None if deferred else torch.empty(nws, device=dev, dtype=torch.float32)
                 direct_w = wsink is not None and need_w
                 direct_b = bsink is not None and need_b
-                gw_ = wsink if direct_w else torch.empty_like(w)
-                gb = bsink if direct_b else (torch.empty_like(w[:, 0, 0, 0]) if need_b else None)
-                with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1, 2.0 * npix_out * co * ci * kh * kw,
-                           4 * (x.numel() + dy.numel() + w.numel())):
-                    _lib.call("itg_conv2d_wgrad", C.byref(dxd), C.byref(ddy), _ptr(gw_), _ptr(gb), C.byref(gwg),
-                              (ACC_DW if direct_w else 0) | (ACC_DB if direct_b else 0), _ptr(ws2), nws, st2)
-                if direct_w or not need_w:
-                    gw_ = None
-                if direct_b:
-                    gb = None
+                if deferred:
+                    gw_ = gb = None
+                else:
+                    gw_ = wsink if direct_w else torch.empty_like(w)
+                    gb = bsink if direct_b else (torch.empty_like(w[:, 0, 0, 0]) if need_b else None)
+                    with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1, 2.0 * npix_out * co * ci * kh * kw,
+                               4 * (x.numel() + dy.numel() + w.numel())):
+                        _lib.call("itg_conv2d_wgrad", C.byref(dxd), C.byref(ddy), _ptr(gw_), _ptr(gb), C.byref(gwg),
+                                  (ACC_DW if direct_w else 0) | (ACC_DB if direct_b else 0), _ptr(ws2), nws, st2)
+                    if direct_w or not need_w:
+                        gw_ = None
+                    if direct_b:
+                        gb = None
         # ---- BatchNorm backward: dx from (x, gu, sums)
         if ctx.sync is not None and _active(ctx.sync):
             local = sums.clone()
