@@ -378,9 +378,17 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   p.res = null_grid();
   const int ups = nin ? nin->upsample : 0;
   if (nin) { p.in_ab = nin->ab; p.in_act = nin->act; p.in_slope = nin->slope; p.in_ups = ups; }
+  p.res_ups = 0;
   if (residual && residual->ptr) {
     if ((rc = check_tensor(residual))) return rc;
-    if (!same_shape(residual, out)) return ITG_ERR_ARG;
+    if (!same_shape(residual, out)) {
+      // a residual of half the patch extent is read through a nearest x2 upsample (the generator's shortcut branch,
+      // reference models/layers.py:294-299 behind generators.py:52: nothing is materialised at the output's resolution)
+      if (residual->n != out->n || residual->gh != out->gh || residual->gw != out->gw || residual->c != out->c ||
+          residual->ld != out->ld || 2 * residual->ph != out->ph || 2 * residual->pw != out->pw)
+        return ITG_ERR_ARG;
+      p.res_ups = 1;
+    }
     p.res = make_grid(residual);
   }
   if (in->n != out->n) return ITG_ERR_ARG;
@@ -465,7 +473,7 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
     }
   }
   p.res = null_grid();
-  p.res_mode = 0; p.res_slope = 0.f;
+  p.res_mode = 0; p.res_slope = 0.f; p.res_ups = 0;
   if (act_out && act_out->ptr && act != ITG_ACT_NONE) {
     // dx is the gradient w.r.t. act(.)'s output `act_out`: hand back the gradient w.r.t. its input instead
     if ((rc = check_tensor(act_out))) return rc;

@@ -36,6 +36,7 @@ struct ConvP {
   float slope;
   int res_mode;                 // 0: out += res;  ITG_ACT_*: out *= act'(res), res = the activation's OUTPUT (fused act backward)
   float res_slope;
+  int res_ups;                  // 1: the residual tensor has half the output's patch extent and is read through a nearest x2 upsample
   int co_rows, nco_tiles;
   unsigned in_bytes, w_bytes;   // buffer-resource extents of the pixel operand / packed weights
   int use_tab;                  // per-row tap-offset table in LDS (narrow layers)

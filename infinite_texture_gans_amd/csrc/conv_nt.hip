@@ -78,7 +78,7 @@ __global__ void splitk_epilogue_kernel(ConvP p) {
         if (co + e < p.out.c) v[e] += p.bias[co + e];
     }
     if (p.res.p) {
-      f32x4 r = *reinterpret_cast<const f32x4*>(p.res.p + grid_off(p.res, n, oy, ox) + co);
+      f32x4 r = *reinterpret_cast<const f32x4*>(p.res.p + grid_off(p.res, n, oy >> p.res_ups, ox >> p.res_ups) + co);
       if (p.res_mode == 0) v += r;
       else v *= act_deriv(r, p.res_mode, p.res_slope);
     }

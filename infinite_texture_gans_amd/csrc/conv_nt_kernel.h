@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
       oy = ty; ox = tx;
     }
     const int off = grid_off(p.out, n, oy, ox);
-    const int roff = p.res.p ? grid_off(p.res, n, oy, ox) : 0;
+    const int roff = p.res.p ? grid_off(p.res, n, oy >> p.res_ups, ox >> p.res_ups) : 0;
 #pragma unroll
     for (int i = 0; i < FI; ++i) {
       int co = co0 + wco0 + 16 * i + cq;

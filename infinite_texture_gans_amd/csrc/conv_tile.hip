@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(cons
         const int t = min(t0 + 2 * wave + (f >> 1), p.MT - 1), u = min(u0 + 16 * (f & 1) + fj, p.MU - 1);
         int oy = t * p.osy + p.ooy, ox = u * p.osx + p.oox;
         if (p.out_mode == 1) { oy = min(max(oy, 0), p.out.H - 1); ox = min(max(ox, 0), p.out.W - 1); }
-        const float* rp = p.res.p + grid_off(p.res, n, oy, ox) + g * 4;
+        const float* rp = p.res.p + grid_off(p.res, n, oy >> p.res_ups, ox >> p.res_ups) + g * 4;
 #pragma unroll
         for (int i = 0; i < FI; ++i)
           resv[i][f] = (16 * i + g * 4 < p.res.ld) ? *reinterpret_cast<const f32x4*>(rp + 16 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(cons
         } else if (has_res) {
           int oy = t * p.osy + p.ooy, ox = u * p.osx + p.oox;
           if (p.out_mode == 1) { oy = min(max(oy, 0), p.out.H - 1); ox = min(max(ox, 0), p.out.W - 1); }
-          r = *reinterpret_cast<const f32x4*>(p.res.p + grid_off(p.res, n, oy, ox) + co);
+          r = *reinterpret_cast<const f32x4*>(p.res.p + grid_off(p.res, n, oy >> p.res_ups, ox >> p.res_ups) + co);
         }
         const f32x4 v = store_out(p, n, t * p.osy + p.ooy, u * p.osx + p.oox, co, acc[i][f], osc,
                                   *reinterpret_cast<const f32x4*>(biasl + co), has_res, r);
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256, 5) void conv_valu_kernel(const ConvP p, int ti
         if (o * 4 + e < p.out.c) bv[e] = p.bias[o * 4 + e];
     }
     f32x4 r = {0.f, 0.f, 0.f, 0.f};
-    if (has_res) r = *reinterpret_cast<const f32x4*>(p.res.p + grid_off(p.res, n, ry, rx) + o * 4);
+    if (has_res) r = *reinterpret_cast<const f32x4*>(p.res.p + grid_off(p.res, n, ry >> p.res_ups, rx >> p.res_ups) + o * 4);
     store_out(p, n, oy, ox, o * 4, acc[o], osc, bv, has_res, r);
   }
 }

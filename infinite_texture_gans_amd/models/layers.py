@@ -31,6 +31,11 @@ def loader_norm_enabled():
     return os.environ.get("ITG_BN_LOADER", "0") == "1"
 
 
+def res_upsample_enabled():
+    """ITG_RES_UPS=0: materialise the upsampled shortcut again (A/B)."""
+    return os.environ.get("ITG_RES_UPS", "1") == "1"
+
+
 def _whole_image(image_location):
     return all(k in image_location for k in ("1st_row", "1st_col", "last_row", "last_col"))
 
@@ -261,6 +266,14 @@ class conv2d_lp(nn.Module):
                                                        and (self.training or _whole_image(image_location)))))
         if bn is not None and not fused:
             x = bn.run(x, act=bn_act[0], slope=bn_act[1], upsample=upsample)
+        # a residual at half the output's patch extent (the un-upsampled shortcut) is read through the x2 upsample by the conv
+        # epilogue on the paths that hand the patch grid to the kernel as it is; the reshaping paths materialise it
+        out_ph = x.t.shape[3] * (2 if (fused and upsample) else 1)
+        half_res = residual is not None and residual.t.shape[3] * 2 == out_ph
+        native = (self.padding_mode == "local" and self.local_padder.merge_patches_into_image
+                  and (self.training or (_whole_image(image_location) and self.local_padder.halo is None)))
+        if half_res and not native:
+            residual = ops.upsample2x(residual)
         if self.padding_mode != "local":
             # per-patch zero padding: every patch is an independent image
             n, gh, gw, ph, pw, ld = x.t.shape
@@ -545,17 +558,21 @@ class ResBlockGenerator(nn.Module):
         elif self.learnable_sc:
             sc = self._shortcut(x, map, upsample_input)
         else:
-            sc = ops.upsample2x(x) if upsample_input else x
+            sc = ops.upsample2x(x) if (upsample_input and not res_upsample_enabled()) else x
         if self.type_norm == "SSM":
             return self.conv2.forward_grid(out, image_location, residual=sc, out_stats=fuse and out_stats)
         return self.conv2.forward_grid(out, image_location, residual=sc, out_stats=fuse and out_stats, bn=self.bn2, bn_act=(A, s))
 
     def _shortcut(self, x, map, upsample_input):
+        """The 1x1 shortcut at the block INPUT's resolution: when the block upsamples, conv2's epilogue reads it through the
+        nearest x2 upsample (the 1x1 conv commutes with it), so the shortcut is never materialised at the output's size."""
         sc = x
         if self.type_norm == "SSM":
             sc = self.bn3.run(sc, map)
         sc = self.conv3.run(sc)
-        return ops.upsample2x(sc) if upsample_input else sc
+        if upsample_input and not res_upsample_enabled():
+            return ops.upsample2x(sc)
+        return sc
 
     def forward(self, x, map=None, image_location="1st_row_1st_col"):
         if isinstance(x, GT):

@@ -229,6 +229,18 @@ def sn_power_iter_multi(layers, training=True, eps=1e-12):
 
 
 # ------------------------------------------------------------------------------- convolution
+def _residual_grad(dy, c, ups):
+    """Gradient of a conv's residual input: dy itself, or its 2x2 sums when the residual was read through a nearest x2
+    upsample (itg_conv2d_fwd with a half-size residual)."""
+    if not ups:
+        return dy
+    n, gh, gw, ph, pw, ld = dy.shape
+    dx = torch.empty((n, gh, gw, ph // 2, pw // 2, ld), device=dy.device, dtype=torch.float32)
+    a, b = _desc(dy, c), _desc(dx, c)
+    _lib.call("itg_upsample2x_bwd", C.byref(a), C.byref(b), _stream())
+    return dx
+
+
 class _Conv(torch.autograd.Function):
     """out = act(conv(x, w*scale) + bias [+ residual]) on patch-grid tensors (merged-image
     coordinates).  ``sn`` = (inv_sigma, u, v) makes ``w`` the spectral-norm ``weight_orig``."""
@@ -266,6 +278,7 @@ class _Conv(torch.autograd.Function):
                       C.byref(g), act, float(slope), _ptr(ws), nws, st)
         ctx.geom, ctx.act, ctx.slope, ctx.c_in, ctx.co = geom, act, slope, c_in, co
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        ctx.res_ups = residual is not None and residual.shape[3] * 2 == out.shape[3]     # read through a nearest x2 upsample
         ctx.sn = sn
         ctx.sinks = sinks          # (weight.grad, bias.grad) buffers to accumulate into, or None
         ctx.packed = packed
@@ -338,40 +351,40 @@ class _Conv(torch.autograd.Function):
                 sinks_ok = not ((need_w and wsink is None) or (need_b and bsink is None))
                 if WGRAD_DEFER is not None and sinks_ok and _queue_wgrad(x, dxd, dy, ddy, g, w, wsink, bsink, need_w, need_b,
                                                                          ctx.sn, st):
-                    gres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
-                    return gx, None, None, gres, None, None, None, None, None, None, None, None, None, None
-                nws = _lib.fn("itg_conv2d_wgrad_workspace")(C.byref(dxd), C.byref(ddy), C.byref(g))
-                ws = torch.empty(nws, device=x.device, dtype=torch.float32)
-                direct_w = wsink is not None and ctx.sn is None and need_w
-                direct_b = bsink is not None and need_b
-                gw_ = wsink if direct_w else torch.empty_like(w)
-                gb = bsink if direct_b else (torch.empty_like(w[:, 0, 0, 0]) if need_b else None)
-                npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
-                with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1, 2.0 * npix_out * co * ci * kh * kw,
-                           4 * (x.numel() + dy.numel() + w.numel())):
-                    # separate accumulate flags: a spectrally normalised layer sinks its bias gradient but takes dW into a
-                    # temporary (no zero-fill launch for it)
-                    _lib.call("itg_conv2d_wgrad", C.byref(dxd), C.byref(ddy), _ptr(gw_), _ptr(gb), C.byref(g),
-                              (ACC_DW if direct_w else 0) | (ACC_DB if direct_b else 0), _ptr(ws), nws, st)
-                if ctx.sn is not None and need_w:
-                    _, u, v = ctx.sn
-                    rows, cols = co, w.numel() // co
-                    d_orig = wsink if wsink is not None else torch.empty_like(w)
-                    # the <G, W> accumulator: a slice of the step's zeroed arena when there is one (no memset launch)
-                    ws2 = ARENA.take(1) if ARENA is not None and ARENA.buf.device == x.device else None
-                    zeroed = ws2 is not None
-                    if ws2 is None:
-                        ws2 = torch.empty(2, device=x.device, dtype=torch.float64)
-                    _lib.call("itg_spectral_norm_bwd", _ptr(gw_), _ptr(w), _ptr(u), _ptr(v), _ptr(inv_sigma), rows, cols,
-                              _ptr(d_orig), (ACC_DW if wsink is not None else 0) | (WS_ZEROED if zeroed else 0), _ptr(ws2), st)
-                    gw_ = None if wsink is not None else d_orig
-                elif direct_w:
-                    gw_ = None
-                if direct_b:
-                    gb = None
-                if not need_w:
-                    gw_ = None
-        gres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
+                    gw_ = gb = None         # the slabs are computed; ops.flush_deferred() finishes the layer
+                else:
+                    nws = _lib.fn("itg_conv2d_wgrad_workspace")(C.byref(dxd), C.byref(ddy), C.byref(g))
+                    ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+                    direct_w = wsink is not None and ctx.sn is None and need_w
+                    direct_b = bsink is not None and need_b
+                    gw_ = wsink if direct_w else torch.empty_like(w)
+                    gb = bsink if direct_b else (torch.empty_like(w[:, 0, 0, 0]) if need_b else None)
+                    npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
+                    with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1, 2.0 * npix_out * co * ci * kh * kw,
+                               4 * (x.numel() + dy.numel() + w.numel())):
+                        # separate accumulate flags: a spectrally normalised layer sinks its bias gradient but takes dW into a
+                        # temporary (no zero-fill launch for it)
+                        _lib.call("itg_conv2d_wgrad", C.byref(dxd), C.byref(ddy), _ptr(gw_), _ptr(gb), C.byref(g),
+                                  (ACC_DW if direct_w else 0) | (ACC_DB if direct_b else 0), _ptr(ws), nws, st)
+                    if ctx.sn is not None and need_w:
+                        _, u, v = ctx.sn
+                        rows, cols = co, w.numel() // co
+                        d_orig = wsink if wsink is not None else torch.empty_like(w)
+                        # the <G, W> accumulator: a slice of the step's zeroed arena when there is one (no memset launch)
+                        ws2 = ARENA.take(1) if ARENA is not None and ARENA.buf.device == x.device else None
+                        zeroed = ws2 is not None
+                        if ws2 is None:
+                            ws2 = torch.empty(2, device=x.device, dtype=torch.float64)
+                        _lib.call("itg_spectral_norm_bwd", _ptr(gw_), _ptr(w), _ptr(u), _ptr(v), _ptr(inv_sigma), rows, cols,
+                                  _ptr(d_orig), (ACC_DW if wsink is not None else 0) | (WS_ZEROED if zeroed else 0), _ptr(ws2), st)
+                        gw_ = None if wsink is not None else d_orig
+                    elif direct_w:
+                        gw_ = None
+                    if direct_b:
+                        gb = None
+                    if not need_w:
+                        gw_ = None
+        gres = _residual_grad(dy, co, ctx.res_ups) if ctx.has_res and ctx.needs_input_grad[3] else None
         return gx, gw_, gb, gres, None, None, None, None, None, None, None, None, None, None
 
 
@@ -787,6 +800,7 @@ class _BNConv(torch.autograd.Function):
         ctx.geom, ctx.bn_cfg, ctx.act, ctx.slope, ctx.c_in, ctx.co = geom, bn_cfg, act, slope, c_in, co
         ctx.count, ctx.sync, ctx.affine = count, sync, gamma is not None
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        ctx.res_ups = residual is not None and residual.shape[3] * 2 == out.shape[3]
         ctx.sinks, ctx.bn_sinks, ctx.packed = sinks, bn_sinks, packed
         ctx.save_for_backward(x, w, stat, out if act != ACT_NONE else None)
         return out
@@ -893,7 +907,7 @@ class _BNConv(torch.autograd.Function):
                   ctx.count, in_act, float(in_slope), C.byref(dgx), _ptr(dg), _ptr(db), acc, st)
         if acc:
             dg = db = None
-        gres = dy if ctx.has_res and ctx.needs_input_grad[5] else None
+        gres = _residual_grad(dy, co, ctx.res_ups) if ctx.has_res and ctx.needs_input_grad[5] else None
         return (gx, dg, db, gw_, gb, gres) + (None,) * 13
 
 
