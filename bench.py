@@ -28,6 +28,10 @@ sys.path.insert(0, ROOT)
 # (measured 1 / 2 / 3 / 4 queues: 679 / 763 / 722 / 749 crops/s on config 1).  Must be set before HIP initialises.
 if "config3" in sys.argv or os.environ.get("ITG_GRAPH") == "1":
     os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")
+if "config3" in sys.argv:
+    # config 3 is launch- and latency-bound (450 launches of ~9 us): the deferred weight-gradient reduce (one launch per backward
+    # pass instead of 2-5 per layer) is worth +4 % there (2 103 -> 2 189 crops/s); config 1 is bound by kernel work and loses 2 %
+    os.environ.setdefault("ITG_DEFER_REDUCE", "1")
 
 import torch  # noqa: E402
 
