@@ -6,6 +6,8 @@ using namespace itgk;
 
 namespace {
 
+inline int pad_v_raw(const itg_conv_geom* g) { return g->pad_h >= 0 ? g->pad_h : g->pad; }
+
 // ------------------------------------------------------------------------------- packing
 // fwd: out[co][k], k = (ky*kw+kx)*ci_ld + ci, rows co >= co zero, k >= K zero
 __global__ void pack_fwd_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out,
@@ -217,6 +219,85 @@ __global__ void thin_dgrad_gather_kernel(const float* __restrict__ Q, int Ho, in
   }
 }
 
+// ------------------------------------------------------------------------------- single-input-channel 3x3 convs
+// The first conv of an SSM modulation MLP (reference models/layers.py:212-215,231: conv3x3(map_dim = 1 -> 128) on the noise
+// map of every patch).  As an implicit GEMM it has K = 9 (padded to 48): 8 TF at 5 % of the MFMA peak, and at config 5's
+// size it is 15 % of the whole generation.  It is a WRITE-bound operator (1 input float, 128 outputs per pixel): 32 lanes
+// own one output pixel's 128 channels (4 each, their 36 filter taps in registers), a workgroup an 8 x 32 output tile whose
+// (8+2) x (32+2) input window sits in LDS; every lane slides a 3 x 3 register window along its row: per pixel 3 LDS
+// broadcasts, 36 fma, one 16-byte store - 1 KB contiguous per wave-instruction.
+constexpr int C1_TH = 8, C1_TW = 32;
+
+__global__ __launch_bounds__(256) void conv_cin1_kernel(GridT in, GridT out, const float* __restrict__ w, int Kpad,
+                                                        const float* __restrict__ bias, const float* __restrict__ scale,
+                                                        int act, float slope, int tiles_x, int tiles_y) {
+  __shared__ float xt[(C1_TH + 2) * (C1_TW + 2)];
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  const int tx_i = b % tiles_x; b /= tiles_x;
+  const int ty_i = b % tiles_y;
+  const int n = b / tiles_y;
+  const int y0 = ty_i * C1_TH, x0 = tx_i * C1_TW;
+  for (int e = tid; e < (C1_TH + 2) * (C1_TW + 2); e += 256) {
+    const int r = e / (C1_TW + 2), c = e - r * (C1_TW + 2);
+    const int iy = y0 + r, ix = x0 + c;                      // valid conv: input pixel (y + ky, x + kx)
+    xt[e] = (iy < in.H && ix < in.W) ? in.p[grid_off(in, n, iy, ix)] : 0.f;
+  }
+  const int cg = tid & 31, row = tid >> 5;                   // channel group (4 channels), tile row
+  const int co = cg * 4;
+  const bool live = co < out.ld;
+  float wr[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wr[t][e] = (live && co + e < out.c) ? w[(size_t)(co + e) * Kpad + t * in.ld] : 0.f;
+  const float osc = scale ? *scale : 1.f;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bv[e] = (bias && live && co + e < out.c) ? bias[co + e] : 0.f;
+  __syncthreads();
+  const int oy = y0 + row;
+  if (!live || oy >= out.H) return;
+  const float* xr = xt + row * (C1_TW + 2);
+  float w0[3], w1[3], w2[3];                                   // the window's three columns (rows ky = 0..2)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { w0[k] = xr[k * (C1_TW + 2)]; w1[k] = xr[k * (C1_TW + 2) + 1]; }
+  // output addresses: one division per row when the tile lies in one patch column (always for a 1 x 1 grid)
+  const bool linear = out.gw == 1 || (x0 % out.pw) + C1_TW <= out.pw;
+  float* const orow = out.p + grid_off(out, n, oy, min(x0, out.W - 1)) + co;
+#pragma unroll 4
+  for (int c = 0; c < C1_TW; ++c) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w2[k] = xr[k * (C1_TW + 2) + c + 2];
+    const int ox = x0 + c;
+    if (ox < out.W) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          a = fmaf(w0[k], wr[3 * k][e], a);
+          a = fmaf(w1[k], wr[3 * k + 1][e], a);
+          a = fmaf(w2[k], wr[3 * k + 2][e], a);
+        }
+        v[e] = act_apply(a * osc + bv[e], act, slope);
+        if (co + e >= out.c) v[e] = 0.f;
+      }
+      float* const dst = linear ? orow + (size_t)c * out.ld : out.p + grid_off(out, n, oy, ox) + co;
+      *reinterpret_cast<f32x4*>(dst) = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { w0[k] = w1[k]; w1[k] = w2[k]; }
+  }
+}
+
+inline bool cin1_conv(const itg_tensor* in, const itg_tensor* out, const itg_conv_geom* g) {
+  static const int enable = env_int("ITG_CIN1_CONV", 1);
+  return enable && in->c == 1 && in->ld == 4 && g->kh == 3 && g->kw == 3 && g->stride == 1 && g->pad == 0 && pad_v_raw(g) == 0 &&
+         out->ld <= 128 && out->c >= 16 && g->precision != ITG_PREC_BF16 && !g->out_stats && !g->in_norm;
+}
+
 inline bool thin_in_conv(const itg_tensor* dy, const itg_tensor* dx, const itg_conv_geom* g) {
   static const int enable = env_int("ITG_THIN_CONV", 1);
   const int ph = g->pad_h >= 0 ? g->pad_h : g->pad;
@@ -348,6 +429,19 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   const itg_in_norm* nin;
   if (!w_packed || !g) return ITG_ERR_ARG;
   if ((rc = in_norm_of(g, in, &nin))) return rc;
+  if (cin1_conv(in, out, g) && !(residual && residual->ptr)) {
+    const int H = in->gh * in->ph, W = in->gw * in->pw;
+    if (in->n != out->n || H - 2 != out->gh * out->ph || W - 2 != out->gw * out->pw) return ITG_ERR_ARG;
+    const GridT gi = make_grid(in), go = make_grid(out);
+    const int tiles_x = (go.W + C1_TW - 1) / C1_TW, tiles_y = (go.H + C1_TH - 1) / C1_TH;
+    const int64_t blocks = (int64_t)out->n * tiles_x * tiles_y;
+    if (blocks > 0x7fffffff) return ITG_ERR_ARG;
+    snprintf(g_last_launch, sizeof(g_last_launch), "conv_cin1_kernel");
+    hipLaunchKernelGGL(conv_cin1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gi, go, w_packed,
+                       round_up(9 * in->ld, BK), bias, out_scale, act, slope, tiles_x, tiles_y);
+    ITG_CHECK_LAUNCH();
+    return ITG_OK;
+  }
   if (thin_out_conv(in, out, g) && !(residual && residual->ptr) && !nin) {
     if (g->out_stats) return ITG_ERR_ARG;       // single-output-channel layers have no BatchNorm consumer on this path
     // taps-as-rows path (see tap_gather_fwd_kernel): a 1x1 conv into P[pixel][16], then the tap gather
