@@ -387,6 +387,142 @@ int try_conv_valu(const ConvP& p, hipStream_t s, int* rc) {
   return 1;
 }
 
+// ------------------------------------------------------------------------------- 4x4 stride-2 convs with <= 4 input channels
+// The discriminator's first layer (reference models/discriminators.py:187-189: conv4x4(img_ch = 3 -> 64, stride 2, pad 1)
+// on the 384^2 fakes / 192^2 reals).  As an implicit GEMM it has K = 48: three pipeline stages, all prologue and epilogue -
+// 60 us for 94 MB of traffic (0.20 of HBM).  Same recipe as conv_tile_kernel: persistent workgroups, the 16 x cin_ld filter
+// bank in LDS, an 8 x 32 OUTPUT tile whose (2*8+2) x (2*32+2) input window (4 floats per pixel: 19 KB) is staged once and
+// prefetched a tile ahead; K chunk q = kernel row q, lane group g = kernel column g, so a fragment is one ds_read_b128 at
+// (2 y + q, 2 x + g).  Zero padding, bias + 1/sigma + activation in the epilogue.
+constexpr int S2_IH = 2 * TT_H + 2, S2_IW = 2 * TT_W + 2, S2_PIX = S2_IH * S2_IW;     // 18 x 66
+constexpr int S2_NLD = (S2_PIX + 255) / 256;                                          // 5 loads per thread and tile
+
+template <int FI>
+__global__ __launch_bounds__(256, 3) void conv_s2k4_kernel(const ConvP p, int tiles_x, int tiles_y, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int co_rows = 16 * FI;
+  float* Wl = lds;                                   // [4][co_rows][20]
+  float* biasl = lds + 4 * co_rows * 20;             // [co_rows]
+  float* Xt = biasl + co_rows;                       // [S2_PIX][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in.p, 0, p.in_bytes, 0x00020000);
+  for (int e = tid; e < 4 * co_rows * 16; e += 256) {
+    const int k16 = e & 15, r = e >> 4;
+    const int row = r % co_rows, q = r / co_rows;
+    const int k = q * 16 + k16;
+    Wl[(q * co_rows + row) * 20 + k16] = (row < p.co_rows && k < p.Kpad) ? p.w[(size_t)row * p.Kpad + k] : 0.f;
+  }
+  for (int e = tid; e < co_rows; e += 256) biasl[e] = (p.bias && e < p.out.c) ? p.bias[e] : 0.f;
+  f32x4 rt[S2_NLD];
+  auto load_tile = [&](int tile) {
+    int b = tile;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+    const int y0 = 2 * ty_i * TT_H - 1, x0 = 2 * tx_i * TT_W - 1;
+#pragma unroll
+    for (int i = 0; i < S2_NLD; ++i) {
+      const int e = tid + i * 256;
+      const int r = e / S2_IW, c = e - r * S2_IW;
+      const int iy = y0 + r, ix = x0 + c;
+      const bool ok = e < S2_PIX && (unsigned)iy < (unsigned)p.in.H && (unsigned)ix < (unsigned)p.in.W;
+      const unsigned o = ok ? (unsigned)grid_off(p.in, n, iy, ix) * 4u : p.in_bytes;
+      rt[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, o, 0, 0));
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < S2_NLD; ++i) {
+      const int e = tid + i * 256;
+      if (e < S2_PIX) *reinterpret_cast<f32x4*>(Xt + e * 4) = rt[i];
+    }
+  };
+  const int fj = lane & 15, g = lane >> 4;
+  int pbase[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) pbase[f] = (2 * (2 * wave + (f >> 1)) * S2_IW + 2 * (16 * (f & 1) + fj) + g) * 4;
+  const float osc = p.scale ? *p.scale : 1.f;
+  int tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile);
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    store_tile();
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < ntiles) load_tile(next);
+    f32x4 acc[FI][4];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                     // kernel row q: 16 k = 4 columns x 4 channels
+      f32x4 a[FI], bq[4];
+#pragma unroll
+      for (int i = 0; i < FI; ++i) a[i] = *reinterpret_cast<const f32x4*>(Wl + (q * co_rows + 16 * i + fj) * 20 + g * 4);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) bq[f] = *reinterpret_cast<const f32x4*>(Xt + pbase[f] + q * S2_IW * 4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], bq[f][s], acc[i][f], 0, 0, 0);
+    }
+    int b = tile;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int t = ty_i * TT_H + 2 * wave + (f >> 1), u = tx_i * TT_W + 16 * (f & 1) + fj;
+      if (t >= p.MT || u >= p.MU) continue;
+      float* const dst = p.out.p + grid_off(p.out, n, t, u);
+#pragma unroll
+      for (int i = 0; i < FI; ++i) {
+        const int co = 16 * i + g * 4;
+        if (co >= p.out.ld) continue;
+        f32x4 v = acc[i][f] * osc + *reinterpret_cast<const f32x4*>(biasl + co);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = act_apply(v[e], p.act, p.slope);
+          if (co + e >= p.out.c) v[e] = 0.f;
+        }
+        *reinterpret_cast<f32x4*>(dst + co) = v;
+      }
+    }
+    __syncthreads();                                  // every wave is done reading Xt
+  }
+}
+
+int try_conv_s2k4(const ConvP& p, hipStream_t s, int* rc) {
+  static const int enable = env_int("ITG_CONV_S2K4", 1);
+  if (!enable || p.ncls > 1 || p.ntaps != 16 || p.kw != 4 || p.isy != 2 || p.isx != 2 || p.ioy != -1 || p.iox != -1) return 0;
+  if (p.osy != 1 || p.osx != 1 || p.ooy != 0 || p.oox != 0 || p.out_mode != 0 || p.pad_mode != ITG_PAD_ZERO) return 0;
+  if (p.prec != ITG_PREC_F32 || p.cin_ld != 4 || p.stats || p.in_ab || p.bn_sums || p.res.p) return 0;
+  if (p.co_rows != 16 && p.co_rows != 32 && p.co_rows != 64) return 0;
+  if ((int64_t)p.MT * p.MU < 64 * 64) return 0;
+  ConvP q = p;
+  const int64_t ib = (int64_t)p.in.n * p.in.gh * p.in.gw * p.in.ph * p.in.pw * p.in.ld * 4;
+  if (ib >= 0xFFFF0000LL) return 0;
+  q.in_bytes = (unsigned)ib;
+  const int tiles_x = (p.MU + TT_W - 1) / TT_W, tiles_y = (p.MT + TT_H - 1) / TT_H;
+  const int64_t ntiles = (int64_t)p.in.n * tiles_x * tiles_y;
+  if (ntiles > 0x7fffffff) return 0;
+  const int FI = p.co_rows / 16;
+  const size_t lds = ((size_t)4 * p.co_rows * 20 + p.co_rows + (size_t)S2_PIX * 4) * sizeof(float);
+  static const int per_cu_env = env_int("ITG_S2K4_CU", 3);
+  const int64_t want = 256 * (int64_t)per_cu_env;
+  const unsigned blocks = (unsigned)(ntiles < want ? ntiles : want);
+  snprintf(g_last_launch, sizeof(g_last_launch), "conv_s2k4_kernel<%d>", FI);
+  if (FI == 4) hipLaunchKernelGGL((conv_s2k4_kernel<4>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles);
+  else if (FI == 2) hipLaunchKernelGGL((conv_s2k4_kernel<2>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles);
+  else hipLaunchKernelGGL((conv_s2k4_kernel<1>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles);
+  *rc = hipGetLastError() == hipSuccess ? ITG_OK : ITG_ERR_LAUNCH;
+  return 1;
+}
+
 // eligibility + launch of the halo-tile kernel; returns 1 when it handled the call
 int try_conv_tile(ConvP& p, hipStream_t s, int* rc) {
   static const int enable = env_int("ITG_CONV_TILE", 1);
@@ -442,7 +578,9 @@ int try_conv_tile(ConvP& p, hipStream_t s, int* rc) {
   if (per_cu > reg_cu) per_cu = reg_cu;
   if (per_cu < 1) per_cu = 1;
   const int64_t want = 256 * (int64_t)per_cu;
-  const unsigned blocks = (unsigned)(ntiles < want ? ntiles : want);
+  static const int even = env_int("ITG_TILE_EVEN", 0);      // equal tile counts per persistent workgroup: measured worse (b6c2 forward 69 -> 76 us)
+  const int64_t per_wg = (ntiles + want - 1) / want;
+  const unsigned blocks = (unsigned)(even ? (ntiles + per_wg - 1) / per_wg : (ntiles < want ? ntiles : want));
   snprintf(g_last_launch, sizeof(g_last_launch), "conv_tile_kernel<%d, %d, %d, %s>", FI, nld <= 6 ? 6 : 11, stm, xfm ? "true" : "false");
   int a_tx = tiles_x, a_ty = tiles_y, a_nt = (int)ntiles, a_cpt = cpt, a_nch = nch;
   void* args[] = {(void*)&q, &a_tx, &a_ty, &a_nt, &a_cpt, &a_nch};

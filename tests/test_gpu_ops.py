@@ -89,6 +89,9 @@ CONV_CASES = [
     ("tile3x3_rep_3_13", 1, (3, 3), 32, 3, 13, 3, 1, 1, "replicate"),                # cin_ld 4: four taps per K chunk
     ("tile3x3_zero_7_2_thin", 2, (2, 3), 36, 7, 2, 3, 1, 1, "constant"),             # <= 4 outputs: 4x4x1-MFMA weight gradient, 16 groups / pass
     ("tile3x3_rep_16_4_thin", 1, (2, 2), 40, 16, 4, 3, 1, 1, "replicate"),           # all four output rows live
+    # 4x4 stride-2 layers with <= 4 input channels on images >= 128^2 (the discriminator's first layer): stride-2 halo-tile kernel
+    ("d4x4_s2_3_64_tile", 1, (3, 3), 48, 3, 64, 4, 2, 1, "zeros"),                    # patch-grid input, 72x72 out: partial tiles
+    ("d4x4_s2_3_24_tile", 2, (1, 1), 130, 3, 24, 4, 2, 1, "zeros"),                   # 32 filter rows, odd tile counts
     # single-input-channel valid 3x3 (the first conv of an SSM modulation MLP on the per-patch noise map): write-bound VALU kernel
     ("ssm_map_1_128_valid", 5, (1, 1), 37, 1, 128, 3, 1, 0, "zeros"),                  # 35x35 out: partial tiles
     ("ssm_map_1_24_valid", 3, (1, 1), 12, 1, 24, 3, 1, 0, "zeros"),                    # fewer channel groups than lanes
