@@ -397,8 +397,10 @@ int try_conv_valu(const ConvP& p, hipStream_t s, int* rc) {
 constexpr int S2_IH = 2 * TT_H + 2, S2_IW = 2 * TT_W + 2, S2_PIX = S2_IH * S2_IW;     // 18 x 66
 constexpr int S2_NLD = (S2_PIX + 255) / 256;                                          // 5 loads per thread and tile
 
-template <int FI>
-__global__ __launch_bounds__(256, 3) void conv_s2k4_kernel(const ConvP p, int tiles_x, int tiles_y, int ntiles) {
+// NW = waves per workgroup: 4 (two output rows of the tile per wave) or 8 (one row per wave: twice the waves behind the same
+// LDS tile - the tile loop is latency-bound, more workgroups / waves per CU is what speeds it up)
+template <int FI, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 3)) void conv_s2k4_kernel(const ConvP p, int tiles_x, int tiles_y, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int co_rows = 16 * FI;
   float* Wl = lds;                                   // [4][co_rows][20]
@@ -406,14 +408,15 @@ __global__ __launch_bounds__(256, 3) void conv_s2k4_kernel(const ConvP p, int ti
   float* Xt = biasl + co_rows;                       // [S2_PIX][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in.p, 0, p.in_bytes, 0x00020000);
-  for (int e = tid; e < 4 * co_rows * 16; e += 256) {
+  for (int e = tid; e < 4 * co_rows * 16; e += 64 * NW) {
     const int k16 = e & 15, r = e >> 4;
     const int row = r % co_rows, q = r / co_rows;
     const int k = q * 16 + k16;
     Wl[(q * co_rows + row) * 20 + k16] = (row < p.co_rows && k < p.Kpad) ? p.w[(size_t)row * p.Kpad + k] : 0.f;
   }
-  for (int e = tid; e < co_rows; e += 256) biasl[e] = (p.bias && e < p.out.c) ? p.bias[e] : 0.f;
-  f32x4 rt[S2_NLD];
+  for (int e = tid; e < co_rows; e += 64 * NW) biasl[e] = (p.bias && e < p.out.c) ? p.bias[e] : 0.f;
+  constexpr int NT = 64 * NW, NLDW = (S2_PIX + NT - 1) / NT, NF = 16 / NW;      // threads, loads per thread and tile, fragments per wave
+  f32x4 rt[NLDW];
   auto load_tile = [&](int tile) {
     int b = tile;
     const int tx_i = b % tiles_x; b /= tiles_x;
@@ -421,8 +424,8 @@ __global__ __launch_bounds__(256, 3) void conv_s2k4_kernel(const ConvP p, int ti
     const int n = b / tiles_y;
     const int y0 = 2 * ty_i * TT_H - 1, x0 = 2 * tx_i * TT_W - 1;
 #pragma unroll
-    for (int i = 0; i < S2_NLD; ++i) {
-      const int e = tid + i * 256;
+    for (int i = 0; i < NLDW; ++i) {
+      const int e = tid + i * NT;
       const int r = e / S2_IW, c = e - r * S2_IW;
       const int iy = y0 + r, ix = x0 + c;
       const bool ok = e < S2_PIX && (unsigned)iy < (unsigned)p.in.H && (unsigned)ix < (unsigned)p.in.W;
@@ -432,15 +435,16 @@ __global__ __launch_bounds__(256, 3) void conv_s2k4_kernel(const ConvP p, int ti
   };
   auto store_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < S2_NLD; ++i) {
-      const int e = tid + i * 256;
+    for (int i = 0; i < NLDW; ++i) {
+      const int e = tid + i * NT;
       if (e < S2_PIX) *reinterpret_cast<f32x4*>(Xt + e * 4) = rt[i];
     }
   };
   const int fj = lane & 15, g = lane >> 4;
-  int pbase[4];
+  // fragment f of wave w: tile row (NF * w + f) / 2, column half (NF * w + f) % 2
+  int pbase[NF];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) pbase[f] = (2 * (2 * wave + (f >> 1)) * S2_IW + 2 * (16 * (f & 1) + fj) + g) * 4;
+  for (int f = 0; f < NF; ++f) pbase[f] = (2 * ((NF * wave + f) >> 1) * S2_IW + 2 * (16 * ((NF * wave + f) & 1) + fj) + g) * 4;
   const float osc = p.scale ? *p.scale : 1.f;
   int tile = blockIdx.x;
   if (tile < ntiles) load_tile(tile);
@@ -450,24 +454,24 @@ __global__ __launch_bounds__(256, 3) void conv_s2k4_kernel(const ConvP p, int ti
     __syncthreads();
     const int next = tile + gridDim.x;
     if (next < ntiles) load_tile(next);
-    f32x4 acc[FI][4];
+    f32x4 acc[FI][NF];
 #pragma unroll
     for (int i = 0; i < FI; ++i)
 #pragma unroll
-      for (int f = 0; f < 4; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int f = 0; f < NF; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                     // kernel row q: 16 k = 4 columns x 4 channels
-      f32x4 a[FI], bq[4];
+      f32x4 a[FI], bq[NF];
 #pragma unroll
       for (int i = 0; i < FI; ++i) a[i] = *reinterpret_cast<const f32x4*>(Wl + (q * co_rows + 16 * i + fj) * 20 + g * 4);
 #pragma unroll
-      for (int f = 0; f < 4; ++f) bq[f] = *reinterpret_cast<const f32x4*>(Xt + pbase[f] + q * S2_IW * 4);
+      for (int f = 0; f < NF; ++f) bq[f] = *reinterpret_cast<const f32x4*>(Xt + pbase[f] + q * S2_IW * 4);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < FI; ++i)
 #pragma unroll
-          for (int f = 0; f < 4; ++f)
+          for (int f = 0; f < NF; ++f)
             acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], bq[f][s], acc[i][f], 0, 0, 0);
     }
     int b = tile;
@@ -475,8 +479,8 @@ __global__ __launch_bounds__(256, 3) void conv_s2k4_kernel(const ConvP p, int ti
     const int ty_i = b % tiles_y;
     const int n = b / tiles_y;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const int t = ty_i * TT_H + 2 * wave + (f >> 1), u = tx_i * TT_W + 16 * (f & 1) + fj;
+    for (int f = 0; f < NF; ++f) {
+      const int t = ty_i * TT_H + ((NF * wave + f) >> 1), u = tx_i * TT_W + 16 * ((NF * wave + f) & 1) + fj;
       if (t >= p.MT || u >= p.MU) continue;
       float* const dst = p.out.p + grid_off(p.out, n, t, u);
 #pragma unroll
@@ -512,13 +516,20 @@ int try_conv_s2k4(const ConvP& p, hipStream_t s, int* rc) {
   if (ntiles > 0x7fffffff) return 0;
   const int FI = p.co_rows / 16;
   const size_t lds = ((size_t)4 * p.co_rows * 20 + p.co_rows + (size_t)S2_PIX * 4) * sizeof(float);
-  static const int per_cu_env = env_int("ITG_S2K4_CU", 3);
-  const int64_t want = 256 * (int64_t)per_cu_env;
+  static const int nw = env_int("ITG_S2K4_WAVES", 8) == 8 ? 8 : 4;         // 8 waves per tile: 43.9 -> 41.0 us on D's first layer
+  static const int per_cu_env = env_int("ITG_S2K4_CU", 0);
+  const int64_t want = 256 * (int64_t)(per_cu_env > 0 ? per_cu_env : (nw == 8 ? 2 : 3));
   const unsigned blocks = (unsigned)(ntiles < want ? ntiles : want);
-  snprintf(g_last_launch, sizeof(g_last_launch), "conv_s2k4_kernel<%d>", FI);
-  if (FI == 4) hipLaunchKernelGGL((conv_s2k4_kernel<4>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles);
-  else if (FI == 2) hipLaunchKernelGGL((conv_s2k4_kernel<2>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles);
-  else hipLaunchKernelGGL((conv_s2k4_kernel<1>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles);
+  snprintf(g_last_launch, sizeof(g_last_launch), "conv_s2k4_kernel<%d, %d>", FI, nw);
+  if (nw == 8) {
+    if (FI == 4) hipLaunchKernelGGL((conv_s2k4_kernel<4, 8>), dim3(blocks), dim3(512), lds, s, q, tiles_x, tiles_y, (int)ntiles);
+    else if (FI == 2) hipLaunchKernelGGL((conv_s2k4_kernel<2, 8>), dim3(blocks), dim3(512), lds, s, q, tiles_x, tiles_y, (int)ntiles);
+    else hipLaunchKernelGGL((conv_s2k4_kernel<1, 8>), dim3(blocks), dim3(512), lds, s, q, tiles_x, tiles_y, (int)ntiles);
+  } else {
+    if (FI == 4) hipLaunchKernelGGL((conv_s2k4_kernel<4, 4>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles);
+    else if (FI == 2) hipLaunchKernelGGL((conv_s2k4_kernel<2, 4>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles);
+    else hipLaunchKernelGGL((conv_s2k4_kernel<1, 4>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles);
+  }
   *rc = hipGetLastError() == hipSuccess ? ITG_OK : ITG_ERR_LAUNCH;
   return 1;
 }
