@@ -76,7 +76,15 @@ class _Prof:
             PROFILE.append(tuple(self.item))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The current HIP stream as a void*.  torch.cuda.current_stream() costs ~10 us of Python per call (device-index plumbing,
+    a Stream object) and every op asks once or twice: ~0.7 ms of the 6.8 ms a train step takes to issue; the raw getter is
+    a single C call."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -241,6 +249,9 @@ def _residual_grad(dy, c, ups):
     return dx
 
 
+_WS_SIZE = {}        # workspace sizes by (kind, shapes, geometry): the plan is a pure function of them (one ctypes call less per launch)
+
+
 class _Conv(torch.autograd.Function):
     """out = act(conv(x, w*scale) + bias [+ residual]) on patch-grid tensors (merged-image
     coordinates).  ``sn`` = (inv_sigma, u, v) makes ``w`` the spectral-norm ``weight_orig``."""
@@ -271,7 +282,10 @@ class _Conv(torch.autograd.Function):
         dx_, do_ = _desc(x, c_in), _desc(out, co)
         dr_ = _desc(residual, co) if residual is not None else _null_desc()
         g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, stats.data_ptr() if stats is not None else None)
-        nws = _lib.fn("itg_conv2d_fwd_workspace")(C.byref(dx_), C.byref(do_), C.byref(g))
+        key = ("f", tuple(x.shape), tuple(out.shape), geom, c_in, co)
+        nws = _WS_SIZE.get(key)
+        if nws is None:
+            nws = _WS_SIZE[key] = _lib.fn("itg_conv2d_fwd_workspace")(C.byref(dx_), C.byref(do_), C.byref(g))
         ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
         with _Prof(_nt_tag(co), 1, 2.0 * n * Ho * Wo * co * ci * kh * kw, 4 * (x.numel() + out.numel() + wp.numel())):
             _lib.call("itg_conv2d_fwd", C.byref(dx_), _ptr(wp), _ptr(bias), _ptr(out_scale), C.byref(dr_), C.byref(do_),
@@ -318,7 +332,10 @@ class _Conv(torch.autograd.Function):
             gx = torch.empty_like(x)
             ddx = _desc(gx, ci)
             npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
-            nws = _lib.fn("itg_conv2d_dgrad_workspace")(C.byref(ddy), C.byref(ddx), C.byref(g))
+            key = ("d", tuple(dy.shape), tuple(gx.shape), ctx.geom, ci, co)
+            nws = _WS_SIZE.get(key)
+            if nws is None:
+                nws = _WS_SIZE[key] = _lib.fn("itg_conv2d_dgrad_workspace")(C.byref(ddy), C.byref(ddx), C.byref(g))
             ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
             with _Prof(_nt_tag(ci), 1, 2.0 * npix_out * co * ci * kh * kw, 4 * (dy.numel() + gx.numel() + wp.numel())):
                 ia = ctx.in_act
@@ -337,7 +354,7 @@ class _Conv(torch.autograd.Function):
                 side = wgrad_stream_for((wsink if wsink is not None else bsink).data_ptr())
             if side is not None:
                 ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
+                ev.record()
                 # the operands were allocated on the main stream: keep them referenced until the owner of the side
                 # stream has joined it (engine.Trainer._join clears the list), so the allocator cannot hand their
                 # memory to a later main-stream kernel while the weight-gradient still reads it
@@ -345,20 +362,27 @@ class _Conv(torch.autograd.Function):
                 side.wait_event(ev)
                 if side not in _wgrad_dirty:
                     _wgrad_dirty.append(side)
-            with (torch.cuda.stream(side) if side is not None else _NullCtx()):
-                st = _stream()
+            # The kernels take their stream as an argument: torch's current stream is NOT switched to the side stream (the
+            # torch.cuda.stream context manager costs ~25 us of host time per layer).  Scratch allocated here therefore belongs
+            # to the main stream and joins the keep-alive list like the operands.
+            if True:
+                st = C.c_void_p(side.cuda_stream) if side is not None else _stream()
                 dxd = _desc(x, ci)
                 sinks_ok = not ((need_w and wsink is None) or (need_b and bsink is None))
                 if WGRAD_DEFER is not None and sinks_ok and _queue_wgrad(x, dxd, dy, ddy, g, w, wsink, bsink, need_w, need_b,
                                                                          ctx.sn, st):
                     gw_ = gb = None         # the slabs are computed; ops.flush_deferred() finishes the layer
                 else:
-                    nws = _lib.fn("itg_conv2d_wgrad_workspace")(C.byref(dxd), C.byref(ddy), C.byref(g))
+                    key = ("w", tuple(x.shape), tuple(dy.shape), ctx.geom, ci, co)
+                    nws = _WS_SIZE.get(key)
+                    if nws is None:
+                        nws = _WS_SIZE[key] = _lib.fn("itg_conv2d_wgrad_workspace")(C.byref(dxd), C.byref(ddy), C.byref(g))
                     ws = torch.empty(nws, device=x.device, dtype=torch.float32)
                     direct_w = wsink is not None and ctx.sn is None and need_w
                     direct_b = bsink is not None and need_b
                     gw_ = wsink if direct_w else torch.empty_like(w)
                     gb = bsink if direct_b else (torch.empty_like(w[:, 0, 0, 0]) if need_b else None)
+                    keep = [ws, gw_, gb]            # scratch of this layer's side-stream kernels (see above)
                     npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
                     with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1, 2.0 * npix_out * co * ci * kh * kw,
                                4 * (x.numel() + dy.numel() + w.numel())):
@@ -375,6 +399,7 @@ class _Conv(torch.autograd.Function):
                         zeroed = ws2 is not None
                         if ws2 is None:
                             ws2 = torch.empty(2, device=x.device, dtype=torch.float64)
+                        keep += [d_orig, ws2]
                         _lib.call("itg_spectral_norm_bwd", _ptr(gw_), _ptr(w), _ptr(u), _ptr(v), _ptr(inv_sigma), rows, cols,
                                   _ptr(d_orig), (ACC_DW if wsink is not None else 0) | (WS_ZEROED if zeroed else 0), _ptr(ws2), st)
                         gw_ = None if wsink is not None else d_orig
@@ -384,6 +409,8 @@ class _Conv(torch.autograd.Function):
                         gb = None
                     if not need_w:
                         gw_ = None
+                    if side is not None:
+                        WGRAD_KEEPALIVE.append(tuple(keep))
         gres = _residual_grad(dy, co, ctx.res_ups) if ctx.has_res and ctx.needs_input_grad[3] else None
         return gx, gw_, gb, gres, None, None, None, None, None, None, None, None, None, None
 
