@@ -41,7 +41,6 @@ struct ConvP {
   unsigned in_bytes, w_bytes;   // buffer-resource extents of the pixel operand / packed weights
   int use_tab;                  // per-row tap-offset table in LDS (narrow layers)
   int xcd_remap;                // deal contiguous runs of tiles to each XCD (its L2 then sees 1/8 of the pixel tiles)
-  int stagger;                  // halo-tile kernels: start workgroup layer j (blockIdx / 256) j * stagger * 8128 cycles late
   double* stats;                // fwd only, or null: [2][out.ld] per-channel sum / sum of squares of the stored output
   // Input transform (itg_in_norm): the conv sees up2x?(act(alpha * in + beta')) of the tensor `in` it is handed, i.e. the
   // BatchNorm-apply + LeakyReLU (+ nearest x2 upsample) of reference models/layers.py:301-311 / generators.py:95-117 is

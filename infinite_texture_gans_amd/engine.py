@@ -573,8 +573,9 @@ class BandTrainer(Trainer):
         from .models.layers import LocalPadder
         if netG.padding_mode != 'local':
             raise ValueError("row sharding is defined for padding_mode='local'")
-        if netG.attention or netG.type_norm != 'BN':
-            raise NotImplementedError("band training covers the BN generator without attention")
+        if netG.attention:
+            # per-patch attention needs the patch-grid layout; a band is held in image layout (one "patch" per image)
+            raise NotImplementedError("band training covers generators without attention")
         # the step itself is Trainer's (real_x: this rank's shard of real crops; z: the FULL merged latent); with more
         # than one rank the generator's forward/backward carries halo exchanges and band-wide BatchNorm sums, which
         # must not queue behind side-stream kernels: stream overlap only for a single rank
@@ -600,10 +601,25 @@ class BandTrainer(Trainer):
         return slice(self.comm.rank * k, (self.comm.rank + 1) * k)
 
     def sample_fake(self, z, maps=None):
-        """-> this rank's share of whole fake images (NCHW), differentiable w.r.t. every band."""
+        """-> this rank's share of whole fake images (NCHW), differentiable w.r.t. every band.
+        SSM generators: ``maps`` are the MERGED noise maps of the whole grid, one per layer, (N, map_dim, nph*r + 4, npw*r + 4)
+        as the reference draws them (utils.py:506-519) - the per-patch crops the reference feeds its generator are windows of
+        these, and the two valid 3x3 convs of the modulation MLP commute with the cropping, so a band runs them on its rows
+        of the merged map (rows a*r .. b*r + 4)."""
         a, b = self.band
         r = self.netG.base_res
-        band = ops.to_nchw(self.netG.forward_grid(z[:, :, a * r:b * r + 2, :].contiguous(), None, "1st_row_1st_col"),
+        band_maps = None
+        if self.netG.type_norm == 'SSM':
+            if maps is None or maps[0] is None:
+                raise ValueError("band training of an SSM generator needs the merged noise maps")
+            band_maps = []
+            for i, m in enumerate(maps):
+                ri = (2 ** i) * r
+                if m.shape[-2] != self.total_rows * ri + 4:
+                    raise ValueError("map %d has %d rows: band training takes the MERGED maps (%d rows), not per-patch crops"
+                                     % (i, m.shape[-2], self.total_rows * ri + 4))
+                band_maps.append(m[:, :, a * ri:b * ri + 4, :].contiguous())
+        band = ops.to_nchw(self.netG.forward_grid(z[:, :, a * r:b * r + 2, :].contiguous(), band_maps, "1st_row_1st_col"),
                            merged=True)
         if self._heights is None:      # static for the model: rows per rank x patch height
             self._heights = self.comm.band_heights(self.total_rows, band.shape[-2] // (b - a))

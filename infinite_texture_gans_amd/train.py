@@ -105,7 +105,7 @@ def train(args):
     def sample():
         if local:
             return U.sample_latents_train(netG, args.z_dim, args.base_res, args.map_dim, args.num_images,
-                                          args.num_patches_height, args.num_patches_width, device)
+                                          args.num_patches_height, args.num_patches_width, device, merged_maps=band)
         return U.sample_latents_zeros(netG, args.z_dim, args.base_res, args.map_dim, args.num_images, device)
 
     print("Starting Training Loop...")

@@ -223,9 +223,10 @@ def _unwrap(netG):
 
 
 def sample_latents_train(netG, z_dim=128, base_res=4, map_dim=1, num_images=1, num_patches_height=3,
-                         num_patches_width=3, device="cpu"):
+                         num_patches_width=3, device="cpu", merged_maps=False):
     """z then SSM maps 0..nl-1, drawn on the CPU generator and moved to ``device``
-    (the reference's RNG order, utils.py:503-519)."""
+    (the reference's RNG order, utils.py:503-519).  ``merged_maps``: leave the maps un-cropped, (N, map_dim, nph*r + 4,
+    npw*r + 4) - what the row-sharded trainer (engine.BandTrainer) slices its bands from."""
     g = _unwrap(netG)
     z = _randn_on(device, num_images, z_dim, num_patches_height * base_res + 2, num_patches_width * base_res + 2)
     maps = [None] * g.n_layers_G
@@ -234,7 +235,7 @@ def sample_latents_train(netG, z_dim=128, base_res=4, map_dim=1, num_images=1, n
         for i in range(g.n_layers_G):
             r = (2 ** i) * base_res
             m = _randn_on(device, num_images, map_dim, num_patches_height * r + 4, num_patches_width * r + 4)
-            maps.append(crop_images(m, r + 4, r + 4, r, device=device))
+            maps.append(m if merged_maps else crop_images(m, r + 4, r + 4, r, device=device))
     return z, maps
 
 

@@ -452,6 +452,90 @@ def test_band_sharded_train_step_matches_reference_golden(tag, world, tmp_path):
                 assert rel_l2(got, v.double()) < 2e-3, (k, rel_l2(got, v.double()))
 
 
+def test_band_trainer_with_ssm_generator_matches_reference_golden():
+    """Row-sharded training of an SSM generator: the band runs the modulation MLP on its rows of the MERGED noise maps (the
+    reference crops those maps per patch, utils.py:506-519; the two valid 3x3 convs commute with the cropping).  One rank
+    (the band = the whole grid in image layout) against the reference golden of the patch-grid step: losses and post-step
+    parameters."""
+    from infinite_texture_gans_amd.engine import BandTrainer
+    from infinite_texture_gans_amd.dist import BandComm
+    from infinite_texture_gans_amd import utils as U
+    fx = load("train_ssm_nl4")
+    a = parse_flags(fx["argv"])
+    G, D = build(a, state(fx, "G0/"), state(fx, "D0/"))
+    G.train(), D.train()
+    args = U.prepare_parser().parse_args([])
+    args.smooth, args.beta1 = a["smooth"], 0.0
+    tr = BandTrainer(G, D, args, cuda, BandComm(0, 1))
+    steps = int(fx["steps"])
+    for s_ in range(steps):
+        maps = [torch.from_numpy(fx["map%d_%d" % (s_, i)]).to(cuda) for i in range(a["n_layers_G"])]
+        l = tr.step(torch.from_numpy(fx["real_x%d" % s_]).to(cuda), torch.from_numpy(fx["z%d" % s_]).to(cuda), maps)
+        assert np.allclose([float(v) for v in l], fx["loss%d" % s_], rtol=1e-4, atol=1e-6), (s_, [float(v) for v in l], fx["loss%d" % s_])
+    gs = G.state_dict()
+    for k, v in state(fx, "G1/").items():
+        if zero_grad_bias(k):
+            assert (gs[k].cpu().double() - v.double()).abs().max() <= 2 * 2e-4 * steps + 1e-7, k
+        else:
+            assert rel_l2(gs[k].cpu(), v) < 2e-3, (k, rel_l2(gs[k].cpu(), v))
+
+
+def _band_ssm_worker(rank, world, port, out_path):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import torch.distributed as dist
+    from infinite_texture_gans_amd.engine import BandTrainer
+    from infinite_texture_gans_amd.dist import BandComm
+    from infinite_texture_gans_amd import utils as U
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fx = load("train_ssm_nl4")
+        a = parse_flags(fx["argv"])
+        G, D = build(a, state(fx, "G0/"), state(fx, "D0/"))
+        G.train(), D.train()
+        args = U.prepare_parser().parse_args([])
+        args.smooth, args.beta1 = a["smooth"], 0.0
+        tr = BandTrainer(G, D, args, cuda, BandComm(rank, world))
+        g = torch.Generator().manual_seed(31)
+        n = 2                                            # two fake images: one per rank in front of D
+        losses = []
+        for s_ in range(2):
+            real = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+            z = torch.randn(n, a["z_dim"], 3 * a["base_res"] + 2, 3 * a["base_res"] + 2, generator=g)
+            maps = [torch.randn(n, a["map_dim"], 3 * a["base_res"] * 2 ** i + 4, 3 * a["base_res"] * 2 ** i + 4, generator=g)
+                    for i in range(a["n_layers_G"])]
+            k = real.shape[0] // world
+            l = tr.step(real[rank * k:(rank + 1) * k].to(cuda), z.to(cuda), [m.to(cuda) for m in maps])
+            losses.append([float(v) for v in l])
+        torch.save({"losses": losses, "G": {k: v.cpu() for k, v in G.state_dict().items()}}, "%s.%d.%d" % (out_path, world, rank))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_band_sharded_ssm_train_step_on_two_ranks_equals_one_rank(tmp_path):
+    """The same SSM generator, two images, 3 patch rows: bands of (2, 1) rows on two ranks with halo exchange, band-wide
+    normalisation sums and sliced noise maps == the one-rank band step (itself pinned to the reference golden above)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ssmband")
+    mp.spawn(_band_ssm_worker, args=(1, free_port(), out), nprocs=1, join=True)
+    mp.spawn(_band_ssm_worker, args=(2, free_port(), out), nprocs=2, join=True)
+    one = torch.load("%s.1.0" % out)
+    two = [torch.load("%s.2.%d" % (out, r)) for r in range(2)]
+    for s_ in range(2):
+        mean = np.mean([r["losses"][s_] for r in two], 0)
+        assert np.allclose(mean, one["losses"][s_], rtol=1e-4, atol=1e-6), (s_, mean, one["losses"][s_])
+    for k, v in one["G"].items():
+        assert torch.equal(two[0]["G"][k], two[1]["G"][k]), k
+        if zero_grad_bias(k):
+            assert (two[0]["G"][k].double() - v.double()).abs().max() <= 2 * 2e-4 * 2 + 1e-7, k
+        elif v.dtype.is_floating_point:
+            assert rel_l2(two[0]["G"][k], v) < 2e-3, (k, rel_l2(two[0]["G"][k], v))
+
+
 def test_bf16_mfma_path_tracks_reference_golden():
     """BASELINE config 3's path (attention generator, convolutions on bf16-operand MFMA with fp32
     accumulation; tensors, BatchNorm, attention and the optimizer stay fp32).  Tolerances are bf16's:
