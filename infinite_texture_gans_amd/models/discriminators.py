@@ -7,7 +7,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..ops import GT
-from .layers import conv4x4, conv3x3, _BNParams, _ConvParams, batched_power_iteration
+from .layers import conv4x4, conv3x3, _BNParams, _INParams, _ConvParams, batched_power_iteration
 
 
 class PatchDiscriminator(nn.Module):
@@ -22,17 +22,18 @@ class PatchDiscriminator(nn.Module):
             conv_fun = conv3x3
         else:
             raise ValueError("kw must be 3 or 4")
-        if norm_layer not in (None, 'batch'):
-            raise NotImplementedError("norm_layer=%r: only None and 'batch' are built (instance norm is unused "
-                                      "by every reference configuration)" % (norm_layer,))
+        if norm_layer not in (None, 'batch', 'instance'):
+            raise ValueError("norm_layer must be None, 'batch' or 'instance', got %r" % (norm_layer,))
         nf = base_ch
         seq = [conv_fun(img_ch, base_ch, SN=SN, s=2, bias=True), nn.LeakyReLU(0.2, False)]
         for n in range(1, n_layers_D):
             nf_prev, nf = nf, min(nf * 2, 512)
             stride = 1 if n == n_layers_D - 1 else 2
             seq.append(conv_fun(nf_prev, nf, s=stride, SN=SN, bias=True))
-            if norm_layer:
+            if norm_layer == 'batch':
                 seq.append(_BNParams(nf, affine=True))
+            elif norm_layer == 'instance':
+                seq.append(_INParams(nf, affine=False))
             seq.append(nn.LeakyReLU(0.2, False))
         seq.append(conv_fun(nf, 1, s=1, SN=SN, bias=True))
         self.model = nn.Sequential(*seq)
@@ -53,7 +54,7 @@ class PatchDiscriminator(nn.Module):
                           defer_act_bwd=chained)
                 in_act = (ops.ACT_LRELU, nxt.negative_slope) if chained else None
                 i += 2
-            elif isinstance(nxt, _BNParams):
+            elif isinstance(nxt, (_BNParams, _INParams)):
                 h = m.run(h, out_grid=(1, 1), in_act=in_act)
                 h = nxt.run(h, act=ops.ACT_LRELU, slope=mods[i + 2].negative_slope)
                 in_act = None

@@ -403,6 +403,28 @@ class _BNParams(nn.BatchNorm2d):
         return ops.to_nchw(self.run(ops.to_grid(x, 1, 1, True)), True)
 
 
+class _INParams(nn.Module):
+    """nn.InstanceNorm2d(affine=False) (reference models/discriminators.py:183-185, `--norm_layer_D instance`): every image
+    is normalised with its own per-channel statistics - the BatchNorm kernels on one image at a time, no parameters, no
+    buffers (so the state_dict is the reference's).  Unused by the BASELINE configurations: correctness, not speed."""
+
+    def __init__(self, num_features, eps=1e-5, affine=False):
+        super().__init__()
+        if affine:
+            raise NotImplementedError("the reference builds its instance norm with affine=False")
+        self.num_features, self.eps = num_features, eps
+
+    def run(self, x, act=ops.ACT_NONE, slope=0.0):
+        outs = [ops.bn_act(GT(x.t[i:i + 1], x.c), None, None, None, None, None, training=True, eps=self.eps, momentum=0.0,
+                           act=act, slope=slope).t for i in range(x.t.shape[0])]
+        return GT(torch.cat(outs, 0), x.c)
+
+    def forward(self, x):
+        if isinstance(x, GT):
+            return self.run(x)
+        return ops.to_nchw(self.run(ops.to_grid(x, 1, 1, True)), True)
+
+
 class StochasticSpatialModulation(nn.Module):
     """(1+gamma)*BN(x)+beta with [gamma,beta] = embed(ReLU(mlp_shared(map))).
     reference models/layers.py:203-234."""

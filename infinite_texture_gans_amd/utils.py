@@ -38,7 +38,7 @@ _FLAGS = [
     ("spec_norm_G", "flag", False, "spectral normalisation in the generator"),
     ("n_layers_D", int, 4, "number of discriminator layers"),
     ("n_layers_G", int, 6, "number of generator layers (4, 5 or 6)"),
-    ("norm_layer_D", str, None, "normalisation layer in the discriminator (None | batch)"),
+    ("norm_layer_D", str, None, "normalisation layer in the discriminator (None | batch | instance)"),
     ("base_res", int, 4, "base resolution of G"),
     ("padding_mode", str, "zeros", "padding used in G: zeros or local"),
     ("type_norm_G", str, "BN", "normalisation used in G: BN or SSM"),

@@ -536,6 +536,42 @@ def test_band_sharded_ssm_train_step_on_two_ranks_equals_one_rank(tmp_path):
             assert rel_l2(two[0]["G"][k], v) < 2e-3, (k, rel_l2(two[0]["G"][k], v))
 
 
+@pytest.mark.parametrize("norm", ["instance", "batch"])
+def test_discriminator_norm_layers_match_torch(norm):
+    """PatchDiscriminator(norm_layer='instance' | 'batch') (reference models/discriminators.py:180-201) against the same
+    stack of torch CPU modules (nn.Conv2d / nn.InstanceNorm2d(affine=False) / nn.BatchNorm2d / LeakyReLU(0.2)) with the
+    same weights: logits, input gradient and every parameter gradient."""
+    import torch.nn as nn
+    from infinite_texture_gans_amd.models.discriminators import PatchDiscriminator
+    torch.manual_seed(3)
+    D = PatchDiscriminator(img_ch=3, base_ch=8, n_layers_D=4, kw=4, SN=False, norm_layer=norm)
+    sd = {k: v.clone() for k, v in D.state_dict().items()}
+    ref_layers, nf = [nn.Conv2d(3, 8, 4, 2, 1), nn.LeakyReLU(0.2)], 8
+    for n in range(1, 4):
+        nf_prev, nf = nf, min(nf * 2, 512)
+        ref_layers += [nn.Conv2d(nf_prev, nf, 4, 1 if n == 3 else 2, 1),
+                       nn.InstanceNorm2d(nf, affine=False) if norm == "instance" else nn.BatchNorm2d(nf, affine=True),
+                       nn.LeakyReLU(0.2)]
+    ref_layers += [nn.Conv2d(nf, 1, 4, 1, 1)]
+    ref = nn.Sequential(*ref_layers)
+    ref.load_state_dict({k[len("model."):]: v for k, v in sd.items()})      # same keys as the reference's nn.Sequential
+    ref.train()
+    D = D.to(cuda).train()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 3, 40, 40, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    xg = x.to(cuda).requires_grad_(True)
+    yg = D(xg)
+    yg.backward(dy.to(cuda))
+    assert rel_l2(yg.detach().cpu(), yr.detach()) < 1e-5
+    assert rel_l2(xg.grad.cpu(), xr.grad) < 1e-4
+    for (k, p), (_, q) in zip(D.named_parameters(), ref.named_parameters()):
+        assert rel_l2(p.grad.cpu(), q.grad) < 1e-4 or float(q.grad.abs().max()) < 1e-6, k
+
+
 def test_bf16_mfma_path_tracks_reference_golden():
     """BASELINE config 3's path (attention generator, convolutions on bf16-operand MFMA with fp32
     accumulation; tensors, BatchNorm, attention and the optimizer stay fp32).  Tolerances are bf16's:
