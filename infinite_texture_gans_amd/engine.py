@@ -566,16 +566,16 @@ class BandTrainer(Trainer):
     gradient of a band is the sum over the ranks that scored its images.  Real crops are sharded over
     ranks as in plain data parallelism.  Results equal the single-process step on the whole batch.
 
-    ``z`` handed to :meth:`step` is the FULL merged latent, identical on all ranks (same seed)."""
+    ``z`` handed to :meth:`step` is the FULL merged latent, identical on all ranks (same seed); SSM generators also take the
+    MERGED noise maps (sample_fake).  Generators with per-patch attention re-grid their band into patches around the
+    attention layer (ResidualPatchGenerator.band_layout)."""
 
     def __init__(self, netG, netD, args, device, comm, netG_ema=None):
         super().__init__(netG, netD, args, device, netG_ema=netG_ema)
         from .models.layers import LocalPadder
         if netG.padding_mode != 'local':
             raise ValueError("row sharding is defined for padding_mode='local'")
-        if netG.attention:
-            # per-patch attention needs the patch-grid layout; a band is held in image layout (one "patch" per image)
-            raise NotImplementedError("band training covers generators without attention")
+
         # the step itself is Trainer's (real_x: this rank's shard of real crops; z: the FULL merged latent); with more
         # than one rank the generator's forward/backward carries halo exchanges and band-wide BatchNorm sums, which
         # must not queue behind side-stream kernels: stream overlap only for a single rank
@@ -583,6 +583,7 @@ class BandTrainer(Trainer):
         self.set_overlap(os.environ.get("ITG_OVERLAP", "1" if comm.world == 1 else "0") == "1")
         self.total_rows = netG.num_patches_h
         self.band = comm.band(self.total_rows)
+        netG.band_layout = (self.band[1] - self.band[0], netG.num_patches_w)     # per-patch attention runs on the band's patch grid
         netG.set_sync(comm.band_sync(self.total_rows))
         for m in netD.modules():
             if isinstance(m, _BNParams):

@@ -64,6 +64,8 @@ class ResidualPatchGenerator(nn.Module):
             names.append("bn")
         return names + ["final"]
 
+    band_layout = None      # (patch rows, patch columns) of the band a row-sharded trainer holds in image layout (engine.BandTrainer)
+
     def set_sync(self, sync):
         """Make every BatchNorm (incl. SSM's inner one) take its statistics over ``sync``'s ranks."""
         for m in self.modules():
@@ -92,7 +94,17 @@ class ResidualPatchGenerator(nn.Module):
             h = getattr(self, "block%d" % i).forward_grid(h, maps[i - 1], image_location, upsample_input=True,
                                                           out_stats=bn and not (i == 3 and self.attention))
             if i == 3 and self.attention:
-                h = self.attention.run(h)
+                if self.band_layout is not None:
+                    # row-sharded training holds the band in image layout (one "patch" per image): attention mixes inside
+                    # each generator patch, so it runs on the band's patch grid and the result goes back to image layout
+                    rows, cols = self.band_layout
+                    n, _, _, H, W, ld = h.t.shape
+                    ph, pw = H // rows, W // cols
+                    g = h.t.view(n, rows, ph, cols, pw, ld).permute(0, 1, 3, 2, 4, 5).contiguous()
+                    o = self.attention.run(GT(g, h.c))
+                    h = GT(o.t.permute(0, 1, 3, 2, 4, 5).reshape(n, 1, 1, H, W, ld), o.c)
+                else:
+                    h = self.attention.run(h)
         if self.type_norm == 'BN':
             return self.final.forward_grid(h, image_location, act=ops.ACT_TANH, bn=self.bn, bn_act=(A, s))
         h = ops.act(h, A, s)

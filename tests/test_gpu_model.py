@@ -480,6 +480,31 @@ def test_band_trainer_with_ssm_generator_matches_reference_golden():
             assert rel_l2(gs[k].cpu(), v) < 2e-3, (k, rel_l2(gs[k].cpu(), v))
 
 
+def test_band_trainer_with_attention_generator_matches_reference_golden():
+    """Row-sharded training of a generator with per-patch attention: the band (image layout) is re-gridded into its patches
+    around the attention layer.  One rank against the reference golden of the 4x4-grid attention model."""
+    from infinite_texture_gans_amd.engine import BandTrainer
+    from infinite_texture_gans_amd.dist import BandComm
+    from infinite_texture_gans_amd import utils as U
+    fx = load("train_bn_nl5_att")
+    a = parse_flags(fx["argv"])
+    G, D = build(a, state(fx, "G0/"), state(fx, "D0/"))
+    G.train(), D.train()
+    args = U.prepare_parser().parse_args([])
+    args.smooth, args.beta1 = a["smooth"], 0.0
+    tr = BandTrainer(G, D, args, cuda, BandComm(0, 1))
+    steps = int(fx["steps"])
+    for s_ in range(steps):
+        l = tr.step(torch.from_numpy(fx["real_x%d" % s_]).to(cuda), torch.from_numpy(fx["z%d" % s_]).to(cuda))
+        assert np.allclose([float(v) for v in l], fx["loss%d" % s_], rtol=1e-4, atol=1e-6), (s_, [float(v) for v in l], fx["loss%d" % s_])
+    gs = G.state_dict()
+    for k, v in state(fx, "G1/").items():
+        if zero_grad_bias(k):
+            assert (gs[k].cpu().double() - v.double()).abs().max() <= 2 * 2e-4 * steps + 1e-7, k
+        else:
+            assert rel_l2(gs[k].cpu(), v) < 2e-3, (k, rel_l2(gs[k].cpu(), v))
+
+
 def _band_ssm_worker(rank, world, port, out_path):
     import os
     import sys
