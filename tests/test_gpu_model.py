@@ -132,6 +132,42 @@ def test_train_step_matches_reference_golden(tag):
                 assert rel_l2(got, v.double()) < 2e-3, (name, k, rel_l2(got, v.double()))
 
 
+def _check_against_golden(fx, a, G, D, tr, losses):
+    steps = int(fx["steps"])
+    for s in range(steps):
+        assert np.allclose(losses[s], fx["loss%d" % s], rtol=1e-4, atol=1e-6), (s, losses[s], fx["loss%d" % s])
+    for name, net in (("G1/", G), ("D1/", D)):
+        sd = net.state_dict()
+        for k, v in state(fx, name).items():
+            got = sd[k].double().cpu()
+            if name != "D1/" and zero_grad_bias(k):
+                assert (got - v.double()).abs().max() <= 2 * 2e-4 * steps + 1e-7, k
+            elif v.dtype == torch.int64:
+                assert torch.equal(sd[k].cpu(), v), (name, k)
+            else:
+                assert rel_l2(got, v.double()) < 2e-3, (name, k, rel_l2(got, v.double()))
+
+
+@pytest.mark.parametrize("tag", ["bn_nl4_sn", "bn_nl4_g44", "bn_nl4_zeros", "bn_nl5_att"])
+def test_loader_side_batchnorm_option_matches_reference_golden(tag, monkeypatch):
+    """The opt-in form of the generator's normalisation (ITG_BN_LOADER=1, itg_in_norm): BatchNorm-apply + LeakyReLU + nearest
+    x2 upsample inside the conv kernels' tile loaders (forward and weight gradient), the BatchNorm backward sums in the
+    input-gradient epilogues.  Same goldens, same tolerances as the default path."""
+    from infinite_texture_gans_amd.models import layers as L
+    monkeypatch.setattr(L, "_ENV_BN_LOADER", True)
+    fx, a, G, D, tr, losses = _train(tag)
+    _check_against_golden(fx, a, G, D, tr, losses)
+
+
+@pytest.mark.parametrize("tag", ["bn_nl4_sn", "ssm_nl4", "bn_nl4_nosn"])
+def test_deferred_weight_gradient_reduce_option_matches_reference_golden(tag):
+    """ITG_DEFER_REDUCE=1 (the default of bench.py --workload config3): per-layer slabs only in the backward pass, ONE
+    itg_wgrad_reduce_multi + itg_spectral_norm_bwd_multi per pass at the join.  Same goldens, same tolerances."""
+    fx, a, G, D, tr, losses = _train(tag, env={"ITG_DEFER_REDUCE": "1"})
+    assert tr.defer_reduce
+    _check_against_golden(fx, a, G, D, tr, losses)
+
+
 @pytest.mark.parametrize("tag", ["bn_nl4_sn", "bn_nl5_att", "ssm_nl4", "bn_nl4_g44", "bn_nl4_nosn", "bn_nl4_zeros"])
 def test_first_train_step_gradient_magnitudes_match_reference_golden(tag):
     """After one Trainer.step the flat gradient buffers still hold the D-step gradients of D and the G-step gradients
@@ -734,8 +770,11 @@ def test_bucketed_gradient_exchange_with_lookahead_equals_the_plain_exchange(tmp
             assert torch.equal(v, res["bucketed"][1]["D"][k]), k
 
 
-def test_midsize_train_step_with_tile_and_thin_kernels_matches_oracle():
-    """A model large enough (64x64 patches on a 3x3 grid = 192x192 fakes, 96x96 reals) that the special kernels of
+@pytest.mark.parametrize("loader_bn", [False, True], ids=["default", "loader_side_batchnorm"])
+def test_midsize_train_step_with_tile_and_thin_kernels_matches_oracle(loader_bn, monkeypatch):
+    """(``loader_side_batchnorm``: the same step with ITG_BN_LOADER=1's kernels - the halo-tile / vector-ALU / thin-output
+    kernels then carry the BatchNorm apply in their loaders and the backward sums in their epilogues.)
+    A model large enough (64x64 patches on a 3x3 grid = 192x192 fakes, 96x96 reals) that the special kernels of
     the full-size step are all on the path - halo-tile forward / input- / weight-gradient kernels for the narrow last
     block, taps-as-rows kernels for D's logit and first layers, split-K, stream overlap, packed panels, gradient
     sinks - held against the CPU oracle's train step on the same state and inputs."""
@@ -745,6 +784,8 @@ def test_midsize_train_step_with_tile_and_thin_kernels_matches_oracle():
     from infinite_texture_gans_amd.engine import Trainer
     from infinite_texture_gans_amd.models.generators import ResidualPatchGenerator
     from infinite_texture_gans_amd.models.discriminators import PatchDiscriminator
+    from infinite_texture_gans_amd.models import layers as L
+    monkeypatch.setattr(L, "_ENV_BN_LOADER", bool(loader_bn))
     torch.manual_seed(21)
     G = ResidualPatchGenerator(z_dim=16, G_ch=8, base_res=4, n_layers_G=5, attention=False, img_ch=3, leak=0.02,
                                type_norm="BN", padding_mode="local")
