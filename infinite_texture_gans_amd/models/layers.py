@@ -106,11 +106,11 @@ class _ConvParams(nn.Module):
         return (w.grad, b.grad if (b is not None and b.grad is not None) else None)
 
     def run(self, x, pad=None, pad_mode=ops.PAD_ZERO, act=ops.ACT_NONE, slope=0.0, residual=None, out_grid=None,
-            pad_h=-1, in_act=None, defer_act_bwd=False, out_stats=False):
+            pad_h=-1, in_act=None, defer_act_bwd=False, out_stats=False, out=None):
         w, sn = self.weight_and_sn()
         return ops.conv(x, w, self.bias, self.k, self.k, self.stride, self.padding if pad is None else pad,
                         pad_mode, act, slope, residual, sn, out_grid, self._sinks(w), pad_h, packed=self._packed,
-                        in_act=in_act, defer_act_bwd=defer_act_bwd, out_stats=out_stats)
+                        in_act=in_act, defer_act_bwd=defer_act_bwd, out_stats=out_stats, out=out)
 
     def run_bn(self, x, bn, in_act, in_slope, upsample=False, pad=None, pad_mode=ops.PAD_ZERO, act=ops.ACT_NONE, slope=0.0,
                residual=None, out_grid=None, pad_h=-1, out_stats=False):
@@ -454,13 +454,16 @@ class StochasticSpatialModulation(nn.Module):
             a = self.mlp_shared[0].run(m, pad=self.p, act=ops.ACT_LRELU, slope=0.0)
             e = self.embed.run(a, pad=self.p)
         else:
-            parts = []
+            # every chunk's modulation goes straight into its slice of ONE result tensor (no concatenation copy afterwards)
+            red = 2 * (1 - self.p)                       # a valid 3x3 conv shrinks the map by 2
+            hh, ww = m.t.shape[3] - 2 * red, m.t.shape[4] - 2 * red
+            et = torch.empty((nb, 1, 1, hh, ww, ops.ld_for(2 * self.in_channel)), device=m.t.device, dtype=torch.float32)
             for i in range(0, nb, chunk):
                 mi = GT(m.t[i:i + chunk], m.c)
                 ai = self.mlp_shared[0].run(mi, pad=self.p, act=ops.ACT_LRELU, slope=0.0)
-                parts.append(self.embed.run(ai, pad=self.p).t)
+                self.embed.run(ai, pad=self.p, out=et[i:i + chunk])
                 del ai
-            e = GT(torch.cat(parts, 0), 2 * self.in_channel)
+            e = GT(et, 2 * self.in_channel)
         n, gh, gw, ph, pw, _ = x.t.shape
         if e.t.shape[3] != ph or e.t.shape[4] != pw or e.t.shape[0] != n * gh * gw:
             raise ValueError("modulation map does not match the activation: %r vs %r" % (e, x))

@@ -258,7 +258,7 @@ class _Conv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, residual, sn, c_in, geom, act, slope, out_grid, sinks=None, packed=None, fuse=(None, False),
-                stats=None):
+                stats=None, out_buf=None):
         kh, kw, stride, pad, pad_mode, pad_h, prec = geom
         pv = pad_h if pad_h >= 0 else pad
         n, gh, gw, ph, pw, ld = x.shape
@@ -278,7 +278,13 @@ class _Conv(torch.autograd.Function):
         else:
             wp, out_scale = torch.empty(_lib.fn("itg_pack_fwd_size")(co, ld, kh, kw), device=x.device, dtype=torch.float32), None
             _lib.call("itg_pack_fwd", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, ld, kh, kw, st)
-        out = torch.empty((n, ogh, ogw, Ho // ogh, Wo // ogw, ld_for(co)), device=x.device, dtype=torch.float32)
+        oshape = (n, ogh, ogw, Ho // ogh, Wo // ogw, ld_for(co))
+        if out_buf is not None:       # inference: the caller's (contiguous) slice of a larger result - no concatenation copy later
+            if tuple(out_buf.shape) != oshape or not out_buf.is_contiguous() or torch.is_grad_enabled():
+                raise _lib.ItgError("conv(out=...): expected a contiguous %s buffer under no_grad" % (oshape,))
+            out = out_buf
+        else:
+            out = torch.empty(oshape, device=x.device, dtype=torch.float32)
         dx_, do_ = _desc(x, c_in), _desc(out, co)
         dr_ = _desc(residual, co) if residual is not None else _null_desc()
         g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, stats.data_ptr() if stats is not None else None)
@@ -412,12 +418,12 @@ class _Conv(torch.autograd.Function):
                     if side is not None:
                         WGRAD_KEEPALIVE.append(tuple(keep))
         gres = _residual_grad(dy, co, ctx.res_ups) if ctx.has_res and ctx.needs_input_grad[3] else None
-        return gx, gw_, gb, gres, None, None, None, None, None, None, None, None, None, None
+        return gx, gw_, gb, gres, None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, residual=None,
          sn=None, out_grid=None, sinks=None, pad_h=-1, precision=None, packed=None, in_act=None, defer_act_bwd=False,
-         out_stats=False):
+         out_stats=False, out=None):
     """x: GT.  Returns GT with ``out_grid`` (default: the input grid).  ``sinks`` = (weight.grad, bias.grad)
     buffers: the backward then accumulates the parameter gradients straight into them (and reports no
     gradient to autograd), which removes one AccumulateGrad add kernel per parameter."""
@@ -430,7 +436,7 @@ def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=AC
     if out_stats and ld_for(w.shape[0]) <= 512 and w.shape[0] > 1:
         stats = _zeros_f64(2 * ld_for(w.shape[0]), x.t.device)
     t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode, pad_h, prec), act, slope, og, sinks, packed,
-                    (in_act, bool(defer_act_bwd)), stats)
+                    (in_act, bool(defer_act_bwd)), stats, out)
     return GT(t, w.shape[0], stats)
 
 
