@@ -76,7 +76,14 @@ typedef struct {
   int32_t pad_mode; /* ITG_PAD_*: how reads outside the merged image resolve */
   int32_t pad_h;    /* vertical padding when it differs from `pad` (row-sharded grids: 0); < 0 = same as pad */
   int32_t precision; /* ITG_PREC_*: MFMA operand type of the contraction (tensors are fp32 in memory either way) */
-  int32_t reserved;  /* 0 */
+  int32_t up2;       /* 0 | 1: the conv runs on the nearest x2 upsample of the tensor it is handed (`in` / `dx` / `x` have HALF
+                      * the conv input's patch extent) and the upsample is folded into the filter: every output-parity class
+                      * (Y % 2, X % 2) sees only 2 x 2 distinct source pixels, so conv3x3(up2x(x)) is four 2 x 2 convolutions of x
+                      * with phase-summed weights - 4/9 of the multiply-adds, a quarter of the input bytes, nothing materialised
+                      * (reference models/generators.py:52 + layers.py:301-311: nn.Upsample in front of every block's first
+                      * conv2d_lp).  3 x 3, stride 1, pad 1 only; panels from itg_pack_up2_fwd / itg_pack_up2_dgrad; the input
+                      * gradient is the 4 x 4 stride-2 convolution of dy with the same phase sums and lands on the half-size
+                      * tensor (the upsample's backward included); no in_norm.                                              */
   double* out_stats; /* itg_conv2d_fwd only, or NULL: 2 * out.ld doubles (sum | sum of squares per channel over every
                       * output pixel), ACCUMULATED into by the conv's epilogue - the BatchNorm statistics of the
                       * layer that consumes this output (nn.BatchNorm2d after every generator conv, reference
@@ -109,13 +116,23 @@ int itg_pack_fwd(const float* w_oihw, const float* scale, float* out, int co, in
                  int kh, int kw, void* stream);
 int itg_pack_dgrad(const float* w_oihw, const float* scale, float* out, int co, int ci, int co_ld,
                    int kh, int kw, int stride, void* stream);
+/* Panels of a 3x3 conv behind a nearest x2 upsample (itg_conv_geom.up2), w_oihw = the layer's [co][ci][3][3] weight:
+ *   fwd   : 4 output-parity classes (ry, rx) x [co_pad][2][2][ci_ld]; tap (jy, jx) of class (ry, rx) reads source pixel
+ *           (y + ry - 1 + jy, x + rx - 1 + jx) and holds  sum_{i in S(ry,jy)} sum_{j in S(rx,jx)} w[i][j],
+ *           S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2};
+ *   dgrad : [ci_pad][4][4][co_ld], the 4x4 stride-2 pad-1 kernel whose transpose the folded forward is:
+ *           tap t holds the sum over T(t), T(0) = {2}, T(1) = {1,2}, T(2) = {0,1}, T(3) = {0} per axis.            */
+int64_t itg_pack_up2_fwd_size(int co, int ci_ld);
+int64_t itg_pack_up2_dgrad_size(int ci, int co_ld);
+int itg_pack_up2_fwd(const float* w_oihw, const float* scale, float* out, int co, int ci, int ci_ld, void* stream);
+int itg_pack_up2_dgrad(const float* w_oihw, const float* scale, float* out, int co, int ci, int co_ld, void* stream);
 
 /* Every panel of a model in ONE launch (the train step repacks a model once per optimizer step:
  * 2 launches per iteration instead of ~65).  The job table is static for a model and lives in DEVICE
  * memory (no per-launch upload, capturable in a hipGraph): n <= ITG_PACK_MAX_JOBS rows of 10 x int64
  *   { w_oihw (pointer), out (pointer), co, ci, ld, kh, kw, stride, dgrad, start }
  * ld = ci_ld for a forward panel (dgrad = 0, itg_pack_fwd layout) or co_ld for a dgrad panel (dgrad = 1,
- * itg_pack_dgrad layout); row j owns flat elements [start_j, start_j + size_j) of the launch, `total` is
+ * itg_pack_dgrad layout); dgrad = 2 / 3: the itg_pack_up2_fwd / itg_pack_up2_dgrad panels (kh = kw = 3); row j owns flat elements [start_j, start_j + size_j) of the launch, `total` is
  * the sum of the panel sizes (itg_pack_*_size).  No scale here: the spectral-norm 1/sigma of such
  * panels is applied through `out_scale` below. */
 #define ITG_PACK_MAX_JOBS 48

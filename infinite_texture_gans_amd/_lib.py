@@ -33,11 +33,11 @@ class InNorm(C.Structure):
 
 class ConvGeom(C.Structure):
     _fields_ = [("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
-                ("pad_mode", C.c_int32), ("pad_h", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32),
+                ("pad_mode", C.c_int32), ("pad_h", C.c_int32), ("precision", C.c_int32), ("up2", C.c_int32),
                 ("out_stats", C.c_void_p), ("in_norm", C.POINTER(InNorm))]
 
-    def __init__(self, kh, kw, stride, pad, pad_mode, pad_h=-1, precision=0, out_stats=None, in_norm=None):
-        super().__init__(kh, kw, stride, pad, pad_mode, pad_h, precision, 0, out_stats,
+    def __init__(self, kh, kw, stride, pad, pad_mode, pad_h=-1, precision=0, out_stats=None, in_norm=None, up2=0):
+        super().__init__(kh, kw, stride, pad, pad_mode, pad_h, precision, int(up2), out_stats,
                          C.pointer(in_norm) if in_norm is not None else None)
         self._in_norm = in_norm      # keep it alive
 
@@ -73,6 +73,10 @@ SIGNATURES = {
     "itg_pack_dgrad_size": (_l, [_i, _i, _i, _i, _i]),
     "itg_pack_fwd": (_i, [_P, _P, _P, _i, _i, _i, _i, _i, _P]),
     "itg_pack_dgrad": (_i, [_P, _P, _P, _i, _i, _i, _i, _i, _i, _P]),
+    "itg_pack_up2_fwd_size": (_l, [_i, _i]),
+    "itg_pack_up2_dgrad_size": (_l, [_i, _i]),
+    "itg_pack_up2_fwd": (_i, [_P, _P, _P, _i, _i, _i, _P]),
+    "itg_pack_up2_dgrad": (_i, [_P, _P, _P, _i, _i, _i, _P]),
     "itg_conv2d_fwd_workspace": (_l, [_TP, _TP, _GP]),
     "itg_conv2d_dgrad_workspace": (_l, [_TP, _TP, _GP]),
     "itg_pack_multi": (_i, [_P, _i, _l, _P]),

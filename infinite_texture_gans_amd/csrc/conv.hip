@@ -56,6 +56,47 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, const float* __re
 }
 
 
+// Panels of conv3x3(up2x(x)) (itg_conv_geom.up2).  Forward: class (ry, rx) major, out[cls][o][k], k = (jy*2+jx)*ci_ld + c;
+// tap jj of parity r sums the 3x3 taps lo..hi per axis:  lo = jj ? 1 + r : 0,  hi = jj ? 2 : r.
+__device__ __forceinline__ float up2_fwd_elem(const float* __restrict__ w, int co, int ci, int ci_ld, int co_pad, int Kpad,
+                                              long long e) {
+  const int k = (int)(e % Kpad);
+  const long long r = e / Kpad;
+  const int o = (int)(r % co_pad), cls = (int)(r / co_pad);
+  const int tap = k / ci_ld, c = k - tap * ci_ld;
+  if (o >= co || tap >= 4 || c >= ci) return 0.f;
+  const int ry = cls >> 1, rx = cls & 1, jy = tap >> 1, jx = tap & 1;
+  const int ylo = jy ? 1 + ry : 0, yhi = jy ? 2 : ry, xlo = jx ? 1 + rx : 0, xhi = jx ? 2 : rx;
+  const float* q = w + ((size_t)o * ci + c) * 9;
+  float v = 0.f;
+  for (int y = ylo; y <= yhi; ++y)
+    for (int x = xlo; x <= xhi; ++x) v += q[y * 3 + x];
+  return v;
+}
+// Input gradient: out[c_in][k], k = (ty*4+tx)*co_ld + o - the forward-layout panel of the 4x4 stride-2 pad-1 conv of dy;
+// tap t sums the 3x3 taps max(0, 2-t) .. min(2, 3-t) per axis.
+__device__ __forceinline__ float up2_dgrad_elem(const float* __restrict__ w, int co, int ci, int co_ld, int Kpad, long long e) {
+  const int k = (int)(e % Kpad);
+  const int c_in = (int)(e / Kpad);
+  const int tap = k / co_ld, o = k - tap * co_ld;
+  if (c_in >= ci || tap >= 16 || o >= co) return 0.f;
+  const int ty = tap >> 2, tx = tap & 3;
+  const int ylo = max(0, 2 - ty), yhi = min(2, 3 - ty), xlo = max(0, 2 - tx), xhi = min(2, 3 - tx);
+  const float* q = w + ((size_t)o * ci + c_in) * 9;
+  float v = 0.f;
+  for (int y = ylo; y <= yhi; ++y)
+    for (int x = xlo; x <= xhi; ++x) v += q[y * 3 + x];
+  return v;
+}
+
+__global__ void pack_up2_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out, int co,
+                                int ci, int ld, int dgrad, long long total) {
+  const float sc = scale ? *scale : 1.f;
+  const int Kpad = dgrad ? round_up_d(16 * ld, BK) : round_up_d(4 * ld, BK);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    out[i] = sc * (dgrad ? up2_dgrad_elem(w, co, ci, ld, Kpad, i) : up2_fwd_elem(w, co, ci, ld, round_up_d(co, 16), Kpad, i));
+}
+
 // every packed panel of a model in one launch.  The job table lives in DEVICE memory (it is static for a
 // model: built once, no per-launch upload, capturable in a hipGraph): row j = 10 x int64
 // {w_oihw, out, co, ci, ld, kh, kw, stride, dgrad, start}; job j owns elements [start_j, start_{j+1}).
@@ -77,7 +118,11 @@ __global__ void pack_multi_kernel(const long long* __restrict__ table, int n, lo
     const int co = (int)b[2], ci = (int)b[3], ld = (int)b[4], kh = (int)b[5], kw = (int)b[6], stride = (int)b[7];
     const long long e = i - b[9];
     float v = 0.f;
-    if (!b[8]) {
+    if (b[8] == 2) {
+      v = up2_fwd_elem(w, co, ci, ld, round_up_d(co, 16), round_up_d(4 * ld, BK), e);
+    } else if (b[8] == 3) {
+      v = up2_dgrad_elem(w, co, ci, ld, round_up_d(16 * ld, BK), e);
+    } else if (!b[8]) {
       const int Kpad = round_up_d(kh * kw * ld, BK);
       int k = (int)(e % Kpad), o = (int)(e / Kpad);
       int tap = k / ld, c = k - tap * ld;
@@ -328,6 +373,12 @@ inline int in_norm_of(const itg_conv_geom* g, const itg_tensor* in, const itg_in
   *out = n;
   return ITG_OK;
 }
+// itg_conv_geom.up2: 3x3, stride 1, pad 1 on the x2 upsample of `lo` (half the patch extent of `hi`, same grid)
+inline int up2_check(const itg_conv_geom* g, const itg_tensor* lo, const itg_tensor* hi) {
+  if (g->kh != 3 || g->kw != 3 || g->stride != 1 || g->pad != 1 || pad_v_raw(g) != 1 || g->in_norm) return ITG_ERR_ARG;
+  if (lo->n != hi->n || lo->gh != hi->gh || lo->gw != hi->gw || 2 * lo->ph != hi->ph || 2 * lo->pw != hi->pw) return ITG_ERR_ARG;
+  return ITG_OK;
+}
 inline void clear_xf(ConvP& p) {
   p.in_ab = nullptr; p.in_act = ITG_ACT_NONE; p.in_slope = 0.f; p.in_ups = 0;
   p.bnx = null_grid(); p.bn_ab = nullptr; p.bn_mr = nullptr; p.bn_act = ITG_ACT_NONE; p.bn_slope = 0.f; p.bn_ups = 0;
@@ -384,6 +435,28 @@ int itg_pack_dgrad(const float* w, const float* scale, float* out, int co, int c
   return ITG_OK;
 }
 
+int64_t itg_pack_up2_fwd_size(int co, int ci_ld) { return (int64_t)4 * round_up(co, 16) * round_up(4 * ci_ld, BK); }
+
+int64_t itg_pack_up2_dgrad_size(int ci, int co_ld) { return (int64_t)round_up(ci, 16) * round_up(16 * co_ld, BK); }
+
+static int pack_up2(const float* w, const float* scale, float* out, int co, int ci, int ld, int dgrad, void* stream) {
+  if (!w || !out || co <= 0 || ci <= 0 || (ld & 3) || ld < (dgrad ? co : ci)) return ITG_ERR_ARG;
+  const int64_t total = dgrad ? itg_pack_up2_dgrad_size(ci, ld) : itg_pack_up2_fwd_size(co, ld);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_up2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, scale, out, co, ci, ld, dgrad,
+                     (long long)total);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_pack_up2_fwd(const float* w, const float* scale, float* out, int co, int ci, int ci_ld, void* stream) {
+  return pack_up2(w, scale, out, co, ci, ci_ld, 0, stream);
+}
+
+int itg_pack_up2_dgrad(const float* w, const float* scale, float* out, int co, int ci, int co_ld, void* stream) {
+  return pack_up2(w, scale, out, co, ci, co_ld, 1, stream);
+}
+
 int itg_pack_multi(const int64_t* table_dev, int n, int64_t total, void* stream) {
   if (!table_dev || n <= 0 || n > ITG_PACK_MAX_JOBS || total <= 0) return ITG_ERR_ARG;
   int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
@@ -395,6 +468,7 @@ int itg_pack_multi(const int64_t* table_dev, int n, int64_t total, void* stream)
 
 int64_t itg_conv2d_fwd_workspace(const itg_tensor* in, const itg_tensor* out, const itg_conv_geom* g) {
   if (!in || !out || !g) return 0;
+  if (g->up2) return plan_nt(grid_pixels(out), round_up(out->c, 16), round_up(4 * in->ld, BK), 4, prec_of(g)).ws_floats;
   if (thin_out_conv(in, out, g)) {
     int64_t Min = grid_pixels(in);
     return Min * 16 + plan_nt(Min, 16, round_up(in->ld, BK), 1, prec_of(g)).ws_floats;
@@ -411,6 +485,10 @@ int64_t itg_conv2d_dgrad_workspace(const itg_tensor* dy, const itg_tensor* dx, c
   }
   int co_rows = round_up(dx->c, 16);
   int64_t H = (int64_t)dx->gh * dx->ph, W = (int64_t)dx->gw * dx->pw;
+  if (g->up2) {
+    const int e = g->pad_mode == ITG_PAD_REPLICATE ? 2 : 0;
+    return plan_nt((int64_t)dx->n * (H + e) * (W + e), co_rows, round_up(16 * dy->ld, BK), 1, prec_of(g)).ws_floats;
+  }
   if (g->stride == 1) {
     int eh = (g->pad_mode == ITG_PAD_REPLICATE) ? 2 * pad_v(g) : 0, ew = (g->pad_mode == ITG_PAD_REPLICATE) ? 2 * g->pad : 0;
     return plan_nt((int64_t)dx->n * (H + eh) * (W + ew), co_rows, round_up(g->kh * g->kw * dy->ld, BK), 1, prec_of(g)).ws_floats;
@@ -429,6 +507,42 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   const itg_in_norm* nin;
   if (!w_packed || !g) return ITG_ERR_ARG;
   if ((rc = in_norm_of(g, in, &nin))) return rc;
+  if (g->up2) {
+    // four output-parity classes in one grid: class (ry, rx) = output pixels (2y + ry, 2x + rx), a 2 x 2 conv of the source
+    // tensor whose taps start at (y + ry - 1, x + rx - 1); the frame clamps / predicates in SOURCE coordinates, which is
+    // the upsampled image's replicate / zero padding (its row -1 is source row -1)
+    if ((rc = up2_check(g, in, out))) return rc;
+    ConvP p;
+    clear_xf(p);
+    p.prec = prec_of(g);
+    p.in = make_grid(in); p.out = make_grid(out);
+    p.res = null_grid(); p.res_ups = 0; p.res_mode = 0; p.res_slope = 0.f;
+    if (residual && residual->ptr) {
+      if ((rc = check_tensor(residual))) return rc;
+      if (!same_shape(residual, out)) return ITG_ERR_ARG;
+      p.res = make_grid(residual);
+    }
+    p.w = w_packed; p.bias = bias; p.scale = out_scale;
+    p.stats = g->out_stats;
+    if (p.stats && out->ld > 512) return ITG_ERR_ARG;
+    p.ntaps = 4; p.kw = 2; p.cin_ld = in->ld;
+    p.Kpad = round_up(4 * in->ld, BK);
+    p.co_rows = round_up(out->c, 16);
+    p.isy = p.isx = 1; p.osy = p.osx = 2;
+    p.pad_mode = g->pad_mode; p.out_mode = 0; p.act = act; p.slope = slope;
+    const int64_t M = (int64_t)in->n * p.in.H * p.in.W;
+    if (M >= ((int64_t)1 << 29)) return ITG_ERR_ARG;
+    p.ncls = 4;
+    for (int c = 0; c < 4; ++c) {
+      const int ry = c >> 1, rx = c & 1;
+      p.cMT[c] = p.in.H; p.cMU[c] = p.in.W; p.cM[c] = (int)M;
+      p.cioy[c] = ry - 1; p.ciox[c] = rx - 1; p.cooy[c] = ry; p.coox[c] = rx;
+      p.cwoff[c] = (unsigned)((size_t)c * p.co_rows * p.Kpad);
+    }
+    p.M = (int)M; p.MT = p.in.H; p.MU = p.in.W;
+    p.ioy = p.cioy[0]; p.iox = p.ciox[0]; p.ooy = 0; p.oox = 0;
+    return dispatch_nt(p, workspace, workspace_floats, (hipStream_t)stream);
+  }
   if (cin1_conv(in, out, g) && !(residual && residual->ptr)) {
     const int H = in->gh * in->ph, W = in->gw * in->pw;
     if (in->n != out->n || H - 2 != out->gh * out->ph || W - 2 != out->gw * out->pw) return ITG_ERR_ARG;
@@ -513,6 +627,39 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
   if (!w_packed_dgrad || !g) return ITG_ERR_ARG;
   if (dy->n != dx->n) return ITG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  if (g->up2) {
+    // dx(z) = sum_t W4(t) dy(2 z + t - 1): the 4 x 4 stride-2 conv of dy with the phase-summed taps (itg_pack_up2_dgrad).
+    // Replicate padding: the frame's source pixels are x(-1) := x(0), ..., so the domain is extended by one source pixel
+    // on every side and the gradients of the frame fold onto the edge pixels (atomics on the zeroed 1-pixel border).
+    if ((rc = up2_check(g, dx, dy))) return rc;
+    ConvP p;
+    clear_xf(p);
+    p.stats = nullptr; p.ncls = 1; p.prec = prec_of(g);
+    p.in = make_grid(dy); p.out = make_grid(dx);
+    p.res = null_grid(); p.res_mode = 0; p.res_slope = 0.f; p.res_ups = 0;
+    if (act_out && act_out->ptr && act != ITG_ACT_NONE) {
+      if ((rc = check_tensor(act_out))) return rc;
+      if (!same_shape(act_out, dx)) return ITG_ERR_ARG;
+      p.res = make_grid(act_out); p.res_mode = act; p.res_slope = slope;
+    }
+    p.w = w_packed_dgrad; p.bias = nullptr; p.scale = out_scale; p.act = ITG_ACT_NONE; p.slope = 0.f;
+    p.cin_ld = dy->ld; p.co_rows = round_up(dx->c, 16);
+    p.ntaps = 16; p.kw = 4; p.Kpad = round_up(16 * dy->ld, BK);
+    p.isy = p.isx = 2; p.osy = p.osx = 1;
+    p.pad_mode = ITG_PAD_ZERO;
+    if (g->pad_mode == ITG_PAD_REPLICATE) {
+      p.MT = p.out.H + 2; p.MU = p.out.W + 2;
+      p.ioy = p.iox = -3; p.ooy = p.oox = -1; p.out_mode = 1;
+      if ((rc = launch_zero_border(p.out, s))) return rc;
+    } else {
+      p.MT = p.out.H; p.MU = p.out.W;
+      p.ioy = p.iox = -1; p.ooy = p.oox = 0; p.out_mode = 0;
+    }
+    const int64_t M = (int64_t)dx->n * p.MT * p.MU;
+    if (M >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
+    p.M = (int)M;
+    return dispatch_nt(p, workspace, workspace_floats, s);
+  }
   if (thin_in_conv(dy, dx, g) && !g->in_norm) {
     const int Ho = dy->gh * dy->ph, Wo = dy->gw * dy->pw, H = dx->gh * dx->ph, W = dx->gw * dx->pw;
     if (conv_out_dim(H, 4, 2, 1) != Ho || conv_out_dim(W, 4, 2, 1) != Wo) return ITG_ERR_ARG;
@@ -641,6 +788,10 @@ int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, co
     TnPlan t = plan_tn(Min, 16, x->ld, prec_of(g));
     return Min * 16 + 16 * (int64_t)x->c + 16 + t.ws_floats + (int64_t)t.splits * t.co_rows;
   }
+  if (g->up2) {
+    TnPlan t = plan_tn(grid_pixels(x), dy->ld, 4 * x->ld, prec_of(g), 4);
+    return t.ws_floats + (int64_t)4 * t.splits * t.co_rows;
+  }
   int64_t M = grid_pixels(dy);
   TileWgPlan tw = plan_wgrad_tile(x, dy, g);
   TnPlan t = tw.ok ? tn_plan_for_tiles(tw, dy->ld, g->kh * g->kw * x->ld) : plan_tn(M, dy->ld, g->kh * g->kw * x->ld, prec_of(g));
@@ -653,6 +804,32 @@ static int wgrad_setup(const itg_tensor* x, const itg_tensor* dy, const itg_conv
   int rc;
   p.x = make_grid(x);
   p.dy = make_grid(dy);
+  p.up2 = 0;
+  if (g->up2) {
+    // conv3x3(up2x(x)): four output-parity classes of 2 x 2 taps over the SOURCE pixel domain (WgP.up2); the replicate
+    // clamp of the gathered operand in source coordinates is the upsampled image's replicate padding
+    if ((rc = up2_check(g, x, dy))) return rc;
+    p.in_ab = nullptr; p.in_act = ITG_ACT_NONE; p.in_slope = 0.f; p.in_ups = 0;
+    p.up2 = 1;
+    const int64_t M = grid_pixels(x);
+    if (M >= ((int64_t)1 << 29)) return ITG_ERR_ARG;
+    p.ntaps = 4; p.kw = 2; p.cin_ld = x->ld; p.Ktot = 4 * x->ld;
+    const int prec = prec_of(g);
+    TnPlan t = plan_tn(M, dy->ld, p.Ktot, prec, 4);
+    if (t.ws_floats + (int64_t)4 * t.splits * t.co_rows > workspace_floats) return ITG_ERR_WORKSPACE;
+    p.Kpad = t.Kpad; p.co_rows = t.co_rows;
+    p.slab = workspace;
+    p.dbslab = want_db ? workspace + t.ws_floats : nullptr;       // [splits][4][co_rows]
+    p.MT = p.x.H; p.MU = p.x.W; p.M = (int)M;
+    p.stride = 1; p.pad = 1; p.pad_h = 1; p.pad_mode = g->pad_mode;
+    p.chunks_per_split = t.chunks_per_split; p.nchunks = t.nchunks;
+    int64_t xb = grid_pixels(x) * x->ld * 4, yb = grid_pixels(dy) * dy->ld * 4;
+    if (xb >= 0xFFFF0000LL || yb >= 0xFFFF0000LL) return ITG_ERR_ARG;
+    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
+    tw_out.ok = 0;
+    t_out = t; prec_out = prec;
+    return ITG_OK;
+  }
   const itg_in_norm* nin;
   if ((rc = in_norm_of(g, x, &nin))) return rc;
   const int ups = nin ? nin->upsample : 0;
@@ -733,6 +910,7 @@ int itg_conv2d_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, const itg_
   if (!g || !workspace || !job) return ITG_ERR_ARG;
   if (x->n != dy->n || g->kh * g->kw > 49) return ITG_ERR_ARG;
   if (thin_out_conv(x, dy, g) && !g->in_norm) return ITG_ERR_ARG;      // taps-as-rows path: not deferrable
+  if (g->up2) return ITG_ERR_ARG;                                       // folded-upsample layers reduce through their own kernel
   WgP p;
   TnPlan t;
   TileWgPlan tw;

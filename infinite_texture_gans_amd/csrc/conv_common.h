@@ -147,6 +147,10 @@ struct WgP {
   int chunks_per_split, nchunks;
   unsigned x_bytes, dy_bytes;
   const float* in_ab; int in_act; float in_slope; int in_ups;     // input transform of x (see ConvP)
+  // itg_conv_geom.up2 (conv_tn_kernel only): x is the half-size source tensor and blockIdx.y = output-parity class (ry, rx):
+  // pixel (t, u) of the SOURCE domain pairs dY(2t + ry, 2u + rx) with the 2 x 2 taps at (t + ry - 1, u + rx - 1); slab and
+  // bias partial of (split, class) sit at index split * 4 + class
+  int up2;
 };
 
 constexpr int BKP = 16;  // pixels per pipeline stage (fp32 operands; 32 with bf16 operands)
@@ -170,7 +174,7 @@ int launch_zero_border(const GridT& g, hipStream_t s);
 int launch_nt_fused(int mode, int bco, int bpix, const ConvP& p, int k, hipStream_t s);
 // conv_wgrad.hip
 TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g);
-TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec = ITG_PREC_F32);
+TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec = ITG_PREC_F32, int ncls = 1);
 TnPlan tn_plan_for_tiles(const TileWgPlan& tw, int co_ld, int Ktot);
 int run_wgrad(WgP& p, const TnPlan& t, const TileWgPlan& tw, int prec, const itg_tensor* x, const itg_tensor* dy,
               const itg_conv_geom* g, float* dw, float* db, int accumulate, float* workspace, hipStream_t s);

@@ -39,8 +39,12 @@ __global__ void zero_border_kernel(GridT g) {
 }
 
 // split-K second stage: out = act(sum_z partial[z] + bias [+ residual]) with the same output mapping
+// (blockIdx.y = parity class of a multi-class launch: one second-stage launch for all of them)
 __global__ void splitk_epilogue_kernel(ConvP p) {
   const int q4 = p.out.ld >> 2;
+  const int cls = blockIdx.y;
+  p.M = p.cM[cls]; p.MT = p.cMT[cls]; p.MU = p.cMU[cls]; p.ooy = p.cooy[cls]; p.oox = p.coox[cls];
+  p.partial += p.cpoff[cls];
   int64_t total = (int64_t)p.M * q4;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int c4 = (int)(i % q4);
@@ -253,19 +257,17 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
   int rc = mode == NT_PLAIN ? launch_nt_shape<NT_PLAIN>(pl.bco, pl.bpix, p, k, s) : launch_nt_fused(mode, pl.bco, pl.bpix, p, k, s);
   if (rc) return rc;
   if (!second_stage) return (want_stats && !p.stats) ? stats_after(p, want_stats, s) : ITG_OK;   // (bn_sums: taken by the epilogue)
-  const int ncls = p.ncls > 1 ? p.ncls : 1;
-  for (int c = 0; c < ncls; ++c) {
-    ConvP q = p;
-    if (p.ncls > 1) {
-      q.MT = p.cMT[c]; q.MU = p.cMU[c]; q.M = p.cM[c];
-      q.ioy = p.cioy[c]; q.iox = p.ciox[c]; q.ooy = p.cooy[c]; q.oox = p.coox[c];
-      q.partial = p.partial + p.cpoff[c];
-      if (q.M <= 0) continue;
+  {
+    const int ncls = p.ncls > 1 ? p.ncls : 1;
+    int mmax = 0;
+    for (int c = 0; c < ncls; ++c) mmax = p.cM[c] > mmax ? p.cM[c] : mmax;
+    int64_t total = (int64_t)mmax * (p.out.ld >> 2);
+    int per = 8192 / ncls;
+    int blocks = (int)((total + 255) / 256 < per ? (total + 255) / 256 : per);
+    if (blocks > 0) {
+      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks, ncls), dim3(256), 0, s, p);
+      ITG_CHECK_LAUNCH();
     }
-    int64_t total = (int64_t)q.M * (q.out.ld >> 2);
-    int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, q);
-    ITG_CHECK_LAUNCH();
   }
   if (want_bn) return bn_reduce_after(p, want_bn, s);
   return (want_stats && !p.stats) ? stats_after(p, want_stats, s) : ITG_OK;

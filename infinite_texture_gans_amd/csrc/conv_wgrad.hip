@@ -42,6 +42,8 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
   const int col0 = col_tile * BCOL, co0 = co_tile * BCO;
   const int wcol0 = (wave % WAVES_COL) * WCOL, wco0 = (wave / WAVES_COL) * WCO;
   const int split = blockIdx.z;
+  const int cls = blockIdx.y, ncls = gridDim.y;            // up2: output-parity class (1 class otherwise)
+  const int ry = p.up2 ? cls >> 1 : 0, rx = p.up2 ? cls & 1 : 0;
   const int chunk_begin = split * p.chunks_per_split;
   const int chunk_end = min(p.nchunks, chunk_begin + p.chunks_per_split);
 
@@ -117,9 +119,9 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
       if (!pact[i]) continue;
       unsigned o;
       if (pdy[i]) {
-        o = live ? (unsigned)grid_off(p.dy, pn, pt_, pu) * 4u : p.dy_bytes;
+        o = live ? (unsigned)grid_off(p.dy, pn, (pt_ << p.up2) + ry, (pu << p.up2) + rx) * 4u : p.dy_bytes;
       } else {
-        int iy = pt_ * p.stride - p.pad_h + pky[i], ix = pu * p.stride - p.pad + pkx[i];
+        int iy = pt_ * p.stride - p.pad_h + pky[i] + ry, ix = pu * p.stride - p.pad + pkx[i] + rx;
         bool ok = live;
         const int ups = XF ? p.in_ups : 0;
         const int Hv = p.x.H << ups, Wv = p.x.W << ups;      // conv coordinates: those of the (x2 upsampled) input
@@ -305,11 +307,11 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
       // a partial of the same 4 channels
       float sdb = 0.f;
       for (int r = (tid >> 2); r < 256; r += YG) sdb += red[r][tid & 3];
-      p.dbslab[(size_t)split * p.co_rows + co0 + tid] = sdb;
+      p.dbslab[((size_t)split * ncls + cls) * p.co_rows + co0 + tid] = sdb;
     }
   }
   // D[row = column index (4 consecutive per lane)][col = co]
-  float* slab = p.slab + (size_t)split * p.co_rows * p.Kpad;
+  float* slab = p.slab + ((size_t)split * ncls + cls) * p.co_rows * p.Kpad;
   const int cq = (lane >> 4) * 4;
 #pragma unroll
   for (int j = 0; j < FJ; ++j) {
@@ -702,7 +704,7 @@ TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_
   t.ok = 0;
   static const int enable = env_int("ITG_WGRAD_TILE", 1);
   const int ph = g->pad_h >= 0 ? g->pad_h : g->pad;
-  if (!enable || g->kh != 3 || g->kw != 3 || g->stride != 1 || g->pad != 1 || ph != 1) return t;
+  if (!enable || g->up2 || g->kh != 3 || g->kw != 3 || g->stride != 1 || g->pad != 1 || ph != 1) return t;
   if (g->precision == ITG_PREC_BF16 || x->ld > 32 || dy->ld > 16 || (dy->ld != 4 && dy->ld != 8 && dy->ld != 16)) return t;
   const int H = dy->gh * dy->ph, W = dy->gw * dy->pw;
   if ((int64_t)H * W < 64 * 64) return t;
@@ -817,6 +819,63 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   for (int idx = threadIdx.x; idx < cn * taps; idx += 256) dst[idx] = (accumulate & ITG_ACC_DW) ? dst[idx] + tile[idx] : tile[idx];
 }
 
+// itg_conv_geom.up2: slab z = [class (ry, rx)][co][(jy*2+jx)*ci_ld + ci] holds the class's 2 x 2 tap gradients; tap (i, j) of
+// the 3 x 3 filter belongs to tap (jy, jx) = ((i + 1 - ry) >> 1, (j + 1 - rx) >> 1) of every class (the adjoint of the
+// phase sums of itg_pack_up2_fwd):  dW[o][c][i][j] (+)= sum_z sum_cls slab[z][cls][o][(jy*2+jx)*ci_ld + c]
+__global__ __launch_bounds__(256) void wgrad_up2_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                               float* __restrict__ db, const float* __restrict__ dbslab,
+                                                               int dbsplits, int splits, int co, int ci, int ci_ld, int co_rows,
+                                                               int Kpad, int accumulate) {
+  __shared__ float t16[64 * 17];
+  __shared__ float part[256];
+  const int nchunk = (ci + 63) / 64;
+  const int o = blockIdx.x / nchunk;
+  const int c0 = (blockIdx.x - o * nchunk) * 64;
+  const int cn = min(64, ci - c0);
+  const size_t cstride = (size_t)co_rows * Kpad, zstride = 4 * cstride;
+  if (db && c0 == 0) {
+    float sdb = 0.f;
+    for (int z = threadIdx.x; z < dbsplits; z += 256) sdb += dbslab[(size_t)z * co_rows + o];
+    part[threadIdx.x] = sdb;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) db[o] = (accumulate & ITG_ACC_DB) ? db[o] + part[0] : part[0];
+  }
+  for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
+    const int c = idx & 63, q = idx >> 6;                  // q = class * 4 + tap
+    float s = 0.f;
+    if (c < cn) {
+      const float* src = slab + (size_t)(q >> 2) * cstride + (size_t)o * Kpad + (size_t)(q & 3) * ci_ld + c0 + c;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int z = 0;
+      for (; z + 4 <= splits; z += 4) {
+        s0 += src[(size_t)z * zstride];
+        s1 += src[(size_t)(z + 1) * zstride];
+        s2 += src[(size_t)(z + 2) * zstride];
+        s3 += src[(size_t)(z + 3) * zstride];
+      }
+      for (; z < splits; ++z) s0 += src[(size_t)z * zstride];
+      s = (s0 + s1) + (s2 + s3);
+    }
+    t16[c * 17 + q] = s;
+  }
+  __syncthreads();
+  float* dst = dw + ((size_t)o * ci + c0) * 9;
+  for (int idx = threadIdx.x; idx < cn * 9; idx += 256) {
+    const int c = idx / 9, t = idx - c * 9, i = t / 3, j = t - i * 3;
+    float v = 0.f;
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {
+      const int jy = (i + 1 - (cls >> 1)) >> 1, jx = (j + 1 - (cls & 1)) >> 1;
+      v += t16[c * 17 + cls * 4 + jy * 2 + jx];
+    }
+    dst[idx] = (accumulate & ITG_ACC_DW) ? dst[idx] + v : v;
+  }
+}
+
 // out[zo][e] = sum over the zo-th group of `group` slabs
 __global__ void slab_group_reduce_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, int64_t e4, int splits,
                                          int group, int ngroups) {
@@ -835,7 +894,7 @@ template <int BCOL, int BCO, int WCOL, int WCO>
 int launch_tn(WgP p, int splits, int prec, hipStream_t s) {
   p.ncol_tiles = (p.Kpad + BCOL - 1) / BCOL;
   p.nco_tiles = (p.co_rows + BCO - 1) / BCO;
-  dim3 grid((unsigned)(p.ncol_tiles * p.nco_tiles), 1, (unsigned)splits);
+  dim3 grid((unsigned)(p.ncol_tiles * p.nco_tiles), p.up2 ? 4u : 1u, (unsigned)splits);
   // offset-table pitch: the taps one column tile can touch (+ the dY slot)
   int taps_tile = (BCOL + p.cin_ld - 1) / p.cin_ld + 1;
   if (taps_tile > p.ntaps) taps_tile = p.ntaps;
@@ -865,7 +924,7 @@ int launch_tn(WgP p, int splits, int prec, hipStream_t s) {
 }
 
 
-TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec) {
+TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec, int ncls) {
   const int kp = prec == ITG_PREC_BF16 ? 32 : BKP;
   TnPlan t;
   t.co_rows = round_up(co_ld, 16);
@@ -881,15 +940,15 @@ TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec) {
   // weighs more: 2 per CU (config 3: 1996 -> 2026 crops/s; config 1 loses 1 % with it)
   static const int want_env = env_int("ITG_TN_BLOCKS", 0);
   const int want_blocks = want_env ? want_env : (prec == ITG_PREC_BF16 ? 512 : 768);
-  int want = (want_blocks + tiles - 1) / tiles;
+  int want = (want_blocks / ncls + tiles - 1) / tiles;      // ncls grids of (tiles x splits) workgroups run as one launch
   int max_splits = (t.nchunks + 7) / 8;             // at least 8 chunks per split
   int splits = want < max_splits ? want : max_splits;
   if (splits < 1) splits = 1;
   t.chunks_per_split = (t.nchunks + splits - 1) / splits;
   t.splits = (t.nchunks + t.chunks_per_split - 1) / t.chunks_per_split;
-  t.slab_floats = (int64_t)t.splits * t.co_rows * t.Kpad;
+  t.slab_floats = (int64_t)t.splits * ncls * t.co_rows * t.Kpad;
   t.ngroups = t.splits > red_group() ? (t.splits + red_group() - 1) / red_group() : 0;
-  t.ws_floats = t.slab_floats + (int64_t)t.ngroups * t.co_rows * t.Kpad;
+  t.ws_floats = t.slab_floats + (int64_t)t.ngroups * ncls * t.co_rows * t.Kpad;
   return t;
 }
 
@@ -936,8 +995,9 @@ int run_wgrad(WgP& p, const TnPlan& t, const TileWgPlan& tw, int prec, const itg
   if (rc) return rc;
   const float* red_src = workspace;
   int red_n = t.splits;
+  const int ncls = p.up2 ? 4 : 1;
   if (t.ngroups > 0) {
-    int64_t e4 = (int64_t)t.co_rows * t.Kpad / 4;
+    int64_t e4 = (int64_t)ncls * t.co_rows * t.Kpad / 4;
     float* stage = workspace + t.slab_floats;
     int64_t tot4 = e4 * t.ngroups;
     int b2 = (int)((tot4 + 255) / 256 < 8192 ? (tot4 + 255) / 256 : 8192);
@@ -948,6 +1008,12 @@ int run_wgrad(WgP& p, const TnPlan& t, const TileWgPlan& tw, int prec, const itg
   }
   if (g->kh * g->kw > 49) return ITG_ERR_ARG;
   int blocks = dy->c * ((x->c + 63) / 64);
+  if (p.up2) {
+    hipLaunchKernelGGL(wgrad_up2_reduce_kernel, dim3(blocks), dim3(256), 0, s, red_src, dw, db, (const float*)p.dbslab,
+                       t.splits * 4, red_n, dy->c, x->c, x->ld, t.co_rows, t.Kpad, accumulate);
+    ITG_CHECK_LAUNCH();
+    return ITG_OK;
+  }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, red_src, dw, db, (const float*)p.dbslab,
                      t.splits, red_n, dy->c, x->c, x->ld, g->kh, g->kw, t.co_rows, t.Kpad, accumulate);
   ITG_CHECK_LAUNCH();

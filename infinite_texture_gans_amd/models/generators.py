@@ -4,7 +4,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..ops import GT
-from .layers import LocalPadder, Attention, conv2d_lp, ResBlockGenerator, _BNParams
+from .layers import LocalPadder, Attention, conv2d_lp, ResBlockGenerator, _BNParams, up2_fold_enabled
 
 
 class ResidualPatchGenerator(nn.Module):
@@ -41,6 +41,10 @@ class ResidualPatchGenerator(nn.Module):
         widths = [c * 8, c * 8, c * 4, c * 2, c, c // 2, c // 4]
         for i in range(1, n_layers_G + 1):
             setattr(self, "block%d" % i, ResBlockGenerator(self, widths[i - 1], widths[i], padding_mode=padding_mode))
+        # blocks 2.. sit behind the x2 upsample (forward_grid): their first conv folds it into its filter, and a step engine
+        # keeps the folded panels for it (layers._ConvParams.up2); SSM modulates at the upsampled resolution: no fold there
+        for i in range(2, n_layers_G + 1):
+            getattr(self, "block%d" % i).conv1.conv.up2 = type_norm == 'BN' and up2_fold_enabled()
         final_chin = widths[n_layers_G]
         if type_norm == 'BN':
             self.bn = _BNParams(final_chin)

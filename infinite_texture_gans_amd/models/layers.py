@@ -27,6 +27,7 @@ def _pad_mode(outer_padding):
 _ENV_BN_LOADER = os.environ.get("ITG_BN_LOADER", "0") == "1"
 _ENV_RES_UPS = os.environ.get("ITG_RES_UPS", "1") == "1"
 _ENV_BN_FUSE = os.environ.get("ITG_BN_FUSE", "1") == "1"
+_ENV_UP2_FOLD = os.environ.get("ITG_UP2_FOLD", "1") == "1"
 
 
 def loader_norm_enabled():
@@ -35,6 +36,13 @@ def loader_norm_enabled():
     normalisation passes per step and adds 0.40 ms to the convolutions whose loaders / epilogues carry them (config 1:
     765 vs 778 crops/s, profiles/r03_bn_loader_ab.txt)."""
     return _ENV_BN_LOADER
+
+
+def up2_fold_enabled():
+    """ITG_UP2_FOLD=0: materialise the x2 upsample in front of every block's first conv again (A/B).  Default: the conv
+    runs in folded form on the half-size tensor (ops.conv(up2=True)): conv3x3(up2x(x)) is four 2 x 2 convs of x with
+    phase-summed weights - 4/9 of the multiply-adds, no upsampled tensor, the upsample's backward inside the input gradient."""
+    return _ENV_UP2_FOLD
 
 
 def res_upsample_enabled():
@@ -76,17 +84,22 @@ class _ConvParams(nn.Module):
     grad_sinks = False
     _preset_inv = None      # 1/sigma computed ahead by a model-level batched power iteration
     _packed = None          # (forward panel, dgrad panel) kept current by engine.PackSet, else packed per call
+    _packed_up2 = False     # the persistent panels are the folded-upsample ones (itg_pack_up2_*)
+    up2 = False             # this conv sits behind a x2 upsample that its owner folds into it (ResBlockGenerator.conv1)
 
     def pack_jobs(self):
         """Allocate this layer's persistent panels and return its two ops.pack_multi jobs."""
         w = self.weight_orig if self.SN else self.weight
         co, ci, k, st = w.shape[0], w.shape[1], self.k, self.stride
-        nf, nd = ops.pack_sizes(co, ci, k, k, st)
-        if self._packed is None or self._packed[0].device != w.device:
+        up2 = bool(self.up2)
+        nf, nd = ops.pack_sizes(co, ci, k, k, st, up2)
+        if (self._packed is None or self._packed[0].device != w.device or self._packed_up2 != up2
+                or self._packed[0].numel() != nf):
             self._packed = (torch.empty(nf, device=w.device, dtype=torch.float32),
                             torch.empty(nd, device=w.device, dtype=torch.float32))
-        return [(w, self._packed[0], co, ci, ops.ld_for(ci), k, k, 1, 0),
-                (w, self._packed[1], co, ci, ops.ld_for(co), k, k, st, 1)]
+        self._packed_up2 = up2
+        return [(w, self._packed[0], co, ci, ops.ld_for(ci), k, k, 1, 2 if up2 else 0),
+                (w, self._packed[1], co, ci, ops.ld_for(co), k, k, st, 3 if up2 else 1)]
 
     def weight_and_sn(self):
         """(weight tensor, sn tuple or None); runs the power iteration in training mode.  u / v are not
@@ -106,11 +119,12 @@ class _ConvParams(nn.Module):
         return (w.grad, b.grad if (b is not None and b.grad is not None) else None)
 
     def run(self, x, pad=None, pad_mode=ops.PAD_ZERO, act=ops.ACT_NONE, slope=0.0, residual=None, out_grid=None,
-            pad_h=-1, in_act=None, defer_act_bwd=False, out_stats=False, out=None):
+            pad_h=-1, in_act=None, defer_act_bwd=False, out_stats=False, out=None, up2=False):
         w, sn = self.weight_and_sn()
+        packed = self._packed if (self._packed is None or self._packed_up2 == bool(up2)) else None    # else: packed per call
         return ops.conv(x, w, self.bias, self.k, self.k, self.stride, self.padding if pad is None else pad,
-                        pad_mode, act, slope, residual, sn, out_grid, self._sinks(w), pad_h, packed=self._packed,
-                        in_act=in_act, defer_act_bwd=defer_act_bwd, out_stats=out_stats, out=out)
+                        pad_mode, act, slope, residual, sn, out_grid, self._sinks(w), pad_h, packed=packed,
+                        in_act=in_act, defer_act_bwd=defer_act_bwd, out_stats=out_stats, out=out, up2=up2)
 
     def run_bn(self, x, bn, in_act, in_slope, upsample=False, pad=None, pad_mode=ops.PAD_ZERO, act=ops.ACT_NONE, slope=0.0,
                residual=None, out_grid=None, pad_h=-1, out_stats=False):
@@ -119,7 +133,8 @@ class _ConvParams(nn.Module):
             raise ValueError("the loader-side BatchNorm is not combined with spectral norm")
         w = self.weight
         return ops.bn_conv(x, bn.as_tuple(), w, self.bias, self.k, self.k, self.stride, self.padding if pad is None else pad,
-                           pad_mode, act, slope, residual, out_grid, self._sinks(w), pad_h, packed=self._packed,
+                           pad_mode, act, slope, residual, out_grid, self._sinks(w), pad_h,
+                           packed=None if self._packed_up2 else self._packed,
                            out_stats=out_stats, in_act=in_act, in_slope=in_slope, upsample=upsample)
 
     def forward(self, x):
@@ -270,11 +285,17 @@ class conv2d_lp(nn.Module):
         fused = (bn is not None and not self.conv.SN and loader_norm_enabled() and ops.MFMA_PRECISION == ops.PREC_F32
                  and (self.padding_mode != "local" or (self.local_padder.halo is None and self.local_padder.merge_patches_into_image
                                                        and (self.training or _whole_image(image_location)))))
+        # the x2 upsample in front of a block's first conv is folded into the conv (ops.conv(up2=True)) on the paths that hand
+        # the patch grid to the kernel as it is; the normalisation then stays at the block input's resolution
+        direct = (self.padding_mode != "local"
+                  or (self.local_padder.merge_patches_into_image and self.local_padder.halo is None
+                      and (self.training or _whole_image(image_location))))
+        fold = bool(upsample) and bn is not None and not fused and up2_fold_enabled() and direct
         if bn is not None and not fused:
-            x = bn.run(x, act=bn_act[0], slope=bn_act[1], upsample=upsample)
+            x = bn.run(x, act=bn_act[0], slope=bn_act[1], upsample=upsample and not fold, consumer_upsamples=fold)
         # a residual at half the output's patch extent (the un-upsampled shortcut) is read through the x2 upsample by the conv
         # epilogue on the paths that hand the patch grid to the kernel as it is; the reshaping paths materialise it
-        out_ph = x.t.shape[3] * (2 if (fused and upsample) else 1)
+        out_ph = x.t.shape[3] * (2 if ((fused or fold) and upsample) else 1)
         half_res = residual is not None and residual.t.shape[3] * 2 == out_ph
         native = (self.padding_mode == "local" and self.local_padder.merge_patches_into_image
                   and (self.training or (_whole_image(image_location) and self.local_padder.halo is None)))
@@ -284,13 +305,13 @@ class conv2d_lp(nn.Module):
             # per-patch zero padding: every patch is an independent image
             n, gh, gw, ph, pw, ld = x.t.shape
             flat = GT(x.t.reshape(n * gh * gw, 1, 1, ph, pw, ld), x.c, x.stats)
-            s_ = 2 if (fused and upsample) else 1
+            s_ = 2 if ((fused or fold) and upsample) else 1
             r = None if residual is None else GT(residual.t.reshape(n * gh * gw, 1, 1, ph * s_, pw * s_, -1), residual.c)
             if fused:
                 y = self.conv.run_bn(flat, bn, bn_act[0], bn_act[1], upsample, pad=1, pad_mode=ops.PAD_ZERO, act=act, slope=slope,
                                      residual=r)
             else:
-                y = self.conv.run(flat, pad=1, pad_mode=ops.PAD_ZERO, act=act, slope=slope, residual=r)
+                y = self.conv.run(flat, pad=1, pad_mode=ops.PAD_ZERO, act=act, slope=slope, residual=r, up2=fold)
             return GT(y.t.reshape(n, gh, gw, ph * s_, pw * s_, -1), y.c)
         lp = self.local_padder
         gh, gw, outer = lp.cfg()
@@ -304,10 +325,10 @@ class conv2d_lp(nn.Module):
         if fused:      # training, or ONE sub-image that is the whole picture (one-shot generation: no state is carried on)
             return self.conv.run_bn(x, bn, bn_act[0], bn_act[1], upsample, pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope,
                                     residual=residual, out_stats=out_stats)
-        if lp.training:
+        if lp.training or fold:     # (fold outside training: ONE sub-image that is the whole picture, no state is carried on)
             # halo + outer padding are resolved inside the conv's tile loader
             return self.conv.run(x, pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope, residual=residual,
-                                 out_stats=out_stats)
+                                 out_stats=out_stats, up2=fold)
         left, top = lp.halo_sources(x, image_location)
         if left is None and top is None and "1st_row" in image_location and "1st_col" in image_location:
             return self.conv.run(x, pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope, residual=residual)
@@ -391,11 +412,11 @@ class _BNParams(nn.BatchNorm2d):
         return (self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked, self.training,
                 self.eps, self.momentum, self.sync, self._sinks())
 
-    def run(self, x, act=ops.ACT_NONE, slope=0.0, upsample=False):
+    def run(self, x, act=ops.ACT_NONE, slope=0.0, upsample=False, consumer_upsamples=False):
         sinks = self._sinks()
         return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked,
                           training=self.training, eps=self.eps, momentum=self.momentum, act=act, slope=slope,
-                          upsample=upsample, sync=self.sync, sinks=sinks)
+                          upsample=upsample, sync=self.sync, sinks=sinks, consumer_upsamples=consumer_upsamples)
 
     def forward(self, x):
         if isinstance(x, GT):

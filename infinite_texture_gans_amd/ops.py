@@ -259,13 +259,13 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, residual, sn, c_in, geom, act, slope, out_grid, sinks=None, packed=None, fuse=(None, False),
                 stats=None, out_buf=None):
-        kh, kw, stride, pad, pad_mode, pad_h, prec = geom
+        kh, kw, stride, pad, pad_mode, pad_h, prec, up2 = geom
         pv = pad_h if pad_h >= 0 else pad
         n, gh, gw, ph, pw, ld = x.shape
         co, ci = w.shape[0], w.shape[1]
         if ci != c_in or w.shape[2] != kh or w.shape[3] != kw:
             raise _lib.ItgError("weight %s does not match conv geometry (c_in=%d, k=%dx%d)" % (tuple(w.shape), c_in, kh, kw))
-        H, W = gh * ph, gw * pw
+        H, W = (gh * ph) << up2, (gw * pw) << up2        # up2: the conv runs on the x2 upsample of x (folded into the filter)
         Ho, Wo = (H + 2 * pv - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
         ogh, ogw = out_grid
         if Ho % ogh or Wo % ogw:
@@ -275,6 +275,9 @@ class _Conv(torch.autograd.Function):
         inv_sigma = sn[0] if sn is not None else None
         if packed is not None:      # panels packed once per optimizer step (engine.PackSet): 1/sigma rides in the epilogue
             wp, out_scale = packed[0], inv_sigma
+        elif up2:
+            wp, out_scale = torch.empty(_lib.fn("itg_pack_up2_fwd_size")(co, ld), device=x.device, dtype=torch.float32), None
+            _lib.call("itg_pack_up2_fwd", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, ld, st)
         else:
             wp, out_scale = torch.empty(_lib.fn("itg_pack_fwd_size")(co, ld, kh, kw), device=x.device, dtype=torch.float32), None
             _lib.call("itg_pack_fwd", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, ld, kh, kw, st)
@@ -287,13 +290,14 @@ class _Conv(torch.autograd.Function):
             out = torch.empty(oshape, device=x.device, dtype=torch.float32)
         dx_, do_ = _desc(x, c_in), _desc(out, co)
         dr_ = _desc(residual, co) if residual is not None else _null_desc()
-        g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, stats.data_ptr() if stats is not None else None)
+        g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, stats.data_ptr() if stats is not None else None, None, up2)
         key = ("f", tuple(x.shape), tuple(out.shape), geom, c_in, co)
         nws = _WS_SIZE.get(key)
         if nws is None:
             nws = _WS_SIZE[key] = _lib.fn("itg_conv2d_fwd_workspace")(C.byref(dx_), C.byref(do_), C.byref(g))
         ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
-        with _Prof(_nt_tag(co), 1, 2.0 * n * Ho * Wo * co * ci * kh * kw, 4 * (x.numel() + out.numel() + wp.numel())):
+        taps = 4 if up2 else kh * kw          # multiply-adds per output element and input channel
+        with _Prof(_nt_tag(co), 1, 2.0 * n * Ho * Wo * co * ci * taps, 4 * (x.numel() + out.numel() + wp.numel())):
             _lib.call("itg_conv2d_fwd", C.byref(dx_), _ptr(wp), _ptr(bias), _ptr(out_scale), C.byref(dr_), C.byref(do_),
                       C.byref(g), act, float(slope), _ptr(ws), nws, st)
         ctx.geom, ctx.act, ctx.slope, ctx.c_in, ctx.co = geom, act, slope, c_in, co
@@ -312,7 +316,8 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x, w, out = ctx.saved_tensors
-        kh, kw, stride, pad, pad_mode, pad_h, prec = ctx.geom
+        kh, kw, stride, pad, pad_mode, pad_h, prec, up2 = ctx.geom
+        taps = 4 if up2 else kh * kw
         co, ci = ctx.co, ctx.c_in
         if BACKWARD_ENTRY_HOOK is not None and ctx.sinks is not None:
             BACKWARD_ENTRY_HOOK(ctx.sinks)
@@ -324,13 +329,17 @@ class _Conv(torch.autograd.Function):
             _lib.call("itg_act_bwd", C.byref(a), C.byref(b), C.byref(c_), ctx.act, float(ctx.slope), st)
         else:
             dy = dout
-        g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec)
+        g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, None, None, up2)
         ddy = _desc(dy, co)
         inv_sigma = ctx.sn[0] if ctx.sn is not None else None
         gx = gw_ = gb = None
         if ctx.needs_input_grad[0]:
             if ctx.packed is not None:
                 wp, out_scale = ctx.packed[1], inv_sigma
+            elif up2:
+                wp, out_scale = torch.empty(_lib.fn("itg_pack_up2_dgrad_size")(ci, dy.shape[5]), device=x.device,
+                                            dtype=torch.float32), None
+                _lib.call("itg_pack_up2_dgrad", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, dy.shape[5], st)
             else:
                 wp, out_scale = torch.empty(_lib.fn("itg_pack_dgrad_size")(ci, dy.shape[5], kh, kw, stride), device=x.device,
                                             dtype=torch.float32), None
@@ -343,7 +352,7 @@ class _Conv(torch.autograd.Function):
             if nws is None:
                 nws = _WS_SIZE[key] = _lib.fn("itg_conv2d_dgrad_workspace")(C.byref(ddy), C.byref(ddx), C.byref(g))
             ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
-            with _Prof(_nt_tag(ci), 1, 2.0 * npix_out * co * ci * kh * kw, 4 * (dy.numel() + gx.numel() + wp.numel())):
+            with _Prof(_nt_tag(ci), 1, 2.0 * npix_out * co * ci * taps, 4 * (dy.numel() + gx.numel() + wp.numel())):
                 ia = ctx.in_act
                 dact = _desc(x, ci) if ia is not None else _null_desc()
                 _lib.call("itg_conv2d_dgrad", C.byref(ddy), _ptr(wp), _ptr(out_scale), C.byref(ddx), C.byref(dact),
@@ -390,7 +399,7 @@ class _Conv(torch.autograd.Function):
                     gb = bsink if direct_b else (torch.empty_like(w[:, 0, 0, 0]) if need_b else None)
                     keep = [ws, gw_, gb]            # scratch of this layer's side-stream kernels (see above)
                     npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
-                    with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1, 2.0 * npix_out * co * ci * kh * kw,
+                    with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1, 2.0 * npix_out * co * ci * taps,
                                4 * (x.numel() + dy.numel() + w.numel())):
                         # separate accumulate flags: a spectrally normalised layer sinks its bias gradient but takes dW into a
                         # temporary (no zero-fill launch for it)
@@ -423,10 +432,12 @@ class _Conv(torch.autograd.Function):
 
 def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, residual=None,
          sn=None, out_grid=None, sinks=None, pad_h=-1, precision=None, packed=None, in_act=None, defer_act_bwd=False,
-         out_stats=False, out=None):
+         out_stats=False, out=None, up2=False):
     """x: GT.  Returns GT with ``out_grid`` (default: the input grid).  ``sinks`` = (weight.grad, bias.grad)
     buffers: the backward then accumulates the parameter gradients straight into them (and reports no
-    gradient to autograd), which removes one AccumulateGrad add kernel per parameter."""
+    gradient to autograd), which removes one AccumulateGrad add kernel per parameter.
+    ``up2``: the result is conv3x3(nearest_up2x(x)) (stride 1, pad 1) computed in folded form from the half-size ``x``
+    (itg_conv_geom.up2); ``packed`` panels must then be the itg_pack_up2_* ones."""
     og = out_grid if out_grid is not None else (x.gh, x.gw)
     r = residual.t if residual is not None else None
     prec = MFMA_PRECISION if precision is None else precision
@@ -435,7 +446,7 @@ def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=AC
     stats = None
     if out_stats and ld_for(w.shape[0]) <= 512 and w.shape[0] > 1:
         stats = _zeros_f64(2 * ld_for(w.shape[0]), x.t.device)
-    t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode, pad_h, prec), act, slope, og, sinks, packed,
+    t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode, pad_h, prec, 1 if up2 else 0), act, slope, og, sinks, packed,
                     (in_act, bool(defer_act_bwd)), stats, out)
     return GT(t, w.shape[0], stats)
 
@@ -478,6 +489,8 @@ def _persistent(key, numel, device, dtype=torch.float32):
 
 def _queue_wgrad(x, dxd, dy, ddy, gwg, w, wsink, bsink, need_w, need_b, sn, st):
     """Deferred form of the weight gradient of one conv; False when the layer cannot be deferred."""
+    if gwg.up2:           # folded-upsample layers reduce their class slabs through a kernel of their own
+        return False
     key = ((wsink if wsink is not None else bsink).data_ptr(), tuple(x.shape), tuple(dy.shape))
     nws = _lib.fn("itg_conv2d_wgrad_workspace")(C.byref(dxd), C.byref(ddy), C.byref(gwg))
     ws = _persistent(("ws",) + key, nws, x.device)
@@ -674,7 +687,8 @@ def _zeros_f64(n, device):
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, rm, rv, nbt, c, training, eps, momentum, act, slope, ups, sync, sinks=None, pre_sums=None):
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, c, training, eps, momentum, act, slope, ups, sync, sinks=None, pre_sums=None,
+                virt_ups=False):
         x = x.contiguous()
         n, gh, gw, ph, pw, ld = x.shape
         dev = x.device
@@ -697,11 +711,11 @@ class _BNAct(torch.autograd.Function):
         y = torch.empty((n, gh, gw, ph * s, pw * s, ld), device=dev, dtype=torch.float32)
         dy_ = _desc(y, c)
         if training:      # coefficients, running statistics and the normalised output in one launch
-            _lib.call("itg_bn_finalize_apply", C.byref(dx_), _ptr(sums), count, 4.0 if ups else 1.0, _ptr(gamma), _ptr(beta),
+            _lib.call("itg_bn_finalize_apply", C.byref(dx_), _ptr(sums), count, 4.0 if (ups or virt_ups) else 1.0, _ptr(gamma), _ptr(beta),
                       float(eps), float(momentum), _ptr(rm), _ptr(rv), _ptr(nbt), _ptr(mean_rstd), _ptr(ab), C.byref(dy_),
                       act, float(slope), st)
         else:
-            _lib.call("itg_bn_finalize", _ptr(sums), count, 4.0 if ups else 1.0, _ptr(gamma), _ptr(beta), float(eps),
+            _lib.call("itg_bn_finalize", _ptr(sums), count, 4.0 if (ups or virt_ups) else 1.0, _ptr(gamma), _ptr(beta), float(eps),
                       float(momentum), _ptr(rm), _ptr(rv), _ptr(nbt), _ptr(mean_rstd), _ptr(ab), c, ld, int(training), st)
             _lib.call("itg_bn_apply", C.byref(dx_), _ptr(ab), C.byref(dy_), act, float(slope), st)
         ctx.meta = (c, act, slope, count, sync, training, gamma is not None)
@@ -745,15 +759,17 @@ class _BNAct(torch.autograd.Function):
                   count, act, float(slope), C.byref(dgx), _ptr(dg), _ptr(db), acc, st)
         if acc:
             dg = db = None
-        return gx, dg, db, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return gx, dg, db, None, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def bn_act(x, gamma, beta, rm, rv, nbt, training=True, eps=1e-5, momentum=0.1, act=ACT_NONE, slope=0.0,
-           upsample=False, sync=None, sinks=None):
+           upsample=False, sync=None, sinks=None, consumer_upsamples=False):
     """y = act(BatchNorm(x)) [nearest-upsampled x2 when ``upsample``]: statistics are taken on x
-    (identical to those of the upsampled tensor), the unbiased running_var uses the x4 count."""
+    (identical to those of the upsampled tensor), the unbiased running_var uses the x4 count.
+    ``consumer_upsamples``: y stays at x's size and the conv that reads it folds the x2 upsample into its filter
+    (ops.conv(up2=True)); the reference normalises the upsampled tensor, so running_var still takes the x4 count."""
     t = _BNAct.apply(x.t, gamma, beta, rm, rv, nbt, x.c, training, eps, momentum, act, slope, upsample, sync, sinks,
-                     x.stats if training else None)
+                     x.stats if training else None, bool(consumer_upsamples))
     return GT(t, x.c)
 
 
@@ -1205,8 +1221,10 @@ def pack_multi(tables):
         _lib.call("itg_pack_multi", _ptr(t), n, total, st)
 
 
-def pack_sizes(co, ci, kh, kw, stride):
+def pack_sizes(co, ci, kh, kw, stride, up2=False):
     """(floats of the forward panel, floats of the dgrad panel) for a conv between patch-grid tensors."""
+    if up2:
+        return (_lib.fn("itg_pack_up2_fwd_size")(co, ld_for(ci)), _lib.fn("itg_pack_up2_dgrad_size")(ci, ld_for(co)))
     return (_lib.fn("itg_pack_fwd_size")(co, ld_for(ci), kh, kw),
             _lib.fn("itg_pack_dgrad_size")(ci, ld_for(co), kh, kw, stride))
 

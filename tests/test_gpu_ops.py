@@ -146,6 +146,54 @@ def test_conv_fwd_dgrad_wgrad(case, prec):
     assert float((dbg.cpu() - dbr).abs().max()) <= tol_b * float(dyl.abs().sum((0, 2, 3)).max())
 
 
+UP2_CASES = [
+    # name, n, (gh,gw), P (source patch), cin, cout, mode
+    ("up2_rep_26_13", 2, (3, 3), 4, 26, 13, "replicate"),
+    ("up2_zero_13_26", 1, (2, 3), 8, 13, 26, "constant"),
+    ("up2_rep_104_52", 1, (3, 3), 8, 104, 52, "replicate"),
+    ("up2_rep_208_104_splitk", 1, (3, 3), 4, 208, 104, "replicate"),          # small M, long K: split-K with 4 classes
+    ("up2_rep_p1", 1, (4, 3), 1, 8, 8, "replicate"),                          # every source pixel is a border pixel
+    ("up2_rep_26_13_big", 1, (3, 3), 32, 26, 13, "replicate"),                # 96^2 -> 192^2: many weight-gradient slabs
+    ("up2_zero_images_52_26", 3, (1, 1), 16, 52, 26, "constant"),             # padding_mode='zeros': every patch an image
+]
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("case", UP2_CASES, ids=[c[0] for c in UP2_CASES])
+def test_conv_behind_upsample_folded_fwd_dgrad_wgrad(case, prec):
+    """ops.conv(up2=True) == conv3x3(nearest_up2x(x)) with the halo / outer padding taken at the upsampled resolution
+    (reference models/generators.py:52 followed by conv2d_lp, layers.py:25-34): output, input gradient (incl. the upsample's
+    backward), weight and bias gradient."""
+    ops = _ops()
+    tol_y, tol_g, tol_b = TOL[prec]
+    from oracle import patches as P
+    name, n, (gh, gw), p, cin, cout, mode = case
+    g = _gen(zlib.crc32(name.encode()) % 1000)
+    x = torch.randn(n * gh * gw, cin, p, p, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    m = P.merge(F.interpolate(xr, scale_factor=2, mode="nearest"), gh, gw)
+    if mode == "replicate":
+        pre = F.conv2d(F.pad(m, (1,) * 4, mode="replicate"), wr, br)
+    else:
+        pre = F.conv2d(m, wr, br, padding=1)
+    yr = pre.detach()
+    dy = torch.randn(yr.shape, generator=g)
+    xg, wg, bg = (t.to(cuda).requires_grad_(True) for t in (x, w, b))
+    gx = ops.to_grid(xg, gh, gw, merged=False)
+    pm = ops.PAD_REPLICATE if mode == "replicate" else ops.PAD_ZERO
+    with ops.mfma_precision(prec):
+        yg = ops.to_nchw(ops.conv(gx, wg, bg, 3, 3, 1, 1, pm, up2=True), merged=True)
+    assert yg.shape == yr.shape
+    assert rel_l2(yg.detach().cpu(), yr) < tol_y
+    dxr, dwr, dbr = torch.autograd.grad(pre, (xr, wr, br), dy)
+    dxg, dwg, dbg = torch.autograd.grad(yg, (xg, wg, bg), dy.to(cuda))
+    assert rel_l2(dxg.cpu(), dxr) < tol_g
+    assert rel_l2(dwg.cpu(), dwr) < tol_g
+    assert float((dbg.cpu() - dbr).abs().max()) <= tol_b * float(dy.abs().sum((0, 2, 3)).max())
+
+
 def test_conv_start_layer_valid_on_merged_latent_and_residual_tanh():
     ops = _ops()
     from oracle import patches as P

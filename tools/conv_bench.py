@@ -38,6 +38,13 @@ EXTRA = [
     ("X D1 K=64 (4->128 s2): fixed cost", 8, (1, 1), 192, 4, 128, 4, 2, 1, "zero"),
     ("X D1 K=256 (16->128 s2)", 8, (1, 1), 192, 16, 128, 4, 2, 1, "zero"),
     ("X D1 K=512 (32->128 s2)", 8, (1, 1), 192, 32, 128, 4, 2, 1, "zero"),
+    # proxies of the upsample-folded c1 layers (conv3x3 o nearest x2 = the transpose of a 4x4 stride-2 conv from the
+    # high-resolution side): dgrad column ~ folded forward, fwd column ~ folded input gradient, wgrad ~ folded wgrad
+    ("X fold b2c1 (208->416 s2, 24^2)", 8, (1, 1), 24, 208, 416, 4, 2, 1, "zero"),
+    ("X fold b3c1 (104->208 s2, 48^2)", 8, (1, 1), 48, 104, 208, 4, 2, 1, "zero"),
+    ("X fold b4c1 (52->104 s2, 96^2)", 8, (1, 1), 96, 52, 104, 4, 2, 1, "zero"),
+    ("X fold b5c1 (26->52 s2, 192^2)", 8, (1, 1), 192, 26, 52, 4, 2, 1, "zero"),
+    ("X fold b6c1 (13->26 s2, 384^2)", 8, (1, 1), 384, 13, 26, 4, 2, 1, "zero"),
 ]
 
 
