@@ -39,21 +39,22 @@ __global__ void zero_border_kernel(GridT g) {
 }
 
 // split-K second stage: out = act(sum_z partial[z] + bias [+ residual]) with the same output mapping
-// (blockIdx.y = parity class of a multi-class launch: one second-stage launch for all of them)
-__global__ void splitk_epilogue_kernel(ConvP p) {
+// (blockIdx.y = parity class of a multi-class launch: one second-stage launch for all of them; the kernel argument stays
+// read-only - a modified copy of the struct would live in scratch memory)
+__global__ void splitk_epilogue_kernel(const ConvP p) {
   const int q4 = p.out.ld >> 2;
   const int cls = blockIdx.y;
-  p.M = p.cM[cls]; p.MT = p.cMT[cls]; p.MU = p.cMU[cls]; p.ooy = p.cooy[cls]; p.oox = p.coox[cls];
-  p.partial += p.cpoff[cls];
-  int64_t total = (int64_t)p.M * q4;
+  const int M = p.cM[cls], MT = p.cMT[cls], MU = p.cMU[cls], ooy = p.cooy[cls], oox = p.coox[cls];
+  const float* const partial = p.partial + p.cpoff[cls];
+  int64_t total = (int64_t)M * q4;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int c4 = (int)(i % q4);
     int m = (int)(i / q4);
     int co = c4 * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     {
-      const float* q = p.partial + (size_t)m * p.co_rows + co;
-      const size_t zs = (size_t)p.M * p.co_rows;
+      const float* q = partial + (size_t)m * p.co_rows + co;
+      const size_t zs = (size_t)M * p.co_rows;
       f32x4 v1 = v, v2 = v, v3 = v;                       // four slab loads in flight, fixed summation order
       int z = 0;
       for (; z + 4 <= p.ksplit; z += 4) {
@@ -67,8 +68,8 @@ __global__ void splitk_epilogue_kernel(ConvP p) {
     }
     if (p.scale) v *= *p.scale;
     int n, t, u;
-    decode_m(m, p.MT, p.MU, n, t, u);
-    int oy = t * p.osy + p.ooy, ox = u * p.osx + p.oox;
+    decode_m(m, MT, MU, n, t, u);
+    int oy = t * p.osy + ooy, ox = u * p.osx + oox;
     bool border = false;
     if (p.out_mode == 1) {
       int ty = min(max(oy, 0), p.out.H - 1), tx = min(max(ox, 0), p.out.W - 1);
