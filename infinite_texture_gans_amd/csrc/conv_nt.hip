@@ -41,7 +41,17 @@ __global__ void zero_border_kernel(GridT g) {
 // split-K second stage: out = act(sum_z partial[z] + bias [+ residual]) with the same output mapping
 // (blockIdx.y = parity class of a multi-class launch: one second-stage launch for all of them; the kernel argument stays
 // read-only - a modified copy of the struct would live in scratch memory)
-__global__ void splitk_epilogue_kernel(const ConvP p) {
+// STATS: also the consumer BatchNorm's statistics of the values as stored (p.stats) - its own instantiation (as a run-time
+// branch it slowed the launches that do not need them); the grid's thread count is then a multiple of ld / 4, so a thread
+// keeps one channel group and its fp64 partials go thread -> LDS -> one global atomic per channel and workgroup (norm.hip)
+template <bool STATS>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvP p) {
+  __shared__ double lstat[STATS ? 2 * 512 : 2];
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if constexpr (STATS) {
+    for (int i = threadIdx.x; i < 2 * p.out.ld; i += 256) lstat[i] = 0.0;
+    __syncthreads();
+  }
   const int q4 = p.out.ld >> 2;
   const int cls = blockIdx.y;
   const int M = p.cM[cls], MT = p.cMT[cls], MU = p.cMU[cls], ooy = p.cooy[cls], oox = p.coox[cls];
@@ -101,6 +111,20 @@ __global__ void splitk_epilogue_kernel(const ConvP p) {
     } else {
       *reinterpret_cast<f32x4*>(dst) = v;
     }
+    if constexpr (STATS) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const double d = v[e]; s1[e] += d; s2[e] += d * d; }
+    }
+  }
+  if constexpr (STATS) {
+    const int cg = (int)((blockIdx.x * 256 + threadIdx.x) % q4);       // fixed: gridDim.x * 256 is a multiple of q4
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      atomicAdd(&lstat[cg * 4 + e], s1[e]);
+      atomicAdd(&lstat[p.out.ld + cg * 4 + e], s2[e]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * p.out.ld; i += 256) atomicAdd(&p.stats[i], lstat[i]);
   }
 }
 
@@ -160,8 +184,10 @@ NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls, int prec) {
   const double fill_min = (fill_env ? fill_env : (prec == ITG_PREC_BF16 ? 200 : 300)) / 100.0;   // bf16 stages are short: 2 (config 3 +1 %)
   static const int allow96 = env_int("ITG_NT_96", 1);
   static const double pen96 = env_int("ITG_PEN96", 104) / 100.0;
+  static const int force_bp = env_int("ITG_NT_BPIX", 0);       // experiments: pin the pixel-tile width of the <= 64-row tiles
   for (int ci = 0; ci < 4; ++ci) {
     int bp = cands_big[ci];
+    if (force_bp && pl.bco <= 64 && bp != force_bp) continue;
     if (pl.bco >= 112 && bp == 256) continue;              // 128x256 / 112x256 are not instantiated
     if (bp == 96 && (pl.bco != 128 || !allow96 || pl.tbk != 16)) continue;   // 128x96 (fp32): 3 workgroups per CU exactly on M = 73728
     int64_t blocks = ((M + bp - 1) / bp) * nco * ncls;
@@ -201,7 +227,7 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
   // themselves; a cleared bit - and always the split-K second stage, where fusing them measured slower - runs the
   // separate statistics launch over the finished output instead.  (Measured neutral on the step: 764.9 vs 764.3 crops/s;
   // it removes 8 of the 13 statistics launches of a generator forward.)
-  static const int stats_paths = env_int("ITG_STATS_PATHS", 3);
+  static const int stats_paths = env_int("ITG_STATS_PATHS", 7);      // bit 2: the split-K second stage takes them (its own instantiation)
   double* const want_stats = p.stats;
   double* const want_bn = p.bn_sums;
   {
@@ -238,6 +264,7 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
     if (inl && words <= TICKET_SLOT) p.tickets = next_ticket_slot();
   }
   const bool second_stage = pl.ksplit > 1 && !p.tickets;
+  const bool stats_in_stage2 = second_stage && p.stats && (stats_paths & 4) && p.out_mode == 0 && p.out.ld <= 512;
   if (second_stage || !(stats_paths & 2)) p.stats = nullptr;
   if (second_stage) p.bn_sums = nullptr;                     // the second stage does not take them: separate reduce launch
   for (int c = 0; c < 4; ++c) p.cpoff[c] = (unsigned)((size_t)c * pl.ksplit * p.M * p.co_rows);
@@ -265,8 +292,22 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
     int64_t total = (int64_t)mmax * (p.out.ld >> 2);
     int per = 8192 / ncls;
     int blocks = (int)((total + 255) / 256 < per ? (total + 255) / 256 : per);
-    if (blocks > 0) {
-      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks, ncls), dim3(256), 0, s, p);
+    if (blocks > 0 && stats_in_stage2) {
+      // thread count a multiple of ld / 4 (a thread then owns one channel group); ~8 elements per thread keeps the global
+      // fp64 atomics (2 ld per workgroup) rare
+      const int q4 = p.out.ld >> 2;
+      int g0 = q4, a = 256;
+      while (a) { int t = g0 % a; g0 = a; a = t; }           // gcd(256, q4)
+      g0 = q4 / g0;
+      int want = (int)((total + 2047) / 2048);
+      if (want > 1024 / ncls) want = 1024 / ncls;
+      if (want < 1) want = 1;
+      blocks = (want + g0 - 1) / g0 * g0;
+      p.stats = want_stats;
+      hipLaunchKernelGGL(splitk_epilogue_kernel<true>, dim3(blocks, ncls), dim3(256), 0, s, p);
+      ITG_CHECK_LAUNCH();
+    } else if (blocks > 0) {
+      hipLaunchKernelGGL(splitk_epilogue_kernel<false>, dim3(blocks, ncls), dim3(256), 0, s, p);
       ITG_CHECK_LAUNCH();
     }
   }
