@@ -373,10 +373,13 @@ inline int in_norm_of(const itg_conv_geom* g, const itg_tensor* in, const itg_in
   *out = n;
   return ITG_OK;
 }
-// itg_conv_geom.up2: 3x3, stride 1, pad 1 on the x2 upsample of `lo` (half the patch extent of `hi`, same grid)
+// itg_conv_geom.up2: 3x3, stride 1, pad 1 on the x2 upsample of `lo` (half the patch extent of `hi`, same grid).
+// pad_h = 0 (row-sharded bands, 1-row grids): `lo` carries one explicit halo row of SOURCE pixels above and below.
 inline int up2_check(const itg_conv_geom* g, const itg_tensor* lo, const itg_tensor* hi) {
-  if (g->kh != 3 || g->kw != 3 || g->stride != 1 || g->pad != 1 || pad_v_raw(g) != 1 || g->in_norm) return ITG_ERR_ARG;
-  if (lo->n != hi->n || lo->gh != hi->gh || lo->gw != hi->gw || 2 * lo->ph != hi->ph || 2 * lo->pw != hi->pw) return ITG_ERR_ARG;
+  const int pv = pad_v_raw(g);
+  if (g->kh != 3 || g->kw != 3 || g->stride != 1 || g->pad != 1 || (pv != 0 && pv != 1) || g->in_norm) return ITG_ERR_ARG;
+  if (lo->n != hi->n || lo->gh != hi->gh || lo->gw != hi->gw || 2 * lo->pw != hi->pw) return ITG_ERR_ARG;
+  if (pv == 1 ? 2 * lo->ph != hi->ph : (lo->gh != 1 || 2 * (lo->ph - 2) != hi->ph)) return ITG_ERR_ARG;
   return ITG_OK;
 }
 inline void clear_xf(ConvP& p) {
@@ -487,7 +490,7 @@ int64_t itg_conv2d_dgrad_workspace(const itg_tensor* dy, const itg_tensor* dx, c
   int64_t H = (int64_t)dx->gh * dx->ph, W = (int64_t)dx->gw * dx->pw;
   if (g->up2) {
     const int e = g->pad_mode == ITG_PAD_REPLICATE ? 2 : 0;
-    return plan_nt((int64_t)dx->n * (H + e) * (W + e), co_rows, round_up(16 * dy->ld, BK), 1, prec_of(g)).ws_floats;
+    return plan_nt((int64_t)dx->n * (H + (pad_v(g) ? e : 0)) * (W + e), co_rows, round_up(16 * dy->ld, BK), 1, prec_of(g)).ws_floats;
   }
   if (g->stride == 1) {
     int eh = (g->pad_mode == ITG_PAD_REPLICATE) ? 2 * pad_v(g) : 0, ew = (g->pad_mode == ITG_PAD_REPLICATE) ? 2 * g->pad : 0;
@@ -530,16 +533,17 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
     p.co_rows = round_up(out->c, 16);
     p.isy = p.isx = 1; p.osy = p.osx = 2;
     p.pad_mode = g->pad_mode; p.out_mode = 0; p.act = act; p.slope = slope;
-    const int64_t M = (int64_t)in->n * p.in.H * p.in.W;
+    const int pv = pad_v(g), Hs = p.out.H / 2;                  // source rows that produce output (pv = 0: in.H - 2)
+    const int64_t M = (int64_t)in->n * Hs * p.in.W;
     if (M >= ((int64_t)1 << 29)) return ITG_ERR_ARG;
     p.ncls = 4;
     for (int c = 0; c < 4; ++c) {
       const int ry = c >> 1, rx = c & 1;
-      p.cMT[c] = p.in.H; p.cMU[c] = p.in.W; p.cM[c] = (int)M;
-      p.cioy[c] = ry - 1; p.ciox[c] = rx - 1; p.cooy[c] = ry; p.coox[c] = rx;
+      p.cMT[c] = Hs; p.cMU[c] = p.in.W; p.cM[c] = (int)M;
+      p.cioy[c] = ry - pv; p.ciox[c] = rx - 1; p.cooy[c] = ry; p.coox[c] = rx;
       p.cwoff[c] = (unsigned)((size_t)c * p.co_rows * p.Kpad);
     }
-    p.M = (int)M; p.MT = p.in.H; p.MU = p.in.W;
+    p.M = (int)M; p.MT = Hs; p.MU = p.in.W;
     p.ioy = p.cioy[0]; p.iox = p.ciox[0]; p.ooy = 0; p.oox = 0;
     return dispatch_nt(p, workspace, workspace_floats, (hipStream_t)stream);
   }
@@ -654,6 +658,9 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
     } else {
       p.MT = p.out.H; p.MU = p.out.W;
       p.ioy = p.iox = -1; p.ooy = p.oox = 0; p.out_mode = 0;
+    }
+    if (pad_v(g) == 0) {       // explicit halo rows: dx row e (halo rows included) gathers dy rows 2 (e - 1) + t - 1, no vertical fold
+      p.MT = p.out.H; p.ioy = -3; p.ooy = 0;
     }
     const int64_t M = (int64_t)dx->n * p.MT * p.MU;
     if (M >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
@@ -789,7 +796,7 @@ int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, co
     return Min * 16 + 16 * (int64_t)x->c + 16 + t.ws_floats + (int64_t)t.splits * t.co_rows;
   }
   if (g->up2) {
-    TnPlan t = plan_tn(grid_pixels(x), dy->ld, 4 * x->ld, prec_of(g), 4);
+    TnPlan t = plan_tn(grid_pixels(dy) / 4, dy->ld, 4 * x->ld, prec_of(g), 4);
     return t.ws_floats + (int64_t)4 * t.splits * t.co_rows;
   }
   int64_t M = grid_pixels(dy);
@@ -811,7 +818,7 @@ static int wgrad_setup(const itg_tensor* x, const itg_tensor* dy, const itg_conv
     if ((rc = up2_check(g, x, dy))) return rc;
     p.in_ab = nullptr; p.in_act = ITG_ACT_NONE; p.in_slope = 0.f; p.in_ups = 0;
     p.up2 = 1;
-    const int64_t M = grid_pixels(x);
+    const int64_t M = grid_pixels(dy) / 4;              // source pixels that produce output (pad_h = 0: x carries 2 halo rows more)
     if (M >= ((int64_t)1 << 29)) return ITG_ERR_ARG;
     p.ntaps = 4; p.kw = 2; p.cin_ld = x->ld; p.Ktot = 4 * x->ld;
     const int prec = prec_of(g);
@@ -820,8 +827,8 @@ static int wgrad_setup(const itg_tensor* x, const itg_tensor* dy, const itg_conv
     p.Kpad = t.Kpad; p.co_rows = t.co_rows;
     p.slab = workspace;
     p.dbslab = want_db ? workspace + t.ws_floats : nullptr;       // [splits][4][co_rows]
-    p.MT = p.x.H; p.MU = p.x.W; p.M = (int)M;
-    p.stride = 1; p.pad = 1; p.pad_h = 1; p.pad_mode = g->pad_mode;
+    p.MT = p.dy.H / 2; p.MU = p.x.W; p.M = (int)M;
+    p.stride = 1; p.pad = 1; p.pad_h = pad_v(g); p.pad_mode = g->pad_mode;
     p.chunks_per_split = t.chunks_per_split; p.nchunks = t.nchunks;
     int64_t xb = grid_pixels(x) * x->ld * 4, yb = grid_pixels(dy) * dy->ld * 4;
     if (xb >= 0xFFFF0000LL || yb >= 0xFFFF0000LL) return ITG_ERR_ARG;

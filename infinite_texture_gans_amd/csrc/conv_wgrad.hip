@@ -775,8 +775,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            float* __restrict__ db, const float* __restrict__ dbslab,
                                                            int dbsplits, int splits, int co, int ci, int ci_ld, int kh,
                                                            int kw, int co_rows, int Kpad, int accumulate) {
-  __shared__ float tile[64 * 49];
+  __shared__ float tile[64 * 50];
   const int taps = kh * kw;
+  const int pitch = taps | 1;           // odd pitch: the 16-tap layers were 16-way bank conflicted at pitch 16 (73 % of the LDS cycles)
   const int nchunk = (ci + 63) / 64;
   const int o = blockIdx.x / nchunk;
   const int c0 = (blockIdx.x - o * nchunk) * 64;
@@ -812,11 +813,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       for (; z < splits; ++z) s0 += q[(size_t)z * zstride];
       s = (s0 + s1) + (s2 + s3);
     }
-    tile[c * taps + t] = s;
+    tile[c * pitch + t] = s;
   }
   __syncthreads();
   float* dst = dw + ((size_t)o * ci + c0) * taps;
-  for (int idx = threadIdx.x; idx < cn * taps; idx += 256) dst[idx] = (accumulate & ITG_ACC_DW) ? dst[idx] + tile[idx] : tile[idx];
+  for (int idx = threadIdx.x; idx < cn * taps; idx += 256) {
+    const int c = idx / taps, t = idx - c * taps;
+    const float v = tile[c * pitch + t];
+    dst[idx] = (accumulate & ITG_ACC_DW) ? dst[idx] + v : v;
+  }
 }
 
 // itg_conv_geom.up2: slab z = [class (ry, rx)][co][(jy*2+jx)*ci_ld + ci] holds the class's 2 x 2 tap gradients; tap (i, j) of

@@ -592,14 +592,6 @@ class BandTrainer(Trainer):
             if isinstance(m, LocalPadder):
                 m.pin(1, 1, netG.outer_padding)
                 m.halo = comm if m.merge_patches_into_image else None
-        # band convs take explicit halo rows at the upsampled resolution: no folded upsample, plain panels again
-        from .models.layers import _ConvParams
-        refold = [m for m in netG.modules() if isinstance(m, _ConvParams) and m.up2]
-        for m in refold:
-            m.up2 = False
-        if refold:
-            self.packG = PackSet(netG)
-            self.packG.repack()
 
     _heights = None
 

@@ -287,9 +287,10 @@ class conv2d_lp(nn.Module):
                                                        and (self.training or _whole_image(image_location)))))
         # the x2 upsample in front of a block's first conv is folded into the conv (ops.conv(up2=True)) on the paths that hand
         # the patch grid to the kernel as it is; the normalisation then stays at the block input's resolution
-        direct = (self.padding_mode != "local"
-                  or (self.local_padder.merge_patches_into_image and self.local_padder.halo is None
-                      and (self.training or _whole_image(image_location))))
+        lp_ = self.local_padder if self.padding_mode == "local" else None
+        direct = (lp_ is None
+                  or (lp_.merge_patches_into_image and lp_.halo is None and (self.training or _whole_image(image_location)))
+                  or (lp_.merge_patches_into_image and lp_.halo is not None and lp_.training))      # band training: halo rows of SOURCE pixels
         fold = bool(upsample) and bn is not None and not fused and up2_fold_enabled() and direct
         if bn is not None and not fused:
             x = bn.run(x, act=bn_act[0], slope=bn_act[1], upsample=upsample and not fold, consumer_upsamples=fold)
@@ -320,7 +321,7 @@ class conv2d_lp(nn.Module):
             return self.conv.run(x, pad=0, act=act, slope=slope, residual=residual, out_grid=(gh, gw), out_stats=out_stats)
         if lp.halo is not None:
             if lp.training:
-                return self._forward_band_train(x, lp, outer, act, slope, residual)
+                return self._forward_band_train(x, lp, outer, act, slope, residual, up2=fold)
             return self._forward_row_sharded(x, lp, outer, act, slope, residual)
         if fused:      # training, or ONE sub-image that is the whole picture (one-shot generation: no state is carried on)
             return self.conv.run_bn(x, bn, bn_act[0], bn_act[1], upsample, pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope,
@@ -339,10 +340,12 @@ class conv2d_lp(nn.Module):
         y = self.conv.run(flat, pad=0, act=act, slope=slope, residual=r)
         return GT(y.t.reshape(n, g1, g2, ph - 2, pw - 2, -1), y.c)
 
-    def _forward_band_train(self, x, lp, outer, act, slope, residual):
+    def _forward_band_train(self, x, lp, outer, act, slope, residual, up2=False):
         """Training with the patch grid sharded by rows: x is this rank's band in image layout
         (n, 1, 1, H, W, ld).  The band is extended by the neighbours' boundary rows (differentiable RCCL
-        exchange; at the image border the outer padding row) and convolved with vertical padding 0."""
+        exchange; at the image border the outer padding row) and convolved with vertical padding 0.
+        ``up2``: x is the band BEFORE the block's x2 upsample; its boundary rows are what the neighbours need (the
+        upsampled halo row is the nearest source row), and the conv folds the upsample (half the exchanged bytes)."""
         t = x.t
         n, g1, g2, H, W, ld = t.shape
         if g1 != 1 or g2 != 1:
@@ -356,7 +359,7 @@ class conv2d_lp(nn.Module):
             bottom = last if outer == "replicate" else torch.zeros_like(last)
         ext = torch.cat((top.unsqueeze(1), rows, bottom.unsqueeze(1)), 1).reshape(n, 1, 1, H + 2, W, ld)
         return self.conv.run(GT(ext, x.c), pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope,
-                             residual=residual, pad_h=0)
+                             residual=residual, pad_h=0, up2=up2)
 
     def _forward_row_sharded(self, x, lp, outer, act, slope, residual):
         """This rank owns a band of patch rows: fetch the neighbours' boundary pixel rows (RCCL send/recv),

@@ -267,6 +267,8 @@ class _Conv(torch.autograd.Function):
             raise _lib.ItgError("weight %s does not match conv geometry (c_in=%d, k=%dx%d)" % (tuple(w.shape), c_in, kh, kw))
         H, W = (gh * ph) << up2, (gw * pw) << up2        # up2: the conv runs on the x2 upsample of x (folded into the filter)
         Ho, Wo = (H + 2 * pv - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+        if up2 and pv == 0:                              # x carries one explicit halo row of SOURCE pixels above and below
+            Ho = 2 * (gh * ph - 2)
         ogh, ogw = out_grid
         if Ho % ogh or Wo % ogw:
             raise _lib.ItgError("conv output %dx%d does not divide into a %dx%d grid" % (Ho, Wo, ogh, ogw))

@@ -194,6 +194,33 @@ def test_conv_behind_upsample_folded_fwd_dgrad_wgrad(case, prec):
     assert float((dbg.cpu() - dbr).abs().max()) <= tol_b * float(dy.abs().sum((0, 2, 3)).max())
 
 
+@pytest.mark.parametrize("mode", ["replicate", "constant"])
+def test_conv_behind_upsample_folded_with_explicit_halo_rows(mode):
+    """Row-sharded band training: the band (image layout) carries one halo row of SOURCE pixels above and below and the
+    conv pads only horizontally (pad_h = 0): output, gradient w.r.t. the band INCLUDING its halo rows, weight / bias gradient."""
+    ops = _ops()
+    g = _gen(11)
+    n, cin, cout, Hs, Ws = 2, 26, 13, 12, 20
+    x = torch.randn(n, cin, Hs + 2, Ws, generator=g)                     # rows 0 and Hs + 1 are the neighbours' boundary rows
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    up = F.interpolate(xr, scale_factor=2, mode="nearest")[:, :, 1:-1]    # the upsampled band with ONE halo row each side
+    hp = F.pad(up, (1, 1, 0, 0), mode="replicate") if mode == "replicate" else F.pad(up, (1, 1, 0, 0))
+    pre = F.conv2d(hp, wr, br)
+    dy = torch.randn(pre.shape, generator=g)
+    xg, wg, bg = (t.to(cuda).requires_grad_(True) for t in (x, w, b))
+    pm = ops.PAD_REPLICATE if mode == "replicate" else ops.PAD_ZERO
+    yg = ops.to_nchw(ops.conv(ops.to_grid(xg, 1, 1, merged=True), wg, bg, 3, 3, 1, 1, pm, pad_h=0, up2=True), merged=True)
+    assert yg.shape == pre.shape
+    assert rel_l2(yg.detach().cpu(), pre.detach()) < 2e-6
+    dxr, dwr, dbr = torch.autograd.grad(pre, (xr, wr, br), dy)
+    dxg, dwg, dbg = torch.autograd.grad(yg, (xg, wg, bg), dy.to(cuda))
+    assert rel_l2(dxg.cpu(), dxr) < 5e-6
+    assert rel_l2(dwg.cpu(), dwr) < 5e-6
+    assert float((dbg.cpu() - dbr).abs().max()) <= 2e-6 * float(dy.abs().sum((0, 2, 3)).max())
+
+
 def test_conv_start_layer_valid_on_merged_latent_and_residual_tanh():
     ops = _ops()
     from oracle import patches as P
