@@ -166,6 +166,7 @@ inline int red_group() {       // slabs summed per thread in either weight-gradi
 int try_conv_valu(const ConvP& p, hipStream_t s, int* rc);
 int try_conv_tile(ConvP& p, hipStream_t s, int* rc);
 int try_conv_s2k4(const ConvP& p, hipStream_t s, int* rc);
+int try_conv_up2_tile(const ConvP& p, hipStream_t s, int* rc);
 // conv_nt.hip
 NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = ITG_PREC_F32);
 int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s);

@@ -500,6 +500,213 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 3)) void conv_s2k4_kernel(c
   }
 }
 
+// ------------------------------------------------------------------------------- folded-upsample forward (halo tiles)
+// conv3x3(nearest x2 (x)) for the narrow layers behind an upsample (itg_conv_geom.up2; the generator's last blocks): a
+// workgroup stages one (8+2) x (32+2) halo tile of the HALF-SIZE tensor and produces the 16 x 64 output pixels above it as
+// four parity classes (ry, rx) of 2 x 2 taps: class tap (jy, jx) of output (2t + ry, 2u + rx) reads source pixel
+// (t + ry - 1 + jy, u + rx - 1 + jx), i.e. halo pixel (lt + ry + jy, lu + rx + jx).  Four filter banks (one per class, K = 4 taps x
+// cin_ld) stay in LDS; per tile 4 x nch K chunks instead of the 4 x (9/4) nch of the unfolded tile kernel on four times the
+// tiles, and the source tensor is read once at a quarter of the size.  Same persistent structure as conv_tile_kernel.
+template <int FI, int NLD, bool STATS>
+__global__ __launch_bounds__(256, 2) void conv_up2_tile_kernel(const ConvP p, int tiles_x, int tiles_y, int ntiles, int cpt, int nch) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int co_rows = 16 * FI;
+  float* Wl = lds;                                                       // [4][nch][co_rows][20]
+  int* koff = reinterpret_cast<int*>(lds + 4 * nch * co_rows * 20);      // [4][nch][4]
+  float* biasl = lds + 4 * nch * co_rows * 20 + 16 * nch;                // [32]
+  double* lstat = reinterpret_cast<double*>(biasl + 32);                 // [2][32]
+  float* Xt = biasl + 32 + 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = p.cin_ld >> 2;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in.p, 0, p.in_bytes, 0x00020000);
+  int e_r[NLD], e_c[NLD], e_lds[NLD];
+  unsigned e_cb[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    int e = tid + i * 256;
+    bool live = e < TT_PIX * q4;
+    int pix = live ? e / q4 : 0, c4 = live ? e - pix * q4 : 0;
+    e_r[i] = live ? pix / (TT_W + 2) : -1;
+    e_c[i] = pix - (pix / (TT_W + 2)) * (TT_W + 2);
+    e_lds[i] = pix * cpt + c4 * 4;
+    e_cb[i] = (unsigned)c4 * 16u;
+  }
+  for (int e = tid; e < 4 * nch * co_rows * 16; e += 256) {
+    const int k16 = e & 15, r = e >> 4;
+    const int row = r % co_rows, qc = r / co_rows;                       // qc = cls * nch + q
+    const int cls = qc / nch, q = qc - cls * nch;
+    const int k = q * 16 + k16;
+    Wl[(qc * co_rows + row) * 20 + k16] = k < p.Kpad ? p.w[((size_t)cls * co_rows + row) * p.Kpad + k] : 0.f;
+  }
+  for (int e = tid; e < 4 * nch * 4; e += 256) {
+    const int cls = e / (nch * 4), r = e - cls * nch * 4;
+    const int k = (r >> 2) * 16 + (r & 3) * 4;
+    const int tap = k / p.cin_ld, c = k - tap * p.cin_ld;
+    const int ry = cls >> 1, rx = cls & 1, jy = tap >> 1, jx = tap & 1;
+    koff[e] = tap < 4 ? ((ry + jy) * (TT_W + 2) + rx + jx) * cpt + c : 0;     // K padding: weights are zero, read something finite
+  }
+  f32x4 rt[NLD];
+  auto load_tile = [&](int tile) {
+    int b = tile;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+    const int y0 = ty_i * TT_H - 1, x0 = tx_i * TT_W - 1;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      int iy = y0 + e_r[i], ix = x0 + e_c[i];
+      bool ok = e_r[i] >= 0;
+      if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.in.H && (unsigned)ix < (unsigned)p.in.W;
+      iy = min(max(iy, 0), p.in.H - 1); ix = min(max(ix, 0), p.in.W - 1);
+      unsigned o = (unsigned)grid_off(p.in, n, iy, ix) * 4u + e_cb[i];
+      rt[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? o : p.in_bytes, 0, 0));
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      if (e_r[i] >= 0) *reinterpret_cast<f32x4*>(Xt + e_lds[i]) = rt[i];
+  };
+  const int fj = lane & 15, g = lane >> 4;
+  int pbase[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) pbase[f] = ((2 * wave + (f >> 1)) * (TT_W + 2) + 16 * (f & 1) + fj) * cpt;
+  const float osc = p.scale ? *p.scale : 1.f;
+  if (tid < 32) biasl[tid] = (p.bias && tid < p.out.c) ? p.bias[tid] : 0.f;
+  if (STATS && tid < 64) lstat[tid] = 0.0;
+  int tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile);
+  __syncthreads();
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  for (; tile < ntiles; tile += gridDim.x) {
+    store_tile();
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < ntiles) load_tile(next);               // in flight during the four classes' MFMA phases and epilogues
+    int b = tile;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+    const int t0 = ty_i * TT_H, u0 = tx_i * TT_W;
+    f32x4 ts1[STATS ? FI : 1], ts2[STATS ? FI : 1];
+    if constexpr (STATS) {
+#pragma unroll
+      for (int i = 0; i < FI; ++i) { ts1[i] = zero4; ts2[i] = zero4; }
+    }
+#pragma unroll 1
+    for (int cls = 0; cls < 4; ++cls) {
+      f32x4 acc[FI][4];
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[i][f] = zero4;
+      const float* Wc = Wl + cls * nch * co_rows * 20;
+      const int* kc = koff + cls * nch * 4;
+      for (int q = 0; q < nch; ++q) {
+        const int ko = kc[q * 4 + g];
+        f32x4 a[FI], bq[4];
+#pragma unroll
+        for (int i = 0; i < FI; ++i) a[i] = *reinterpret_cast<const f32x4*>(Wc + (q * co_rows + 16 * i + fj) * 20 + g * 4);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) bq[f] = *reinterpret_cast<const f32x4*>(Xt + pbase[f] + ko);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+              acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], bq[f][s], acc[i][f], 0, 0, 0);
+      }
+      const int ry = cls >> 1, rx = cls & 1;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int t = t0 + 2 * wave + (f >> 1), u = u0 + 16 * (f & 1) + fj;
+        if (t >= p.MT || u >= p.MU || 2 * t + ry >= p.out.H || 2 * u + rx >= p.out.W) continue;     // (odd extents: the classes differ in size)
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+          const int co = 16 * i + g * 4;
+          if (co >= p.out.ld) continue;
+          const f32x4 v = store_out(p, n, 2 * t + ry, 2 * u + rx, co, acc[i][f], osc, *reinterpret_cast<const f32x4*>(biasl + co),
+                                    false, zero4);
+          if constexpr (STATS) { ts1[i] += v; ts2[i] += v * v; }
+        }
+      }
+    }
+    if constexpr (STATS) {
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {
+            ts1[i][e] += __shfl_xor(ts1[i][e], o, 64);
+            ts2[i][e] += __shfl_xor(ts2[i][e], o, 64);
+          }
+          if (fj == 0) {
+            atomicAdd(&lstat[16 * i + g * 4 + e], (double)ts1[i][e]);
+            atomicAdd(&lstat[32 + 16 * i + g * 4 + e], (double)ts2[i][e]);
+          }
+        }
+    }
+    __syncthreads();                                  // every wave is done reading Xt
+  }
+  if constexpr (STATS) {
+    __syncthreads();
+    if (tid < 32 && tid < p.out.ld) {
+      atomicAdd(&p.stats[tid], lstat[tid]);
+      atomicAdd(&p.stats[p.out.ld + tid], lstat[32 + tid]);
+    }
+  }
+}
+
+// eligibility + launch; p is the 4-class ConvP of itg_conv2d_fwd's up2 branch (class geometry in the c* arrays)
+int try_conv_up2_tile(const ConvP& p, hipStream_t s, int* rc) {
+  static const int enable = env_int("ITG_UP2_TILE", 1);
+  if (!enable || p.ncls != 4 || p.ntaps != 4 || p.kw != 2 || p.cioy[0] != -1 || p.ciox[0] != -1 || p.out_mode != 0) return 0;
+  if (p.prec != ITG_PREC_F32 || p.cin_ld > 32 || p.co_rows > 32 || p.res.p || p.in_ab || p.bn_sums) return 0;
+  if ((int64_t)p.MT * p.MU < 48 * 48) return 0;
+  const int FI = p.co_rows / 16;
+  if (FI == 2 && p.stats) return 0;                           // (two row tiles + statistics: register budget; separate pass by the caller)
+  ConvP q = p;
+  const int64_t ib = (int64_t)p.in.n * p.in.gh * p.in.gw * p.in.ph * p.in.pw * p.in.ld * 4;
+  if (ib >= 0xFFFF0000LL) return 0;
+  q.in_bytes = (unsigned)ib;
+  const int cpt = (p.cin_ld % 8 == 4) ? p.cin_ld : p.cin_ld + 4;
+  const int nch = p.Kpad / 16;
+  const int tiles_x = (p.MU + TT_W - 1) / TT_W, tiles_y = (p.MT + TT_H - 1) / TT_H;
+  const int64_t ntiles = (int64_t)p.in.n * tiles_x * tiles_y;
+  const size_t lds = ((size_t)4 * nch * 16 * FI * 20 + 16 * nch + 32 + 128 + (size_t)TT_PIX * cpt) * sizeof(float);
+  const int nld = (TT_PIX * (p.cin_ld >> 2) + 255) / 256;
+  if (ntiles > 0x7fffffff || lds > 80 * 1024 || nld > 11) return 0;
+  const bool st = p.stats != nullptr, small = nld <= 6;
+  const void* kern = FI == 1 ? (small ? (st ? (const void*)&conv_up2_tile_kernel<1, 6, true> : (const void*)&conv_up2_tile_kernel<1, 6, false>)
+                                      : (st ? (const void*)&conv_up2_tile_kernel<1, 11, true> : (const void*)&conv_up2_tile_kernel<1, 11, false>))
+                             : (small ? (const void*)&conv_up2_tile_kernel<2, 6, false> : (const void*)&conv_up2_tile_kernel<2, 11, false>);
+  static const void* attr_set[8] = {nullptr};
+  {
+    bool seen = false;
+    int slot = 0;
+    for (; slot < 8 && attr_set[slot]; ++slot) seen = seen || attr_set[slot] == kern;
+    if (!seen && slot < 8) {
+      if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) { (void)hipGetLastError(); return 0; }
+      attr_set[slot] = kern;
+    }
+  }
+  int per_cu = (int)((160 * 1024) / lds);
+  static const int cu_env = env_int("ITG_UP2_TILE_CU", 0);
+  if (per_cu > 2) per_cu = 2;
+  if (cu_env > 0) per_cu = cu_env;
+  if (per_cu < 1) per_cu = 1;
+  const int64_t want = 256 * (int64_t)per_cu;
+  const unsigned blocks = (unsigned)(ntiles < want ? ntiles : want);
+  snprintf(g_last_launch, sizeof(g_last_launch), "conv_up2_tile_kernel<%d, %d, %s>", FI, small ? 6 : 11, st ? "true" : "false");
+  int a_tx = tiles_x, a_ty = tiles_y, a_nt = (int)ntiles, a_cpt = cpt, a_nch = nch;
+  void* args[] = {(void*)&q, &a_tx, &a_ty, &a_nt, &a_cpt, &a_nch};
+  (void)hipLaunchKernel(kern, dim3(blocks), dim3(256), args, lds, s);
+  *rc = hipGetLastError() == hipSuccess ? ITG_OK : ITG_ERR_LAUNCH;
+  return 1;
+}
+
 int try_conv_s2k4(const ConvP& p, hipStream_t s, int* rc) {
   static const int enable = env_int("ITG_CONV_S2K4", 1);
   if (!enable || p.ncls > 1 || p.ntaps != 16 || p.kw != 4 || p.isy != 2 || p.isx != 2 || p.ioy != -1 || p.iox != -1) return 0;

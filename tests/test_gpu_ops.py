@@ -155,6 +155,10 @@ UP2_CASES = [
     ("up2_rep_p1", 1, (4, 3), 1, 8, 8, "replicate"),                          # every source pixel is a border pixel
     ("up2_rep_26_13_big", 1, (3, 3), 32, 26, 13, "replicate"),                # 96^2 -> 192^2: many weight-gradient slabs
     ("up2_zero_images_52_26", 3, (1, 1), 16, 52, 26, "constant"),             # padding_mode='zeros': every patch an image
+    # narrow layers on source images >= 48^2: the folded halo-tile forward kernel (four class filter banks in LDS)
+    ("up2_tile_rep_26_13_partial", 2, (3, 3), 20, 26, 13, "replicate"),       # 60 x 60 source: partial tiles both ways
+    ("up2_tile_zero_13_26", 1, (2, 3), 28, 13, 26, "constant"),               # two filter-row tiles, 56 x 84 source
+    ("up2_tile_rep_8_3", 1, (2, 2), 32, 8, 3, "replicate"),                   # cin_ld 8: two taps per K chunk
 ]
 
 
@@ -581,6 +585,30 @@ def test_conv_epilogue_accumulates_batchnorm_statistics(name, n, grid, p, ci, co
         outs.append((ops.bn_act(src, gamma, beta, rm, rv, nbt, True, 1e-5, 0.1, ops.ACT_LRELU, 0.02).t, rm, rv))
     assert rel_l2(outs[0][0].cpu(), outs[1][0].cpu()) < 1e-6
     assert rel_l2(outs[0][1].cpu(), outs[1][1].cpu()) < 1e-6 and rel_l2(outs[0][2].cpu(), outs[1][2].cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("name,n,grid,p,ci,co", [
+    ("up2_generic_classes", 2, (3, 3), 8, 52, 26),
+    ("up2_split_k_second_stage", 2, (3, 3), 4, 208, 104),
+    ("up2_halo_tile_kernel", 1, (2, 2), 40, 26, 13),
+])
+def test_folded_upsample_conv_epilogue_accumulates_batchnorm_statistics(name, n, grid, p, ci, co):
+    """The same statistics from the folded-upsample forward paths (parity classes in one grid, their split-K second stage,
+    the folded halo-tile kernel)."""
+    ops = _ops()
+    g = _gen(80 + co)
+    gh, gw = grid
+    x = torch.randn(n * gh * gw, ci, p, p, generator=g)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)
+    b = torch.randn(co, generator=g) * 0.1
+    xg = ops.to_grid(x.to(cuda), gh, gw, merged=False)
+    y = ops.conv(xg, w.to(cuda), b.to(cuda), 3, 3, 1, 1, ops.PAD_REPLICATE, out_stats=True, up2=True)
+    y0 = ops.conv(xg, w.to(cuda), b.to(cuda), 3, 3, 1, 1, ops.PAD_REPLICATE, up2=True)
+    assert y.stats is not None and torch.equal(y.t, y0.t)
+    ld = y.t.shape[-1]
+    t = y.t.double().reshape(-1, ld)
+    want = torch.cat((t.sum(0), (t * t).sum(0)))
+    assert rel_l2(y.stats.cpu(), want.cpu()) < 1e-6, rel_l2(y.stats.cpu(), want.cpu())
 
 
 def test_stream_placement_probe_picks_streams_that_overlap():
