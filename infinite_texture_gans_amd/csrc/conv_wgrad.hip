@@ -19,8 +19,12 @@ constexpr int tn_min_blocks(int bcol, int wcol, int wco, bool bf, int depth) {
 
 // XF: the input transform of WgP (BatchNorm-apply + activation + upsample of x in the loader); its own instantiation so that
 // the plain kernel is exactly the round-2 code
-template <int BCOL, int BCO, int WCOL, int WCO, bool BF, int DEPTH, bool XF>
-__global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) void conv_tn_kernel(WgP p, int otp) {
+// FLAT: both tensors are plain images (1 x 1 patch grids: the discriminator's layers), zero padding, no parity classes, at
+// most 15 taps per column tile and MU >= the pixels of a stage: the offset producer is then straight-line code (no patch
+// arithmetic, no clamp, one pass, selects instead of branches) that the scheduler may place between the MFMAs of the stage
+// - the generic producer cost 10 % of D's weight-gradient time (timing experiment with the producer switched off after the pipeline had filled: D3 678 -> 608 us).
+template <int BCOL, int BCO, int WCOL, int WCO, bool BF, int DEPTH, bool XF, bool FLAT = false>
+__global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) void conv_tn_kernel(const WgP p, int otp) {
   constexpr int FI = WCOL / 16, FJ = WCO / 16;
   constexpr int WAVES_COL = BCOL / WCOL;
   static_assert(WAVES_COL * (BCO / WCO) == 4, "4 waves per workgroup");
@@ -29,6 +33,7 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
   constexpr int LHX = BCOL + 8, LHY = BCO + 8;       // bf16 tiles: row pitch in halfwords (8-B aligned rows)
   constexpr int XG = BCOL / 4, YG = BCO / 4;         // float4 groups per pixel row
   constexpr int XL = (KP * XG + 255) / 256, YL = (KP * YG + 255) / 256;
+  constexpr bool XFULL = (KP * XG) % 256 == 0, YFULL = (KP * YG) % 256 == 0;      // every thread stages a row in every pass: no row guards
   __shared__ __attribute__((aligned(16))) float smem[2 * BKP * (LDX + LDY)];
   static_assert(2 * 32 * (LHX + LHY) * 2 <= 2 * BKP * (LDX + LDY) * 4, "bf16 tiles fit the fp32 allocation");
   float* Xs = smem;
@@ -112,7 +117,26 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
     decode_m(m < p.M ? m : 0, p.MT, p.MU, pn, pt_, pu);
     if (m >= p.M) pn = p.x.n;      // marks invalid
   }
+  // FLAT: this thread's single entry (pass 0); inactive threads park their store in the spare word behind the table
+  const unsigned ld4x = (unsigned)p.x.ld * 4u, ld4y = (unsigned)p.dy.ld * 4u;
+  const int fslot = pact[0] ? prow * OTP + pe0 / KP : (DEPTH + 1) * KP * OTP;
   auto produce = [&](int buf) {
+    if constexpr (FLAT) {
+      const bool live = pn < p.x.n;
+      const int iy = pt_ * p.stride - p.pad_h + pky[0], ix = pu * p.stride - p.pad + pkx[0];
+      const bool okx = live && (unsigned)iy < (unsigned)p.x.H && (unsigned)ix < (unsigned)p.x.W;
+      const unsigned ox = okx ? (unsigned)((pn * p.x.H + iy) * p.x.W + ix) * ld4x : p.x_bytes;
+      const unsigned oy = live ? (unsigned)((pn * p.MT + pt_) * p.MU + pu) * ld4y : p.dy_bytes;
+      otab[pact[0] ? buf * KP * OTP + fslot : fslot] = pdy[0] ? oy : ox;
+      pu += KP;
+      const bool w = pu >= p.MU;                                   // MU >= KP: at most one row wrap per stage
+      pu -= w ? p.MU : 0;
+      pt_ += w ? 1 : 0;
+      const bool w2 = pt_ >= p.MT;
+      pt_ = w2 ? 0 : pt_;
+      pn += w2 ? 1 : 0;
+      return;
+    }
     const bool live = pn < p.x.n;
 #pragma unroll
     for (int i = 0; i < PE; ++i) {
@@ -158,13 +182,16 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
     } else {
 #pragma unroll
       for (int i = 0; i < XL; ++i) {
-        unsigned o = xok[i] ? otab[(slot * KP + xr[i]) * OTP + xj[i]] + xcb[i] : p.x_bytes;
+        // table read unconditional (clamped index), validity by select: no exec-mask branch around the ds_read
+        const unsigned t = otab[(slot * KP + min(xr[i], KP - 1)) * OTP + min(xj[i], OTP - 1)];
+        const unsigned o = xok[i] ? t + xcb[i] : p.x_bytes;       // (an invalid pixel's entry is x_bytes: adding the column stays out of range)
         rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxr, o, 0, 0));
       }
     }
 #pragma unroll
     for (int i = 0; i < YL; ++i) {
-      unsigned o = yok[i] ? otab[(slot * KP + yr[i]) * OTP + nt] + ycb[i] : p.dy_bytes;
+      const unsigned t = otab[(slot * KP + min(yr[i], KP - 1)) * OTP + nt];
+      const unsigned o = yok[i] ? t + ycb[i] : p.dy_bytes;
       ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ryr, o, 0, 0));
     }
   };
@@ -173,7 +200,7 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
   auto store_tiles = [&](int buf, int set, const f32x4 (&rx)[XL], const f32x4 (&ry)[YL]) {
 #pragma unroll
     for (int i = 0; i < XL; ++i)
-      if (xr[i] < KP) {
+      if (XFULL || xr[i] < KP) {
         f32x4 v = rx[i];
         if constexpr (xf) {
           const int c = (int)(xcb[i] >> 2);
@@ -191,7 +218,7 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
       }
 #pragma unroll
     for (int i = 0; i < YL; ++i) {
-      if (yr[i] < KP) {
+      if (YFULL || yr[i] < KP) {
         if constexpr (BF) *reinterpret_cast<uint2*>(Yh + (buf * KP + yr[i]) * LHY + yc[i]) = pack_bf16x4(ry[i]);
         else *reinterpret_cast<f32x4*>(Ys + (buf * KP + yr[i]) * LDY + yc[i]) = ry[i];
       }
@@ -263,7 +290,7 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
       for (int kk = 0; kk < nk; ++kk) {
         const int buf = kk & 1;
         if (kk + 1 < nk) load_tiles(buf ^ 1, 0, rxs[0], rys[0]);   // table of stage kk + 1: written one barrier ago
-        if (kk + 2 < nk) produce(buf);                           // stage kk + 2 -> the slot stage kk's loads have finished with
+        if (FLAT || kk + 2 < nk) produce(buf);                   // stage kk + 2 -> the slot stage kk's loads have finished with
         compute(buf);
         if (kk + 1 < nk) store_tiles(buf ^ 1, 0, rxs[0], rys[0]);
         __syncthreads();
@@ -283,13 +310,13 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
       for (int kk = 0; kk < nk; kk += 2) {
         const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
         if (kk + 2 < nk) load_tiles(s2, 0, rxs[0], rys[0]);
-        if (kk + 3 < nk) produce(s0);                            // stage kk + 3
+        if (FLAT || kk + 3 < nk) produce(s0);                    // stage kk + 3 (FLAT: unconditional - entries past the last stage are never read)
         compute(0);
         if (kk + 1 < nk) store_tiles(1, DEPTH - 1, rxs[DEPTH - 1], rys[DEPTH - 1]);
         __syncthreads();
         if (kk + 1 >= nk) break;
         if (kk + 3 < nk) load_tiles(s0, DEPTH - 1, rxs[DEPTH - 1], rys[DEPTH - 1]);
-        if (kk + 4 < nk) produce(s1);                            // stage kk + 4
+        if (FLAT || kk + 4 < nk) produce(s1);                    // stage kk + 4
         compute(1);
         if (kk + 2 < nk) store_tiles(0, 0, rxs[0], rys[0]);
         __syncthreads();
@@ -909,10 +936,19 @@ int launch_tn(WgP p, int splits, int prec, hipStream_t s) {
   static const int depth_env = env_int("ITG_TN_DEPTH", 0);
   const int depth = depth_env ? depth_env : (p.chunks_per_split >= 128 ? 1 : 2);
   const int kp = prec == ITG_PREC_BF16 ? 32 : BKP;
-  snprintf(g_last_launch, sizeof(g_last_launch), "conv_tn_kernel<%d, %d, %d, %d, %s, %d, %s>", BCOL, BCO, WCOL, WCO,
-           prec == ITG_PREC_BF16 ? "true" : "false", prec == ITG_PREC_BF16 ? 1 : depth, p.in_ab ? "true" : "false");
+  static const int flat_env = env_int("ITG_TN_FLAT", 1);
+  const bool flat = flat_env && !p.in_ab && prec != ITG_PREC_BF16 && !p.up2 && p.x.gh == 1 && p.x.gw == 1 && p.dy.gh == 1 &&
+                    p.dy.gw == 1 && p.pad_mode != ITG_PAD_REPLICATE && otp <= 16 && p.MU >= kp;
+  snprintf(g_last_launch, sizeof(g_last_launch), "conv_tn_kernel<%d, %d, %d, %d, %s, %d, %s, %s>", BCOL, BCO, WCOL, WCO,
+           prec == ITG_PREC_BF16 ? "true" : "false", prec == ITG_PREC_BF16 ? 1 : depth, p.in_ab ? "true" : "false",
+           flat ? "true" : "false");
   const size_t abb = p.in_ab ? (size_t)2 * p.cin_ld * 4 : 0;      // alpha | beta' of the input transform behind the offset table
-  if (p.in_ab) {
+  if (flat) {                                                      // (+ the spare word inactive producer threads write to)
+    if (depth == 2)
+      hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 2, false, true>), grid, dim3(256), (size_t)3 * kp * otp * 4 + 16, s, p, otp);
+    else
+      hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 1, false, true>), grid, dim3(256), (size_t)2 * kp * otp * 4 + 16, s, p, otp);
+  } else if (p.in_ab) {
     if (prec == ITG_PREC_BF16) return ITG_ERR_ARG;                 // the loader transform exists for fp32 operands
     if (depth == 2)
       hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 2, true>), grid, dim3(256), (size_t)3 * kp * otp * 4 + abb, s, p, otp);
