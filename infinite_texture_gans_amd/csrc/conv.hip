@@ -59,10 +59,10 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, const float* __re
 // Panels of conv3x3(up2x(x)) (itg_conv_geom.up2).  Forward: class (ry, rx) major, out[cls][o][k], k = (jy*2+jx)*ci_ld + c;
 // tap jj of parity r sums the 3x3 taps lo..hi per axis:  lo = jj ? 1 + r : 0,  hi = jj ? 2 : r.
 __device__ __forceinline__ float up2_fwd_elem(const float* __restrict__ w, int co, int ci, int ci_ld, int co_pad, int Kpad,
-                                              long long e) {
-  const int k = (int)(e % Kpad);
-  const long long r = e / Kpad;
-  const int o = (int)(r % co_pad), cls = (int)(r / co_pad);
+                                              unsigned e) {
+  const int k = (int)(e % (unsigned)Kpad);
+  const unsigned r = e / (unsigned)Kpad;
+  const int o = (int)(r % (unsigned)co_pad), cls = (int)(r / (unsigned)co_pad);
   const int tap = k / ci_ld, c = k - tap * ci_ld;
   if (o >= co || tap >= 4 || c >= ci) return 0.f;
   const int ry = cls >> 1, rx = cls & 1, jy = tap >> 1, jx = tap & 1;
@@ -75,9 +75,9 @@ __device__ __forceinline__ float up2_fwd_elem(const float* __restrict__ w, int c
 }
 // Input gradient: out[c_in][k], k = (ty*4+tx)*co_ld + o - the forward-layout panel of the 4x4 stride-2 pad-1 conv of dy;
 // tap t sums the 3x3 taps max(0, 2-t) .. min(2, 3-t) per axis.
-__device__ __forceinline__ float up2_dgrad_elem(const float* __restrict__ w, int co, int ci, int co_ld, int Kpad, long long e) {
-  const int k = (int)(e % Kpad);
-  const int c_in = (int)(e / Kpad);
+__device__ __forceinline__ float up2_dgrad_elem(const float* __restrict__ w, int co, int ci, int co_ld, int Kpad, unsigned e) {
+  const int k = (int)(e % (unsigned)Kpad);
+  const int c_in = (int)(e / (unsigned)Kpad);
   const int tap = k / co_ld, o = k - tap * co_ld;
   if (c_in >= ci || tap >= 16 || o >= co) return 0.f;
   const int ty = tap >> 2, tx = tap & 3;
@@ -94,7 +94,8 @@ __global__ void pack_up2_kernel(const float* __restrict__ w, const float* __rest
   const float sc = scale ? *scale : 1.f;
   const int Kpad = dgrad ? round_up_d(16 * ld, BK) : round_up_d(4 * ld, BK);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
-    out[i] = sc * (dgrad ? up2_dgrad_elem(w, co, ci, ld, Kpad, i) : up2_fwd_elem(w, co, ci, ld, round_up_d(co, 16), Kpad, i));
+    out[i] = sc * (dgrad ? up2_dgrad_elem(w, co, ci, ld, Kpad, (unsigned)i)
+                         : up2_fwd_elem(w, co, ci, ld, round_up_d(co, 16), Kpad, (unsigned)i));
 }
 
 // every packed panel of a model in one launch.  The job table lives in DEVICE memory (it is static for a
@@ -102,51 +103,66 @@ __global__ void pack_up2_kernel(const float* __restrict__ w, const float* __rest
 // {w_oihw, out, co, ci, ld, kh, kw, stride, dgrad, start}; job j owns elements [start_j, start_{j+1}).
 constexpr int PACK_ROW = 10;
 
+// One thread packs FOUR consecutive panel elements (panel sizes and therefore job starts are multiples of 16, ld % 4 == 0:
+// the four share their filter tap and differ in the channel that is contiguous in the panel) with 32-bit index
+// arithmetic and one 16-byte store - the 64-bit divisions per element of the first version were most of its 60 us.
 __global__ void pack_multi_kernel(const long long* __restrict__ table, int n, long long total) {
   __shared__ long long T[ITG_PACK_MAX_JOBS * PACK_ROW];
   for (int i = threadIdx.x; i < n * PACK_ROW; i += blockDim.x) T[i] = table[i];
   __syncthreads();
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+  const long long items = total >> 2;
+  for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < items; it += (long long)gridDim.x * blockDim.x) {
+    const long long i = it << 2;
     int lo = 0, hi = n - 1;
     while (lo < hi) {                       // last job with start <= i
       int mid = (lo + hi + 1) >> 1;
       if (T[mid * PACK_ROW + 9] <= i) lo = mid; else hi = mid - 1;
     }
     const long long* b = T + lo * PACK_ROW;
-    const float* w = reinterpret_cast<const float*>(b[0]);
+    const float* __restrict__ w = reinterpret_cast<const float*>(b[0]);
     float* out = reinterpret_cast<float*>(b[1]);
     const int co = (int)b[2], ci = (int)b[3], ld = (int)b[4], kh = (int)b[5], kw = (int)b[6], stride = (int)b[7];
-    const long long e = i - b[9];
-    float v = 0.f;
-    if (b[8] == 2) {
-      v = up2_fwd_elem(w, co, ci, ld, round_up_d(co, 16), round_up_d(4 * ld, BK), e);
-    } else if (b[8] == 3) {
-      v = up2_dgrad_elem(w, co, ci, ld, round_up_d(16 * ld, BK), e);
-    } else if (!b[8]) {
-      const int Kpad = round_up_d(kh * kw * ld, BK);
-      int k = (int)(e % Kpad), o = (int)(e / Kpad);
-      int tap = k / ld, c = k - tap * ld;
-      if (o < co && tap < kh * kw && c < ci) {
-        int y = tap / kw, x = tap - y * kw;
-        v = w[(((size_t)o * ci + c) * kh + y) * kw + x];
+    const int kind = (int)b[8];
+    const unsigned e = (unsigned)(i - b[9]);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (kind == 2) {
+      const int co_pad = round_up_d(co, 16), Kpad = round_up_d(4 * ld, BK);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = up2_fwd_elem(w, co, ci, ld, co_pad, Kpad, e + j);
+    } else if (kind == 3) {
+      const int Kpad = round_up_d(16 * ld, BK);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = up2_dgrad_elem(w, co, ci, ld, Kpad, e + j);
+    } else if (kind == 0) {
+      const unsigned Kpad = (unsigned)round_up_d(kh * kw * ld, BK);
+      const int k = (int)(e % Kpad), o = (int)(e / Kpad);
+      const int tap = k / ld, c = k - tap * ld;
+      if (o < co && tap < kh * kw) {
+        const float* q = w + ((size_t)o * ci + c) * (kh * kw) + tap;      // [o][c][tap]: the four channels are kh * kw apart
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j < ci) v[j] = q[(size_t)j * kh * kw];
       }
     } else {
       const int skh = kh / stride, skw = kw / stride;
-      const int Kpad = round_up_d(skh * skw * ld, BK);
-      const int ci_pad = round_up_d(ci, 16);
-      int k = (int)(e % Kpad);
-      long long r = e / Kpad;
-      int c_in = (int)(r % ci_pad), cls = (int)(r / ci_pad);
-      int ry = cls / stride, rx = cls - ry * stride;
-      int tap = k / ld, o = k - tap * ld;
-      if (c_in < ci && o < co && tap < skh * skw) {
-        int jy = tap / skw, jx = tap - jy * skw;
-        int ay = (ry + 1) % stride, ax = (rx + 1) % stride;     // pad = 1 for stride-2 convs (ABI)
-        int y = ay + stride * (skh - 1 - jy), x = ax + stride * (skw - 1 - jx);
-        v = w[(((size_t)o * ci + c_in) * kh + y) * kw + x];
+      const unsigned Kpad = (unsigned)round_up_d(skh * skw * ld, BK);
+      const unsigned ci_pad = (unsigned)round_up_d(ci, 16);
+      const int k = (int)(e % Kpad);
+      const unsigned r = e / Kpad;
+      const int c_in = (int)(r % ci_pad), cls = (int)(r / ci_pad);
+      const int ry = cls / stride, rx = cls - ry * stride;
+      const int tap = k / ld, o = k - tap * ld;
+      if (c_in < ci && tap < skh * skw) {
+        const int jy = tap / skw, jx = tap - jy * skw;
+        const int ay = (ry + 1) % stride, ax = (rx + 1) % stride;     // pad = 1 for stride-2 convs (ABI)
+        const int y = ay + stride * (skh - 1 - jy), x = ax + stride * (skw - 1 - jx);
+        const float* q = w + (((size_t)o * ci + c_in) * kh + y) * kw + x;    // the four output channels are ci * kh * kw apart
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (o + j < co) v[j] = q[(size_t)j * ci * kh * kw];
       }
     }
-    out[e] = v;
+    *reinterpret_cast<f32x4*>(out + e) = v;
   }
 }
 
@@ -462,7 +478,9 @@ int itg_pack_up2_dgrad(const float* w, const float* scale, float* out, int co, i
 
 int itg_pack_multi(const int64_t* table_dev, int n, int64_t total, void* stream) {
   if (!table_dev || n <= 0 || n > ITG_PACK_MAX_JOBS || total <= 0) return ITG_ERR_ARG;
-  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (total & 3) return ITG_ERR_ARG;
+  const int64_t items = total >> 2;
+  int blocks = (int)((items + 255) / 256 < 8192 ? (items + 255) / 256 : 8192);
   hipLaunchKernelGGL(pack_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const long long*)table_dev, n,
                      (long long)total);
   ITG_CHECK_LAUNCH();
