@@ -762,7 +762,8 @@ int try_conv_tile(ConvP& p, hipStream_t s, int* rc) {
   const int64_t ntiles = (int64_t)p.in.n * tiles_x * tiles_y;
   const size_t lds = ((size_t)nch * 16 * FI * 20 + ((nch * 4 + 3) & ~3) + 32 + 128 + 128 + (size_t)TT_PIX * cpt) * sizeof(float);
   const int nld = (TT_PIX * (p.cin_ld >> 2) + 255) / 256;
-  if (ntiles > 0x7fffffff || lds > 64 * 1024 || nld > 11) return 0;
+  static const int lds_cap = env_int("ITG_TILE_LDS_KB", 80) * 1024;       // 26 -> 26 channels (b5c2) needs 76 KB: two workgroups per CU
+  if (ntiles > 0x7fffffff || lds > (size_t)lds_cap || nld > 11) return 0;
   const int stm = p.bn_sums ? TS_BNS : (p.stats ? TS_STATS : TS_NONE);
   const bool xfm = p.in_ab != nullptr;
   if (xfm && stm == TS_BNS) return 0;
@@ -785,7 +786,7 @@ int try_conv_tile(ConvP& p, hipStream_t s, int* rc) {
     int slot = 0;
     for (; slot < 24 && attr_set[slot]; ++slot) seen = seen || attr_set[slot] == kern;
     if (!seen && slot < 24) {
-      (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       attr_set[slot] = kern;
     }
   }
