@@ -386,9 +386,18 @@ class _Conv(torch.autograd.Function):
                 st = C.c_void_p(side.cuda_stream) if side is not None else _stream()
                 dxd = _desc(x, ci)
                 sinks_ok = not ((need_w and wsink is None) or (need_b and bsink is None))
+                one = []
                 if WGRAD_DEFER is not None and sinks_ok and _queue_wgrad(x, dxd, dy, ddy, g, w, wsink, bsink, need_w, need_b,
                                                                          ctx.sn, st):
                     gw_ = gb = None         # the slabs are computed; ops.flush_deferred() finishes the layer
+                elif (SN_FUSED_REDUCE and ctx.sn is not None and need_w and sinks_ok
+                      and _queue_wgrad(x, dxd, dy, ddy, g, w, wsink, bsink, need_w, need_b, ctx.sn, st, queue=one)):
+                    # spectrally normalised layer: the reduce launch also accumulates <G, W> and one apply launch finishes the
+                    # layer - 3-4 launches instead of 5 (contraction, [group stage], reduce, dot, apply), same stream
+                    _finish_jobs(one, st)
+                    if side is not None:
+                        WGRAD_KEEPALIVE.append(one[0][2])
+                    gw_ = gb = None
                 else:
                     key = ("w", tuple(x.shape), tuple(dy.shape), ctx.geom, ci, co)
                     nws = _WS_SIZE.get(key)
@@ -478,6 +487,7 @@ _wgrad_slot = {}
 # transposition, bias gradients, the <G, W> dots of spectrally normalised layers) plus one itg_spectral_norm_bwd_multi -
 # instead of 2-5 small launches per layer (79 second-stage + 20 spectral-norm launches per train step before).
 WGRAD_DEFER = None
+SN_FUSED_REDUCE = os.environ.get("ITG_SN_FUSED_REDUCE", "1") == "1"      # see _Conv.backward
 _WGRAD_WS = {}           # persistent slab workspaces / spectral-norm temporaries, keyed by layer and shape (never freed: the
                          # slabs must outlive the conv call, and a captured hipGraph replays their addresses)
 
@@ -489,8 +499,9 @@ def _persistent(key, numel, device, dtype=torch.float32):
     return t
 
 
-def _queue_wgrad(x, dxd, dy, ddy, gwg, w, wsink, bsink, need_w, need_b, sn, st):
-    """Deferred form of the weight gradient of one conv; False when the layer cannot be deferred."""
+def _queue_wgrad(x, dxd, dy, ddy, gwg, w, wsink, bsink, need_w, need_b, sn, st, queue=None):
+    """Deferred form of the weight gradient of one conv (appended to ``queue``, default WGRAD_DEFER); False when the
+    layer cannot be deferred."""
     if gwg.up2:           # folded-upsample layers reduce their class slabs through a kernel of their own
         return False
     key = ((wsink if wsink is not None else bsink).data_ptr(), tuple(x.shape), tuple(dy.shape))
@@ -523,17 +534,13 @@ def _queue_wgrad(x, dxd, dy, ddy, gwg, w, wsink, bsink, need_w, need_b, sn, st):
         job.accumulate = (ACC_DW if need_w else 0) | (ACC_DB if need_b else 0)
         keep = ()
     job.db = bsink.data_ptr() if (need_b and bsink is not None) else None
-    WGRAD_DEFER.append((job, snjob, (ws, x, dy) + keep))
+    (WGRAD_DEFER if queue is None else queue).append((job, snjob, (ws, x, dy) + keep))
     return True
 
 
-def flush_deferred():
-    """Finish every queued weight gradient on the CURRENT stream (which must have been ordered behind the streams the
-    slabs were computed on: wgrad_streams_join)."""
-    jobs = WGRAD_DEFER
-    if not jobs:
-        return
-    st = _stream()
+def _finish_jobs(jobs, st):
+    """The reduce stage of queued weight gradients on stream ``st``: itg_wgrad_reduce_multi (+ the <G, W> dots) and
+    itg_spectral_norm_bwd_multi."""
     n = _lib.WGRAD_MAX_JOBS
     for i in range(0, len(jobs), n):
         chunk = [j[0] for j in jobs[i:i + n]]
@@ -542,6 +549,15 @@ def flush_deferred():
     for i in range(0, len(sn), n):
         chunk = sn[i:i + n]
         _lib.call("itg_spectral_norm_bwd_multi", (_lib.SnJob * len(chunk))(*chunk), len(chunk), st)
+
+
+def flush_deferred():
+    """Finish every queued weight gradient on the CURRENT stream (which must have been ordered behind the streams the
+    slabs were computed on: wgrad_streams_join)."""
+    jobs = WGRAD_DEFER
+    if not jobs:
+        return
+    _finish_jobs(jobs, _stream())
     if not torch.cuda.is_current_stream_capturing():
         WGRAD_KEEPALIVE.append(tuple(j[2] for j in jobs))       # operands stay referenced until the owner's join clears the list
     del jobs[:]
