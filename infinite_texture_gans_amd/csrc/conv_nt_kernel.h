@@ -24,12 +24,6 @@ constexpr int nt_min_blocks(int bco, int bpix, int wco, int wpix, int tbk) {
 // the plain kernels are exactly the round-2 code (as run-time branches the two cost them 2-20 %).
 template <int BCO, int BPIX, int WCO, int WPIX, int TBK, int DEPTH, bool TAB, int MODE>
 __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void conv_nt_kernel(const ConvP p) {
-  // per-class geometry (class 0 for ordinary launches); all wave-uniform scalars
-  const int cls = blockIdx.y;
-  const int cMT = p.cMT[cls], cMU = p.cMU[cls], cM = p.cM[cls];
-  const int cioy = p.cioy[cls], ciox = p.ciox[cls], cooy = p.cooy[cls], coox = p.coox[cls];
-  const float* const cw = p.w + p.cwoff[cls];
-  float* const cpartial = p.partial + p.cpoff[cls];
   // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share an L2): hand every XCD one contiguous run of
   // tile ids instead, so that an L2 serves neighbouring pixel tiles (shared halo rows, all output-channel tiles of a
   // pixel tile) and not a 1-in-8 sample of the whole image.  Bijective for any grid size; speed only.
@@ -38,6 +32,17 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
     const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = bx & 7;
     bx = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bx >> 3);
   }
+  // parity classes of a multi-class launch (stride-2 input gradient, folded upsample) are the FASTEST index of the tile id:
+  // the four classes of a pixel tile gather the same source pixels, so they run on one XCD at the same time and share them
+  // through its L2 (as blockIdx.y they ran a quarter of the launch apart: D2's input gradient fetched 447 MB for 19 MB of dy)
+  const int ncls = p.ncls > 1 ? p.ncls : 1;
+  const int cls = bx % ncls;
+  bx /= ncls;
+  // per-class geometry (class 0 for ordinary launches); all wave-uniform scalars
+  const int cMT = p.cMT[cls], cMU = p.cMU[cls], cM = p.cM[cls];
+  const int cioy = p.cioy[cls], ciox = p.ciox[cls], cooy = p.cooy[cls], coox = p.coox[cls];
+  const float* const cw = p.w + p.cwoff[cls];
+  float* const cpartial = p.partial + p.cpoff[cls];
   if ((int)(bx / p.nco_tiles) * BPIX >= cM) return;
   constexpr int FI = WCO / 16, FJ = WPIX / 16;
   constexpr int WAVES_CO = BCO / WCO;
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
     __syncthreads();
     int* const flag = reinterpret_cast<int*>(smem);          // the K loop ended with a barrier: its buffers are free
     if (tid == 0) {
-      unsigned* const tk = p.tickets + (blockIdx.y * gridDim.x + blockIdx.x);
+      unsigned* const tk = p.tickets + blockIdx.x;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -438,7 +443,9 @@ int launch_nt(const ConvP& p, int tbk, hipStream_t s) {
   int64_t npix = ((int64_t)p.M + BPIX - 1) / BPIX;
   int64_t blocks = npix * q.nco_tiles;
   if (blocks <= 0 || blocks > 0x7fffffff) return ITG_ERR_ARG;
-  dim3 grid((unsigned)blocks, (unsigned)(p.ncls > 1 ? p.ncls : 1), (unsigned)p.ksplit);
+  const int64_t gx = blocks * (p.ncls > 1 ? p.ncls : 1);       // classes are the fastest index of the tile id (see the kernel)
+  if (gx > 0x7fffffff) return ITG_ERR_ARG;
+  dim3 grid((unsigned)gx, 1, (unsigned)p.ksplit);
   size_t tab_bytes = (size_t)BPIX * (p.ntaps + 1) * sizeof(unsigned);
   q.use_tab = (p.cin_ld < 64 && tab_bytes <= 24 * 1024) ? 1 : 0;
   static const int xcd = env_int("ITG_NT_XCD", 1);

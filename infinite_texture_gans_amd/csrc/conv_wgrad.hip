@@ -42,12 +42,16 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
   unsigned short* Yh = Xh + 2 * KP * LHX;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col_tile = blockIdx.x % p.ncol_tiles;
-  const int co_tile = blockIdx.x / p.ncol_tiles;
+  // up2: the output-parity class is the fastest index of the tile id (the four classes of a tile gather the same source
+  // pixels: adjacent workgroups share them through one L2)
+  const int ncls = p.up2 ? 4 : 1;
+  const int cls = (int)blockIdx.x % ncls;
+  const int tile_id = (int)blockIdx.x / ncls;
+  const int col_tile = tile_id % p.ncol_tiles;
+  const int co_tile = tile_id / p.ncol_tiles;
   const int col0 = col_tile * BCOL, co0 = co_tile * BCO;
   const int wcol0 = (wave % WAVES_COL) * WCOL, wco0 = (wave / WAVES_COL) * WCO;
   const int split = blockIdx.z;
-  const int cls = blockIdx.y, ncls = gridDim.y;            // up2: output-parity class (1 class otherwise)
   const int ry = p.up2 ? cls >> 1 : 0, rx = p.up2 ? cls & 1 : 0;
   const int chunk_begin = split * p.chunks_per_split;
   const int chunk_end = min(p.nchunks, chunk_begin + p.chunks_per_split);
@@ -926,7 +930,7 @@ template <int BCOL, int BCO, int WCOL, int WCO>
 int launch_tn(WgP p, int splits, int prec, hipStream_t s) {
   p.ncol_tiles = (p.Kpad + BCOL - 1) / BCOL;
   p.nco_tiles = (p.co_rows + BCO - 1) / BCO;
-  dim3 grid((unsigned)(p.ncol_tiles * p.nco_tiles), p.up2 ? 4u : 1u, (unsigned)splits);
+  dim3 grid((unsigned)(p.ncol_tiles * p.nco_tiles * (p.up2 ? 4 : 1)), 1, (unsigned)splits);
   // offset-table pitch: the taps one column tile can touch (+ the dY slot)
   int taps_tile = (BCOL + p.cin_ld - 1) / p.cin_ld + 1;
   if (taps_tile > p.ntaps) taps_tile = p.ntaps;
