@@ -273,6 +273,13 @@ int itg_bn_bwd_reduce(const itg_tensor* x, const itg_tensor* dy, const float* ab
 int itg_bn_bwd_apply(const itg_tensor* x, const itg_tensor* dy, const float* ab, const float* mean_rstd,
                      const double* sums_local, const double* sums, double count, int act, float slope,
                      const itg_tensor* dx, float* dgamma, float* dbeta, int accumulate, void* stream);
+/* The same with a second gradient of the BatchNorm's input added into dx (`addend`: x's shape, NULL = none, not dx
+ * itself): the block input of reference models/layers.py:301-322 feeds bn1 AND the residual shortcut, and autograd's sum
+ * of the two gradients is otherwise a launch of its own. */
+int itg_bn_bwd_apply_add(const itg_tensor* x, const itg_tensor* dy, const float* ab, const float* mean_rstd,
+                         const double* sums_local, const double* sums, double count, int act, float slope,
+                         const itg_tensor* dx, float* dgamma, float* dbeta, int accumulate, const itg_tensor* addend,
+                         void* stream);
 
 /* ---- SSM modulation (reference models/layers.py:228-234): out = (1+gamma)*xhat + beta,
  * gamma/beta the two halves of `emb` (channels [0,c) and [c,2c)), then optional act ---- */

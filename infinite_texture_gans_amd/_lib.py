@@ -99,6 +99,7 @@ SIGNATURES = {
     "itg_bn_apply": (_i, [_TP, _P, _TP, _i, _f, _P]),
     "itg_bn_bwd_reduce": (_i, [_TP, _TP, _P, _P, _i, _f, _P, _P]),
     "itg_bn_bwd_apply": (_i, [_TP, _TP, _P, _P, _P, _P, _d, _i, _f, _TP, _P, _P, _i, _P]),
+    "itg_bn_bwd_apply_add": (_i, [_TP, _TP, _P, _P, _P, _P, _d, _i, _f, _TP, _P, _P, _i, _TP, _P]),
     "itg_ssm_modulate_fwd": (_i, [_TP, _P, _TP, _TP, _i, _f, _P]),
     "itg_ssm_modulate_bwd": (_i, [_TP, _P, _TP, _TP, _i, _f, _TP, _TP, _P]),
     "itg_act_fwd": (_i, [_TP, _TP, _i, _f, _P]),

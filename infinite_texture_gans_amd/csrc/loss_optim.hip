@@ -28,9 +28,17 @@ __device__ __forceinline__ float bce_elem(float x, float t) {
 // single workgroup: deterministic
 __global__ __launch_bounds__(1024) void bce_fwd_kernel(const float* __restrict__ x, int64_t n, float t,
                                                        float* __restrict__ out) {
-  double s = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += (double)bce_elem(x[i], t);
-  s = block_sum_d(s);
+  // four independent partial sums per thread: four loads in flight (the loop is latency-bound: 17 dependent rounds for
+  // D(fake)'s 17 672 logits took 18 us), fixed summation order
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int64_t i = threadIdx.x;
+  const int64_t st = blockDim.x;
+  for (; i + 3 * st < n; i += 4 * st) {
+    const float a = x[i], b = x[i + st], c = x[i + 2 * st], d = x[i + 3 * st];
+    s0 += (double)bce_elem(a, t); s1 += (double)bce_elem(b, t); s2 += (double)bce_elem(c, t); s3 += (double)bce_elem(d, t);
+  }
+  for (; i < n; i += st) s0 += (double)bce_elem(x[i], t);
+  double s = block_sum_d((s0 + s1) + (s2 + s3));
   if (threadIdx.x == 0) *out = (float)(s / (double)n);
 }
 

@@ -268,7 +268,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   block_flush(lds, s, sx, cg, ld, sums);
 }
 
-template <bool UPS>
+// ADD: dx also takes a second gradient of the BatchNorm's input (`addend`, x's shape): the tensor feeds the residual
+// shortcut as well (reference models/layers.py:313-322), and the sum of its two gradients is otherwise a launch of its own
+template <bool UPS, bool ADD>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            const float* __restrict__ ab,
                                                            const float* __restrict__ mean_rstd,
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            int64_t npix, int ld, int c, int ph, int pw, int act,
                                                            float slope, float* __restrict__ dx,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           int accumulate) {
+                                                           int accumulate, const float* __restrict__ addend) {
   const int q4 = ld >> 2;
   const int64_t T = (int64_t)gridDim.x * 256;
   const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       float xh = (v[e] - mu[e]) * rs[e];
       o[e] = a[e] * (ge - m1[e] - xh * m2[e]);
     }
+    if constexpr (ADD) o += *reinterpret_cast<const f32x4*>(addend + pix * ld + cg * 4);
     *reinterpret_cast<f32x4*>(dx + pix * ld + cg * 4) = o;
   }
 }
@@ -481,29 +484,42 @@ int itg_bn_bwd_reduce(const itg_tensor* x, const itg_tensor* dy, const float* ab
   return ITG_OK;
 }
 
-int itg_bn_bwd_apply(const itg_tensor* x, const itg_tensor* dy, const float* ab, const float* mean_rstd,
-                     const double* sums_local, const double* sums, double count, int act, float slope,
-                     const itg_tensor* dx, float* dgamma, float* dbeta, int accumulate, void* stream) {
+int itg_bn_bwd_apply_add(const itg_tensor* x, const itg_tensor* dy, const float* ab, const float* mean_rstd,
+                         const double* sums_local, const double* sums, double count, int act, float slope,
+                         const itg_tensor* dx, float* dgamma, float* dbeta, int accumulate, const itg_tensor* addend,
+                         void* stream) {
   if (!sums_local) sums_local = sums;
   int rc;
   if ((rc = check_tensor(x)) || (rc = check_tensor(dy)) || (rc = check_tensor(dx))) return rc;
   bool ups;
   if (!ab || !mean_rstd || !sums || count <= 0 || !same_shape(x, dx)) return ITG_ERR_ARG;
   if ((rc = ups_mode(x, dy, &ups))) return rc;
+  const float* ad = nullptr;
+  if (addend && addend->ptr) {
+    if ((rc = check_tensor(addend))) return rc;
+    if (!same_shape(x, addend) || addend->ptr == dx->ptr) return ITG_ERR_ARG;
+    ad = (const float*)addend->ptr;
+  }
   int64_t npix = grid_pixels(x);
   int q4 = x->ld >> 2;
   int blocks = sweep_blocks(npix * q4, q4, 4, 4096);
   if ((int64_t)blocks * 256 < x->ld) blocks = sweep_blocks((int64_t)x->ld * q4, q4, 1, 4096);
-  if (ups)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)x->ptr, (const float*)dy->ptr, ab, mean_rstd, sums, sums_local, 1.0 / count,
-                       npix, x->ld, x->c, x->ph, x->pw, act, slope, (float*)dx->ptr, dgamma, dbeta, accumulate);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)x->ptr, (const float*)dy->ptr, ab, mean_rstd, sums, sums_local, 1.0 / count,
-                       npix, x->ld, x->c, x->ph, x->pw, act, slope, (float*)dx->ptr, dgamma, dbeta, accumulate);
+#define ITG_BWD_APPLY(U, A)                                                                                                     \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<U, A>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr,        \
+                     (const float*)dy->ptr, ab, mean_rstd, sums, sums_local, 1.0 / count, npix, x->ld, x->c, x->ph, x->pw, act, \
+                     slope, (float*)dx->ptr, dgamma, dbeta, accumulate, ad)
+  if (ups) { if (ad) ITG_BWD_APPLY(true, true); else ITG_BWD_APPLY(true, false); }
+  else { if (ad) ITG_BWD_APPLY(false, true); else ITG_BWD_APPLY(false, false); }
+#undef ITG_BWD_APPLY
   ITG_CHECK_LAUNCH();
   return ITG_OK;
+}
+
+int itg_bn_bwd_apply(const itg_tensor* x, const itg_tensor* dy, const float* ab, const float* mean_rstd,
+                     const double* sums_local, const double* sums, double count, int act, float slope,
+                     const itg_tensor* dx, float* dgamma, float* dbeta, int accumulate, void* stream) {
+  return itg_bn_bwd_apply_add(x, dy, ab, mean_rstd, sums_local, sums, count, act, slope, dx, dgamma, dbeta, accumulate, nullptr,
+                              stream);
 }
 
 // per-channel sum over all pixels -> out (fp32[ld]); acc is fp64[ld] scratch owned by the caller

@@ -28,6 +28,7 @@ _ENV_BN_LOADER = os.environ.get("ITG_BN_LOADER", "0") == "1"
 _ENV_RES_UPS = os.environ.get("ITG_RES_UPS", "1") == "1"
 _ENV_BN_FUSE = os.environ.get("ITG_BN_FUSE", "1") == "1"
 _ENV_UP2_FOLD = os.environ.get("ITG_UP2_FOLD", "1") == "1"
+_ENV_BN_FORK = os.environ.get("ITG_BN_FORK", "1") == "1"      # the shortcut's gradient is added inside bn1's backward kernel
 
 
 def loader_norm_enabled():
@@ -276,7 +277,7 @@ class conv2d_lp(nn.Module):
             self.conv = conv3x3(ch_in, ch_out, SN, 1, 1)
 
     def forward_grid(self, x, image_location="1st_row_1st_col", act=ops.ACT_NONE, slope=0.0, residual=None, out_stats=False,
-                     bn=None, bn_act=(ops.ACT_NONE, 0.0), upsample=False):
+                     bn=None, bn_act=(ops.ACT_NONE, 0.0), upsample=False, fork_out=None):
         """x: GT patches (or, for the generator's ``start`` layer, the merged latent as a 1x1-grid GT).
         ``out_stats``: the output feeds a training-mode BatchNorm - its statistics are taken in this conv's epilogue.
         ``bn`` (a _BNParams) + ``bn_act`` = (activation, slope) + ``upsample``: the conv's input is
@@ -293,7 +294,12 @@ class conv2d_lp(nn.Module):
                   or (lp_.merge_patches_into_image and lp_.halo is not None and lp_.training))      # band training: halo rows of SOURCE pixels
         fold = bool(upsample) and bn is not None and not fused and up2_fold_enabled() and direct
         if bn is not None and not fused:
-            x = bn.run(x, act=bn_act[0], slope=bn_act[1], upsample=upsample and not fold, consumer_upsamples=fold)
+            # fork_out (a list): the caller reads the BatchNorm's input a second time (residual shortcut); it gets an alias of
+            # it whose gradient the BatchNorm backward absorbs (ops.bn_act(fork=True))
+            x = bn.run(x, act=bn_act[0], slope=bn_act[1], upsample=upsample and not fold, consumer_upsamples=fold,
+                       fork=fork_out is not None)
+            if fork_out is not None and x.fork is not None:
+                fork_out.append(x.fork)
         # a residual at half the output's patch extent (the un-upsampled shortcut) is read through the x2 upsample by the conv
         # epilogue on the paths that hand the patch grid to the kernel as it is; the reshaping paths materialise it
         out_ph = x.t.shape[3] * (2 if ((fused or fold) and upsample) else 1)
@@ -415,11 +421,11 @@ class _BNParams(nn.BatchNorm2d):
         return (self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked, self.training,
                 self.eps, self.momentum, self.sync, self._sinks())
 
-    def run(self, x, act=ops.ACT_NONE, slope=0.0, upsample=False, consumer_upsamples=False):
+    def run(self, x, act=ops.ACT_NONE, slope=0.0, upsample=False, consumer_upsamples=False, fork=False):
         sinks = self._sinks()
         return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked,
                           training=self.training, eps=self.eps, momentum=self.momentum, act=act, slope=slope,
-                          upsample=upsample, sync=self.sync, sinks=sinks, consumer_upsamples=consumer_upsamples)
+                          upsample=upsample, sync=self.sync, sinks=sinks, consumer_upsamples=consumer_upsamples, fork=fork)
 
     def forward(self, x):
         if isinstance(x, GT):
@@ -606,7 +612,11 @@ class ResBlockGenerator(nn.Module):
         else:
             # BatchNorm-apply + LeakyReLU (+ the x2 upsample) happen in conv1's / conv2's tile loaders where the conv path
             # gathers its halo itself (conv2d_lp.forward_grid); otherwise as their own pass
-            out = self.conv1.forward_grid(x, image_location, out_stats=fuse, bn=self.bn1, bn_act=(A, s), upsample=upsample_input)
+            fo = [] if (_ENV_BN_FORK and not forked and self.training and torch.is_grad_enabled()) else None
+            out = self.conv1.forward_grid(x, image_location, out_stats=fuse, bn=self.bn1, bn_act=(A, s), upsample=upsample_input,
+                                          fork_out=fo)
+            if fo:
+                x = fo[0]          # the shortcut below reads the block input through bn1's alias (its gradient joins bn1's)
         if forked:
             main.wait_stream(side)
             sc.t.record_stream(main)                 # allocated on the side stream, read by conv2's epilogue on this one

@@ -110,12 +110,13 @@ def _req_cuda(t, what):
 
 class GT:
     """Patch-grid NHWC activation: ``t`` is (n, gh, gw, ph, pw, ld), ``c`` logical channels."""
-    __slots__ = ("t", "c", "stats")
+    __slots__ = ("t", "c", "stats", "fork")
 
     def __init__(self, t, c, stats=None):
         # stats: fp64 [2 * ld] per-channel (sum, sum of squares) of ``t`` when the conv that produced it accumulated
         # them in its epilogue (conv(..., out_stats=True)); the BatchNorm that consumes ``t`` then skips its stats pass
-        self.t, self.c, self.stats = t, int(c), stats
+        # fork: set by bn_act(fork=True): the alias of the BatchNorm's input whose gradient the BatchNorm backward absorbs
+        self.t, self.c, self.stats, self.fork = t, int(c), stats, None
 
     n = property(lambda s: s.t.shape[0])
     gh = property(lambda s: s.t.shape[1])
@@ -706,7 +707,9 @@ def _zeros_f64(n, device):
 class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, rm, rv, nbt, c, training, eps, momentum, act, slope, ups, sync, sinks=None, pre_sums=None,
-                virt_ups=False):
+                virt_ups=False, fork=False):
+        ctx.set_materialize_grads(False)
+        x_in = x
         x = x.contiguous()
         n, gh, gw, ph, pw, ld = x.shape
         dev = x.device
@@ -739,11 +742,18 @@ class _BNAct(torch.autograd.Function):
         ctx.meta = (c, act, slope, count, sync, training, gamma is not None)
         ctx.sinks = sinks
         ctx.save_for_backward(x, stat)
+        if fork:
+            # second output: x itself (an alias).  Whatever consumes it (the block's residual shortcut) hands its gradient to
+            # THIS backward, which adds it inside itg_bn_bwd_apply_add - instead of autograd summing the two gradients of x
+            # with an add launch of its own
+            return y, x_in.view_as(x_in)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, g_alias=None):
         x, stat = ctx.saved_tensors
+        if dy is None:          # only the alias was used downstream
+            return (g_alias,) + (None,) * 17
         c, act, slope, count, sync, training, affine = ctx.meta
         if not training:
             raise _lib.ItgError("BatchNorm backward is only implemented for training-mode statistics")
@@ -773,19 +783,33 @@ class _BNAct(torch.autograd.Function):
             else:
                 dg = torch.empty(c, device=x.device, dtype=torch.float32)
                 db = torch.empty(c, device=x.device, dtype=torch.float32)
-        _lib.call("itg_bn_bwd_apply", C.byref(dx_), C.byref(ddy_), _ptr(ab), _ptr(mean_rstd), _ptr(local), _ptr(sums),
-                  count, act, float(slope), C.byref(dgx), _ptr(dg), _ptr(db), acc, st)
+        if g_alias is not None:
+            g_alias = g_alias.contiguous()
+            dadd = _desc(g_alias, c)
+            _lib.call("itg_bn_bwd_apply_add", C.byref(dx_), C.byref(ddy_), _ptr(ab), _ptr(mean_rstd), _ptr(local), _ptr(sums),
+                      count, act, float(slope), C.byref(dgx), _ptr(dg), _ptr(db), acc, C.byref(dadd), st)
+        else:
+            _lib.call("itg_bn_bwd_apply", C.byref(dx_), C.byref(ddy_), _ptr(ab), _ptr(mean_rstd), _ptr(local), _ptr(sums),
+                      count, act, float(slope), C.byref(dgx), _ptr(dg), _ptr(db), acc, st)
         if acc:
             dg = db = None
-        return gx, dg, db, None, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return gx, dg, db, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def bn_act(x, gamma, beta, rm, rv, nbt, training=True, eps=1e-5, momentum=0.1, act=ACT_NONE, slope=0.0,
-           upsample=False, sync=None, sinks=None, consumer_upsamples=False):
+           upsample=False, sync=None, sinks=None, consumer_upsamples=False, fork=False):
     """y = act(BatchNorm(x)) [nearest-upsampled x2 when ``upsample``]: statistics are taken on x
     (identical to those of the upsampled tensor), the unbiased running_var uses the x4 count.
     ``consumer_upsamples``: y stays at x's size and the conv that reads it folds the x2 upsample into its filter
     (ops.conv(up2=True)); the reference normalises the upsampled tensor, so running_var still takes the x4 count."""
+    if fork and training and torch.is_grad_enabled() and x.t.requires_grad:
+        # ``fork``: the result carries ``.fork``, an alias of x; a consumer that reads x through it (the residual shortcut of
+        # a generator block) gets its gradient summed into the BatchNorm's own input gradient by the backward kernel
+        t, alias = _BNAct.apply(x.t, gamma, beta, rm, rv, nbt, x.c, training, eps, momentum, act, slope, upsample, sync, sinks,
+                                x.stats if training else None, bool(consumer_upsamples), True)
+        y = GT(t, x.c)
+        y.fork = GT(alias, x.c)
+        return y
     t = _BNAct.apply(x.t, gamma, beta, rm, rv, nbt, x.c, training, eps, momentum, act, slope, upsample, sync, sinks,
                      x.stats if training else None, bool(consumer_upsamples))
     return GT(t, x.c)
