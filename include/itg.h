@@ -89,7 +89,16 @@ typedef struct {
                       * layer that consumes this output (nn.BatchNorm2d after every generator conv, reference
                       * models/layers.py:279-280,301-322) without a second pass over the tensor (out.ld <= 512) */
   const itg_in_norm* in_norm; /* NULL, or the input transform described above */
+  int32_t flags;     /* ITG_GEOM_*; zero-initialise the struct */
+  int32_t reserved;  /* 0 */
 } itg_conv_geom;
+/* itg_conv2d_dgrad with ITG_PAD_REPLICATE folds the gradients of the replicated frame onto the 1-pixel border of dx
+ * with atomics and zeroes that border first (one small launch per call).  ITG_GEOM_FRAME_ZEROED: the caller has zeroed
+ * it already - itg_zero_frames does so for up to ITG_ZERO_FRAMES_MAX tensors in ONE launch (the step engine keeps the
+ * dx buffers of the generator's convs and clears all their frames at the start of the backward pass). */
+#define ITG_GEOM_FRAME_ZEROED 1
+#define ITG_ZERO_FRAMES_MAX 32
+int itg_zero_frames(const itg_tensor* tensors, int n, void* stream);
 
 /* ITG_PREC_F32: v_mfma_f32_16x16x4_f32, the reference's arithmetic (BASELINE configs 1, 2, 4, 5).
  * ITG_PREC_BF16: operands rounded to bf16 while staged into LDS, v_mfma_f32_16x16x32_bf16 with fp32

@@ -34,14 +34,16 @@ class InNorm(C.Structure):
 class ConvGeom(C.Structure):
     _fields_ = [("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("pad_mode", C.c_int32), ("pad_h", C.c_int32), ("precision", C.c_int32), ("up2", C.c_int32),
-                ("out_stats", C.c_void_p), ("in_norm", C.POINTER(InNorm))]
+                ("out_stats", C.c_void_p), ("in_norm", C.POINTER(InNorm)), ("flags", C.c_int32), ("reserved", C.c_int32)]
 
-    def __init__(self, kh, kw, stride, pad, pad_mode, pad_h=-1, precision=0, out_stats=None, in_norm=None, up2=0):
+    def __init__(self, kh, kw, stride, pad, pad_mode, pad_h=-1, precision=0, out_stats=None, in_norm=None, up2=0, flags=0):
         super().__init__(kh, kw, stride, pad, pad_mode, pad_h, precision, int(up2), out_stats,
-                         C.pointer(in_norm) if in_norm is not None else None)
+                         C.pointer(in_norm) if in_norm is not None else None, int(flags), 0)
         self._in_norm = in_norm      # keep it alive
 
 
+GEOM_FRAME_ZEROED = 1
+ZERO_FRAMES_MAX = 32
 PACK_MAX_JOBS = 48
 WGRAD_MAX_JOBS = 24
 
@@ -77,6 +79,7 @@ SIGNATURES = {
     "itg_pack_up2_dgrad_size": (_l, [_i, _i]),
     "itg_pack_up2_fwd": (_i, [_P, _P, _P, _i, _i, _i, _P]),
     "itg_pack_up2_dgrad": (_i, [_P, _P, _P, _i, _i, _i, _P]),
+    "itg_zero_frames": (_i, [_TP, _i, _P]),
     "itg_conv2d_fwd_workspace": (_l, [_TP, _TP, _GP]),
     "itg_conv2d_dgrad_workspace": (_l, [_TP, _TP, _GP]),
     "itg_pack_multi": (_i, [_P, _i, _l, _P]),

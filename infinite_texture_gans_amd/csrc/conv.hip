@@ -672,7 +672,7 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
     if (g->pad_mode == ITG_PAD_REPLICATE) {
       p.MT = p.out.H + 2; p.MU = p.out.W + 2;
       p.ioy = p.iox = -3; p.ooy = p.oox = -1; p.out_mode = 1;
-      if ((rc = launch_zero_border(p.out, s))) return rc;
+      if (!(g->flags & ITG_GEOM_FRAME_ZEROED) && (rc = launch_zero_border(p.out, s))) return rc;
     } else {
       p.MT = p.out.H; p.MU = p.out.W;
       p.ioy = p.iox = -1; p.ooy = p.oox = 0; p.out_mode = 0;
@@ -764,7 +764,7 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
       p.ioy = -(g->kh - 1); p.iox = -(g->kw - 1);
       p.ooy = -padh; p.oox = -g->pad;
       p.out_mode = 1;
-      if ((rc = launch_zero_border(p.out, s))) return rc;
+      if (!(g->flags & ITG_GEOM_FRAME_ZEROED) && (rc = launch_zero_border(p.out, s))) return rc;
     } else {
       p.MT = p.out.H; p.MU = p.out.W;
       p.ioy = -(g->kh - 1 - padh); p.iox = -(g->kw - 1 - g->pad);
@@ -950,6 +950,8 @@ int itg_conv2d_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, const itg_
   job->stage = t.ngroups > 0 ? workspace + t.slab_floats : nullptr;
   return ITG_OK;
 }
+
+int itg_zero_frames(const itg_tensor* tensors, int n, void* stream) { return launch_zero_frames(tensors, n, (hipStream_t)stream); }
 
 int itg_wgrad_reduce_multi(const itg_wgrad_job* jobs, int n, void* stream) {
   return launch_reduce_multi(jobs, n, (hipStream_t)stream);

@@ -171,6 +171,7 @@ int try_conv_up2_tile(const ConvP& p, hipStream_t s, int* rc);
 NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = ITG_PREC_F32);
 int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s);
 int launch_zero_border(const GridT& g, hipStream_t s);
+int launch_zero_frames(const itg_tensor* t, int n, hipStream_t s);
 // conv_nt_fused.hip
 int launch_nt_fused(int mode, int bco, int bpix, const ConvP& p, int k, hipStream_t s);
 // conv_wgrad.hip

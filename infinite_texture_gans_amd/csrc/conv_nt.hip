@@ -128,6 +128,50 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvP p) {
   }
 }
 
+// the frames of several tensors in one launch (itg_zero_frames)
+struct FrameJobs { GridT g[ITG_ZERO_FRAMES_MAX]; long long start[ITG_ZERO_FRAMES_MAX + 1]; int n; };
+__global__ void zero_frames_kernel(const FrameJobs fj) {
+  const long long total = fj.start[fj.n];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int j = 0;
+    while (j + 1 < fj.n && i >= fj.start[j + 1]) ++j;
+    const GridT& g = fj.g[j];
+    const long long w = i - fj.start[j];
+    const int per = 2 * g.W + 2 * (g.H - 2 > 0 ? g.H - 2 : 0);
+    const int q4 = g.ld >> 2;
+    const int c4 = (int)(w % q4);
+    const long long r = w / q4;
+    const int b = (int)(r % per), n = (int)(r / per);
+    int Y, X;
+    if (b < g.W) { Y = 0; X = b; }
+    else if (b < 2 * g.W) { Y = g.H - 1; X = b - g.W; }
+    else { int k = b - 2 * g.W; Y = 1 + (k >> 1); X = (k & 1) ? g.W - 1 : 0; }
+    if (g.H == 1 && b >= g.W) continue;
+    *reinterpret_cast<f32x4*>(g.p + grid_off(g, n, Y, X) + c4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+int launch_zero_frames(const itg_tensor* t, int n, hipStream_t s) {
+  if (!t || n <= 0 || n > ITG_ZERO_FRAMES_MAX) return ITG_ERR_ARG;
+  FrameJobs fj;
+  fj.n = n;
+  long long tot = 0;
+  for (int i = 0; i < n; ++i) {
+    int rc = check_tensor(&t[i]);
+    if (rc) return rc;
+    fj.g[i] = make_grid(&t[i]);
+    fj.start[i] = tot;
+    const GridT& g = fj.g[i];
+    tot += (long long)g.n * (2 * g.W + 2 * (g.H - 2 > 0 ? g.H - 2 : 0)) * (g.ld >> 2);
+  }
+  fj.start[n] = tot;
+  if (tot <= 0) return ITG_OK;
+  const int blocks = (int)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
+  hipLaunchKernelGGL(zero_frames_kernel, dim3(blocks), dim3(256), 0, s, fj);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
 // ---- split-K ticket words (in-launch combine)
 constexpr int TICKET_SLOT = 1024, TICKET_SLOTS = 256;
 __device__ unsigned g_ticket_words[TICKET_SLOT * TICKET_SLOTS];      // zero at load; every use leaves its words zero again

@@ -244,6 +244,8 @@ class Trainer:
         self._one = torch.ones((), device=device)               # the seed of every backward pass (no ones_like fill per pass)
         self.hinge = getattr(args, "loss", "standard") == "hinge"
         self.packG, self.packD = PackSet(netG), PackSet(netD)
+        # dx buffers of the generator's replicate-padded convs, kept across steps (ops.begin_frames); ITG_FRAMES=0: per-layer zeroing
+        self._frames = {} if os.environ.get("ITG_FRAMES", "1") == "1" else None
         self.repack()
         self.arena = ops.ZeroArena(device)
         # stream overlap (D(real) beside the generator forward, weight gradients beside the input-gradient chain).
@@ -462,7 +464,12 @@ class Trainer:
         if next_real is not None and self._can_prefetch():
             self._prefetch_d_real(next_real)
         self._arm_exchange(self.flatG)
-        g_loss.backward(self._one)
+        if self._frames is not None:
+            ops.begin_frames(self._frames)       # one launch zeroes the frames of all replicate-padded dx buffers
+        try:
+            g_loss.backward(self._one)
+        finally:
+            ops.end_frames()
         self._mark("G step: backward through D and G (G wgrads on side streams)")
         self._join()
         self._allreduce(self.flatG)

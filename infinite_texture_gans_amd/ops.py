@@ -347,7 +347,21 @@ class _Conv(torch.autograd.Function):
                 wp, out_scale = torch.empty(_lib.fn("itg_pack_dgrad_size")(ci, dy.shape[5], kh, kw, stride), device=x.device,
                                             dtype=torch.float32), None
                 _lib.call("itg_pack_dgrad", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, dy.shape[5], kh, kw, stride, st)
-            gx = torch.empty_like(x)
+            gx = None
+            if FRAMES is not None and pad_mode == PAD_REPLICATE and stride == 1 and (pad > 0 or pad_h > 0):
+                # replicate-padded layer inside a step engine's backward pass: its dx buffer is kept across steps and its
+                # frame was zeroed with every other layer's in one launch (begin_frames) - no zeroing launch in front of
+                # this input gradient
+                fkey = (w.data_ptr(), tuple(x.shape))
+                if fkey in _FRAMES_READY:
+                    _FRAMES_READY.discard(fkey)
+                    gx = FRAMES[fkey][0]
+                    g.flags = _lib.GEOM_FRAME_ZEROED
+                elif fkey not in FRAMES:
+                    gx = torch.empty_like(x)
+                    FRAMES[fkey] = (gx, ci)              # from the next pass on
+            if gx is None:
+                gx = torch.empty_like(x)
             ddx = _desc(gx, ci)
             npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
             key = ("d", tuple(dy.shape), tuple(gx.shape), ctx.geom, ci, co)
@@ -487,6 +501,33 @@ _wgrad_slot = {}
 # flush_deferred() finishes every queued layer of the backward pass in ONE launch (itg_wgrad_reduce_multi: slab sums, OIHW
 # transposition, bias gradients, the <G, W> dots of spectrally normalised layers) plus one itg_spectral_norm_bwd_multi -
 # instead of 2-5 small launches per layer (79 second-stage + 20 spectral-norm launches per train step before).
+# Frames of the replicate-padded layers' input gradients (see _Conv.backward): a step engine sets FRAMES to its dict for the
+# duration of a backward pass (begin_frames / end_frames)
+FRAMES = None
+_FRAMES_READY = set()
+
+
+def begin_frames(frames):
+    """Zero the 1-pixel frames of every dx buffer registered in ``frames`` with one launch per ZERO_FRAMES_MAX buffers and
+    make them available to the backward pass that follows."""
+    global FRAMES
+    FRAMES = frames
+    _FRAMES_READY.clear()
+    items = list(frames.items())
+    st = _stream()
+    for i in range(0, len(items), _lib.ZERO_FRAMES_MAX):
+        chunk = items[i:i + _lib.ZERO_FRAMES_MAX]
+        arr = (_T * len(chunk))(*[_desc(t, c) for _, (t, c) in chunk])
+        _lib.call("itg_zero_frames", arr, len(chunk), st)
+        _FRAMES_READY.update(k for k, _ in chunk)
+
+
+def end_frames():
+    global FRAMES
+    FRAMES = None
+    _FRAMES_READY.clear()
+
+
 WGRAD_DEFER = None
 SN_FUSED_REDUCE = os.environ.get("ITG_SN_FUSED_REDUCE", "1") == "1"      # see _Conv.backward
 _WGRAD_WS = {}           # persistent slab workspaces / spectral-norm temporaries, keyed by layer and shape (never freed: the
