@@ -92,6 +92,9 @@ CONV_CASES = [
     # 4x4 stride-2 layers with <= 4 input channels on images >= 128^2 (the discriminator's first layer): stride-2 halo-tile kernel
     ("d4x4_s2_3_64_tile", 1, (3, 3), 48, 3, 64, 4, 2, 1, "zeros"),                    # patch-grid input, 72x72 out: partial tiles
     ("d4x4_s2_3_24_tile", 2, (1, 1), 130, 3, 24, 4, 2, 1, "zeros"),                   # 32 filter rows, odd tile counts
+    # narrow stride-2 layer with an ODD input extent: its input gradient is the four-parity-class transposed conv that the
+    # folded-upsample halo-tile kernel serves (classes of different sizes: 51 / 50 rows)
+    ("d4x4_s2_8_16_odd_classes_tile", 2, (1, 1), 101, 8, 16, 4, 2, 1, "zeros"),
     # single-input-channel valid 3x3 (the first conv of an SSM modulation MLP on the per-patch noise map): write-bound VALU kernel
     ("ssm_map_1_128_valid", 5, (1, 1), 37, 1, 128, 3, 1, 0, "zeros"),                  # 35x35 out: partial tiles
     ("ssm_map_1_24_valid", 3, (1, 1), 12, 1, 24, 3, 1, 0, "zeros"),                    # fewer channel groups than lanes
