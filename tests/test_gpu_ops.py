@@ -272,6 +272,66 @@ def test_bn_act_train_fwd_bwd_running_stats(c, ups):
     assert rel_l2(dgg.cpu(), dgr) < 1e-5 and rel_l2(dbg.cpu(), dbr) < 1e-5
 
 
+@pytest.mark.parametrize("c,ups", [(13, False), (104, True)])
+def test_bn_backward_absorbs_the_gradient_of_a_second_reader_of_its_input(c, ups):
+    """ops.bn_act(fork=True): ``.fork`` is an alias of the BatchNorm's input; a second consumer reading it (the residual
+    shortcut of a generator block, reference models/layers.py:313-322) gets its gradient added inside the BatchNorm backward
+    kernel (itg_bn_bwd_apply_add) - the input gradient equals autograd's sum over both readers."""
+    ops = _ops()
+    g = _gen(200 + c)
+    x = torch.randn(6, c, 5, 5, generator=g) * 1.5 + 0.3
+    gamma, beta = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    w2 = torch.randn(x.shape, generator=g)                       # the second reader: sum(x * w2)
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if ups else xr
+    yr = F.leaky_relu(F.batch_norm(xin, torch.zeros(c), torch.ones(c), gr, br, True, 0.1, 1e-5), 0.02)
+    dy = torch.randn(yr.shape, generator=g)
+    dxr, dgr, dbr = torch.autograd.grad([yr, (xr * w2).sum()], (xr, gr, br), [dy, torch.ones(())])
+    xg, gg, bg = (t.to(cuda).requires_grad_(True) for t in (x, gamma, beta))
+    xgrid = ops.GT(ops.to_grid(xg, 6, 1, merged=False).t * 1.0, c)         # a non-leaf, as a block input is
+    y = ops.bn_act(xgrid, gg, bg, torch.zeros(c, device=cuda), torch.ones(c, device=cuda),
+                   torch.zeros((), dtype=torch.int64, device=cuda), True, 1e-5, 0.1, ops.ACT_LRELU, 0.02, ups, fork=True)
+    assert y.fork is not None and y.fork.t.shape == xgrid.t.shape
+    second = (ops.to_nchw(y.fork, merged=False) * w2.to(cuda)).sum()
+    dxg, dgg, dbg = torch.autograd.grad([ops.to_nchw(y, merged=False), second], (xg, gg, bg),
+                                        [dy.to(cuda), torch.ones((), device=cuda)])
+    assert rel_l2(dxg.cpu(), dxr) < 1e-5
+    assert rel_l2(dgg.cpu(), dgr) < 1e-5 and rel_l2(dbg.cpu(), dbr) < 1e-5
+
+
+def test_frames_of_replicate_padded_input_gradients_zeroed_in_one_launch():
+    """ops.begin_frames / end_frames (what engine.Trainer wraps the generator's backward pass in): from the second pass on
+    the dx buffers are the kept ones, their frames zeroed by ONE itg_zero_frames launch, and the input gradients equal
+    those of the per-layer path - also after the kept buffers have been dirtied by the previous pass."""
+    ops = _ops()
+    g = _gen(77)
+    layers = []
+    for (ci, co, p) in [(13, 26, 8), (26, 13, 16)]:
+        x = torch.randn(2 * 9, ci, p, p, generator=g)
+        w = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).to(cuda)
+        layers.append((x.to(cuda), w, ci, torch.randn(2 * 9, co, p, p, generator=g).to(cuda)))
+
+    def grads(x_scale):
+        out = []
+        for x, w, ci, dy in layers:
+            xg = (x * x_scale).requires_grad_(True)
+            y = ops.to_nchw(ops.conv(ops.to_grid(xg, 3, 3, merged=False), w, None, 3, 3, 1, 1, ops.PAD_REPLICATE), merged=False)
+            out.append(torch.autograd.grad(y, xg, dy)[0])
+        return out
+
+    want = grads(1.0)
+    frames = {}
+    for k in range(3):                      # pass 0 registers the buffers, passes 1 and 2 run on them
+        ops.begin_frames(frames)
+        try:
+            got = grads(1.0)
+        finally:
+            ops.end_frames()
+        assert len(frames) == 2
+        for a, b in zip(got, want):
+            assert rel_l2(a.cpu(), b.cpu()) < 1e-6, k
+
+
 def test_bn_eval_uses_running_stats():
     ops = _ops()
     g = _gen(1)
