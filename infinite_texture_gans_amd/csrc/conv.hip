@@ -814,7 +814,8 @@ int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, co
     return Min * 16 + 16 * (int64_t)x->c + 16 + t.ws_floats + (int64_t)t.splits * t.co_rows;
   }
   if (g->up2) {
-    TnPlan t = plan_tn(grid_pixels(dy) / 4, dy->ld, 4 * x->ld, prec_of(g), 4);
+    const TileWgPlan tw = plan_wgrad_up2_tile(x, dy, g);
+    TnPlan t = tw.ok ? tn_plan_for_up2_tiles(tw, dy->ld, x->ld) : plan_tn(grid_pixels(dy) / 4, dy->ld, 4 * x->ld, prec_of(g), 4);
     return t.ws_floats + (int64_t)4 * t.splits * t.co_rows;
   }
   int64_t M = grid_pixels(dy);
@@ -840,7 +841,8 @@ static int wgrad_setup(const itg_tensor* x, const itg_tensor* dy, const itg_conv
     if (M >= ((int64_t)1 << 29)) return ITG_ERR_ARG;
     p.ntaps = 4; p.kw = 2; p.cin_ld = x->ld; p.Ktot = 4 * x->ld;
     const int prec = prec_of(g);
-    TnPlan t = plan_tn(M, dy->ld, p.Ktot, prec, 4);
+    const TileWgPlan tw = plan_wgrad_up2_tile(x, dy, g);        // narrow layers on large images: folded halo-tile kernel
+    TnPlan t = tw.ok ? tn_plan_for_up2_tiles(tw, dy->ld, x->ld) : plan_tn(M, dy->ld, p.Ktot, prec, 4);
     if (t.ws_floats + (int64_t)4 * t.splits * t.co_rows > workspace_floats) return ITG_ERR_WORKSPACE;
     p.Kpad = t.Kpad; p.co_rows = t.co_rows;
     p.slab = workspace;
@@ -851,7 +853,7 @@ static int wgrad_setup(const itg_tensor* x, const itg_tensor* dy, const itg_conv
     int64_t xb = grid_pixels(x) * x->ld * 4, yb = grid_pixels(dy) * dy->ld * 4;
     if (xb >= 0xFFFF0000LL || yb >= 0xFFFF0000LL) return ITG_ERR_ARG;
     p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
-    tw_out.ok = 0;
+    tw_out = tw;
     t_out = t; prec_out = prec;
     return ITG_OK;
   }

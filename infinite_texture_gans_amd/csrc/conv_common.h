@@ -178,6 +178,8 @@ int launch_nt_fused(int mode, int bco, int bpix, const ConvP& p, int k, hipStrea
 TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g);
 TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec = ITG_PREC_F32, int ncls = 1);
 TnPlan tn_plan_for_tiles(const TileWgPlan& tw, int co_ld, int Ktot);
+TileWgPlan plan_wgrad_up2_tile(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g);
+TnPlan tn_plan_for_up2_tiles(const TileWgPlan& tw, int co_ld, int cin_ld);
 int run_wgrad(WgP& p, const TnPlan& t, const TileWgPlan& tw, int prec, const itg_tensor* x, const itg_tensor* dy,
               const itg_conv_geom* g, float* dw, float* db, int accumulate, float* workspace, hipStream_t s);
 int run_wgrad_slabs(WgP& p, const TnPlan& t, const TileWgPlan& tw, int prec, hipStream_t s);

@@ -730,6 +730,272 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_kernel(const WgP p, int til
 }
 
 
+// ------------------------------------------------------------------------ folded-upsample weight gradient (halo tiles)
+// Weight gradient of conv3x3(nearest x2 (x)) (itg_conv_geom.up2) for the narrow layers behind an upsample: per parity
+// class (ry, rx) the 2 x 2 tap gradients  dWc[co][(jy, jx), c] = sum over source pixels (t, u) of
+// dY(2t + ry, 2u + rx)[co] * X(t + ry - 1 + jy, u + rx - 1 + jx)[c].  A persistent workgroup keeps the (8+2) x (32+2)
+// halo tile of the HALF-SIZE x in LDS and walks the four classes over it: the class's 8 x 32 dY pixels (every other
+// pixel of a 16 x 64 block) are staged into one of two LDS buffers while the previous class runs on the MFMA pipe; the
+// accumulators of all four classes (4 x 4 NJ row tiles) stay in registers across tiles.  Slabs, bias partials and reduce
+// stages as the generic parity-class path ([block][class][co][Kpad], wgrad_up2_reduce_kernel).
+template <int NJ, int NLD>
+__global__ __launch_bounds__(256, 2) void wgrad_up2_tile_kernel(const WgP p, int tiles_x, int tiles_y, int ntiles, int cpt) {
+  constexpr int MF = 4 * NJ;
+  constexpr int CPD = 16;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Xt = lds;                                         // [TT_PIX][cpt]
+  float* Yt = lds + TT_PIX * cpt;                          // [2][TT_H * TT_W][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = p.cin_ld >> 2, yq4 = p.dy.ld >> 2;
+  const __amdgpu_buffer_rsrc_t rxr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x.p, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ryr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy.p, 0, p.dy_bytes, 0x00020000);
+  int e_r[NLD], e_c[NLD], e_lds[NLD];
+  unsigned e_cb[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    int e = tid + i * 256;
+    bool live = e < TT_PIX * q4;
+    int pix = live ? e / q4 : 0, c4 = live ? e - pix * q4 : 0;
+    e_r[i] = live ? pix / (TT_W + 2) : -1;
+    e_c[i] = pix - (pix / (TT_W + 2)) * (TT_W + 2);
+    e_lds[i] = pix * cpt + c4 * 4;
+    e_cb[i] = (unsigned)c4 * 16u;
+  }
+  constexpr int YLD = 4;                                   // dY: 256 pixels x yq4 (<= 4) channel groups / 256 threads
+  int y_r[YLD], y_c[YLD], y_lds[YLD];
+  const unsigned y_cb = (unsigned)(tid % yq4) * 16u;
+#pragma unroll
+  for (int i = 0; i < YLD; ++i) {
+    int e = tid + i * 256;
+    bool live = e < TT_H * TT_W * yq4;
+    int pix = live ? e / yq4 : 0;
+    y_r[i] = live ? pix / TT_W : -1;
+    y_c[i] = pix - (pix / TT_W) * TT_W;
+    y_lds[i] = pix * CPD + (e % yq4) * 4;
+  }
+  for (int e = tid; e < 2 * TT_H * TT_W * CPD; e += 256) Yt[e] = 0.f;    // channel groups >= dy.ld stay zero
+  f32x4 rt[NLD], ry[YLD];
+  auto tile_origin = [&](int tile, int& n, int& t0, int& u0) {
+    int b = tile;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    n = b / tiles_y;
+    t0 = ty_i * TT_H; u0 = tx_i * TT_W;
+  };
+  auto load_x = [&](int tile) {
+    int n, t0, u0;
+    tile_origin(tile, n, t0, u0);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      int iy = t0 - 1 + e_r[i], ix = u0 - 1 + e_c[i];
+      bool ok = e_r[i] >= 0;
+      if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.x.H && (unsigned)ix < (unsigned)p.x.W;
+      iy = min(max(iy, 0), p.x.H - 1); ix = min(max(ix, 0), p.x.W - 1);
+      unsigned o = (unsigned)grid_off(p.x, n, iy, ix) * 4u + e_cb[i];
+      rt[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxr, ok ? o : p.x_bytes, 0, 0));
+    }
+  };
+  auto load_y = [&](int tile, int cls) {
+    int n, t0, u0;
+    tile_origin(tile, n, t0, u0);
+    const int ryc = cls >> 1, rxc = cls & 1;
+#pragma unroll
+    for (int i = 0; i < YLD; ++i) {
+      int t = t0 + y_r[i], u = u0 + y_c[i];
+      bool ok = y_r[i] >= 0 && t < p.MT && u < p.MU;
+      unsigned o = (unsigned)grid_off(p.dy, n, ok ? 2 * t + ryc : 0, ok ? 2 * u + rxc : 0) * 4u + y_cb;
+      ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ryr, ok ? o : p.dy_bytes, 0, 0));
+    }
+  };
+  f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
+  auto store_x = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      if (e_r[i] >= 0) *reinterpret_cast<f32x4*>(Xt + e_lds[i]) = rt[i];
+  };
+  auto store_y = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < YLD; ++i)
+      if (y_r[i] >= 0) { *reinterpret_cast<f32x4*>(Yt + buf * TT_H * TT_W * CPD + y_lds[i]) = ry[i]; dbacc += ry[i]; }
+  };
+  // MFMA rows: (tap, 4-channel group) q = 16 j + fr of the class's 4 taps; a lane's ds_read_b128 feeds four row tiles
+  const int fr = lane & 15, g = lane >> 4;
+  const int nq = 4 * q4;
+  int qbase[NJ];                                             // class (0, 0) offsets; class (ry, rx) adds (ry * (TT_W + 2) + rx) * cpt
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    int q = min(16 * j + fr, nq - 1);
+    int tap = q / q4, c4 = q - tap * q4;
+    qbase[j] = ((tap >> 1) * (TT_W + 2) + (tap & 1)) * cpt + 4 * c4;
+  }
+  // Two passes over the tiles, two classes (ry = half; rx = 0, 1) each: the accumulators of FOUR classes plus the next
+  // tile's prefetch registers do not fit the 256-register budget of two workgroups per CU (28 spills); the half-size x
+  // tile is read twice instead (33 MB more for the 26-channel layer).
+  int rrow[NJ][4];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int q = 16 * j + 4 * g + e;
+      int tap = q / q4, c4 = q - tap * q4;
+      rrow[j][e] = q < nq ? tap * p.cin_ld + 4 * c4 : -1;
+    }
+  const int mrows = 4 * p.cin_ld;
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    f32x4 acc[2][MF];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < MF; ++i) acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int tile = blockIdx.x;
+    if (tile < ntiles) { load_x(tile); load_y(tile, 2 * half); }
+    __syncthreads();                                     // (first pass: Yt zeroed; second: the slab writers are done with lds)
+    for (; tile < ntiles; tile += gridDim.x) {
+      store_x();
+      store_y(0);
+      __syncthreads();
+      const int next = tile + gridDim.x;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (c == 0) load_y(tile, 2 * half + 1);
+        else if (next < ntiles) { load_x(next); load_y(next, 2 * half); }
+        const int coff = (half * (TT_W + 2) + c) * cpt;
+        const float* Yb = Yt + c * TT_H * TT_W * CPD;
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {
+          const float* xrow = Xt + ((2 * wave + rr) * (TT_W + 2) + g) * cpt + coff;
+          const float* yrow = Yb + ((2 * wave + rr) * TT_W + g) * CPD + fr;
+#pragma unroll 2
+          for (int s4 = 0; s4 < TT_W / 4; ++s4) {
+            const float bv = yrow[s4 * 4 * CPD];
+            const float* xs = xrow + s4 * 4 * cpt;
+            f32x4 av[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) av[j] = *reinterpret_cast<const f32x4*>(xs + qbase[j]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                acc[c][4 * j + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][e], bv, acc[c][4 * j + e], 0, 0, 0);
+          }
+        }
+        if (c == 0) store_y(1);
+        __syncthreads();
+      }
+    }
+    // ---- per class: sum the 4 waves' accumulators in wave order through LDS, R[m = tap * cin_ld + c][16], write the slab
+    float* R = lds;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                if (rrow[j][e] < 0) continue;
+                float* dst = R + (rrow[j][e] + t) * 16 + fr;
+                *dst = (w == 0 ? 0.f : *dst) + acc[c][4 * j + t][e];
+              }
+        }
+        __syncthreads();
+      }
+      float* slab = p.slab + ((size_t)blockIdx.x * 4 + 2 * half + c) * p.co_rows * p.Kpad;
+      for (int idx = tid; idx < p.co_rows * p.Kpad; idx += 256) {
+        int co = idx / p.Kpad, m = idx - co * p.Kpad;
+        slab[idx] = m < mrows ? R[m * 16 + co] : 0.f;
+      }
+      __syncthreads();
+    }
+    if (half == 0) {                                     // the R rows overwrote the tiles' space: dY groups >= dy.ld are zero again
+      for (int e = tid; e < 2 * TT_H * TT_W * CPD; e += 256) Yt[e] = 0.f;
+    }
+  }
+  if (p.dbslab) {       // bias gradient: the dY pixels of all four classes, summed per channel in a fixed order (class 0's row)
+    f32x4* red = reinterpret_cast<f32x4*>(lds);
+    red[tid] = dbacc;
+    __syncthreads();
+    if (tid < 16) {
+      float sdb = 0.f;
+      if ((tid >> 2) < yq4)
+        for (int r = (tid >> 2); r < 256; r += yq4) sdb += red[r][tid & 3];
+      for (int cls = 0; cls < 4; ++cls) p.dbslab[((size_t)blockIdx.x * 4 + cls) * p.co_rows + tid] = cls == 0 ? sdb : 0.f;
+    }
+  }
+}
+
+// plan of the folded halo-tile weight gradient (narrow layers on large images), or ok = 0
+TileWgPlan plan_wgrad_up2_tile(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g) {
+  TileWgPlan t;
+  t.ok = 0; t.thin = 0; t.gpp = 16; t.coef_off = 0;
+  static const int enable = env_int("ITG_UP2_WTILE", 1);
+  const int ph = g->pad_h >= 0 ? g->pad_h : g->pad;
+  if (!enable || !g->up2 || ph != 1 || g->precision == ITG_PREC_BF16 || x->ld > 32 || dy->ld > 16 || (dy->ld & 3)) return t;
+  const int H = x->gh * x->ph, W = x->gw * x->pw;          // source domain
+  if ((int64_t)H * W < 48 * 48) return t;
+  const int nq = 4 * (x->ld >> 2);
+  t.mf = (nq + 15) / 16;                                   // NJ
+  if (t.mf > 2) return t;
+  const int nld = (TT_PIX * (x->ld >> 2) + 255) / 256;
+  if (nld > 11) return t;
+  t.nld = nld <= 6 ? 6 : 11;
+  t.cpt = (x->ld % 8 == 4) ? x->ld : x->ld + 4;
+  t.tiles_x = (W + TT_W - 1) / TT_W; t.tiles_y = (H + TT_H - 1) / TT_H;
+  t.ntiles = (int64_t)x->n * t.tiles_x * t.tiles_y;
+  size_t fl = (size_t)TT_PIX * t.cpt + (size_t)2 * TT_H * TT_W * 16;
+  const size_t red = (size_t)4 * 32 * 16 + 256 * 4;               // R buffer / bias partials reuse the tiles' space
+  if (red > fl) fl = red;
+  t.lds = fl * sizeof(float);
+  if (t.lds > 80 * 1024 || t.ntiles > 0x7fffffff) return t;
+  static const int cu_env = env_int("ITG_UP2_WTILE_CU", 0);
+  int per_cu = (int)((160 * 1024) / t.lds);
+  if (per_cu > 2) per_cu = 2;
+  if (cu_env > 0) per_cu = cu_env;
+  if (per_cu < 1) per_cu = 1;
+  const int64_t want = 256 * (int64_t)per_cu;
+  t.blocks = (int)(t.ntiles < want ? t.ntiles : want);
+  t.ok = 1;
+  return t;
+}
+
+// TnPlan of the folded halo-tile weight gradient: one slab per (persistent workgroup, class)
+TnPlan tn_plan_for_up2_tiles(const TileWgPlan& tw, int co_ld, int cin_ld) {
+  TnPlan t;
+  t.bcol = -1; t.bco = 16;
+  t.co_rows = round_up(co_ld, 16);
+  t.Kpad = round_up(4 * cin_ld, 16);
+  t.splits = tw.blocks; t.chunks_per_split = 0; t.nchunks = 0;
+  t.slab_floats = (int64_t)t.splits * 4 * t.co_rows * t.Kpad;
+  t.ngroups = t.splits > red_group() ? (t.splits + red_group() - 1) / red_group() : 0;
+  t.ws_floats = t.slab_floats + (int64_t)t.ngroups * 4 * t.co_rows * t.Kpad;
+  return t;
+}
+
+int launch_wgrad_up2_tile(const WgP& p, const TileWgPlan& t, hipStream_t s) {
+  const void* kern = t.mf == 1 ? (t.nld <= 6 ? (const void*)&wgrad_up2_tile_kernel<1, 6> : (const void*)&wgrad_up2_tile_kernel<1, 11>)
+                               : (t.nld <= 6 ? (const void*)&wgrad_up2_tile_kernel<2, 6> : (const void*)&wgrad_up2_tile_kernel<2, 11>);
+  static const void* attr_set[4] = {nullptr};
+  {
+    bool seen = false;
+    int slot = 0;
+    for (; slot < 4 && attr_set[slot]; ++slot) seen = seen || attr_set[slot] == kern;
+    if (!seen && slot < 4) {
+      if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) { (void)hipGetLastError(); return ITG_ERR_LAUNCH; }
+      attr_set[slot] = kern;
+    }
+  }
+  snprintf(g_last_launch, sizeof(g_last_launch), "wgrad_up2_tile_kernel<%d, %d>", t.mf, t.nld <= 6 ? 6 : 11);
+  WgP q = p;
+  int a_tx = t.tiles_x, a_ty = t.tiles_y, a_nt = (int)t.ntiles, a_cpt = t.cpt;
+  void* args[] = {(void*)&q, &a_tx, &a_ty, &a_nt, &a_cpt};
+  (void)hipLaunchKernel(kern, dim3((unsigned)t.blocks), dim3(256), args, t.lds, s);
+  return hipGetLastError() == hipSuccess ? ITG_OK : ITG_ERR_LAUNCH;
+}
+
+
 TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g) {
   TileWgPlan t;
   t.ok = 0;
@@ -1015,7 +1281,9 @@ TnPlan tn_plan_for_tiles(const TileWgPlan& tw, int co_ld, int Ktot) {
 // the contraction of one layer into its slabs (no reduce stage)
 int run_wgrad_slabs(WgP& p, const TnPlan& t, const TileWgPlan& tw, int prec, hipStream_t s) {
   int rc;
-  if (tw.ok) {
+  if (tw.ok && p.up2) {
+    rc = launch_wgrad_up2_tile(p, tw, s);
+  } else if (tw.ok) {
     rc = ITG_OK;
     const bool small = tw.nld <= 6;
     if (tw.thin) launch_wgrad_thin(p, tw, s);

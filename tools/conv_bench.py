@@ -47,6 +47,10 @@ EXTRA = [
     ("X fold b6c1 (13->26 s2, 384^2)", 8, (1, 1), 384, 13, 26, 4, 2, 1, "zero"),
     ("X tile b5c2 26->26 P64", 8, (3, 3), 64, 26, 26, 3, 1, 1, "rep"),       # halo-tile kernel with 76 KB of LDS (ITG_TILE_LDS_KB)
     ("X tile b4c2 52->52 P32", 8, (3, 3), 32, 52, 52, 3, 1, 1, "rep"),
+    # the folded-upsample layers themselves (mode "rep-up2": ops.conv(up2=True) on the half-size input; P = source patch)
+    ("X up2 b6c1 26->13 P64", 8, (3, 3), 64, 26, 13, 3, 1, 1, "rep-up2"),
+    ("X up2 b5c1 52->26 P32", 8, (3, 3), 32, 52, 26, 3, 1, 1, "rep-up2"),
+    ("X up2 b4c1 104->52 P16", 8, (3, 3), 16, 104, 52, 3, 1, 1, "rep-up2"),
 ]
 
 
@@ -86,23 +90,24 @@ def main():
         x[..., ci:] = 0
         w = torch.randn(co, ci, k, k, device=dev) / (ci * k * k) ** 0.5
         b = torch.zeros(co, device=dev)
-        pm = ops.PAD_REPLICATE if mode == "rep" else ops.PAD_ZERO
+        up2 = mode.endswith("-up2")
+        pm = ops.PAD_REPLICATE if mode.startswith("rep") else ops.PAD_ZERO
         og = (gh, gw) if k == 3 else (1, 1)
         gx = ops.GT(x.requires_grad_(True), ci)
         wq = w.requires_grad_(True)
-        y = ops.conv(gx, wq, b, k, k, s, pad, pm, out_grid=og)
+        y = ops.conv(gx, wq, b, k, k, s, pad, pm, out_grid=og, up2=up2)
         npix = y.t.numel() // y.t.shape[-1]
-        flops = 2.0 * npix * co * ci * k * k
+        flops = 2.0 * npix * co * ci * (4 if up2 else k * k)
         dy = torch.randn_like(y.t)
-        t_f = timeit(lambda: ops.conv(ops.GT(x.detach(), ci), w.detach(), b, k, k, s, pad, pm, out_grid=og))
+        t_f = timeit(lambda: ops.conv(ops.GT(x.detach(), ci), w.detach(), b, k, k, s, pad, pm, out_grid=og, up2=up2))
         # dgrad only / wgrad only: (bias-free forward + backward) recorded together, the bias-free forward's time subtracted
-        t_f0 = timeit(lambda: ops.conv(ops.GT(x.detach(), ci), w.detach(), None, k, k, s, pad, pm, out_grid=og))
+        t_f0 = timeit(lambda: ops.conv(ops.GT(x.detach(), ci), w.detach(), None, k, k, s, pad, pm, out_grid=og, up2=up2))
         xg = x.detach().requires_grad_(True)
         t_d = timeit(lambda: torch.autograd.grad(
-            ops.conv(ops.GT(xg, ci), w.detach(), None, k, k, s, pad, pm, out_grid=og).t, xg, dy)) - t_f0
+            ops.conv(ops.GT(xg, ci), w.detach(), None, k, k, s, pad, pm, out_grid=og, up2=up2).t, xg, dy)) - t_f0
         wg = w.detach().requires_grad_(True)
         t_w = timeit(lambda: torch.autograd.grad(
-            ops.conv(ops.GT(x.detach(), ci), wg, None, k, k, s, pad, pm, out_grid=og).t, wg, dy)) - t_f0
+            ops.conv(ops.GT(x.detach(), ci), wg, None, k, k, s, pad, pm, out_grid=og, up2=up2).t, wg, dy)) - t_f0
         tot[0] += t_f; tot[1] += t_d; tot[2] += t_w
         print("%-24s %7.2f GF | fwd %7.1f us %6.1f TF | dgrad %7.1f us %6.1f TF | wgrad %7.1f us %6.1f TF" % (
             name, flops / 1e9, t_f * 1e6, flops / t_f / 1e12, t_d * 1e6, flops / t_d / 1e12, t_w * 1e6,
