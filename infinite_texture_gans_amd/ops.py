@@ -529,7 +529,7 @@ def end_frames():
 
 
 WGRAD_DEFER = None
-SN_FUSED_REDUCE = os.environ.get("ITG_SN_FUSED_REDUCE", "1") == "1"      # see _Conv.backward
+SN_FUSED_REDUCE = os.environ.get("ITG_SN_FUSED_REDUCE", "0") == "1"      # see _Conv.backward: 10 launches fewer per step, 0.2 % slower
 _WGRAD_WS = {}           # persistent slab workspaces / spectral-norm temporaries, keyed by layer and shape (never freed: the
                          # slabs must outlive the conv call, and a captured hipGraph replays their addresses)
 
