@@ -282,6 +282,27 @@ class Trainer:
                                              two_buckets=early and getattr(netG, "type_norm", "BN") == "BN"),
             }
 
+        self._warm_collectives()
+
+    def _warm_collectives(self):
+        """RCCL sets up channels, proxy threads and per-size algorithm state lazily inside the first collectives of a process
+        (hundreds of milliseconds): run the step's all-reduces once on zeroed buffers of the real sizes here, so that the
+        first training steps - and a short benchmark - do not pay for it.  (ITG_WARM_COLLECTIVES=0 skips it.)"""
+        from .dist import _active
+        if (self.sync is None or not _active(self.sync) or torch.device(self.device).type != "cuda"
+                or os.environ.get("ITG_WARM_COLLECTIVES", "1") != "1"):
+            return
+        for flat in (self.flatD, self.flatG):
+            buf = torch.zeros_like(flat.grad)
+            ex = self._exchange.get(id(flat)) if self._exchange else None
+            parts = [buf] if ex is None or not ex.split else [buf[ex.split:], buf[:ex.split]]
+            for _ in range(3):
+                for part in parts:
+                    self.sync.all_reduce(part)
+        stat = torch.zeros(2 * 512, device=self.device, dtype=torch.float64)       # sync-BN statistics size class
+        self.sync.all_reduce(stat)
+        torch.cuda.synchronize()
+
     def set_overlap(self, on):
         """Stream overlap on / off (off: every kernel runs alone on the current stream, e.g. to time it).  The branch
         stream and the weight-gradient streams are chosen by measurement so that each sits on its own hardware queue
