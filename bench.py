@@ -633,5 +633,18 @@ def main():
     print(json.dumps(out), flush=True)
 
 
+def _teardown():
+    """Leave the process group cleanly (ProcessGroupNCCL warns about leaked resources otherwise); never raises."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:       # noqa: BLE001 - the JSON line is out; a failing teardown must not change the exit code
+        pass
+
+
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        _teardown()
