@@ -869,7 +869,8 @@ def test_lookahead_d_real_schedule_equals_the_plain_step():
     args = U.prepare_parser().parse_args([])
     args.smooth, args.beta1 = a["smooth"], 0.0
     tr = Trainer(G, D, args, cuda)
-    assert tr.overlap
+    if not tr.overlap:
+        pytest.skip("the look-ahead schedule needs the stream overlap (ITG_OVERLAP=0 in the environment)")
     steps = int(fx["steps"])
     reals = [torch.from_numpy(fx["real_x%d" % s]).to(cuda) for s in range(steps)]
     zs = [torch.from_numpy(fx["z%d" % s]).to(cuda) for s in range(steps)]
