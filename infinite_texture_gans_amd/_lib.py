@@ -43,6 +43,7 @@ class ConvGeom(C.Structure):
 
 
 GEOM_FRAME_ZEROED = 1
+GEOM_WINO = 2
 ZERO_FRAMES_MAX = 32
 PACK_MAX_JOBS = 48
 WGRAD_MAX_JOBS = 24
@@ -80,6 +81,9 @@ SIGNATURES = {
     "itg_pack_up2_fwd": (_i, [_P, _P, _P, _i, _i, _i, _P]),
     "itg_pack_up2_dgrad": (_i, [_P, _P, _P, _i, _i, _i, _P]),
     "itg_zero_frames": (_i, [_TP, _i, _P]),
+    "itg_pack_wino_size": (_l, [_i, _i]),
+    "itg_pack_wino_fwd": (_i, [_P, _P, _P, _i, _i, _i, _P]),
+    "itg_pack_wino_dgrad": (_i, [_P, _P, _P, _i, _i, _i, _P]),
     "itg_conv2d_fwd_workspace": (_l, [_TP, _TP, _GP]),
     "itg_conv2d_dgrad_workspace": (_l, [_TP, _TP, _GP]),
     "itg_pack_multi": (_i, [_P, _i, _l, _P]),

@@ -1,6 +1,7 @@
 // Weight packing, the taps-as-rows paths of the single-output-channel / 3-input-channel layers, and the C ABI of the
 // convolution family for gfx950 (MI355X).  Kernels: conv_nt.hip, conv_tile.hip, conv_wgrad.hip.
 #include "conv_common.h"
+#include "winograd_f44.h"
 
 using namespace itgk;
 
@@ -89,6 +90,35 @@ __device__ __forceinline__ float up2_dgrad_elem(const float* __restrict__ w, int
   return v;
 }
 
+// Winograd F(4 x 4, 4 x 4) panels (conv_wino.hip): U[xi = a * 7 + b][row][k] = sum_ij G[a][i] G[b][j] g[i][j].
+// forward: row = co, k = ci, g = w[co][ci];  input gradient: row = ci, k = co, g[i][j] = w[co][ci][3 - i][3 - j]
+__device__ __forceinline__ float wino_elem(const float* __restrict__ w, int co, int ci, int ld, int dgrad, unsigned e) {
+  const int rows = dgrad ? ci : co, kdim = dgrad ? co : ci;
+  const unsigned Kpad = (unsigned)round_up_d(ld, BK), rows_pad = (unsigned)round_up_d(rows, 16);
+  const int k = (int)(e % Kpad);
+  const unsigned r = e / Kpad;
+  const int row = (int)(r % rows_pad), xi = (int)(r / rows_pad);
+  if (row >= rows || k >= kdim || xi >= 49) return 0.f;
+  const int a = xi / 7, b = xi - a * 7;
+  const float* g = w + ((size_t)(dgrad ? k : row) * ci + (dgrad ? row : k)) * 16;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t = fmaf(WINO_G[b][j], dgrad ? g[(3 - i) * 4 + (3 - j)] : g[i * 4 + j], t);
+    v = fmaf(WINO_G[a][i], t, v);
+  }
+  return v;
+}
+
+__global__ void pack_wino_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out, int co,
+                                 int ci, int ld, int dgrad, long long total) {
+  const float sc = scale ? *scale : 1.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    out[i] = sc * wino_elem(w, co, ci, ld, dgrad, (unsigned)i);
+}
+
 __global__ void pack_up2_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out, int co,
                                 int ci, int ld, int dgrad, long long total) {
   const float sc = scale ? *scale : 1.f;
@@ -133,6 +163,9 @@ __global__ void pack_multi_kernel(const long long* __restrict__ table, int n, lo
       const int Kpad = round_up_d(16 * ld, BK);
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = up2_dgrad_elem(w, co, ci, ld, Kpad, e + j);
+    } else if (kind == 4 || kind == 5) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = wino_elem(w, co, ci, ld, kind == 5, e + j);
     } else if (kind == 0) {
       const unsigned Kpad = (unsigned)round_up_d(kh * kw * ld, BK);
       const int k = (int)(e % Kpad), o = (int)(e / Kpad);
@@ -399,6 +432,7 @@ inline int up2_check(const itg_conv_geom* g, const itg_tensor* lo, const itg_ten
   return ITG_OK;
 }
 inline void clear_xf(ConvP& p) {
+  p.ucls = 0; p.u_in = p.u_w = p.u_out = 0;
   p.in_ab = nullptr; p.in_act = ITG_ACT_NONE; p.in_slope = 0.f; p.in_ups = 0;
   p.bnx = null_grid(); p.bn_ab = nullptr; p.bn_mr = nullptr; p.bn_act = ITG_ACT_NONE; p.bn_slope = 0.f; p.bn_ups = 0;
   p.bn_sums = nullptr;
@@ -476,6 +510,27 @@ int itg_pack_up2_dgrad(const float* w, const float* scale, float* out, int co, i
   return pack_up2(w, scale, out, co, ci, co_ld, 1, stream);
 }
 
+int64_t itg_pack_wino_size(int rows, int k_ld) { return (int64_t)49 * round_up(rows, 16) * round_up(k_ld, BK); }
+
+static int pack_wino(const float* w, const float* scale, float* out, int co, int ci, int ld, int dgrad, void* stream) {
+  if (!w || !out || co <= 0 || ci <= 0 || (ld & 3) || ld < (dgrad ? co : ci)) return ITG_ERR_ARG;
+  const int64_t total = itg_pack_wino_size(dgrad ? ci : co, ld);
+  if (total >= ((int64_t)1 << 32)) return ITG_ERR_ARG;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(pack_wino_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, scale, out, co, ci, ld, dgrad,
+                     (long long)total);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_pack_wino_fwd(const float* w, const float* scale, float* out, int co, int ci, int ci_ld, void* stream) {
+  return pack_wino(w, scale, out, co, ci, ci_ld, 0, stream);
+}
+
+int itg_pack_wino_dgrad(const float* w, const float* scale, float* out, int co, int ci, int co_ld, void* stream) {
+  return pack_wino(w, scale, out, co, ci, co_ld, 1, stream);
+}
+
 int itg_pack_multi(const int64_t* table_dev, int n, int64_t total, void* stream) {
   if (!table_dev || n <= 0 || n > ITG_PACK_MAX_JOBS || total <= 0) return ITG_ERR_ARG;
   if (total & 3) return ITG_ERR_ARG;
@@ -487,8 +542,15 @@ int itg_pack_multi(const int64_t* table_dev, int n, int64_t total, void* stream)
   return ITG_OK;
 }
 
+// ITG_GEOM_WINO: geometry the Winograd pipeline takes (conv_wino.hip)
+static inline bool wino_geom(const itg_conv_geom* g) {
+  return (g->flags & ITG_GEOM_WINO) && g->kh == 4 && g->kw == 4 && g->stride == 1 && g->pad == 1 && pad_v_raw(g) == 1 &&
+         g->pad_mode == ITG_PAD_ZERO && !g->up2 && !g->in_norm;
+}
+
 int64_t itg_conv2d_fwd_workspace(const itg_tensor* in, const itg_tensor* out, const itg_conv_geom* g) {
   if (!in || !out || !g) return 0;
+  if (g->flags & ITG_GEOM_WINO) return wino_geom(g) ? wino_workspace_floats(in, out) : 0;
   if (g->up2) return plan_nt(grid_pixels(out), round_up(out->c, 16), round_up(4 * in->ld, BK), 4, prec_of(g)).ws_floats;
   if (thin_out_conv(in, out, g)) {
     int64_t Min = grid_pixels(in);
@@ -499,6 +561,7 @@ int64_t itg_conv2d_fwd_workspace(const itg_tensor* in, const itg_tensor* out, co
 
 int64_t itg_conv2d_dgrad_workspace(const itg_tensor* dy, const itg_tensor* dx, const itg_conv_geom* g) {
   if (!dy || !dx || !g) return 0;
+  if (g->flags & ITG_GEOM_WINO) return wino_geom(g) ? wino_workspace_floats(dy, dx) : 0;
   if (thin_in_conv(dy, dx, g)) {
     const int rows = 64;
     const int64_t Mo = grid_pixels(dy);
@@ -528,6 +591,13 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   const itg_in_norm* nin;
   if (!w_packed || !g) return ITG_ERR_ARG;
   if ((rc = in_norm_of(g, in, &nin))) return rc;
+  if (g->flags & ITG_GEOM_WINO) {
+    if (!wino_geom(g) || g->out_stats) return ITG_ERR_ARG;
+    const itg_tensor* r = (residual && residual->ptr) ? residual : nullptr;
+    if (r && (rc = check_tensor(r))) return rc;
+    return wino_conv(in, w_packed, bias, out_scale, r, 0, 0.f, out, 1, act, slope, prec_of(g), workspace, workspace_floats,
+                     (hipStream_t)stream);
+  }
   if (g->up2) {
     // four output-parity classes in one grid: class (ry, rx) = output pixels (2y + ry, 2x + rx), a 2 x 2 conv of the source
     // tensor whose taps start at (y + ry - 1, x + rx - 1); the frame clamps / predicates in SOURCE coordinates, which is
@@ -649,6 +719,14 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
   if (!w_packed_dgrad || !g) return ITG_ERR_ARG;
   if (dy->n != dx->n) return ITG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  if (g->flags & ITG_GEOM_WINO) {
+    // the input gradient of a 4 x 4 stride-1 pad-1 conv is the pad-2 correlation of dy with the flipped, transposed filter
+    if (!wino_geom(g)) return ITG_ERR_ARG;
+    const itg_tensor* r = (act_out && act_out->ptr && act != ITG_ACT_NONE) ? act_out : nullptr;
+    if (r && ((rc = check_tensor(r)) || !same_shape(r, dx))) return rc ? rc : ITG_ERR_ARG;
+    return wino_conv(dy, w_packed_dgrad, nullptr, out_scale, r, r ? act : 0, slope, dx, 2, ITG_ACT_NONE, 0.f, prec_of(g), workspace,
+                     workspace_floats, s);
+  }
   if (g->up2) {
     // dx(z) = sum_t W4(t) dy(2 z + t - 1): the 4 x 4 stride-2 conv of dy with the phase-summed taps (itg_pack_up2_dgrad).
     // Replicate padding: the frame's source pixels are x(-1) := x(0), ..., so the domain is extended by one source pixel

@@ -56,6 +56,11 @@ struct ConvP {
   float* partial;      // split-K slabs [ksplit][M][co_rows] (ksplit > 1)
   unsigned* tickets;   // split-K, in-launch combine: one zeroed word per (class, workgroup of a split), or null = second-stage launch
   int ksplit, kchunks; // K chunks (of BK) per split
+  // uniform classes (ucls > 0; the 49 GEMMs of a Winograd-domain convolution, conv_wino.hip): ucls independent problems of
+  // the geometry in slot 0 in ONE grid, class c on the input at p.in.p + c * u_in, the panel at p.w + c * u_w, the output at
+  // p.out.p + c * u_out (floats); no split-K.  The class is the SLOWEST index of the tile id (classes share nothing).
+  int ucls;
+  unsigned u_in, u_w, u_out;
   // stride-2 input-gradient: the 4 output-parity classes run as ONE grid (blockIdx.y = class)
   int ncls;
   int cMT[4], cMU[4], cM[4], cioy[4], ciox[4], cooy[4], coox[4];
@@ -167,6 +172,11 @@ int try_conv_valu(const ConvP& p, hipStream_t s, int* rc);
 int try_conv_tile(ConvP& p, hipStream_t s, int* rc);
 int try_conv_s2k4(const ConvP& p, hipStream_t s, int* rc);
 int try_conv_up2_tile(const ConvP& p, hipStream_t s, int* rc);
+// conv_wino.hip: Winograd F(4 x 4, 4 x 4) for wide 4 x 4 stride-1 layers (the discriminator's 256 -> 512 layer)
+int64_t wino_workspace_floats(const itg_tensor* in, const itg_tensor* out);
+int wino_conv(const itg_tensor* in, const float* u_panel, const float* bias, const float* out_scale, const itg_tensor* res, int res_mode,
+              float res_slope, const itg_tensor* out, int pad, int act, float slope, int prec, float* workspace,
+              int64_t workspace_floats, hipStream_t s);
 // conv_nt.hip
 NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = ITG_PREC_F32);
 int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s);

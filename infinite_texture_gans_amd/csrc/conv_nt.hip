@@ -296,7 +296,10 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
     p.cioy[0] = p.ioy; p.ciox[0] = p.iox; p.cooy[0] = p.ooy; p.coox[0] = p.oox;
     p.cwoff[0] = 0;
   }
-  NtPlan pl = plan_nt((int64_t)p.M * ncls_, p.co_rows, p.Kpad, ncls_, p.prec);
+  NtPlan pl = plan_nt((int64_t)p.M * (p.ucls ? p.ucls : ncls_), p.co_rows, p.Kpad, p.ucls ? p.ucls : ncls_, p.prec);
+  if (p.ucls) {                      // uniform classes: thousands of workgroups already, and the slab layout has no class stride
+    pl.ksplit = 1; pl.kchunks = (p.Kpad + pl.tbk - 1) / pl.tbk; pl.ws_floats = 0;
+  }
   if (pl.ws_floats > workspace_floats || (pl.ws_floats && !workspace)) return ITG_ERR_WORKSPACE;
   p.ksplit = pl.ksplit; p.kchunks = pl.kchunks; p.partial = workspace;
   p.tickets = nullptr;

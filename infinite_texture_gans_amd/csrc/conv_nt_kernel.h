@@ -36,13 +36,23 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
   // the four classes of a pixel tile gather the same source pixels, so they run on one XCD at the same time and share them
   // through its L2 (as blockIdx.y they ran a quarter of the launch apart: D2's input gradient fetched 447 MB for 19 MB of dy)
   const int ncls = p.ncls > 1 ? p.ncls : 1;
-  const int cls = bx % ncls;
-  bx /= ncls;
+  int cls = bx % ncls;
+  int ucl = 0;                     // uniform classes (ConvP.ucls): the class is the slowest index, geometry of slot 0
+  if (p.ucls) {
+    const int per = (int)gridDim.x / p.ucls;
+    ucl = bx / per;
+    bx -= ucl * per;
+    cls = 0;
+  } else {
+    bx /= ncls;
+  }
   // per-class geometry (class 0 for ordinary launches); all wave-uniform scalars
   const int cMT = p.cMT[cls], cMU = p.cMU[cls], cM = p.cM[cls];
   const int cioy = p.cioy[cls], ciox = p.ciox[cls], cooy = p.cooy[cls], coox = p.coox[cls];
-  const float* const cw = p.w + p.cwoff[cls];
+  const float* const cw = p.w + (p.ucls ? (size_t)ucl * p.u_w : (size_t)p.cwoff[cls]);
   float* const cpartial = p.partial + p.cpoff[cls];
+  const float* const in_base = p.in.p + (size_t)ucl * p.u_in;
+  float* const out_base = p.out.p + (size_t)ucl * p.u_out;
   if ((int)(bx / p.nco_tiles) * BPIX >= cM) return;
   constexpr int FI = WCO / 16, FJ = WPIX / 16;
   constexpr int WAVES_CO = BCO / WCO;
@@ -81,7 +91,7 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
   // ---- loader state.  Both operands are fetched with raw buffer loads: a lane's byte offset is
   // (pixel offset + channel offset); rows that read padding / lie past M carry an offset equal to the
   // buffer size, so the hardware range check returns zeros - no branches, no selects in the K loop.
-  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in.p, 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)in_base, 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)cw, 0, p.w_bytes, 0x00020000);
   int pn[PL], py[PL], px[PL];
   bool pv[PL];
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
       } else {
         st1[i] += v; st2[i] += v * v;
       }
-      float* dst = p.out.p + off + co;
+      float* dst = out_base + off + co;
       if (border) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) atomicAdd(dst + e, v[e]);
@@ -443,7 +453,7 @@ int launch_nt(const ConvP& p, int tbk, hipStream_t s) {
   int64_t npix = ((int64_t)p.M + BPIX - 1) / BPIX;
   int64_t blocks = npix * q.nco_tiles;
   if (blocks <= 0 || blocks > 0x7fffffff) return ITG_ERR_ARG;
-  const int64_t gx = blocks * (p.ncls > 1 ? p.ncls : 1);       // classes are the fastest index of the tile id (see the kernel)
+  const int64_t gx = blocks * (p.ucls ? p.ucls : (p.ncls > 1 ? p.ncls : 1));      // classes inside the tile id (see the kernel)
   if (gx > 0x7fffffff) return ITG_ERR_ARG;
   dim3 grid((unsigned)gx, 1, (unsigned)p.ksplit);
   size_t tab_bytes = (size_t)BPIX * (p.ntaps + 1) * sizeof(unsigned);

@@ -85,22 +85,30 @@ class _ConvParams(nn.Module):
     grad_sinks = False
     _preset_inv = None      # 1/sigma computed ahead by a model-level batched power iteration
     _packed = None          # (forward panel, dgrad panel) kept current by engine.PackSet, else packed per call
-    _packed_up2 = False     # the persistent panels are the folded-upsample ones (itg_pack_up2_*)
+    _packed_kind = "plain"  # what the persistent panels are: "plain" | "up2" (itg_pack_up2_*) | "wino" (itg_pack_wino_*)
     up2 = False             # this conv sits behind a x2 upsample that its owner folds into it (ResBlockGenerator.conv1)
+
+    @property
+    def wino(self):
+        """Wide 4 x 4 stride-1 layer (the discriminator's 256 -> 512 layer): forward and input gradient run as Winograd
+        F(4 x 4, 4 x 4) when the call qualifies (ops.wino_applicable)."""
+        return (ops.WINOGRAD and self.k == 4 and self.stride == 1 and self.padding == 1 and self.ch_in >= 64 and self.ch_out >= 64
+                and self.ch_in % 16 == 0 and ops.MFMA_PRECISION == ops.PREC_F32)
 
     def pack_jobs(self):
         """Allocate this layer's persistent panels and return its two ops.pack_multi jobs."""
         w = self.weight_orig if self.SN else self.weight
         co, ci, k, st = w.shape[0], w.shape[1], self.k, self.stride
-        up2 = bool(self.up2)
-        nf, nd = ops.pack_sizes(co, ci, k, k, st, up2)
-        if (self._packed is None or self._packed[0].device != w.device or self._packed_up2 != up2
+        kind = "wino" if self.wino else ("up2" if self.up2 else "plain")
+        nf, nd = ops.pack_sizes(co, ci, k, k, st, kind == "up2", kind == "wino")
+        if (self._packed is None or self._packed[0].device != w.device or self._packed_kind != kind
                 or self._packed[0].numel() != nf):
             self._packed = (torch.empty(nf, device=w.device, dtype=torch.float32),
                             torch.empty(nd, device=w.device, dtype=torch.float32))
-        self._packed_up2 = up2
-        return [(w, self._packed[0], co, ci, ops.ld_for(ci), k, k, 1, 2 if up2 else 0),
-                (w, self._packed[1], co, ci, ops.ld_for(co), k, k, st, 3 if up2 else 1)]
+        self._packed_kind = kind
+        kf, kd = {"plain": (0, 1), "up2": (2, 3), "wino": (4, 5)}[kind]
+        return [(w, self._packed[0], co, ci, ops.ld_for(ci), k, k, 1, kf),
+                (w, self._packed[1], co, ci, ops.ld_for(co), k, k, st, kd)]
 
     def weight_and_sn(self):
         """(weight tensor, sn tuple or None); runs the power iteration in training mode.  u / v are not
@@ -122,10 +130,14 @@ class _ConvParams(nn.Module):
     def run(self, x, pad=None, pad_mode=ops.PAD_ZERO, act=ops.ACT_NONE, slope=0.0, residual=None, out_grid=None,
             pad_h=-1, in_act=None, defer_act_bwd=False, out_stats=False, out=None, up2=False):
         w, sn = self.weight_and_sn()
-        packed = self._packed if (self._packed is None or self._packed_up2 == bool(up2)) else None    # else: packed per call
-        return ops.conv(x, w, self.bias, self.k, self.k, self.stride, self.padding if pad is None else pad,
+        p_ = self.padding if pad is None else pad
+        wino = self.wino and ops.wino_applicable(x, self.k, self.k, self.stride, p_, pad_h, pad_mode, ops.MFMA_PRECISION, up2,
+                                                 out_stats, out)
+        kind = "wino" if wino else ("up2" if up2 else "plain")
+        packed = self._packed if (self._packed is None or self._packed_kind == kind) else None    # else: packed per call
+        return ops.conv(x, w, self.bias, self.k, self.k, self.stride, p_,
                         pad_mode, act, slope, residual, sn, out_grid, self._sinks(w), pad_h, packed=packed,
-                        in_act=in_act, defer_act_bwd=defer_act_bwd, out_stats=out_stats, out=out, up2=up2)
+                        in_act=in_act, defer_act_bwd=defer_act_bwd, out_stats=out_stats, out=out, up2=up2, wino=wino)
 
     def run_bn(self, x, bn, in_act, in_slope, upsample=False, pad=None, pad_mode=ops.PAD_ZERO, act=ops.ACT_NONE, slope=0.0,
                residual=None, out_grid=None, pad_h=-1, out_stats=False):
@@ -135,7 +147,7 @@ class _ConvParams(nn.Module):
         w = self.weight
         return ops.bn_conv(x, bn.as_tuple(), w, self.bias, self.k, self.k, self.stride, self.padding if pad is None else pad,
                            pad_mode, act, slope, residual, out_grid, self._sinks(w), pad_h,
-                           packed=None if self._packed_up2 else self._packed,
+                           packed=self._packed if self._packed_kind == "plain" else None,
                            out_stats=out_stats, in_act=in_act, in_slope=in_slope, upsample=upsample)
 
     def forward(self, x):

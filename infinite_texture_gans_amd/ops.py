@@ -260,7 +260,7 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, residual, sn, c_in, geom, act, slope, out_grid, sinks=None, packed=None, fuse=(None, False),
                 stats=None, out_buf=None):
-        kh, kw, stride, pad, pad_mode, pad_h, prec, up2 = geom
+        kh, kw, stride, pad, pad_mode, pad_h, prec, up2, wino = geom
         pv = pad_h if pad_h >= 0 else pad
         n, gh, gw, ph, pw, ld = x.shape
         co, ci = w.shape[0], w.shape[1]
@@ -278,6 +278,9 @@ class _Conv(torch.autograd.Function):
         inv_sigma = sn[0] if sn is not None else None
         if packed is not None:      # panels packed once per optimizer step (engine.PackSet): 1/sigma rides in the epilogue
             wp, out_scale = packed[0], inv_sigma
+        elif wino:
+            wp, out_scale = torch.empty(_lib.fn("itg_pack_wino_size")(co, ld), device=x.device, dtype=torch.float32), None
+            _lib.call("itg_pack_wino_fwd", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, ld, st)
         elif up2:
             wp, out_scale = torch.empty(_lib.fn("itg_pack_up2_fwd_size")(co, ld), device=x.device, dtype=torch.float32), None
             _lib.call("itg_pack_up2_fwd", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, ld, st)
@@ -293,13 +296,14 @@ class _Conv(torch.autograd.Function):
             out = torch.empty(oshape, device=x.device, dtype=torch.float32)
         dx_, do_ = _desc(x, c_in), _desc(out, co)
         dr_ = _desc(residual, co) if residual is not None else _null_desc()
-        g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, stats.data_ptr() if stats is not None else None, None, up2)
+        g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, stats.data_ptr() if stats is not None else None, None, up2,
+               _lib.GEOM_WINO if wino else 0)
         key = ("f", tuple(x.shape), tuple(out.shape), geom, c_in, co)
         nws = _WS_SIZE.get(key)
         if nws is None:
             nws = _WS_SIZE[key] = _lib.fn("itg_conv2d_fwd_workspace")(C.byref(dx_), C.byref(do_), C.byref(g))
         ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
-        taps = 4 if up2 else kh * kw          # multiply-adds per output element and input channel
+        taps = 4 if up2 else (49.0 / 16.0 if wino else kh * kw)          # multiply-adds per output element and input channel
         with _Prof(_nt_tag(co), 1, 2.0 * n * Ho * Wo * co * ci * taps, 4 * (x.numel() + out.numel() + wp.numel())):
             _lib.call("itg_conv2d_fwd", C.byref(dx_), _ptr(wp), _ptr(bias), _ptr(out_scale), C.byref(dr_), C.byref(do_),
                       C.byref(g), act, float(slope), _ptr(ws), nws, st)
@@ -319,7 +323,7 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x, w, out = ctx.saved_tensors
-        kh, kw, stride, pad, pad_mode, pad_h, prec, up2 = ctx.geom
+        kh, kw, stride, pad, pad_mode, pad_h, prec, up2, wino = ctx.geom
         taps = 4 if up2 else kh * kw
         co, ci = ctx.co, ctx.c_in
         if BACKWARD_ENTRY_HOOK is not None and ctx.sinks is not None:
@@ -332,13 +336,17 @@ class _Conv(torch.autograd.Function):
             _lib.call("itg_act_bwd", C.byref(a), C.byref(b), C.byref(c_), ctx.act, float(ctx.slope), st)
         else:
             dy = dout
-        g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, None, None, up2)
+        g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, None, None, up2, _lib.GEOM_WINO if wino else 0)
         ddy = _desc(dy, co)
         inv_sigma = ctx.sn[0] if ctx.sn is not None else None
         gx = gw_ = gb = None
         if ctx.needs_input_grad[0]:
             if ctx.packed is not None:
                 wp, out_scale = ctx.packed[1], inv_sigma
+            elif wino:
+                wp, out_scale = torch.empty(_lib.fn("itg_pack_wino_size")(ci, dy.shape[5]), device=x.device,
+                                            dtype=torch.float32), None
+                _lib.call("itg_pack_wino_dgrad", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, dy.shape[5], st)
             elif up2:
                 wp, out_scale = torch.empty(_lib.fn("itg_pack_up2_dgrad_size")(ci, dy.shape[5]), device=x.device,
                                             dtype=torch.float32), None
@@ -369,7 +377,8 @@ class _Conv(torch.autograd.Function):
             if nws is None:
                 nws = _WS_SIZE[key] = _lib.fn("itg_conv2d_dgrad_workspace")(C.byref(ddy), C.byref(ddx), C.byref(g))
             ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
-            with _Prof(_nt_tag(ci), 1, 2.0 * npix_out * co * ci * taps, 4 * (dy.numel() + gx.numel() + wp.numel())):
+            with _Prof(_nt_tag(ci), 1, 2.0 * npix_out * co * ci * (49.0 / 16.0 if wino else taps),
+                       4 * (dy.numel() + gx.numel() + wp.numel())):
                 ia = ctx.in_act
                 dact = _desc(x, ci) if ia is not None else _null_desc()
                 _lib.call("itg_conv2d_dgrad", C.byref(ddy), _ptr(wp), _ptr(out_scale), C.byref(ddx), C.byref(dact),
@@ -456,9 +465,19 @@ class _Conv(torch.autograd.Function):
         return gx, gw_, gb, gres, None, None, None, None, None, None, None, None, None, None, None
 
 
+WINOGRAD = os.environ.get("ITG_WINOGRAD", "1") == "1"
+
+
+def wino_applicable(x, kh, kw, stride, pad, pad_h, pad_mode, prec, up2=False, out_stats=False, out=None):
+    """Whether conv(..., wino=True) takes the Winograd F(4 x 4, 4 x 4) pipeline for this call (else the direct kernels)."""
+    return (WINOGRAD and kh == 4 and kw == 4 and stride == 1 and pad == 1 and pad_h in (-1, 1) and pad_mode == PAD_ZERO
+            and prec == PREC_F32 and not up2 and x.gh == 1 and x.gw == 1 and x.t.shape[5] % 16 == 0 and not out_stats
+            and out is None)
+
+
 def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, residual=None,
          sn=None, out_grid=None, sinks=None, pad_h=-1, precision=None, packed=None, in_act=None, defer_act_bwd=False,
-         out_stats=False, out=None, up2=False):
+         out_stats=False, out=None, up2=False, wino=False):
     """x: GT.  Returns GT with ``out_grid`` (default: the input grid).  ``sinks`` = (weight.grad, bias.grad)
     buffers: the backward then accumulates the parameter gradients straight into them (and reports no
     gradient to autograd), which removes one AccumulateGrad add kernel per parameter.
@@ -472,7 +491,10 @@ def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=AC
     stats = None
     if out_stats and ld_for(w.shape[0]) <= 512 and w.shape[0] > 1:
         stats = _zeros_f64(2 * ld_for(w.shape[0]), x.t.device)
-    t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode, pad_h, prec, 1 if up2 else 0), act, slope, og, sinks, packed,
+    # wino: Winograd F(4 x 4, 4 x 4) for the forward and the input gradient (4 x 4, stride 1, pad 1, zero padding, plain images,
+    # fp32; itg_conv_geom.flags & ITG_GEOM_WINO); ``packed`` panels must then be the itg_pack_wino_* ones
+    wino = bool(wino) and wino_applicable(x, kh, kw, stride, pad, pad_h, pad_mode, prec, up2, stats is not None, out)
+    t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode, pad_h, prec, 1 if up2 else 0, 1 if wino else 0), act, slope, og, sinks, packed,
                     (in_act, bool(defer_act_bwd)), stats, out)
     return GT(t, w.shape[0], stats)
 
@@ -1304,8 +1326,10 @@ def pack_multi(tables):
         _lib.call("itg_pack_multi", _ptr(t), n, total, st)
 
 
-def pack_sizes(co, ci, kh, kw, stride, up2=False):
+def pack_sizes(co, ci, kh, kw, stride, up2=False, wino=False):
     """(floats of the forward panel, floats of the dgrad panel) for a conv between patch-grid tensors."""
+    if wino:
+        return (_lib.fn("itg_pack_wino_size")(co, ld_for(ci)), _lib.fn("itg_pack_wino_size")(ci, ld_for(co)))
     if up2:
         return (_lib.fn("itg_pack_up2_fwd_size")(co, ld_for(ci)), _lib.fn("itg_pack_up2_dgrad_size")(ci, ld_for(co)))
     return (_lib.fn("itg_pack_fwd_size")(co, ld_for(ci), kh, kw),

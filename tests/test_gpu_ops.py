@@ -149,6 +149,50 @@ def test_conv_fwd_dgrad_wgrad(case, prec):
     assert float((dbg.cpu() - dbr).abs().max()) <= tol_b * float(dyl.abs().sum((0, 2, 3)).max())
 
 
+WINO_CASES = [
+    # name, n, size, cin, cout
+    ("wino_64_96_crop", 2, 22, 64, 96),            # 21 x 21 outputs: the last tile row / column is cropped
+    ("wino_128_64_odd", 3, 15, 128, 64),           # 14 x 14 outputs: 3.5 tiles per side
+    ("wino_256_512_d3", 1, 48, 256, 512),          # the discriminator's layer at config 1's map size (47 x 47 outputs)
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
+def test_conv_winograd_f44_fwd_dgrad_wgrad(case):
+    """ops.conv(wino=True): a wide 4 x 4 stride-1 pad-1 conv (reference models/discriminators.py:196-206) through Winograd
+    F(4 x 4, 4 x 4) - transformed input, 49 uniform-class GEMMs, output transform with bias + LeakyReLU; the input gradient
+    through the same pipeline on dy (flipped filter, padding 2) incl. the fused activation backward of the producing layer;
+    the weight gradient stays on the direct kernel.  Tolerances 2e-5 / 3e-5: the transforms cost ~15x the rounding error of
+    the direct fp32 form (4.6e-6 against 3e-7 measured against fp64)."""
+    ops = _ops()
+    name, n, size, cin, cout = case
+    g = _gen(zlib.crc32(name.encode()) % 1000)
+    x = torch.randn(n, cin, size, size, generator=g)
+    w = torch.randn(cout, cin, 4, 4, generator=g) / (cin * 16) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pre = F.conv2d(xr, wr, br, padding=1)
+    yr = F.leaky_relu(pre, 0.2).detach()
+    dy = torch.randn(yr.shape, generator=g)
+    xg, wg, bg = (t.to(cuda).requires_grad_(True) for t in (x, w, b))
+    gx = ops.to_grid(xg, 1, 1, merged=True)
+    y = ops.conv(gx, wg, bg, 4, 4, 1, 1, ops.PAD_ZERO, ops.ACT_LRELU, 0.2, wino=True)
+    assert ops._lib.fn("itg_last_conv_kernel")().decode().startswith("conv_nt_kernel")
+    yg = ops.to_nchw(y, merged=True)
+    assert yg.shape == yr.shape
+    assert rel_l2(yg.detach().cpu(), yr) < 2e-5, rel_l2(yg.detach().cpu(), yr)
+    y0 = ops.to_nchw(ops.conv(gx, wg, bg, 4, 4, 1, 1, ops.PAD_ZERO, ops.ACT_LRELU, 0.2), merged=True)     # direct kernel
+    assert 1e-7 < rel_l2(yg.detach().cpu(), y0.detach().cpu()) < 2e-5       # really another algorithm, same result
+    # reference gradients through the activation pattern of the output under test: an lrelu'(y) flip where |y| ~ 1e-6 is
+    # not a kernel error (one flipped element of 10^6 is 7e-4 of the input gradient's norm)
+    dyl = dy * torch.where(yg.detach().cpu() > 0, 1.0, 0.2)
+    dxr, dwr, dbr = torch.autograd.grad(pre, (xr, wr, br), dyl)
+    dxg, dwg, dbg = torch.autograd.grad(yg, (xg, wg, bg), dy.to(cuda))
+    assert rel_l2(dxg.cpu(), dxr) < 3e-5, rel_l2(dxg.cpu(), dxr)
+    assert rel_l2(dwg.cpu(), dwr) < 3e-5
+    assert float((dbg.cpu() - dbr).abs().max()) <= 2e-6 * float(dyl.abs().sum((0, 2, 3)).max())
+
+
 UP2_CASES = [
     # name, n, (gh,gw), P (source patch), cin, cout, mode
     ("up2_rep_26_13", 2, (3, 3), 4, 26, 13, "replicate"),
