@@ -103,13 +103,67 @@ __device__ __forceinline__ float wino_elem(const float* __restrict__ w, int co, 
   const float* g = w + ((size_t)(dgrad ? k : row) * ci + (dgrad ? row : k)) * 16;
   float v = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int j = 0; j < 4; ++j) {             // the order wino_pack4 sums in: the two agree to the bit
     float t = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t = fmaf(WINO_G[b][j], dgrad ? g[(3 - i) * 4 + (3 - j)] : g[i * 4 + j], t);
-    v = fmaf(WINO_G[a][i], t, v);
+    for (int i = 0; i < 4; ++i) t = fmaf(WINO_G[a][i], dgrad ? g[15 - (i * 4 + j)] : g[i * 4 + j], t);
+    v = fmaf(WINO_G[b][j], t, v);
   }
   return v;
+}
+
+// The same panel, one thread = FOUR consecutive k of one row and all 49 classes of them: the 16 taps of a filter are
+// read once (64 contiguous bytes) instead of 49 times, the stores are 16 bytes wide.  item < rows_pad * Kpad / 4.
+__device__ __forceinline__ void wino_pack4(const float* __restrict__ w, float* __restrict__ out, int co, int ci, int ld,
+                                           int dgrad, unsigned item) {
+  const int rows = dgrad ? ci : co, kdim = dgrad ? co : ci;
+  const unsigned Kpad = (unsigned)round_up_d(ld, BK), rows_pad = (unsigned)round_up_d(rows, 16);
+  const unsigned kq = Kpad >> 2;
+  const int row = (int)(item / kq), k0 = (int)(item - (unsigned)row * kq) * 4;
+  float g[4][16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = k0 + q;
+    if (row < rows && k < kdim) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(w + ((size_t)(dgrad ? k : row) * ci + (dgrad ? row : k)) * 16);
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const f32x4 x = src[h];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[q][dgrad ? 15 - (h * 4 + u) : h * 4 + u] = x[u];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) g[q][u] = 0.f;
+    }
+  }
+  const size_t plane = (size_t)rows_pad * Kpad;
+  float* o = out + (size_t)row * Kpad + k0;
+#pragma unroll
+  for (int a = 0; a < 7; ++a) {
+    float t[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s = fmaf(WINO_G[a][i], g[q][i * 4 + j], s);
+        t[q][j] = s;
+      }
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+      f32x4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s = fmaf(WINO_G[b][j], t[q][j], s);
+        v[q] = s;
+      }
+      *reinterpret_cast<f32x4*>(o + (size_t)(a * 7 + b) * plane) = v;
+    }
+  }
 }
 
 __global__ void pack_wino_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out, int co,
@@ -164,8 +218,13 @@ __global__ void pack_multi_kernel(const long long* __restrict__ table, int n, lo
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = up2_dgrad_elem(w, co, ci, ld, Kpad, e + j);
     } else if (kind == 4 || kind == 5) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = wino_elem(w, co, ci, ld, kind == 5, e + j);
+      // the job's 49 * units items are dealt out in runs of 256: run 49 * u does unit run u (wino_pack4), the other 48 of
+      // every 49 runs have nothing to do - the working wavefronts are full and spread over the grid
+      const unsigned L = e >> 2, run = L >> 8;
+      const unsigned units = (unsigned)(round_up_d(kind == 5 ? ci : co, 16) * round_up_d(ld, BK)) >> 2;
+      const unsigned unit = (run / 49u) * 256u + (L & 255u);
+      if (run % 49u == 0 && unit < units) wino_pack4(w, out, co, ci, ld, kind == 5, unit);
+      continue;
     } else if (kind == 0) {
       const unsigned Kpad = (unsigned)round_up_d(kh * kw * ld, BK);
       const int k = (int)(e % Kpad), o = (int)(e / Kpad);

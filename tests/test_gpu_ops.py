@@ -748,3 +748,41 @@ def test_stream_placement_probe_picks_streams_that_overlap():
         assert together < 1.6 * us, (alone, together)
     with pytest.raises(Exception):
         _lib.call("itg_stream_spin", -1, C.c_void_p(cur.cuda_stream))
+
+
+def test_pack_multi_panels_equal_the_single_panel_entry_points_bit_exact():
+    """itg_pack_multi writes every persistent weight panel of a model in one launch (plain, folded-upsample and Winograd
+    panels, forward and input-gradient each): every panel equals the one its own entry point packs, to the bit - incl.
+    channel counts that leave padded rows / columns and the Winograd job's one-thread-per-four-filters path."""
+    ops = _ops()
+    from infinite_texture_gans_amd import _lib
+    g = _gen(77)
+    st = None
+    layers = [  # (co, ci, k, stride, kind)
+        (52, 26, 3, 1, "plain"), (128, 64, 4, 2, "plain"), (13, 26, 3, 1, "up2"), (104, 208, 3, 1, "up2"),
+        (96, 64, 4, 1, "wino"), (72, 80, 4, 1, "wino"), (1, 512, 4, 1, "plain")]
+    jobs, want = [], []
+    for co, ci, k, s, kind in layers:
+        w = torch.randn(co, ci, k, k, generator=g).to(cuda)
+        nf, nd = ops.pack_sizes(co, ci, k, k, s, kind == "up2", kind == "wino")
+        pf = torch.full((nf,), float("nan"), device=cuda)
+        pd = torch.full((nd,), float("nan"), device=cuda)
+        kf, kd = {"plain": (0, 1), "up2": (2, 3), "wino": (4, 5)}[kind]
+        ldi, ldo = ops.ld_for(ci), ops.ld_for(co)
+        jobs += [(w, pf, co, ci, ldi, k, k, 1, kf), (w, pd, co, ci, ldo, k, k, s, kd)]
+        sf, sd = torch.empty(nf, device=cuda), torch.empty(nd, device=cuda)
+        P = lambda t: t.data_ptr()                                                       # noqa: E731
+        if kind == "wino":
+            _lib.call("itg_pack_wino_fwd", P(w), None, P(sf), co, ci, ldi, st)
+            _lib.call("itg_pack_wino_dgrad", P(w), None, P(sd), co, ci, ldo, st)
+        elif kind == "up2":
+            _lib.call("itg_pack_up2_fwd", P(w), None, P(sf), co, ci, ldi, st)
+            _lib.call("itg_pack_up2_dgrad", P(w), None, P(sd), co, ci, ldo, st)
+        else:
+            _lib.call("itg_pack_fwd", P(w), None, P(sf), co, ci, ldi, k, k, st)
+            _lib.call("itg_pack_dgrad", P(w), None, P(sd), co, ci, ldo, k, k, s, st)
+        want += [sf, sd]
+    ops.pack_multi(ops.pack_tables(jobs, cuda))
+    torch.cuda.synchronize()
+    for (job, ref) in zip(jobs, want):
+        assert torch.equal(job[1], ref), (job[2:], (job[1] != ref).sum().item())
