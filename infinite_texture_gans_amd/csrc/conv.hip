@@ -943,8 +943,17 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
   return dispatch_nt(p, workspace, workspace_floats, s);
 }
 
+// the weight gradient of an ITG_GEOM_WINO layer also goes through the transformed domain (conv_wino.hip) when both tensors
+// are plain fp32 images with 16-aligned pitches; ITG_WINOGRAD_WGRAD=0 keeps the direct contraction (A/B switch)
+static bool wino_wgrad_ok(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g) {
+  static const int on = env_int("ITG_WINOGRAD_WGRAD", 1);
+  return on && wino_geom(g) && prec_of(g) == ITG_PREC_F32 && x->gh == 1 && x->gw == 1 && dy->gh == 1 && dy->gw == 1 &&
+         !(x->ld & 15) && !(dy->ld & 15) && x->n == dy->n && plan_wino_wgrad(x, dy).tn.ngroups == 0;
+}
+
 int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g) {
   if (!x || !dy || !g) return 0;
+  if (wino_wgrad_ok(x, dy, g)) return plan_wino_wgrad(x, dy).ws_floats;
   if (thin_out_conv(x, dy, g) && !g->in_norm) {
     int64_t Min = grid_pixels(x);
     TnPlan t = plan_tn(Min, 16, x->ld, prec_of(g));
@@ -968,6 +977,7 @@ static int wgrad_setup(const itg_tensor* x, const itg_tensor* dy, const itg_conv
   p.x = make_grid(x);
   p.dy = make_grid(dy);
   p.up2 = 0;
+  p.ucls = 0; p.u_x = 0; p.u_dy = 0;
   if (g->up2) {
     // conv3x3(up2x(x)): four output-parity classes of 2 x 2 taps over the SOURCE pixel domain (WgP.up2); the replicate
     // clamp of the gathered operand in source coordinates is the upsampled image's replicate padding
@@ -1058,6 +1068,13 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
     ITG_CHECK_LAUNCH();
     return ITG_OK;
   }
+  if (wino_wgrad_ok(x, dy, g)) {
+    const WinoWgPlan w = plan_wino_wgrad(x, dy);
+    if (workspace_floats < w.ws_floats) return ITG_ERR_WORKSPACE;
+    if ((rc = wino_wgrad_slabs(x, dy, g->pad, prec_of(g), w, workspace, db != nullptr, s))) return rc;
+    return launch_wgrad_reduce(workspace + w.slab_off, 1, workspace + w.db_off, w.R, dw, db, dy->c, x->c, x->ld, 4, 4, w.co_rows,
+                               w.Kpad, accumulate, s);
+  }
   WgP p;
   TnPlan t;
   TileWgPlan tw;
@@ -1075,6 +1092,17 @@ int itg_conv2d_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, const itg_
   if (x->n != dy->n || g->kh * g->kw > 49) return ITG_ERR_ARG;
   if (thin_out_conv(x, dy, g) && !g->in_norm) return ITG_ERR_ARG;      // taps-as-rows path: not deferrable
   if (g->up2) return ITG_ERR_ARG;                                       // folded-upsample layers reduce through their own kernel
+  if (wino_wgrad_ok(x, dy, g)) {
+    const WinoWgPlan w = plan_wino_wgrad(x, dy);
+    if (workspace_floats < w.ws_floats) return ITG_ERR_WORKSPACE;
+    if ((rc = wino_wgrad_slabs(x, dy, g->pad, prec_of(g), w, workspace, true, (hipStream_t)stream))) return rc;
+    job->slab = workspace + w.slab_off; job->dbslab = workspace + w.db_off;
+    job->splits = 1; job->dbsplits = w.R;
+    job->co = dy->c; job->ci = x->c; job->ci_ld = x->ld; job->kh = 4; job->kw = 4;
+    job->co_rows = w.co_rows; job->Kpad = w.Kpad;
+    job->ngroups = 0; job->group = red_group(); job->stage = nullptr;
+    return ITG_OK;
+  }
   WgP p;
   TnPlan t;
   TileWgPlan tw;

@@ -156,6 +156,10 @@ struct WgP {
   // pixel (t, u) of the SOURCE domain pairs dY(2t + ry, 2u + rx) with the 2 x 2 taps at (t + ry - 1, u + rx - 1); slab and
   // bias partial of (split, class) sit at index split * 4 + class
   int up2;
+  // uniform classes (conv_tn_kernel only; conv_wino.hip's weight gradient): blockIdx.y = class, whose operands sit u_x / u_dy
+  // floats behind x / dy (x_bytes / dy_bytes are the bytes of ONE class) and whose slab is slab[split][class]
+  int ucls;
+  unsigned u_x, u_dy;
 };
 
 constexpr int BKP = 16;  // pixels per pipeline stage (fp32 operands; 32 with bf16 operands)
@@ -193,6 +197,14 @@ TnPlan tn_plan_for_up2_tiles(const TileWgPlan& tw, int co_ld, int cin_ld);
 int run_wgrad(WgP& p, const TnPlan& t, const TileWgPlan& tw, int prec, const itg_tensor* x, const itg_tensor* dy,
               const itg_conv_geom* g, float* dw, float* db, int accumulate, float* workspace, hipStream_t s);
 int run_wgrad_slabs(WgP& p, const TnPlan& t, const TileWgPlan& tw, int prec, hipStream_t s);
+int launch_wgrad_reduce(const float* slab, int splits, const float* dbslab, int dbsplits, float* dw, float* db, int co, int ci,
+                        int ci_ld, int kh, int kw, int co_rows, int Kpad, int accumulate, hipStream_t s);
+// conv_wino.hip: the Winograd weight gradient of the same layers -> ONE slab in the generic layout [co_rows][16 * ci_ld] plus
+// bias partials, finished by the generic reduce stage (single or multi-layer)
+struct WinoWgPlan { int T, R, co_rows, Kpad; int64_t tiles, v_off, m_off, u_off, slab_off, db_off, ws_floats; TnPlan tn; };
+WinoWgPlan plan_wino_wgrad(const itg_tensor* x, const itg_tensor* dy);
+int wino_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, int pad, int prec, const WinoWgPlan& w, float* workspace,
+                     bool want_db, hipStream_t s);
 int launch_reduce_multi(const itg_wgrad_job* jobs, int n, hipStream_t s);
 
 }  // namespace itgk

@@ -66,8 +66,9 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
   // One thread per (pixel row, slot) - spread over the four waves - tracks its pixel and does the clamp / patch-grid
   // address arithmetic ONCE per stage; a load is then a ds_read + add instead of ~40 VALU per load and stage
   // (the kernel issued 2.3 VALU per MFMA that way and kept the MFMA pipe 58 % busy).
-  const __amdgpu_buffer_rsrc_t rxr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x.p, 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ryr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy.p, 0, p.dy_bytes, 0x00020000);
+  const int ucl = (int)blockIdx.y;                            // uniform class (WgP.ucls), else 0
+  const __amdgpu_buffer_rsrc_t rxr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x.p + (size_t)ucl * p.u_x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ryr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy.p + (size_t)ucl * p.u_dy), 0, p.dy_bytes, 0x00020000);
   extern __shared__ unsigned otab[];                           // [DEPTH + 1][KP][otp], otp = taps of a column tile + 1
   const int OTP = otp;
   const int tap_lo = col0 / p.cin_ld;
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
     }
   }
   // D[row = column index (4 consecutive per lane)][col = co]
-  float* slab = p.slab + ((size_t)split * ncls + cls) * p.co_rows * p.Kpad;
+  float* slab = p.slab + (((size_t)split * ncls + cls) * (p.ucls ? p.ucls : 1) + ucl) * p.co_rows * p.Kpad;
   const int cq = (lane >> 4) * 4;
 #pragma unroll
   for (int j = 0; j < FJ; ++j) {
@@ -1196,7 +1197,7 @@ template <int BCOL, int BCO, int WCOL, int WCO>
 int launch_tn(WgP p, int splits, int prec, hipStream_t s) {
   p.ncol_tiles = (p.Kpad + BCOL - 1) / BCOL;
   p.nco_tiles = (p.co_rows + BCO - 1) / BCO;
-  dim3 grid((unsigned)(p.ncol_tiles * p.nco_tiles * (p.up2 ? 4 : 1)), 1, (unsigned)splits);
+  dim3 grid((unsigned)(p.ncol_tiles * p.nco_tiles * (p.up2 ? 4 : 1)), (unsigned)(p.ucls ? p.ucls : 1), (unsigned)splits);
   // offset-table pitch: the taps one column tile can touch (+ the dY slot)
   int taps_tile = (BCOL + p.cin_ld - 1) / p.cin_ld + 1;
   if (taps_tile > p.ntaps) taps_tile = p.ntaps;
@@ -1329,6 +1330,16 @@ int run_wgrad(WgP& p, const TnPlan& t, const TileWgPlan& tw, int prec, const itg
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, red_src, dw, db, (const float*)p.dbslab,
                      t.splits, red_n, dy->c, x->c, x->ld, g->kh, g->kw, t.co_rows, t.Kpad, accumulate);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int launch_wgrad_reduce(const float* slab, int splits, const float* dbslab, int dbsplits, float* dw, float* db, int co, int ci,
+                        int ci_ld, int kh, int kw, int co_rows, int Kpad, int accumulate, hipStream_t s) {
+  if (kh * kw > 49) return ITG_ERR_ARG;
+  const int blocks = co * ((ci + 63) / 64);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, slab, dw, db, dbslab, dbsplits, splits, co, ci, ci_ld, kh,
+                     kw, co_rows, Kpad, accumulate);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }

@@ -434,7 +434,9 @@ class _Conv(torch.autograd.Function):
                     gb = bsink if direct_b else (torch.empty_like(w[:, 0, 0, 0]) if need_b else None)
                     keep = [ws, gw_, gb]            # scratch of this layer's side-stream kernels (see above)
                     npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
-                    with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1, 2.0 * npix_out * co * ci * taps,
+                    wino_wg = bool(g.flags & _lib.GEOM_WINO) and WINOGRAD_WGRAD
+                    with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1,
+                               2.0 * npix_out * co * ci * (49.0 / 16.0 if wino_wg else taps),
                                4 * (x.numel() + dy.numel() + w.numel())):
                         # separate accumulate flags: a spectrally normalised layer sinks its bias gradient but takes dW into a
                         # temporary (no zero-fill launch for it)
@@ -466,6 +468,7 @@ class _Conv(torch.autograd.Function):
 
 
 WINOGRAD = os.environ.get("ITG_WINOGRAD", "1") == "1"
+WINOGRAD_WGRAD = os.environ.get("ITG_WINOGRAD_WGRAD", "1") == "1"     # read by the library itself; here for the flop accounting
 
 
 def wino_applicable(x, kh, kw, stride, pad, pad_h, pad_mode, prec, up2=False, out_stats=False, out=None):
@@ -573,7 +576,9 @@ def _queue_wgrad(x, dxd, dy, ddy, gwg, w, wsink, bsink, need_w, need_b, sn, st, 
     ws = _persistent(("ws",) + key, nws, x.device)
     job = _lib.WgradJob()
     co, ci, kh, kw = w.shape
-    with _Prof(_nt_tag(co).replace("nt", "tn"), 1, 2.0 * (dy.numel() // dy.shape[5]) * co * ci * kh * kw,
+    wino_wg = bool(gwg.flags & _lib.GEOM_WINO) and WINOGRAD_WGRAD
+    with _Prof(_nt_tag(co).replace("nt", "tn"), 1,
+               2.0 * (dy.numel() // dy.shape[5]) * co * ci * (49.0 / 16.0 if wino_wg else kh * kw),
                4 * (x.numel() + dy.numel() + w.numel())):
         rc = _lib.fn("itg_conv2d_wgrad_slabs")(C.byref(dxd), C.byref(ddy), C.byref(gwg), _ptr(ws), nws, C.byref(job), st)
     if rc == -1:                    # ITG_ERR_ARG: a path without slabs (single-output-channel taps-as-rows layer)

@@ -162,7 +162,8 @@ def test_conv_winograd_f44_fwd_dgrad_wgrad(case):
     """ops.conv(wino=True): a wide 4 x 4 stride-1 pad-1 conv (reference models/discriminators.py:196-206) through Winograd
     F(4 x 4, 4 x 4) - transformed input, 49 uniform-class GEMMs, output transform with bias + LeakyReLU; the input gradient
     through the same pipeline on dy (flipped filter, padding 2) incl. the fused activation backward of the producing layer;
-    the weight gradient stays on the direct kernel.  Tolerances 2e-5 / 3e-5: the transforms cost ~15x the rounding error of
+    the weight gradient as 49 contractions over the tiles of A dY A^T and B^T d B, brought back by G^T . G, the bias gradient
+    from the all-ones point of the transformed dy.  Tolerances 2e-5 / 3e-5: the transforms cost ~15x the rounding error of
     the direct fp32 form (4.6e-6 against 3e-7 measured against fp64)."""
     ops = _ops()
     name, n, size, cin, cout = case
@@ -189,8 +190,13 @@ def test_conv_winograd_f44_fwd_dgrad_wgrad(case):
     dxr, dwr, dbr = torch.autograd.grad(pre, (xr, wr, br), dyl)
     dxg, dwg, dbg = torch.autograd.grad(yg, (xg, wg, bg), dy.to(cuda))
     assert rel_l2(dxg.cpu(), dxr) < 3e-5, rel_l2(dxg.cpu(), dxr)
-    assert rel_l2(dwg.cpu(), dwr) < 3e-5
+    assert rel_l2(dwg.cpu(), dwr) < 3e-5, rel_l2(dwg.cpu(), dwr)
     assert float((dbg.cpu() - dbr).abs().max()) <= 2e-6 * float(dyl.abs().sum((0, 2, 3)).max())
+    # the direct weight-gradient kernel on the same operands: another algorithm, same result
+    pre0 = ops.to_nchw(ops.conv(gx, wg, bg, 4, 4, 1, 1, ops.PAD_ZERO), merged=True)
+    dw0, db0 = torch.autograd.grad(pre0, (wg, bg), dyl.to(cuda))
+    assert 1e-7 < rel_l2(dwg.cpu(), dw0.cpu()) < 3e-5, rel_l2(dwg.cpu(), dw0.cpu())
+    assert float((dbg - db0).abs().max()) <= 2e-6 * float(dyl.abs().sum((0, 2, 3)).max())
 
 
 UP2_CASES = [
