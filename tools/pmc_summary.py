@@ -30,7 +30,7 @@ def short(name):
 
 
 def load(d):
-    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)   # newest run of the tag
     per = collections.defaultdict(dict)             # dispatch -> counter -> value (+ name, duration)
     for r in csv.DictReader(open(f)):
         e = per[int(r["Dispatch_Id"])]

@@ -30,7 +30,7 @@ def find(d, pat):
     hits = glob.glob(os.path.join(d, "**", pat), recursive=True)
     if not hits:
         raise SystemExit("no %s under %s" % (pat, d))
-    return hits[0]
+    return max(hits, key=os.path.getmtime)       # a re-used tag keeps older runs beside the new one: take the newest
 
 
 def pmc(d, counter):
