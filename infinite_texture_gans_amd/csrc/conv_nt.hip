@@ -299,6 +299,10 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
   NtPlan pl = plan_nt((int64_t)p.M * (p.ucls ? p.ucls : ncls_), p.co_rows, p.Kpad, p.ucls ? p.ucls : ncls_, p.prec);
   if (p.ucls) {                      // uniform classes: thousands of workgroups already, and the slab layout has no class stride
     pl.ksplit = 1; pl.kchunks = (p.Kpad + pl.tbk - 1) / pl.tbk; pl.ws_floats = 0;
+    // 49 classes x (tiles / bpix) x (co / 128) workgroups: the 64-pixel tile quantises best on 256 CUs x 4 resident
+    // workgroups (forward GEMM of the generated batch 206 -> 186 us, the real batch's 74 -> 70; 96 / 128 are slower)
+    static const int wbp = env_int("ITG_WINO_BPIX", 64);
+    if (wbp && pl.bco == 128) pl.bpix = wbp;
   }
   if (pl.ws_floats > workspace_floats || (pl.ws_floats && !workspace)) return ITG_ERR_WORKSPACE;
   p.ksplit = pl.ksplit; p.kchunks = pl.kchunks; p.partial = workspace;

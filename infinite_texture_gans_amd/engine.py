@@ -550,6 +550,10 @@ class Trainer:
         state and step counters, BN/SN buffers all live in device memory, nothing is read back."""
         self._g_real, self._g_z = real_x.clone(), z.clone()
         self._g_maps = None if maps is None or maps[0] is None else [m.clone() for m in maps]
+        if "ITG_NESTED_FORK" not in os.environ:
+            # a replayed graph places its branches itself: D(real)'s weight gradients leaving their branch stream help the
+            # eager queues (+1 %) and cost the replay 5 % (config 1: 1 047 vs 1 101 crops/s, the eager number; config 3 neutral)
+            self.nested_fork = False
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
