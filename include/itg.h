@@ -97,16 +97,23 @@ typedef struct {
  * it already - itg_zero_frames does so for up to ITG_ZERO_FRAMES_MAX tensors in ONE launch (the step engine keeps the
  * dx buffers of the generator's convs and clears all their frames at the start of the backward pass). */
 #define ITG_GEOM_FRAME_ZEROED 1
-/* ITG_GEOM_WINO: a 4 x 4, stride-1, pad-1, zero-padded conv between plain images (1 x 1 grids, ld multiples of 16) runs as
- * Winograd F(4 x 4, 4 x 4): 49 multiplications per 4 x 4 output tile instead of 256 (the discriminator's 256 -> 512 layer,
- * reference models/discriminators.py:196-206).  w_packed must then be the itg_pack_wino_fwd panel (itg_conv2d_fwd) or the
- * itg_pack_wino_dgrad panel (itg_conv2d_dgrad); the *_workspace queries size the transformed-domain buffers.  fp32 error
- * ~5e-6 rel-L2 against 3e-7 of the direct form (tools/gen_winograd.py).  itg_conv2d_wgrad ignores the flag. */
+/* ITG_GEOM_WINO: a wide stride-1 pad-1 conv (ld multiples of 16) runs as Winograd F(4 x 4, R x R):
+ *   kh = kw = 4, zero padding: 49 multiplications per 4 x 4 output tile instead of 256 (the discriminator's 256 -> 512 layer,
+ *     reference models/discriminators.py:196-206); panels itg_pack_wino_fwd / itg_pack_wino_dgrad;
+ *   kh = kw = 3, zero or replicate padding, any patch grid: 36 instead of 144 (the generator's wide blocks, reference
+ *     models/layers.py:25-34,301-311); panels itg_pack_wino3_fwd / itg_pack_wino3_dgrad.
+ * w_packed must be that panel (itg_conv2d_fwd: the fwd one, itg_conv2d_dgrad: the dgrad one); the *_workspace queries size
+ * the transformed-domain buffers; residual (also half-extent), bias, out_scale, activation, act_out and out_stats (as a pass
+ * of its own over the output) are honoured; itg_conv2d_wgrad / _wgrad_slabs take the transformed route as well (fp32 operands).
+ * fp32 error of R = 4: ~5e-6 rel-L2 against 3e-7 of the direct form (tools/gen_winograd.py). */
 #define ITG_GEOM_WINO 2
 int64_t itg_pack_wino_size(int rows, int k_ld);    /* 49 * round_up(rows, 16) * round_up(k_ld, 16) floats */
+int64_t itg_pack_wino3_size(int rows, int k_ld);   /* 36 * ... */
 /* fwd panel U[xi][co_pad][ci_ld'] = G g G^T of g = w[co][ci]; dgrad panel U'[xi][ci_pad][co_ld'] of the flipped filter */
 int itg_pack_wino_fwd(const float* w_oihw, const float* scale, float* out, int co, int ci, int ci_ld, void* stream);
 int itg_pack_wino_dgrad(const float* w_oihw, const float* scale, float* out, int co, int ci, int co_ld, void* stream);
+int itg_pack_wino3_fwd(const float* w_oihw, const float* scale, float* out, int co, int ci, int ci_ld, void* stream);
+int itg_pack_wino3_dgrad(const float* w_oihw, const float* scale, float* out, int co, int ci, int co_ld, void* stream);
 #define ITG_ZERO_FRAMES_MAX 32
 int itg_zero_frames(const itg_tensor* tensors, int n, void* stream);
 
@@ -152,7 +159,7 @@ int itg_pack_up2_dgrad(const float* w_oihw, const float* scale, float* out, int 
  *   { w_oihw (pointer), out (pointer), co, ci, ld, kh, kw, stride, dgrad, start }
  * ld = ci_ld for a forward panel (dgrad = 0, itg_pack_fwd layout) or co_ld for a dgrad panel (dgrad = 1,
  * itg_pack_dgrad layout); dgrad = 2 / 3: the itg_pack_up2_fwd / itg_pack_up2_dgrad panels (kh = kw = 3); 4 / 5: the
- * itg_pack_wino_fwd / itg_pack_wino_dgrad panels (kh = kw = 4); row j owns flat elements [start_j, start_j + size_j) of the launch, `total` is
+ * itg_pack_wino_fwd / itg_pack_wino_dgrad panels (kh = kw = 4); 6 / 7: the itg_pack_wino3_* panels (kh = kw = 3); row j owns flat elements [start_j, start_j + size_j) of the launch, `total` is
  * the sum of the panel sizes (itg_pack_*_size).  No scale here: the spectral-norm 1/sigma of such
  * panels is applied through `out_scale` below. */
 #define ITG_PACK_MAX_JOBS 48

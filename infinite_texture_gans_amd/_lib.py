@@ -82,7 +82,10 @@ SIGNATURES = {
     "itg_pack_up2_dgrad": (_i, [_P, _P, _P, _i, _i, _i, _P]),
     "itg_zero_frames": (_i, [_TP, _i, _P]),
     "itg_pack_wino_size": (_l, [_i, _i]),
+    "itg_pack_wino3_size": (_l, [_i, _i]),
     "itg_pack_wino_fwd": (_i, [_P, _P, _P, _i, _i, _i, _P]),
+    "itg_pack_wino3_fwd": (_i, [_P, _P, _P, _i, _i, _i, _P]),
+    "itg_pack_wino3_dgrad": (_i, [_P, _P, _P, _i, _i, _i, _P]),
     "itg_pack_wino_dgrad": (_i, [_P, _P, _P, _i, _i, _i, _P]),
     "itg_conv2d_fwd_workspace": (_l, [_TP, _TP, _GP]),
     "itg_conv2d_dgrad_workspace": (_l, [_TP, _TP, _GP]),

@@ -2,6 +2,7 @@
 // convolution family for gfx950 (MI355X).  Kernels: conv_nt.hip, conv_tile.hip, conv_wgrad.hip.
 #include "conv_common.h"
 #include "winograd_f44.h"
+#include "winograd_f43.h"
 
 using namespace itgk;
 
@@ -90,87 +91,107 @@ __device__ __forceinline__ float up2_dgrad_elem(const float* __restrict__ w, int
   return v;
 }
 
-// Winograd F(4 x 4, 4 x 4) panels (conv_wino.hip): U[xi = a * 7 + b][row][k] = sum_ij G[a][i] G[b][j] g[i][j].
-// forward: row = co, k = ci, g = w[co][ci];  input gradient: row = ci, k = co, g[i][j] = w[co][ci][3 - i][3 - j]
+// Winograd F(4 x 4, R x R) panels (conv_wino.hip), NP = 4 + R - 1: U[xi = a * NP + b][row][k] = sum_ij G[a][i] G[b][j] g[i][j].
+// forward: row = co, k = ci, g = w[co][ci];  input gradient: row = ci, k = co, g[i][j] = w[co][ci][R - 1 - i][R - 1 - j]
+template <int R> __device__ __forceinline__ constexpr float wino_g(int i, int j) { return R == 4 ? WINO_G[i][j < 4 ? j : 0] : WINO3_G[i < 6 ? i : 0][j < 3 ? j : 0]; }
+
+template <int R>
 __device__ __forceinline__ float wino_elem(const float* __restrict__ w, int co, int ci, int ld, int dgrad, unsigned e) {
+  constexpr int NP = 4 + R - 1;
   const int rows = dgrad ? ci : co, kdim = dgrad ? co : ci;
   const unsigned Kpad = (unsigned)round_up_d(ld, BK), rows_pad = (unsigned)round_up_d(rows, 16);
   const int k = (int)(e % Kpad);
   const unsigned r = e / Kpad;
   const int row = (int)(r % rows_pad), xi = (int)(r / rows_pad);
-  if (row >= rows || k >= kdim || xi >= 49) return 0.f;
-  const int a = xi / 7, b = xi - a * 7;
-  const float* g = w + ((size_t)(dgrad ? k : row) * ci + (dgrad ? row : k)) * 16;
+  if (row >= rows || k >= kdim || xi >= NP * NP) return 0.f;
+  const int a = xi / NP, b = xi - a * NP;
+  const float* g = w + ((size_t)(dgrad ? k : row) * ci + (dgrad ? row : k)) * (R * R);
   float v = 0.f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {             // the order wino_pack4 sums in: the two agree to the bit
+  for (int j = 0; j < R; ++j) {             // the order wino_pack4 sums in: the two agree to the bit
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) t = fmaf(WINO_G[a][i], dgrad ? g[15 - (i * 4 + j)] : g[i * 4 + j], t);
-    v = fmaf(WINO_G[b][j], t, v);
+    for (int i = 0; i < R; ++i) {
+      float ga = 0.f;                        // G[a][i] with a run-time a: select over the NP rows
+#pragma unroll
+      for (int aa = 0; aa < NP; ++aa) ga = a == aa ? wino_g<R>(aa, i) : ga;
+      t = fmaf(ga, dgrad ? g[R * R - 1 - (i * R + j)] : g[i * R + j], t);
+    }
+    float gb = 0.f;
+#pragma unroll
+    for (int bb = 0; bb < NP; ++bb) gb = b == bb ? wino_g<R>(bb, j) : gb;
+    v = fmaf(gb, t, v);
   }
   return v;
 }
 
-// The same panel, one thread = FOUR consecutive k of one row and all 49 classes of them: the 16 taps of a filter are
-// read once (64 contiguous bytes) instead of 49 times, the stores are 16 bytes wide.  item < rows_pad * Kpad / 4.
+// The same panel, one thread = FOUR consecutive k of one row and all NP^2 classes of them: the taps of a filter are
+// read once instead of NP^2 times, the stores are 16 bytes wide.  item < rows_pad * Kpad / 4.
+template <int R>
 __device__ __forceinline__ void wino_pack4(const float* __restrict__ w, float* __restrict__ out, int co, int ci, int ld,
                                            int dgrad, unsigned item) {
+  constexpr int NP = 4 + R - 1, RR = R * R;
   const int rows = dgrad ? ci : co, kdim = dgrad ? co : ci;
   const unsigned Kpad = (unsigned)round_up_d(ld, BK), rows_pad = (unsigned)round_up_d(rows, 16);
   const unsigned kq = Kpad >> 2;
   const int row = (int)(item / kq), k0 = (int)(item - (unsigned)row * kq) * 4;
-  float g[4][16];
+  float g[4][RR];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int k = k0 + q;
     if (row < rows && k < kdim) {
-      const f32x4* src = reinterpret_cast<const f32x4*>(w + ((size_t)(dgrad ? k : row) * ci + (dgrad ? row : k)) * 16);
+      const float* src = w + ((size_t)(dgrad ? k : row) * ci + (dgrad ? row : k)) * RR;
+      if constexpr (R == 4) {
 #pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        const f32x4 x = src[h];
+        for (int h = 0; h < 4; ++h) {
+          const f32x4 x = reinterpret_cast<const f32x4*>(src)[h];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) g[q][dgrad ? 15 - (h * 4 + u) : h * 4 + u] = x[u];
+          for (int u = 0; u < 4; ++u) g[q][dgrad ? 15 - (h * 4 + u) : h * 4 + u] = x[u];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < RR; ++u) g[q][dgrad ? RR - 1 - u : u] = src[u];
       }
     } else {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) g[q][u] = 0.f;
+      for (int u = 0; u < RR; ++u) g[q][u] = 0.f;
     }
   }
   const size_t plane = (size_t)rows_pad * Kpad;
   float* o = out + (size_t)row * Kpad + k0;
 #pragma unroll
-  for (int a = 0; a < 7; ++a) {
-    float t[4][4];
+  for (int a = 0; a < NP; ++a) {
+    float t[4][R];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < R; ++j) {
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s = fmaf(WINO_G[a][i], g[q][i * 4 + j], s);
+        for (int i = 0; i < R; ++i) s = fmaf(wino_g<R>(a, i), g[q][i * R + j], s);
         t[q][j] = s;
       }
 #pragma unroll
-    for (int b = 0; b < 7; ++b) {
+    for (int b = 0; b < NP; ++b) {
       f32x4 v;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s = fmaf(WINO_G[b][j], t[q][j], s);
+        for (int j = 0; j < R; ++j) s = fmaf(wino_g<R>(b, j), t[q][j], s);
         v[q] = s;
       }
-      *reinterpret_cast<f32x4*>(o + (size_t)(a * 7 + b) * plane) = v;
+      *reinterpret_cast<f32x4*>(o + (size_t)(a * NP + b) * plane) = v;
     }
   }
 }
 
+template <int R>
 __global__ void pack_wino_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out, int co,
                                  int ci, int ld, int dgrad, long long total) {
   const float sc = scale ? *scale : 1.f;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
-    out[i] = sc * wino_elem(w, co, ci, ld, dgrad, (unsigned)i);
+    out[i] = sc * wino_elem<R>(w, co, ci, ld, dgrad, (unsigned)i);
 }
 
 __global__ void pack_up2_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out, int co,
@@ -223,7 +244,13 @@ __global__ void pack_multi_kernel(const long long* __restrict__ table, int n, lo
       const unsigned L = e >> 2, run = L >> 8;
       const unsigned units = (unsigned)(round_up_d(kind == 5 ? ci : co, 16) * round_up_d(ld, BK)) >> 2;
       const unsigned unit = (run / 49u) * 256u + (L & 255u);
-      if (run % 49u == 0 && unit < units) wino_pack4(w, out, co, ci, ld, kind == 5, unit);
+      if (run % 49u == 0 && unit < units) wino_pack4<4>(w, out, co, ci, ld, kind == 5, unit);
+      continue;
+    } else if (kind == 6 || kind == 7) {      // F(4 x 4, 3 x 3): 36 classes
+      const unsigned L = e >> 2, run = L >> 8;
+      const unsigned units = (unsigned)(round_up_d(kind == 7 ? ci : co, 16) * round_up_d(ld, BK)) >> 2;
+      const unsigned unit = (run / 36u) * 256u + (L & 255u);
+      if (run % 36u == 0 && unit < units) wino_pack4<3>(w, out, co, ci, ld, kind == 7, unit);
       continue;
     } else if (kind == 0) {
       const unsigned Kpad = (unsigned)round_up_d(kh * kw * ld, BK);
@@ -570,24 +597,37 @@ int itg_pack_up2_dgrad(const float* w, const float* scale, float* out, int co, i
 }
 
 int64_t itg_pack_wino_size(int rows, int k_ld) { return (int64_t)49 * round_up(rows, 16) * round_up(k_ld, BK); }
+int64_t itg_pack_wino3_size(int rows, int k_ld) { return (int64_t)36 * round_up(rows, 16) * round_up(k_ld, BK); }
 
-static int pack_wino(const float* w, const float* scale, float* out, int co, int ci, int ld, int dgrad, void* stream) {
+static int pack_wino(const float* w, const float* scale, float* out, int co, int ci, int ld, int dgrad, int R, void* stream) {
   if (!w || !out || co <= 0 || ci <= 0 || (ld & 3) || ld < (dgrad ? co : ci)) return ITG_ERR_ARG;
-  const int64_t total = itg_pack_wino_size(dgrad ? ci : co, ld);
+  const int64_t total = R == 4 ? itg_pack_wino_size(dgrad ? ci : co, ld) : itg_pack_wino3_size(dgrad ? ci : co, ld);
   if (total >= ((int64_t)1 << 32)) return ITG_ERR_ARG;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(pack_wino_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, scale, out, co, ci, ld, dgrad,
-                     (long long)total);
+  if (R == 4)
+    hipLaunchKernelGGL(pack_wino_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, scale, out, co, ci, ld, dgrad,
+                       (long long)total);
+  else
+    hipLaunchKernelGGL(pack_wino_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, scale, out, co, ci, ld, dgrad,
+                       (long long)total);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }
 
+int itg_pack_wino3_fwd(const float* w, const float* scale, float* out, int co, int ci, int ci_ld, void* stream) {
+  return pack_wino(w, scale, out, co, ci, ci_ld, 0, 3, stream);
+}
+
+int itg_pack_wino3_dgrad(const float* w, const float* scale, float* out, int co, int ci, int co_ld, void* stream) {
+  return pack_wino(w, scale, out, co, ci, co_ld, 1, 3, stream);
+}
+
 int itg_pack_wino_fwd(const float* w, const float* scale, float* out, int co, int ci, int ci_ld, void* stream) {
-  return pack_wino(w, scale, out, co, ci, ci_ld, 0, stream);
+  return pack_wino(w, scale, out, co, ci, ci_ld, 0, 4, stream);
 }
 
 int itg_pack_wino_dgrad(const float* w, const float* scale, float* out, int co, int ci, int co_ld, void* stream) {
-  return pack_wino(w, scale, out, co, ci, co_ld, 1, stream);
+  return pack_wino(w, scale, out, co, ci, co_ld, 1, 4, stream);
 }
 
 int itg_pack_multi(const int64_t* table_dev, int n, int64_t total, void* stream) {
@@ -602,14 +642,18 @@ int itg_pack_multi(const int64_t* table_dev, int n, int64_t total, void* stream)
 }
 
 // ITG_GEOM_WINO: geometry the Winograd pipeline takes (conv_wino.hip)
+// 4 x 4 stride 1 pad 1 with zero padding (R = 4), or 3 x 3 stride 1 pad 1 with zero or replicate padding (R = 3)
 static inline bool wino_geom(const itg_conv_geom* g) {
-  return (g->flags & ITG_GEOM_WINO) && g->kh == 4 && g->kw == 4 && g->stride == 1 && g->pad == 1 && pad_v_raw(g) == 1 &&
-         g->pad_mode == ITG_PAD_ZERO && !g->up2 && !g->in_norm;
+  if (!(g->flags & ITG_GEOM_WINO) || g->kh != g->kw || g->stride != 1 || g->pad != 1 || pad_v_raw(g) != 1 || g->up2 || g->in_norm)
+    return false;
+  return (g->kh == 4 && g->pad_mode == ITG_PAD_ZERO) || (g->kh == 3 && (g->pad_mode == ITG_PAD_ZERO || g->pad_mode == ITG_PAD_REPLICATE));
 }
+// the input gradient of a replicate-padded layer is evaluated on the padded extent and folded (conv_wino.hip)
+static inline int wino_fold(const itg_conv_geom* g) { return g->pad_mode == ITG_PAD_REPLICATE ? 1 : 0; }
 
 int64_t itg_conv2d_fwd_workspace(const itg_tensor* in, const itg_tensor* out, const itg_conv_geom* g) {
   if (!in || !out || !g) return 0;
-  if (g->flags & ITG_GEOM_WINO) return wino_geom(g) ? wino_workspace_floats(in, out) : 0;
+  if (g->flags & ITG_GEOM_WINO) return wino_geom(g) ? wino_workspace_floats(in, out, g->kh, 0) : 0;
   if (g->up2) return plan_nt(grid_pixels(out), round_up(out->c, 16), round_up(4 * in->ld, BK), 4, prec_of(g)).ws_floats;
   if (thin_out_conv(in, out, g)) {
     int64_t Min = grid_pixels(in);
@@ -620,7 +664,7 @@ int64_t itg_conv2d_fwd_workspace(const itg_tensor* in, const itg_tensor* out, co
 
 int64_t itg_conv2d_dgrad_workspace(const itg_tensor* dy, const itg_tensor* dx, const itg_conv_geom* g) {
   if (!dy || !dx || !g) return 0;
-  if (g->flags & ITG_GEOM_WINO) return wino_geom(g) ? wino_workspace_floats(dy, dx) : 0;
+  if (g->flags & ITG_GEOM_WINO) return wino_geom(g) ? wino_workspace_floats(dy, dx, g->kh, wino_fold(g)) : 0;
   if (thin_in_conv(dy, dx, g)) {
     const int rows = 64;
     const int64_t Mo = grid_pixels(dy);
@@ -651,11 +695,18 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   if (!w_packed || !g) return ITG_ERR_ARG;
   if ((rc = in_norm_of(g, in, &nin))) return rc;
   if (g->flags & ITG_GEOM_WINO) {
-    if (!wino_geom(g) || g->out_stats) return ITG_ERR_ARG;
+    if (!wino_geom(g)) return ITG_ERR_ARG;
     const itg_tensor* r = (residual && residual->ptr) ? residual : nullptr;
     if (r && (rc = check_tensor(r))) return rc;
-    return wino_conv(in, w_packed, bias, out_scale, r, 0, 0.f, out, 1, act, slope, prec_of(g), workspace, workspace_floats,
-                     (hipStream_t)stream);
+    int rups = 0;
+    if (r && !same_shape(r, out)) {          // half-extent residual: read through a nearest x2 upsample (see below)
+      if (r->gh != out->gh || r->gw != out->gw || r->c != out->c || 2 * r->ph != out->ph || 2 * r->pw != out->pw) return ITG_ERR_ARG;
+      rups = 1;
+    }
+    if ((rc = wino_conv(in, w_packed, bias, out_scale, r, rups, 0, 0.f, out, g->kh, 1, g->pad_mode, 0, act, slope, prec_of(g), workspace,
+                        workspace_floats, (hipStream_t)stream))) return rc;
+    // the consumer BatchNorm's statistics: their own pass over the finished output
+    return g->out_stats ? itg_bn_stats(out, g->out_stats, stream) : ITG_OK;
   }
   if (g->up2) {
     // four output-parity classes in one grid: class (ry, rx) = output pixels (2y + ry, 2x + rx), a 2 x 2 conv of the source
@@ -779,12 +830,15 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
   if (dy->n != dx->n) return ITG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (g->flags & ITG_GEOM_WINO) {
-    // the input gradient of a 4 x 4 stride-1 pad-1 conv is the pad-2 correlation of dy with the flipped, transposed filter
+    // the input gradient of an R x R stride-1 pad-1 conv is the pad-(R - 2) correlation of dy with the flipped, transposed
+    // filter; replicate padding: evaluated on the padded extent (pad R - 1), the frame folded onto dx's zeroed border
     if (!wino_geom(g)) return ITG_ERR_ARG;
     const itg_tensor* r = (act_out && act_out->ptr && act != ITG_ACT_NONE) ? act_out : nullptr;
     if (r && ((rc = check_tensor(r)) || !same_shape(r, dx))) return rc ? rc : ITG_ERR_ARG;
-    return wino_conv(dy, w_packed_dgrad, nullptr, out_scale, r, r ? act : 0, slope, dx, 2, ITG_ACT_NONE, 0.f, prec_of(g), workspace,
-                     workspace_floats, s);
+    const int fold = wino_fold(g);
+    if (fold && !(g->flags & ITG_GEOM_FRAME_ZEROED) && (rc = launch_zero_border(make_grid(dx), s))) return rc;
+    return wino_conv(dy, w_packed_dgrad, nullptr, out_scale, r, 0, r ? act : 0, slope, dx, g->kh, g->kh - 2 + fold, ITG_PAD_ZERO, fold,
+                     ITG_ACT_NONE, 0.f, prec_of(g), workspace, workspace_floats, s);
   }
   if (g->up2) {
     // dx(z) = sum_t W4(t) dy(2 z + t - 1): the 4 x 4 stride-2 conv of dy with the phase-summed taps (itg_pack_up2_dgrad).
@@ -947,13 +1001,13 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
 // are plain fp32 images with 16-aligned pitches; ITG_WINOGRAD_WGRAD=0 keeps the direct contraction (A/B switch)
 static bool wino_wgrad_ok(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g) {
   static const int on = env_int("ITG_WINOGRAD_WGRAD", 1);
-  return on && wino_geom(g) && prec_of(g) == ITG_PREC_F32 && x->gh == 1 && x->gw == 1 && dy->gh == 1 && dy->gw == 1 &&
-         !(x->ld & 15) && !(dy->ld & 15) && x->n == dy->n && plan_wino_wgrad(x, dy).tn.ngroups == 0;
+  return on && wino_geom(g) && prec_of(g) == ITG_PREC_F32 && !(x->ld & 15) && !(dy->ld & 15) && x->n == dy->n &&
+         plan_wino_wgrad(x, dy, g->kh).tn.ngroups == 0;
 }
 
 int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g) {
   if (!x || !dy || !g) return 0;
-  if (wino_wgrad_ok(x, dy, g)) return plan_wino_wgrad(x, dy).ws_floats;
+  if (wino_wgrad_ok(x, dy, g)) return plan_wino_wgrad(x, dy, g->kh).ws_floats;
   if (thin_out_conv(x, dy, g) && !g->in_norm) {
     int64_t Min = grid_pixels(x);
     TnPlan t = plan_tn(Min, 16, x->ld, prec_of(g));
@@ -1069,10 +1123,10 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
     return ITG_OK;
   }
   if (wino_wgrad_ok(x, dy, g)) {
-    const WinoWgPlan w = plan_wino_wgrad(x, dy);
+    const WinoWgPlan w = plan_wino_wgrad(x, dy, g->kh);
     if (workspace_floats < w.ws_floats) return ITG_ERR_WORKSPACE;
-    if ((rc = wino_wgrad_slabs(x, dy, g->pad, prec_of(g), w, workspace, db != nullptr, s))) return rc;
-    return launch_wgrad_reduce(workspace + w.slab_off, 1, workspace + w.db_off, w.R, dw, db, dy->c, x->c, x->ld, 4, 4, w.co_rows,
+    if ((rc = wino_wgrad_slabs(x, dy, g->pad, g->pad_mode, prec_of(g), w, workspace, db != nullptr, s))) return rc;
+    return launch_wgrad_reduce(workspace + w.slab_off, 1, workspace + w.db_off, w.Rr, dw, db, dy->c, x->c, x->ld, g->kh, g->kw, w.co_rows,
                                w.Kpad, accumulate, s);
   }
   WgP p;
@@ -1093,12 +1147,12 @@ int itg_conv2d_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, const itg_
   if (thin_out_conv(x, dy, g) && !g->in_norm) return ITG_ERR_ARG;      // taps-as-rows path: not deferrable
   if (g->up2) return ITG_ERR_ARG;                                       // folded-upsample layers reduce through their own kernel
   if (wino_wgrad_ok(x, dy, g)) {
-    const WinoWgPlan w = plan_wino_wgrad(x, dy);
+    const WinoWgPlan w = plan_wino_wgrad(x, dy, g->kh);
     if (workspace_floats < w.ws_floats) return ITG_ERR_WORKSPACE;
-    if ((rc = wino_wgrad_slabs(x, dy, g->pad, prec_of(g), w, workspace, true, (hipStream_t)stream))) return rc;
+    if ((rc = wino_wgrad_slabs(x, dy, g->pad, g->pad_mode, prec_of(g), w, workspace, true, (hipStream_t)stream))) return rc;
     job->slab = workspace + w.slab_off; job->dbslab = workspace + w.db_off;
-    job->splits = 1; job->dbsplits = w.R;
-    job->co = dy->c; job->ci = x->c; job->ci_ld = x->ld; job->kh = 4; job->kw = 4;
+    job->splits = 1; job->dbsplits = w.Rr;
+    job->co = dy->c; job->ci = x->c; job->ci_ld = x->ld; job->kh = g->kh; job->kw = g->kw;
     job->co_rows = w.co_rows; job->Kpad = w.Kpad;
     job->ngroups = 0; job->group = red_group(); job->stage = nullptr;
     return ITG_OK;

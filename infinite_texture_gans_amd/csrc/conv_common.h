@@ -176,11 +176,12 @@ int try_conv_valu(const ConvP& p, hipStream_t s, int* rc);
 int try_conv_tile(ConvP& p, hipStream_t s, int* rc);
 int try_conv_s2k4(const ConvP& p, hipStream_t s, int* rc);
 int try_conv_up2_tile(const ConvP& p, hipStream_t s, int* rc);
-// conv_wino.hip: Winograd F(4 x 4, 4 x 4) for wide 4 x 4 stride-1 layers (the discriminator's 256 -> 512 layer)
-int64_t wino_workspace_floats(const itg_tensor* in, const itg_tensor* out);
-int wino_conv(const itg_tensor* in, const float* u_panel, const float* bias, const float* out_scale, const itg_tensor* res, int res_mode,
-              float res_slope, const itg_tensor* out, int pad, int act, float slope, int prec, float* workspace,
-              int64_t workspace_floats, hipStream_t s);
+// conv_wino.hip: Winograd F(4 x 4, R x R) for wide stride-1 layers (R = 4: the discriminator's 256 -> 512 layer; R = 3: the
+// generator's wide blocks)
+int64_t wino_workspace_floats(const itg_tensor* in, const itg_tensor* out, int R, int fold);
+int wino_conv(const itg_tensor* in, const float* u_panel, const float* bias, const float* out_scale, const itg_tensor* res, int res_ups,
+              int res_mode, float res_slope, const itg_tensor* out, int R, int pad, int pad_mode, int fold, int act, float slope,
+              int prec, float* workspace, int64_t workspace_floats, hipStream_t s);
 // conv_nt.hip
 NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = ITG_PREC_F32);
 int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s);
@@ -201,9 +202,9 @@ int launch_wgrad_reduce(const float* slab, int splits, const float* dbslab, int 
                         int ci_ld, int kh, int kw, int co_rows, int Kpad, int accumulate, hipStream_t s);
 // conv_wino.hip: the Winograd weight gradient of the same layers -> ONE slab in the generic layout [co_rows][16 * ci_ld] plus
 // bias partials, finished by the generic reduce stage (single or multi-layer)
-struct WinoWgPlan { int T, R, co_rows, Kpad; int64_t tiles, v_off, m_off, u_off, slab_off, db_off, ws_floats; TnPlan tn; };
-WinoWgPlan plan_wino_wgrad(const itg_tensor* x, const itg_tensor* dy);
-int wino_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, int pad, int prec, const WinoWgPlan& w, float* workspace,
+struct WinoWgPlan { int R, Ty, Tx, Rr, co_rows, Kpad; int64_t tiles, v_off, m_off, u_off, slab_off, db_off, ws_floats; TnPlan tn; };
+WinoWgPlan plan_wino_wgrad(const itg_tensor* x, const itg_tensor* dy, int R);
+int wino_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, int pad, int pad_mode, int prec, const WinoWgPlan& w, float* workspace,
                      bool want_db, hipStream_t s);
 int launch_reduce_multi(const itg_wgrad_job* jobs, int n, hipStream_t s);
 

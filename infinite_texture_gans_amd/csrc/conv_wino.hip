@@ -1,20 +1,26 @@
-// Winograd F(4 x 4, 4 x 4) for wide 4 x 4 stride-1 convolutions on plain images (gfx950).
+// Winograd F(4 x 4, R x R), R = 4 and 3, for wide stride-1 convolutions (gfx950).
 //
-// The discriminator's 256 -> 512 layer (reference models/discriminators.py:196-206: conv4x4, stride 1, padding 1 on the
+// R = 4: the discriminator's 256 -> 512 layer (reference models/discriminators.py:196-206: conv4x4, stride 1, padding 1 on the
 // 48 x 48 maps) is the one layer of the model that is MFMA-bound AND has a fast algorithm: 49 multiplications per 4 x 4
-// output tile instead of 256.  y = A^T [ (G g G^T) .* (B^T d B) ] A per (output channel, input channel) pair, summed over
-// input channels in the transformed domain - i.e. 49 independent GEMMs [tiles x Cin] x [Cin x Cout]:
-//   wino_in_kernel    d (7 x 7 input tiles, stride 4, zero padding)  ->  V[xi][tile][ci]        (B^T d B per channel)
-//   conv_nt_kernel    49 uniform classes of a 1 x 1 convolution        ->  M[xi][tile][co]        (ConvP.ucls)
-//   wino_out_kernel   A^T m A per tile and channel, 1/sigma, bias, activation (or the producing layer's activation
-//                     derivative for an input gradient), cropped to the output extent
-// The panel U[xi][co][ci] = G g G^T comes from itg_pack_wino_* (conv.hip).  The input gradient of the layer is the same
-// pipeline on dy with the flipped, transposed filter and padding 2.  fp32 throughout; measured error 4.6e-6 rel-L2 against
-// fp64 (direct fp32: 3e-7), tools/gen_winograd.py has the matrices.
+// output tile instead of 256.  R = 3: the generator's wide blocks (416 / 208 channels on 4 x 4 / 8 x 8 patches, reference
+// models/layers.py:25-34,301-311): 36 instead of 144, and a 6 x 6 input tile IS one locally padded 4 x 4 patch.
+// y = A^T [ (G g G^T) .* (B^T d B) ] A per (output channel, input channel) pair, summed over input channels in the
+// transformed domain - i.e. NP^2 independent GEMMs [tiles x Cin] x [Cin x Cout] (NP = 4 + R - 1):
+//   wino_in_kernel    d (NP x NP input tiles, stride 4, gathered in merged patch-grid coordinates, zero or replicate frame)
+//                                                                      ->  V[xi][tile][ci]        (B^T d B per channel)
+//   conv_nt_kernel    NP^2 uniform classes of a 1 x 1 convolution      ->  M[xi][tile][co]        (ConvP.ucls)
+//   wino_out_kernel   A^T m A per tile and channel, 1/sigma, bias, residual (also through a x2 upsample), activation (or the
+//                     producing layer's activation derivative for an input gradient), cropped to the output extent; for the
+//                     input gradient of a replicate-padded layer the (H + 2) x (W + 2) result folds its frame onto the
+//                     border pixels with atomics (the caller has zeroed dx's frame)
+// The panel U[xi][co][ci] = G g G^T comes from itg_pack_wino*_ (conv.hip).  The input gradient of the layer is the same
+// pipeline on dy with the flipped, transposed filter and padding R - 1 - pad.  fp32 throughout; measured error of R = 4:
+// 4.6e-6 rel-L2 against fp64 (direct fp32: 3e-7); tools/gen_winograd.py has the matrices.
 #include <algorithm>
 #include <cstring>
 #include "conv_common.h"
 #include "winograd_f44.h"
+#include "winograd_f43.h"
 
 namespace itgk {
 
@@ -22,78 +28,101 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// one thread = (tile, channel pair): 7 x 7 loads of 8 bytes, V = B^T d B, 49 coalesced 8-byte stores
-__global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ x, int n, int H, int W, int ld, int pad, int T,
-                                                       float* __restrict__ V) {
-  const int cpairs = ld >> 1;
-  const int64_t tiles = (int64_t)n * T * T;
+template <int R> struct WM;
+template <> struct WM<4> {
+  static constexpr int NP = 7;
+  static __device__ constexpr float at(int k, int i) { return WINO_AT[k][i]; }
+  static __device__ constexpr float g(int i, int j) { return WINO_G[i][j]; }
+  static __device__ constexpr float bt(int i, int j) { return WINO_BT[i][j]; }
+};
+template <> struct WM<3> {
+  static constexpr int NP = 6;
+  static __device__ constexpr float at(int k, int i) { return WINO3_AT[k][i]; }
+  static __device__ constexpr float g(int i, int j) { return WINO3_G[i][j]; }
+  static __device__ constexpr float bt(int i, int j) { return WINO3_BT[i][j]; }
+};
+
+// one thread = (tile, channel pair): NP x NP loads of 8 bytes, V = B^T d B, NP^2 coalesced 8-byte stores
+template <int R>
+__global__ __launch_bounds__(256) void wino_in_kernel(const GridT x, int pad, int pad_mode, int Ty, int Tx, float* __restrict__ V) {
+  constexpr int NP = WM<R>::NP;
+  const int ld = x.ld, cpairs = ld >> 1;
+  const int64_t tiles = (int64_t)x.n * Ty * Tx;
   const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gt >= tiles * cpairs) return;
   const int cp = (int)(gt % cpairs);
   const int64_t tile = gt / cpairs;
-  const int tx = (int)(tile % T), ty = (int)((tile / T) % T), img = (int)(tile / ((int64_t)T * T));
+  const int tx = (int)(tile % Tx), ty = (int)((tile / Tx) % Ty), img = (int)(tile / ((int64_t)Ty * Tx));
   const int y0 = 4 * ty - pad, x0 = 4 * tx - pad;
-  f32x2 tmp[7][7];                       // tmp[i][b] = sum_j BT[b][j] d[i][j]
+  const bool rep = pad_mode == ITG_PAD_REPLICATE;
+  f32x2 tmp[NP][NP];                     // tmp[i][b] = sum_j BT[b][j] d[i][j]
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    f32x2 d[7];
-    const int iy = y0 + i;
+  for (int i = 0; i < NP; ++i) {
+    f32x2 d[NP];
+    int iy = y0 + i;
+    const bool oky = (unsigned)iy < (unsigned)x.H;
+    iy = min(max(iy, 0), x.H - 1);
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      const int ix = x0 + j;
-      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      d[j] = ok ? *reinterpret_cast<const f32x2*>(x + (((size_t)img * H + iy) * W + ix) * ld + 2 * cp) : f32x2{0.f, 0.f};
+    for (int j = 0; j < NP; ++j) {
+      int ix = x0 + j;
+      const bool ok = rep || (oky && (unsigned)ix < (unsigned)x.W);
+      ix = min(max(ix, 0), x.W - 1);
+      d[j] = ok ? *reinterpret_cast<const f32x2*>(x.p + grid_off(x, img, iy, ix) + 2 * cp) : f32x2{0.f, 0.f};
     }
 #pragma unroll
-    for (int b = 0; b < 7; ++b) {
+    for (int b = 0; b < NP; ++b) {
       f32x2 a = {0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 7; ++j)
-        if (WINO_BT[b][j] != 0.f) a += WINO_BT[b][j] * d[j];
+      for (int j = 0; j < NP; ++j)
+        if (WM<R>::bt(b, j) != 0.f) a += WM<R>::bt(b, j) * d[j];
       tmp[i][b] = a;
     }
   }
   const size_t plane = (size_t)tiles * ld;
   float* const vb = V + (size_t)tile * ld + 2 * cp;
 #pragma unroll
-  for (int a = 0; a < 7; ++a)
+  for (int a = 0; a < NP; ++a)
 #pragma unroll
-    for (int b = 0; b < 7; ++b) {
+    for (int b = 0; b < NP; ++b) {
       f32x2 v = {0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 7; ++i)
-        if (WINO_BT[a][i] != 0.f) v += WINO_BT[a][i] * tmp[i][b];
-      *reinterpret_cast<f32x2*>(vb + (size_t)(a * 7 + b) * plane) = v;
+      for (int i = 0; i < NP; ++i)
+        if (WM<R>::bt(a, i) != 0.f) v += WM<R>::bt(a, i) * tmp[i][b];
+      *reinterpret_cast<f32x2*>(vb + (size_t)(a * NP + b) * plane) = v;
     }
 }
 
-// one thread = (tile, output-channel pair): 49 loads, Y = A^T m A (4 x 4), epilogue, <= 16 stores
-// res_mode 0: y += res;  ITG_ACT_*: y *= act'(res) (res = the activation's OUTPUT, as itg_conv2d_dgrad's act_out)
-__global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ Mm, int n, int Ho, int Wo, int c, int ld, int T,
+// one thread = (tile, output-channel pair): NP^2 loads, Y = A^T m A (4 x 4), epilogue, <= 16 stores
+// res_mode 0: y += res (read at (oy >> res_ups, ox >> res_ups));  ITG_ACT_*: y *= act'(res) (res = the activation's OUTPUT, as
+// itg_conv2d_dgrad's act_out).  fold = 1: the tiles cover the (H + 2) x (W + 2) gradient of a replicate-padded tensor; element
+// (py, px) lands on pixel (clamp(py - 1), clamp(px - 1)), frame pixels of `out` by atomic adds onto their zeroed start.
+template <int R>
+__global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ Mm, const GridT out, int Ty, int Tx, int fold,
                                                         const float* __restrict__ bias, const float* __restrict__ scale,
-                                                        const float* __restrict__ res, int res_mode, float res_slope, int act,
-                                                        float slope, float* __restrict__ y) {
-  const int cpairs = ld >> 1;
-  const int64_t tiles = (int64_t)n * T * T;
+                                                        const GridT res, int res_ups, int res_mode, float res_slope, int act,
+                                                        float slope) {
+  constexpr int NP = WM<R>::NP;
+  const int ld = out.ld, c = out.c, cpairs = ld >> 1;
+  const int64_t tiles = (int64_t)out.n * Ty * Tx;
   const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gt >= tiles * cpairs) return;
   const int cp = (int)(gt % cpairs);
   const int64_t tile = gt / cpairs;
-  const int tx = (int)(tile % T), ty = (int)((tile / T) % T), img = (int)(tile / ((int64_t)T * T));
+  const int tx = (int)(tile % Tx), ty = (int)((tile / Tx) % Ty), img = (int)(tile / ((int64_t)Ty * Tx));
   const size_t plane = (size_t)tiles * ld;
   const float* const mb = Mm + (size_t)tile * ld + 2 * cp;
-  f32x2 tmp[7][4];                        // tmp[a][l] = sum_b m[a][b] AT[l][b]
+  f32x2 tmp[NP][4];                       // tmp[a][l] = sum_b m[a][b] AT[l][b]
 #pragma unroll
-  for (int a = 0; a < 7; ++a) {
-    f32x2 m[7];
+  for (int a = 0; a < NP; ++a) {
+    f32x2 m[NP];
 #pragma unroll
-    for (int b = 0; b < 7; ++b) m[b] = *reinterpret_cast<const f32x2*>(mb + (size_t)(a * 7 + b) * plane);
+    for (int b = 0; b < NP; ++b) m[b] = *reinterpret_cast<const f32x2*>(mb + (size_t)(a * NP + b) * plane);
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
       f32x2 v = {0.f, 0.f};
 #pragma unroll
-      for (int b = 0; b < 7; ++b)
-        if (WINO_AT[l][b] != 0.f) v += WINO_AT[l][b] * m[b];
+      for (int b = 0; b < NP; ++b)
+        if (WM<R>::at(l, b) != 0.f) v += WM<R>::at(l, b) * m[b];
       tmp[a][l] = v;
     }
   }
@@ -103,22 +132,24 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
     if (2 * cp < c) bv[0] = bias[2 * cp];
     if (2 * cp + 1 < c) bv[1] = bias[2 * cp + 1];
   }
+  const int He = out.H + 2 * fold, We = out.W + 2 * fold;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int oy = 4 * ty + k;
-    if (oy >= Ho) continue;
+    const int py = 4 * ty + k;
+    if (py >= He) continue;
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
-      const int ox = 4 * tx + l;
-      if (ox >= Wo) continue;
+      const int px = 4 * tx + l;
+      if (px >= We) continue;
       f32x2 v = {0.f, 0.f};
 #pragma unroll
-      for (int a = 0; a < 7; ++a)
-        if (WINO_AT[k][a] != 0.f) v += WINO_AT[k][a] * tmp[a][l];
+      for (int a = 0; a < NP; ++a)
+        if (WM<R>::at(k, a) != 0.f) v += WM<R>::at(k, a) * tmp[a][l];
       v = v * osc + bv;
-      const size_t off = (((size_t)img * Ho + oy) * Wo + ox) * ld + 2 * cp;
-      if (res) {
-        const f32x2 r = *reinterpret_cast<const f32x2*>(res + off);
+      const int oy = min(max(py - fold, 0), out.H - 1), ox = min(max(px - fold, 0), out.W - 1);
+      const bool border = fold && ((oy == 0) | (oy == out.H - 1) | (ox == 0) | (ox == out.W - 1));
+      if (res.p) {
+        const f32x2 r = *reinterpret_cast<const f32x2*>(res.p + grid_off(res, img, oy >> res_ups, ox >> res_ups) + 2 * cp);
         if (res_mode == 0) v += r;
         else {
 #pragma unroll
@@ -131,23 +162,30 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
         v[e] = act_apply(v[e], act, slope);
         if (2 * cp + e >= c) v[e] = 0.f;
       }
-      *reinterpret_cast<f32x2*>(y + off) = v;
+      float* dst = out.p + grid_off(out, img, oy, ox) + 2 * cp;
+      if (border) {
+        atomicAdd(dst, v[0]);
+        atomicAdd(dst + 1, v[1]);
+      } else {
+        *reinterpret_cast<f32x2*>(dst) = v;
+      }
     }
   }
 }
 
 // ---- weight gradient: dg = G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G per (output channel, input channel) pair
-// one thread = (tile, output-channel pair): the 4 x 4 tile of dy (zero past the output extent) -> dM = A dY A^T, 49 stores
-__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, int n, int Ho, int Wo, int ld, int T,
-                                                       float* __restrict__ dM) {
-  const int cpairs = ld >> 1;
-  const int64_t tiles = (int64_t)n * T * T;
+// one thread = (tile, output-channel pair): the 4 x 4 tile of dy (zero past the output extent) -> dM = A dY A^T, NP^2 stores
+template <int R>
+__global__ __launch_bounds__(256) void wino_dy_kernel(const GridT dy, int Ty, int Tx, float* __restrict__ dM) {
+  constexpr int NP = WM<R>::NP;
+  const int ld = dy.ld, cpairs = ld >> 1;
+  const int64_t tiles = (int64_t)dy.n * Ty * Tx;
   const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gt >= tiles * cpairs) return;
   const int cp = (int)(gt % cpairs);
   const int64_t tile = gt / cpairs;
-  const int tx = (int)(tile % T), ty = (int)((tile / T) % T), img = (int)(tile / ((int64_t)T * T));
-  f32x2 tmp[4][7];                        // tmp[k][b] = sum_l dY[k][l] AT[l][b]
+  const int tx = (int)(tile % Tx), ty = (int)((tile / Tx) % Ty), img = (int)(tile / ((int64_t)Ty * Tx));
+  f32x2 tmp[4][NP];                        // tmp[k][b] = sum_l dY[k][l] AT[l][b]
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     f32x2 d[4];
@@ -155,202 +193,228 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
       const int ox = 4 * tx + l;
-      d[l] = (oy < Ho && ox < Wo) ? *reinterpret_cast<const f32x2*>(dy + (((size_t)img * Ho + oy) * Wo + ox) * ld + 2 * cp)
-                                  : f32x2{0.f, 0.f};
+      d[l] = (oy < dy.H && ox < dy.W)
+                 ? *reinterpret_cast<const f32x2*>(dy.p + grid_off(dy, img, min(oy, dy.H - 1), min(ox, dy.W - 1)) + 2 * cp)
+                 : f32x2{0.f, 0.f};
     }
 #pragma unroll
-    for (int b = 0; b < 7; ++b) {
+    for (int b = 0; b < NP; ++b) {
       f32x2 v = {0.f, 0.f};
 #pragma unroll
       for (int l = 0; l < 4; ++l)
-        if (WINO_AT[l][b] != 0.f) v += WINO_AT[l][b] * d[l];
+        if (WM<R>::at(l, b) != 0.f) v += WM<R>::at(l, b) * d[l];
       tmp[k][b] = v;
     }
   }
   const size_t plane = (size_t)tiles * ld;
   float* const mb = dM + (size_t)tile * ld + 2 * cp;
 #pragma unroll
-  for (int a = 0; a < 7; ++a)
+  for (int a = 0; a < NP; ++a)
 #pragma unroll
-    for (int b = 0; b < 7; ++b) {
+    for (int b = 0; b < NP; ++b) {
       f32x2 v = {0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (WINO_AT[k][a] != 0.f) v += WINO_AT[k][a] * tmp[k][b];
-      *reinterpret_cast<f32x2*>(mb + (size_t)(a * 7 + b) * plane) = v;
+        if (WM<R>::at(k, a) != 0.f) v += WM<R>::at(k, a) * tmp[k][b];
+      *reinterpret_cast<f32x2*>(mb + (size_t)(a * NP + b) * plane) = v;
     }
 }
 
 // bias-gradient partials: the interpolation point 1 has A row (1, 1, 1, 1), so class (1, 1) of dM holds every tile's sum of
-// dy; dbslab[r][c] = sum of the r-th run of tiles, in a fixed order (the generic reduce stage adds the R rows)
+// dy; dbslab[r][c] = sum of the r-th run of tiles, in a fixed order (the generic reduce stage adds the Rr rows)
 static_assert(WINO_AT[0][1] == 1.f && WINO_AT[1][1] == 1.f && WINO_AT[2][1] == 1.f && WINO_AT[3][1] == 1.f, "point 1 is column 1");
-__global__ __launch_bounds__(256) void wino_db_kernel(const float* __restrict__ dM8, int64_t tiles, int ld, int co_rows, int R,
+static_assert(WINO3_AT[0][1] == 1.f && WINO3_AT[1][1] == 1.f && WINO3_AT[2][1] == 1.f && WINO3_AT[3][1] == 1.f, "point 1 is column 1");
+__global__ __launch_bounds__(256) void wino_db_kernel(const float* __restrict__ dM11, int64_t tiles, int ld, int co_rows, int Rr,
                                                        float* __restrict__ dbslab) {
   const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
   if (c >= co_rows) return;
-  const int64_t per = (tiles + R - 1) / R, t0 = r * per, t1 = t0 + per < tiles ? t0 + per : tiles;
+  const int64_t per = (tiles + Rr - 1) / Rr, t0 = r * per, t1 = t0 + per < tiles ? t0 + per : tiles;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < ld) {
     int64_t t = t0;
     for (; t + 4 <= t1; t += 4) {
-      s0 += dM8[t * ld + c]; s1 += dM8[(t + 1) * ld + c]; s2 += dM8[(t + 2) * ld + c]; s3 += dM8[(t + 3) * ld + c];
+      s0 += dM11[t * ld + c]; s1 += dM11[(t + 1) * ld + c]; s2 += dM11[(t + 2) * ld + c]; s3 += dM11[(t + 3) * ld + c];
     }
-    for (; t < t1; ++t) s0 += dM8[t * ld + c];
+    for (; t < t1; ++t) s0 += dM11[t * ld + c];
   }
   dbslab[(size_t)r * co_rows + c] = (s0 + s1) + (s2 + s3);
 }
 
 // one thread = (co, ci): dU[z][xi][co][ci] summed over the splits z in order, dg = G^T dU G, written as the generic slab
-// [co][(i * 4 + j) * ci_ld + ci] (wgrad_reduce_kernel's input)
+// [co][(i * R + j) * ci_ld + ci] (wgrad_reduce_kernel's input)
+template <int R>
 __global__ __launch_bounds__(256) void wino_wg_out_kernel(const float* __restrict__ dU, int splits, int co_rows, int Kp, int ci_ld,
                                                            float* __restrict__ slab) {
+  constexpr int NP = WM<R>::NP;
   const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gt >= (int64_t)co_rows * ci_ld) return;
   const int ci = (int)(gt % ci_ld), co = (int)(gt / ci_ld);
   const size_t plane = (size_t)co_rows * Kp;
   const float* src = dU + (size_t)co * Kp + ci;
-  float tmp[7][4];                        // tmp[a][j] = sum_b dU[a][b] G[b][j]
+  float tmp[NP][R];                       // tmp[a][j] = sum_b dU[a][b] G[b][j]
 #pragma unroll
-  for (int a = 0; a < 7; ++a) {
-    float u[7];
+  for (int a = 0; a < NP; ++a) {
+    float u[NP];
 #pragma unroll
-    for (int b = 0; b < 7; ++b) {
+    for (int b = 0; b < NP; ++b) {
       float v = 0.f;
-      for (int z = 0; z < splits; ++z) v += src[((size_t)z * 49 + a * 7 + b) * plane];
+      for (int z = 0; z < splits; ++z) v += src[((size_t)z * NP * NP + a * NP + b) * plane];
       u[b] = v;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < R; ++j) {
       float v = 0.f;
 #pragma unroll
-      for (int b = 0; b < 7; ++b)
-        if (WINO_G[b][j] != 0.f) v += WINO_G[b][j] * u[b];
+      for (int b = 0; b < NP; ++b)
+        if (WM<R>::g(b, j) != 0.f) v += WM<R>::g(b, j) * u[b];
       tmp[a][j] = v;
     }
   }
-  float* dst = slab + (size_t)co * (16 * ci_ld) + ci;
+  float* dst = slab + (size_t)co * (R * R * ci_ld) + ci;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < R; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < R; ++j) {
       float v = 0.f;
 #pragma unroll
-      for (int a = 0; a < 7; ++a)
-        if (WINO_G[a][i] != 0.f) v += WINO_G[a][i] * tmp[a][j];
-      dst[(size_t)(i * 4 + j) * ci_ld] = v;
+      for (int a = 0; a < NP; ++a)
+        if (WM<R>::g(a, i) != 0.f) v += WM<R>::g(a, i) * tmp[a][j];
+      dst[(size_t)(i * R + j) * ci_ld] = v;
     }
 }
 
+// tiles per image of the transformed problem whose outputs cover He x We pixels
+inline void wino_tiles(int He, int We, int& Ty, int& Tx) { Ty = (He + 3) / 4; Tx = (We + 3) / 4; }
+
 }  // namespace
 
-// workspace: V[49][tiles][in.ld] | M[49][tiles][out.ld]
-int64_t wino_workspace_floats(const itg_tensor* in, const itg_tensor* out) {
-  const int Ho = out->gh * out->ph, Wo = out->gw * out->pw;
-  const int T = (std::max(Ho, Wo) + 3) / 4;
-  const int64_t tiles = (int64_t)in->n * T * T;
-  return 49 * tiles * ((int64_t)in->ld + out->ld);
+// workspace: V[NP^2][tiles][in.ld] | M[NP^2][tiles][out.ld]; fold: see wino_conv
+int64_t wino_workspace_floats(const itg_tensor* in, const itg_tensor* out, int R, int fold) {
+  const int He = out->gh * out->ph + 2 * fold, We = out->gw * out->pw + 2 * fold;
+  int Ty, Tx;
+  wino_tiles(He, We, Ty, Tx);
+  const int NP = 4 + R - 1;
+  const int64_t tiles = (int64_t)in->n * Ty * Tx;
+  return (int64_t)NP * NP * tiles * ((int64_t)in->ld + out->ld);
 }
 
-// in / out / res: plain images (1 x 1 grids); pad: zero padding of the 4 x 4 stride-1 correlation in -> out
-int wino_conv(const itg_tensor* in, const float* u_panel, const float* bias, const float* out_scale, const itg_tensor* res, int res_mode,
-              float res_slope, const itg_tensor* out, int pad, int act, float slope, int prec, float* workspace,
-              int64_t workspace_floats, hipStream_t s) {
+// in -> out: R x R stride-1 correlation with padding `pad` (zero or replicate frame, gathered in merged patch-grid coordinates).
+// fold = 1 (input gradient of a replicate-padded layer): out has in's extent, the correlation is evaluated on (H + 2) x (W + 2)
+// with pad = R - 1 and its frame folded onto out's border pixels, whose 1-pixel frame the caller has zeroed.
+int wino_conv(const itg_tensor* in, const float* u_panel, const float* bias, const float* out_scale, const itg_tensor* res, int res_ups,
+              int res_mode, float res_slope, const itg_tensor* out, int R, int pad, int pad_mode, int fold, int act, float slope,
+              int prec, float* workspace, int64_t workspace_floats, hipStream_t s) {
   const int H = in->gh * in->ph, W = in->gw * in->pw, Ho = out->gh * out->ph, Wo = out->gw * out->pw;
-  if (in->gh != 1 || in->gw != 1 || out->gh != 1 || out->gw != 1 || in->n != out->n) return ITG_ERR_ARG;
-  if (Ho != H + 2 * pad - 3 || Wo != W + 2 * pad - 3 || (in->ld & 15) || (out->ld & 3)) return ITG_ERR_ARG;
-  if (res && (res->n != out->n || res->gh != 1 || res->gw != 1 || res->ph != out->ph || res->pw != out->pw || res->ld != out->ld))
+  if (in->n != out->n || (R != 3 && R != 4)) return ITG_ERR_ARG;
+  const int He = Ho + 2 * fold, We = Wo + 2 * fold;
+  if (He != H + 2 * pad - (R - 1) || We != W + 2 * pad - (R - 1) || (in->ld & 15) || (out->ld & 3)) return ITG_ERR_ARG;
+  if (fold && pad_mode != ITG_PAD_ZERO) return ITG_ERR_ARG;       // the folded form gathers dy with zeros outside
+  if (res && (res->n != out->n || res->ld != out->ld || (res->gh * res->ph) << res_ups != Ho || (res->gw * res->pw) << res_ups != Wo))
     return ITG_ERR_ARG;
-  const int T = (std::max(Ho, Wo) + 3) / 4;
-  const int64_t tiles = (int64_t)in->n * T * T;
-  const int64_t vf = 49 * tiles * in->ld, mf = 49 * tiles * out->ld;
+  int Ty, Tx;
+  wino_tiles(He, We, Ty, Tx);
+  const int NP = 4 + R - 1, NC = NP * NP;
+  const int64_t tiles = (int64_t)in->n * Ty * Tx;
+  const int64_t vf = NC * tiles * in->ld, mf = NC * tiles * out->ld;
   if (!workspace || workspace_floats < vf + mf) return ITG_ERR_WORKSPACE;
   if (tiles * std::max(in->ld, out->ld) * 4 >= 0xFFFF0000LL) return ITG_ERR_ARG;
   float* V = workspace;
   float* Mm = workspace + vf;
   {
     const int64_t th = tiles * (in->ld >> 1);
-    hipLaunchKernelGGL(wino_in_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, (const float*)in->ptr, in->n, H, W,
-                       in->ld, pad, T, V);
+    const dim3 grid((unsigned)((th + 255) / 256));
+    if (R == 4) hipLaunchKernelGGL(wino_in_kernel<4>, grid, dim3(256), 0, s, make_grid(in), pad, pad_mode, Ty, Tx, V);
+    else hipLaunchKernelGGL(wino_in_kernel<3>, grid, dim3(256), 0, s, make_grid(in), pad, pad_mode, Ty, Tx, V);
     ITG_CHECK_LAUNCH();
   }
   {
-    // the 49 GEMMs: a 1 x 1 convolution over the tile "images" [n][T][T][ci] with 49 uniform classes
+    // the NP^2 GEMMs: a 1 x 1 convolution over the tile "images" [n][Ty][Tx][ci] with NP^2 uniform classes
     ConvP p;
     memset(&p, 0, sizeof(p));
-    itg_tensor vin = {V, in->n, 1, 1, T, T, in->c, in->ld};
-    itg_tensor vout = {Mm, in->n, 1, 1, T, T, out->c, out->ld};
+    itg_tensor vin = {V, in->n, 1, 1, Ty, Tx, in->c, in->ld};
+    itg_tensor vout = {Mm, in->n, 1, 1, Ty, Tx, out->c, out->ld};
     p.in = make_grid(&vin); p.out = make_grid(&vout); p.res = null_grid(); p.bnx = null_grid();
     p.w = u_panel; p.bias = nullptr; p.scale = nullptr;
     p.ntaps = 1; p.kw = 1; p.cin_ld = in->ld; p.Kpad = round_up(in->ld, BK);
-    p.MT = T; p.MU = T; p.M = (int)tiles;
+    p.MT = Ty; p.MU = Tx; p.M = (int)tiles;
     p.isy = p.isx = 1; p.osy = p.osx = 1;
     p.pad_mode = ITG_PAD_ZERO; p.act = ITG_ACT_NONE;
     p.co_rows = round_up(out->c, 16);
     p.prec = prec;
     p.ncls = 1;
-    p.ucls = 49;
+    p.ucls = NC;
     p.u_in = (unsigned)(tiles * in->ld); p.u_out = (unsigned)(tiles * out->ld); p.u_w = (unsigned)((size_t)p.co_rows * p.Kpad);
     int rc = dispatch_nt(p, nullptr, 0, s);
     if (rc) return rc;
   }
   {
     const int64_t th = tiles * (out->ld >> 1);
-    hipLaunchKernelGGL(wino_out_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, (const float*)Mm, out->n, Ho, Wo, out->c,
-                       out->ld, T, bias, out_scale, res ? (const float*)res->ptr : nullptr, res_mode, res_slope, act, slope,
-                       (float*)out->ptr);
+    const dim3 grid((unsigned)((th + 255) / 256));
+    const GridT rg = res ? make_grid(res) : null_grid();
+    if (R == 4)
+      hipLaunchKernelGGL(wino_out_kernel<4>, grid, dim3(256), 0, s, (const float*)Mm, make_grid(out), Ty, Tx, fold, bias, out_scale, rg,
+                         res_ups, res_mode, res_slope, act, slope);
+    else
+      hipLaunchKernelGGL(wino_out_kernel<3>, grid, dim3(256), 0, s, (const float*)Mm, make_grid(out), Ty, Tx, fold, bias, out_scale, rg,
+                         res_ups, res_mode, res_slope, act, slope);
     ITG_CHECK_LAUNCH();
   }
   return ITG_OK;
 }
 
-// ---- weight gradient (x, dy plain images; 4 x 4 stride-1 correlation with zero padding `pad`)
-// workspace: V[49][tiles][x.ld] | dM[49][tiles][dy.ld] | dU[splits][49][co_rows][Kp] | slab[co_rows][16 * x.ld] | db[R][co_rows]
-WinoWgPlan plan_wino_wgrad(const itg_tensor* x, const itg_tensor* dy) {
+// ---- weight gradient (R x R stride-1 correlation with padding `pad`, zero or replicate frame)
+// workspace: V[NP^2][tiles][x.ld] | dM[NP^2][tiles][dy.ld] | dU[splits][NP^2][co_rows][Kp] | slab[co_rows][R^2 * x.ld] | db[Rr][co_rows]
+WinoWgPlan plan_wino_wgrad(const itg_tensor* x, const itg_tensor* dy, int R) {
   WinoWgPlan w;
   const int Ho = dy->gh * dy->ph, Wo = dy->gw * dy->pw;
-  w.T = (std::max(Ho, Wo) + 3) / 4;
-  w.tiles = (int64_t)x->n * w.T * w.T;
-  w.tn = plan_tn(w.tiles, dy->ld, x->ld, ITG_PREC_F32, 49);
+  const int NC = (4 + R - 1) * (4 + R - 1);
+  w.R = R;
+  wino_tiles(Ho, Wo, w.Ty, w.Tx);
+  w.tiles = (int64_t)x->n * w.Ty * w.Tx;
+  w.tn = plan_tn(w.tiles, dy->ld, x->ld, ITG_PREC_F32, NC);
   w.co_rows = w.tn.co_rows;
-  w.Kpad = 16 * x->ld;
-  w.R = (int)std::min<int64_t>(16, std::max<int64_t>(1, w.tiles / 32));
+  w.Kpad = R * R * x->ld;
+  w.Rr = (int)std::min<int64_t>(16, std::max<int64_t>(1, w.tiles / 32));
   w.v_off = 0;
-  w.m_off = w.v_off + 49 * w.tiles * x->ld;
-  w.u_off = w.m_off + 49 * w.tiles * dy->ld;
+  w.m_off = w.v_off + NC * w.tiles * x->ld;
+  w.u_off = w.m_off + NC * w.tiles * dy->ld;
   w.slab_off = w.u_off + w.tn.slab_floats;
   w.db_off = w.slab_off + (int64_t)w.co_rows * w.Kpad;
-  w.ws_floats = w.db_off + (int64_t)w.R * w.co_rows;
+  w.ws_floats = w.db_off + (int64_t)w.Rr * w.co_rows;
   return w;
 }
 
-int wino_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, int pad, int prec, const WinoWgPlan& w, float* workspace,
+int wino_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, int pad, int pad_mode, int prec, const WinoWgPlan& w, float* workspace,
                      bool want_db, hipStream_t s) {
   const int H = x->gh * x->ph, W = x->gw * x->pw, Ho = dy->gh * dy->ph, Wo = dy->gw * dy->pw;
-  if (x->gh != 1 || x->gw != 1 || dy->gh != 1 || dy->gw != 1 || x->n != dy->n) return ITG_ERR_ARG;
-  if (Ho != H + 2 * pad - 3 || Wo != W + 2 * pad - 3 || (x->ld & 15) || (dy->ld & 15) || prec != ITG_PREC_F32) return ITG_ERR_ARG;
+  const int R = w.R, NP = 4 + R - 1, NC = NP * NP;
+  if (x->n != dy->n || (R != 3 && R != 4)) return ITG_ERR_ARG;
+  if (Ho != H + 2 * pad - (R - 1) || Wo != W + 2 * pad - (R - 1) || (x->ld & 15) || (dy->ld & 15) || prec != ITG_PREC_F32) return ITG_ERR_ARG;
   if (w.tiles * std::max(x->ld, dy->ld) * 4 >= 0xFFFF0000LL || w.tn.ngroups > 0) return ITG_ERR_ARG;
   float* V = workspace + w.v_off;
   float* dM = workspace + w.m_off;
   float* dU = workspace + w.u_off;
   {
     const int64_t th = w.tiles * (x->ld >> 1);
-    hipLaunchKernelGGL(wino_in_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, (const float*)x->ptr, x->n, H, W, x->ld,
-                       pad, w.T, V);
+    const dim3 grid((unsigned)((th + 255) / 256));
+    if (R == 4) hipLaunchKernelGGL(wino_in_kernel<4>, grid, dim3(256), 0, s, make_grid(x), pad, pad_mode, w.Ty, w.Tx, V);
+    else hipLaunchKernelGGL(wino_in_kernel<3>, grid, dim3(256), 0, s, make_grid(x), pad, pad_mode, w.Ty, w.Tx, V);
     ITG_CHECK_LAUNCH();
   }
   {
     const int64_t th = w.tiles * (dy->ld >> 1);
-    hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, (const float*)dy->ptr, dy->n, Ho, Wo,
-                       dy->ld, w.T, dM);
+    const dim3 grid((unsigned)((th + 255) / 256));
+    if (R == 4) hipLaunchKernelGGL(wino_dy_kernel<4>, grid, dim3(256), 0, s, make_grid(dy), w.Ty, w.Tx, dM);
+    else hipLaunchKernelGGL(wino_dy_kernel<3>, grid, dim3(256), 0, s, make_grid(dy), w.Ty, w.Tx, dM);
     ITG_CHECK_LAUNCH();
   }
   if (want_db) {
-    hipLaunchKernelGGL(wino_db_kernel, dim3((unsigned)((w.co_rows + 255) / 256), (unsigned)w.R), dim3(256), 0, s,
-                       (const float*)(dM + (size_t)8 * w.tiles * dy->ld), w.tiles, dy->ld, w.co_rows, w.R, workspace + w.db_off);
+    hipLaunchKernelGGL(wino_db_kernel, dim3((unsigned)((w.co_rows + 255) / 256), (unsigned)w.Rr), dim3(256), 0, s,
+                       (const float*)(dM + (size_t)(NP + 1) * w.tiles * dy->ld), w.tiles, dy->ld, w.co_rows, w.Rr, workspace + w.db_off);
     ITG_CHECK_LAUNCH();
   }
   {
-    // the 49 contractions over the tiles: the weight gradient of a 1 x 1 convolution between the tile "images" (one row of
+    // the NP^2 contractions over the tiles: the weight gradient of a 1 x 1 convolution between the tile "images" (one row of
     // `tiles` pixels), one uniform class per transformed point
     WgP p;
     memset(&p, 0, sizeof(p));
@@ -365,7 +429,7 @@ int wino_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, int pad, int pre
     p.chunks_per_split = w.tn.chunks_per_split; p.nchunks = w.tn.nchunks;
     p.x_bytes = (unsigned)(w.tiles * x->ld * 4); p.dy_bytes = (unsigned)(w.tiles * dy->ld * 4);
     p.in_ab = nullptr; p.in_act = ITG_ACT_NONE;
-    p.ucls = 49; p.u_x = (unsigned)(w.tiles * x->ld); p.u_dy = (unsigned)(w.tiles * dy->ld);
+    p.ucls = NC; p.u_x = (unsigned)(w.tiles * x->ld); p.u_dy = (unsigned)(w.tiles * dy->ld);
     TileWgPlan none;
     memset(&none, 0, sizeof(none));
     int rc = run_wgrad_slabs(p, w.tn, none, prec, s);
@@ -373,8 +437,13 @@ int wino_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, int pad, int pre
   }
   {
     const int64_t th = (int64_t)w.co_rows * x->ld;
-    hipLaunchKernelGGL(wino_wg_out_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, (const float*)dU, w.tn.splits,
-                       w.co_rows, w.tn.Kpad, x->ld, workspace + w.slab_off);
+    const dim3 grid((unsigned)((th + 255) / 256));
+    if (R == 4)
+      hipLaunchKernelGGL(wino_wg_out_kernel<4>, grid, dim3(256), 0, s, (const float*)dU, w.tn.splits, w.co_rows, w.tn.Kpad, x->ld,
+                         workspace + w.slab_off);
+    else
+      hipLaunchKernelGGL(wino_wg_out_kernel<3>, grid, dim3(256), 0, s, (const float*)dU, w.tn.splits, w.co_rows, w.tn.Kpad, x->ld,
+                         workspace + w.slab_off);
     ITG_CHECK_LAUNCH();
   }
   return ITG_OK;

@@ -603,8 +603,11 @@ class BandTrainer(Trainer):
     attention layer (ResidualPatchGenerator.band_layout)."""
 
     def __init__(self, netG, netD, args, device, comm, netG_ema=None):
+        from .models.layers import LocalPadder, _ConvParams
+        for m in netG.modules():          # bands carry explicit halo rows (pad_h = 0): the generator's convs keep the direct
+            if isinstance(m, _ConvParams):     # kernels and their panels (decided before the panels are allocated)
+                m.wino_ok = False
         super().__init__(netG, netD, args, device, netG_ema=netG_ema)
-        from .models.layers import LocalPadder
         if netG.padding_mode != 'local':
             raise ValueError("row sharding is defined for padding_mode='local'")
 

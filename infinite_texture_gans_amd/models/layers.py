@@ -88,12 +88,19 @@ class _ConvParams(nn.Module):
     _packed_kind = "plain"  # what the persistent panels are: "plain" | "up2" (itg_pack_up2_*) | "wino" (itg_pack_wino_*)
     up2 = False             # this conv sits behind a x2 upsample that its owner folds into it (ResBlockGenerator.conv1)
 
+    wino_ok = True          # engine.BandTrainer clears it on the generator: its bands carry explicit halo rows (pad_h = 0)
+
     @property
     def wino(self):
-        """Wide 4 x 4 stride-1 layer (the discriminator's 256 -> 512 layer): forward and input gradient run as Winograd
-        F(4 x 4, 4 x 4) when the call qualifies (ops.wino_applicable)."""
-        return (ops.WINOGRAD and self.k == 4 and self.stride == 1 and self.padding == 1 and self.ch_in >= 64 and self.ch_out >= 64
-                and self.ch_in % 16 == 0 and ops.MFMA_PRECISION == ops.PREC_F32)
+        """Wide stride-1 layer whose forward, input gradient and weight gradient run in the Winograd domain when the call
+        qualifies (ops.wino_applicable): the discriminator's 4 x 4 256 -> 512 layer (F(4 x 4, 4 x 4)) and the generator's wide
+        3 x 3 layers that are not behind a folded upsample (F(4 x 4, 3 x 3): 416 -> 416, 208 -> 208)."""
+        if not (ops.WINOGRAD and self.wino_ok and self.stride == 1 and self.ch_in % 16 == 0 and ops.MFMA_PRECISION == ops.PREC_F32):
+            return False
+        if self.k == 4:
+            return self.padding == 1 and self.ch_in >= 64 and self.ch_out >= 64
+        return (self.k == 3 and ops.WINOGRAD_G and not self.up2 and self.ch_in >= 96 and self.ch_out >= 96
+                and ops.ld_for(self.ch_out) % 16 == 0)
 
     def pack_jobs(self):
         """Allocate this layer's persistent panels and return its two ops.pack_multi jobs."""
@@ -106,7 +113,7 @@ class _ConvParams(nn.Module):
             self._packed = (torch.empty(nf, device=w.device, dtype=torch.float32),
                             torch.empty(nd, device=w.device, dtype=torch.float32))
         self._packed_kind = kind
-        kf, kd = {"plain": (0, 1), "up2": (2, 3), "wino": (4, 5)}[kind]
+        kf, kd = {"plain": (0, 1), "up2": (2, 3), "wino": (6, 7) if k == 3 else (4, 5)}[kind]
         return [(w, self._packed[0], co, ci, ops.ld_for(ci), k, k, 1, kf),
                 (w, self._packed[1], co, ci, ops.ld_for(co), k, k, st, kd)]
 
@@ -132,7 +139,7 @@ class _ConvParams(nn.Module):
         w, sn = self.weight_and_sn()
         p_ = self.padding if pad is None else pad
         wino = self.wino and ops.wino_applicable(x, self.k, self.k, self.stride, p_, pad_h, pad_mode, ops.MFMA_PRECISION, up2,
-                                                 out_stats, out)
+                                                 out_stats, out, self.ch_out)
         kind = "wino" if wino else ("up2" if up2 else "plain")
         packed = self._packed if (self._packed is None or self._packed_kind == kind) else None    # else: packed per call
         return ops.conv(x, w, self.bias, self.k, self.k, self.stride, p_,

@@ -279,8 +279,9 @@ class _Conv(torch.autograd.Function):
         if packed is not None:      # panels packed once per optimizer step (engine.PackSet): 1/sigma rides in the epilogue
             wp, out_scale = packed[0], inv_sigma
         elif wino:
-            wp, out_scale = torch.empty(_lib.fn("itg_pack_wino_size")(co, ld), device=x.device, dtype=torch.float32), None
-            _lib.call("itg_pack_wino_fwd", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, ld, st)
+            sfx = "wino3" if kh == 3 else "wino"
+            wp, out_scale = torch.empty(_lib.fn("itg_pack_%s_size" % sfx)(co, ld), device=x.device, dtype=torch.float32), None
+            _lib.call("itg_pack_%s_fwd" % sfx, _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, ld, st)
         elif up2:
             wp, out_scale = torch.empty(_lib.fn("itg_pack_up2_fwd_size")(co, ld), device=x.device, dtype=torch.float32), None
             _lib.call("itg_pack_up2_fwd", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, ld, st)
@@ -303,7 +304,7 @@ class _Conv(torch.autograd.Function):
         if nws is None:
             nws = _WS_SIZE[key] = _lib.fn("itg_conv2d_fwd_workspace")(C.byref(dx_), C.byref(do_), C.byref(g))
         ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
-        taps = 4 if up2 else (49.0 / 16.0 if wino else kh * kw)          # multiply-adds per output element and input channel
+        taps = 4 if up2 else ((kh + 3) ** 2 / 16.0 if wino else kh * kw)          # multiply-adds per output element and input channel
         with _Prof(_nt_tag(co), 1, 2.0 * n * Ho * Wo * co * ci * taps, 4 * (x.numel() + out.numel() + wp.numel())):
             _lib.call("itg_conv2d_fwd", C.byref(dx_), _ptr(wp), _ptr(bias), _ptr(out_scale), C.byref(dr_), C.byref(do_),
                       C.byref(g), act, float(slope), _ptr(ws), nws, st)
@@ -344,9 +345,10 @@ class _Conv(torch.autograd.Function):
             if ctx.packed is not None:
                 wp, out_scale = ctx.packed[1], inv_sigma
             elif wino:
-                wp, out_scale = torch.empty(_lib.fn("itg_pack_wino_size")(ci, dy.shape[5]), device=x.device,
+                sfx = "wino3" if kh == 3 else "wino"
+                wp, out_scale = torch.empty(_lib.fn("itg_pack_%s_size" % sfx)(ci, dy.shape[5]), device=x.device,
                                             dtype=torch.float32), None
-                _lib.call("itg_pack_wino_dgrad", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, dy.shape[5], st)
+                _lib.call("itg_pack_%s_dgrad" % sfx, _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, dy.shape[5], st)
             elif up2:
                 wp, out_scale = torch.empty(_lib.fn("itg_pack_up2_dgrad_size")(ci, dy.shape[5]), device=x.device,
                                             dtype=torch.float32), None
@@ -364,7 +366,7 @@ class _Conv(torch.autograd.Function):
                 if fkey in _FRAMES_READY:
                     _FRAMES_READY.discard(fkey)
                     gx = FRAMES[fkey][0]
-                    g.flags = _lib.GEOM_FRAME_ZEROED
+                    g.flags |= _lib.GEOM_FRAME_ZEROED
                 elif fkey not in FRAMES:
                     gx = torch.empty_like(x)
                     FRAMES[fkey] = (gx, ci)              # from the next pass on
@@ -377,7 +379,7 @@ class _Conv(torch.autograd.Function):
             if nws is None:
                 nws = _WS_SIZE[key] = _lib.fn("itg_conv2d_dgrad_workspace")(C.byref(ddy), C.byref(ddx), C.byref(g))
             ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
-            with _Prof(_nt_tag(ci), 1, 2.0 * npix_out * co * ci * (49.0 / 16.0 if wino else taps),
+            with _Prof(_nt_tag(ci), 1, 2.0 * npix_out * co * ci * ((kh + 3) ** 2 / 16.0 if wino else taps),
                        4 * (dy.numel() + gx.numel() + wp.numel())):
                 ia = ctx.in_act
                 dact = _desc(x, ci) if ia is not None else _null_desc()
@@ -436,7 +438,7 @@ class _Conv(torch.autograd.Function):
                     npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
                     wino_wg = bool(g.flags & _lib.GEOM_WINO) and WINOGRAD_WGRAD
                     with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1,
-                               2.0 * npix_out * co * ci * (49.0 / 16.0 if wino_wg else taps),
+                               2.0 * npix_out * co * ci * ((kh + 3) ** 2 / 16.0 if wino_wg else taps),
                                4 * (x.numel() + dy.numel() + w.numel())):
                         # separate accumulate flags: a spectrally normalised layer sinks its bias gradient but takes dW into a
                         # temporary (no zero-fill launch for it)
@@ -468,14 +470,23 @@ class _Conv(torch.autograd.Function):
 
 
 WINOGRAD = os.environ.get("ITG_WINOGRAD", "1") == "1"
+# F(4 x 4, 3 x 3) for the generator's wide 3 x 3 layers (416 -> 416, 208 -> 208 on 12 x 12 / 24 x 24 images): built, parity-tested,
+# and measured neutral (1 104.8 vs 1 108.8 crops/s, conv time 7.44 vs 7.48 ms per step): a quarter of the multiplications, but
+# three to five dependent launches of 8-20 us where the direct path has one or two - these layers are launch-latency-bound.  Opt-in.
+WINOGRAD_G = os.environ.get("ITG_WINOGRAD_G", "0") == "1"
 WINOGRAD_WGRAD = os.environ.get("ITG_WINOGRAD_WGRAD", "1") == "1"     # read by the library itself; here for the flop accounting
 
 
-def wino_applicable(x, kh, kw, stride, pad, pad_h, pad_mode, prec, up2=False, out_stats=False, out=None):
-    """Whether conv(..., wino=True) takes the Winograd F(4 x 4, 4 x 4) pipeline for this call (else the direct kernels)."""
-    return (WINOGRAD and kh == 4 and kw == 4 and stride == 1 and pad == 1 and pad_h in (-1, 1) and pad_mode == PAD_ZERO
-            and prec == PREC_F32 and not up2 and x.gh == 1 and x.gw == 1 and x.t.shape[5] % 16 == 0 and not out_stats
-            and out is None)
+def wino_applicable(x, kh, kw, stride, pad, pad_h, pad_mode, prec, up2=False, out_stats=False, out=None, co=None):
+    """Whether conv(..., wino=True) takes the Winograd pipeline for this call (else the direct kernels): F(4 x 4, 4 x 4) for
+    4 x 4 zero-padded convs, F(4 x 4, 3 x 3) for 3 x 3 zero- or replicate-padded ones; stride 1, pad 1, fp32, channel pitches
+    that are multiples of 16 on both sides (the input gradient runs the same pipeline on dy)."""
+    if not (WINOGRAD and kh == kw and stride == 1 and pad == 1 and pad_h in (-1, 1) and prec == PREC_F32 and not up2
+            and x.t.shape[5] % 16 == 0 and out is None and (co is None or ld_for(co) % 16 == 0)):
+        return False
+    if kh == 4:
+        return pad_mode == PAD_ZERO
+    return kh == 3 and WINOGRAD_G and pad_mode in (PAD_ZERO, PAD_REPLICATE)
 
 
 def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, residual=None,
@@ -496,7 +507,7 @@ def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=AC
         stats = _zeros_f64(2 * ld_for(w.shape[0]), x.t.device)
     # wino: Winograd F(4 x 4, 4 x 4) for the forward and the input gradient (4 x 4, stride 1, pad 1, zero padding, plain images,
     # fp32; itg_conv_geom.flags & ITG_GEOM_WINO); ``packed`` panels must then be the itg_pack_wino_* ones
-    wino = bool(wino) and wino_applicable(x, kh, kw, stride, pad, pad_h, pad_mode, prec, up2, stats is not None, out)
+    wino = bool(wino) and wino_applicable(x, kh, kw, stride, pad, pad_h, pad_mode, prec, up2, stats is not None, out, w.shape[0])
     t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode, pad_h, prec, 1 if up2 else 0, 1 if wino else 0), act, slope, og, sinks, packed,
                     (in_act, bool(defer_act_bwd)), stats, out)
     return GT(t, w.shape[0], stats)
@@ -578,7 +589,7 @@ def _queue_wgrad(x, dxd, dy, ddy, gwg, w, wsink, bsink, need_w, need_b, sn, st, 
     co, ci, kh, kw = w.shape
     wino_wg = bool(gwg.flags & _lib.GEOM_WINO) and WINOGRAD_WGRAD
     with _Prof(_nt_tag(co).replace("nt", "tn"), 1,
-               2.0 * (dy.numel() // dy.shape[5]) * co * ci * (49.0 / 16.0 if wino_wg else kh * kw),
+               2.0 * (dy.numel() // dy.shape[5]) * co * ci * ((kh + 3) ** 2 / 16.0 if wino_wg else kh * kw),
                4 * (x.numel() + dy.numel() + w.numel())):
         rc = _lib.fn("itg_conv2d_wgrad_slabs")(C.byref(dxd), C.byref(ddy), C.byref(gwg), _ptr(ws), nws, C.byref(job), st)
     if rc == -1:                    # ITG_ERR_ARG: a path without slabs (single-output-channel taps-as-rows layer)
@@ -1334,7 +1345,8 @@ def pack_multi(tables):
 def pack_sizes(co, ci, kh, kw, stride, up2=False, wino=False):
     """(floats of the forward panel, floats of the dgrad panel) for a conv between patch-grid tensors."""
     if wino:
-        return (_lib.fn("itg_pack_wino_size")(co, ld_for(ci)), _lib.fn("itg_pack_wino_size")(ci, ld_for(co)))
+        f = _lib.fn("itg_pack_wino3_size" if kh == 3 else "itg_pack_wino_size")
+        return (f(co, ld_for(ci)), f(ci, ld_for(co)))
     if up2:
         return (_lib.fn("itg_pack_up2_fwd_size")(co, ld_for(ci)), _lib.fn("itg_pack_up2_dgrad_size")(ci, ld_for(co)))
     return (_lib.fn("itg_pack_fwd_size")(co, ld_for(ci), kh, kw),

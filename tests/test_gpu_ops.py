@@ -756,6 +756,61 @@ def test_stream_placement_probe_picks_streams_that_overlap():
         _lib.call("itg_stream_spin", -1, C.c_void_p(cur.cuda_stream))
 
 
+WINO3_CASES = [
+    # name, n, (gh, gw), P, cin, cout, mode, residual (None | "same" | "half")
+    ("w3_rep_416_b1", 2, (3, 3), 4, 416, 416, "replicate", "same"),          # the generator's first block: one tile per patch
+    ("w3_rep_208_b2", 1, (3, 3), 8, 208, 208, "replicate", "half"),          # second block: shortcut read through the x2 upsample
+    ("w3_zero_96_112_odd", 2, (2, 3), 5, 96, 112, "constant", None),         # 10 x 15 image: partial tiles both ways
+    ("w3_rep_112_96_p3", 1, (3, 2), 3, 112, 96, "replicate", None),          # 9 x 6 image: the fold's padded extent is 11 x 8
+]
+
+
+@pytest.mark.parametrize("case", WINO3_CASES, ids=[c[0] for c in WINO3_CASES])
+def test_conv_winograd_f43_on_patch_grids_fwd_dgrad_wgrad(case, monkeypatch):
+    """ops.conv(wino=True) for wide 3 x 3 stride-1 pad-1 convs on patch grids (the generator's conv2d_lp, reference
+    models/layers.py:25-34 behind LocalPadder :145-173): Winograd F(4 x 4, 3 x 3) gathering its 6 x 6 tiles in merged-image
+    coordinates with the replicate / zero frame, residual (also half-size through the upsample) + LeakyReLU + BatchNorm
+    statistics on the way out; the input gradient on the padded extent with the replicated frame folded onto the border;
+    the weight gradient in the transformed domain.  Against F.conv2d on the merged image and against the direct kernels."""
+    ops = _ops()
+    monkeypatch.setattr(ops, "WINOGRAD_G", True)             # opt-in path (ITG_WINOGRAD_G=1): measured neutral on the train step
+    name, n, (gh, gw), P, cin, cout, mode, resk = case
+    g = _gen(zlib.crc32(name.encode()) % 1000)
+    H, W = gh * P, gw * P
+    x = torch.randn(n, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    res = None
+    if resk == "same":
+        res = torch.randn(n, cout, H, W, generator=g)
+    elif resk == "half":
+        res = torch.randn(n, cout, H // 2, W // 2, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pre = F.conv2d(F.pad(xr, (1, 1, 1, 1), mode=mode), wr, br)
+    if res is not None:
+        pre = pre + (res if resk == "same" else F.interpolate(res, scale_factor=2, mode="nearest"))
+    yr = F.leaky_relu(pre, 0.2).detach()
+    dy = torch.randn(yr.shape, generator=g)
+    pm = ops.PAD_REPLICATE if mode == "replicate" else ops.PAD_ZERO
+    xg, wg, bg = (t.to(cuda).requires_grad_(True) for t in (x, w, b))
+    gx = ops.to_grid(xg, gh, gw, merged=True)
+    gres = None if res is None else ops.to_grid(res.to(cuda), gh, gw, merged=True)
+    y = ops.conv(gx, wg, bg, 3, 3, 1, 1, pm, ops.ACT_LRELU, 0.2, residual=gres, out_stats=True, wino=True)
+    yg = ops.to_nchw(y, merged=True)
+    assert yg.shape == yr.shape
+    assert rel_l2(yg.detach().cpu(), yr) < 1e-5, rel_l2(yg.detach().cpu(), yr)
+    y0 = ops.conv(gx, wg, bg, 3, 3, 1, 1, pm, ops.ACT_LRELU, 0.2, residual=gres, out_stats=True)          # direct kernels
+    y0n = ops.to_nchw(y0, merged=True)
+    assert 1e-8 < rel_l2(yg.detach().cpu(), y0n.detach().cpu()) < 1e-5       # really another algorithm, same result
+    assert rel_l2(y.stats.cpu(), y0.stats.cpu()) < 1e-5                       # the consumer BatchNorm's statistics
+    dyl = dy * torch.where(yg.detach().cpu() > 0, 1.0, 0.2)                   # the activation pattern of the output under test
+    dxr, dwr, dbr = torch.autograd.grad(pre, (xr, wr, br), dyl)
+    dxg, dwg, dbg = torch.autograd.grad(yg, (xg, wg, bg), dy.to(cuda))
+    assert rel_l2(dxg.cpu(), dxr) < 2e-5, rel_l2(dxg.cpu(), dxr)
+    assert rel_l2(dwg.cpu(), dwr) < 2e-5, rel_l2(dwg.cpu(), dwr)
+    assert float((dbg.cpu() - dbr).abs().max()) <= 2e-6 * float(dyl.abs().sum((0, 2, 3)).max())
+
+
 def test_pack_multi_panels_equal_the_single_panel_entry_points_bit_exact():
     """itg_pack_multi writes every persistent weight panel of a model in one launch (plain, folded-upsample and Winograd
     panels, forward and input-gradient each): every panel equals the one its own entry point packs, to the bit - incl.
@@ -766,21 +821,22 @@ def test_pack_multi_panels_equal_the_single_panel_entry_points_bit_exact():
     st = None
     layers = [  # (co, ci, k, stride, kind)
         (52, 26, 3, 1, "plain"), (128, 64, 4, 2, "plain"), (13, 26, 3, 1, "up2"), (104, 208, 3, 1, "up2"),
-        (96, 64, 4, 1, "wino"), (72, 80, 4, 1, "wino"), (1, 512, 4, 1, "plain")]
+        (96, 64, 4, 1, "wino"), (72, 80, 4, 1, "wino"), (1, 512, 4, 1, "plain"), (112, 96, 3, 1, "wino"), (40, 208, 3, 1, "wino")]
     jobs, want = [], []
     for co, ci, k, s, kind in layers:
         w = torch.randn(co, ci, k, k, generator=g).to(cuda)
         nf, nd = ops.pack_sizes(co, ci, k, k, s, kind == "up2", kind == "wino")
         pf = torch.full((nf,), float("nan"), device=cuda)
         pd = torch.full((nd,), float("nan"), device=cuda)
-        kf, kd = {"plain": (0, 1), "up2": (2, 3), "wino": (4, 5)}[kind]
+        kf, kd = {"plain": (0, 1), "up2": (2, 3), "wino": (6, 7) if k == 3 else (4, 5)}[kind]
         ldi, ldo = ops.ld_for(ci), ops.ld_for(co)
         jobs += [(w, pf, co, ci, ldi, k, k, 1, kf), (w, pd, co, ci, ldo, k, k, s, kd)]
         sf, sd = torch.empty(nf, device=cuda), torch.empty(nd, device=cuda)
         P = lambda t: t.data_ptr()                                                       # noqa: E731
         if kind == "wino":
-            _lib.call("itg_pack_wino_fwd", P(w), None, P(sf), co, ci, ldi, st)
-            _lib.call("itg_pack_wino_dgrad", P(w), None, P(sd), co, ci, ldo, st)
+            sfx = "wino3" if k == 3 else "wino"
+            _lib.call("itg_pack_%s_fwd" % sfx, P(w), None, P(sf), co, ci, ldi, st)
+            _lib.call("itg_pack_%s_dgrad" % sfx, P(w), None, P(sd), co, ci, ldo, st)
         elif kind == "up2":
             _lib.call("itg_pack_up2_fwd", P(w), None, P(sf), co, ci, ldi, st)
             _lib.call("itg_pack_up2_dgrad", P(w), None, P(sd), co, ci, ldo, st)
