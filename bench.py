@@ -190,6 +190,10 @@ def gpu_leg(a):
                 "step_necessary_gflop": round(nec_gf, 1),
                 "step_executed_gflop": round(sum(x[1] for x in agg.values()) / 1e9, 1),
                 "step_frac_of_mfma_peak": round(sum(x[1] for x in agg.values()) / (dt / a.steps) / 1e12 / peak_tf, 4),
+                # the same step priced at the REFERENCE algorithm's flop count (direct convolutions, materialised upsample): what a
+                # direct implementation would have to sustain to match this step time - an equivalence figure, not a utilisation
+                "step_reference_equivalent_tflops": round(nec_gf / (dt / a.steps) / 1e3, 1),
+                "algorithms": _algorithms_note(),
                 "traffic_source": traffic_note,
                 "streams": dict(ops.STREAM_PLACEMENT),
                 "membound": membound_leg(dev)}
@@ -219,6 +223,21 @@ def exchange_desc(tr):
 
 GRAPH_DEFAULT = {"config1": "0", "config3": "1", "config4": "0", "config5": "0"}   # config 3's 5.5 ms step is shorter than its host time
 _WORKLOAD = ["config1"]
+
+
+def _algorithms_note():
+    """Which convolutions of the step do NOT run the reference's direct algorithm (switch state of this process)."""
+    from infinite_texture_gans_amd import ops
+    from infinite_texture_gans_amd.models.layers import up2_fold_enabled
+    parts = []
+    if ops.WINOGRAD and ops.MFMA_PRECISION == ops.PREC_F32:
+        parts.append("Winograd F(4x4,4x4) for the discriminator's 256->512 layer: forward, input gradient%s (49 of 256 multiplications)"
+                     % (", weight gradient" if ops.WINOGRAD_WGRAD else ""))
+        if ops.WINOGRAD_G:
+            parts.append("Winograd F(4x4,3x3) for the generator's 416- and 208-channel 3x3 layers (36 of 144)")
+    if up2_fold_enabled():
+        parts.append("nearest-x2 upsample folded into the generator blocks' first conv (4 of 9 taps' multiply-adds)")
+    return "; ".join(parts + ["every other convolution direct"]) if parts else "direct convolutions throughout"
 
 
 def graph_mode():
