@@ -79,6 +79,7 @@ CONV_CASES = [
     ("lp3x3_rep_8_8_manysplits", 2, (3, 3), 32, 8, 8, 3, 1, 1, "replicate"),       # wgrad two-stage slab reduce
     ("d4x4_s2_32_48_mid", 2, (1, 1), 40, 32, 48, 4, 2, 1, "zeros"),
     ("d4x4_s1_32_1_taps_as_rows", 2, (1, 1), 13, 32, 1, 4, 1, 1, "zeros"),          # logit layer: single output channel
+    ("d4x4_s1_512_1_logit", 2, (1, 1), 23, 512, 1, 4, 1, 1, "zeros"),               # ... at the discriminator's size: streaming input gradient
     ("d4x4_s1_64_1_taps_as_rows_grid", 1, (2, 3), 6, 64, 1, 4, 1, 1, "zeros"),
     ("d4x4_s2_3_64_first_layer", 1, (1, 1), 36, 3, 64, 4, 2, 1, "zeros"),           # K = 16 taps x 4: 64x64 wgrad tile
     ("fake_grid_into_D_16ch", 2, (3, 3), 6, 3, 16, 4, 2, 1, "zeros"),                # taps-as-rows input gradient, odd size
