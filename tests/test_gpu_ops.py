@@ -1,5 +1,6 @@
 """GPU parity, op level: every C-ABI kernel family against the CPU oracle (torch-CPU primitives
 + oracle.patches) on the same seeded inputs.  fp32 tolerances are written at each check."""
+import os
 import zlib
 
 import numpy as np
@@ -159,7 +160,7 @@ WINO_CASES = [
 
 
 @pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
-def test_conv_winograd_f44_fwd_dgrad_wgrad(case):
+def test_conv_winograd_f44_fwd_dgrad_wgrad(case, monkeypatch):
     """ops.conv(wino=True): a wide 4 x 4 stride-1 pad-1 conv (reference models/discriminators.py:196-206) through Winograd
     F(4 x 4, 4 x 4) - transformed input, 49 uniform-class GEMMs, output transform with bias + LeakyReLU; the input gradient
     through the same pipeline on dy (flipped filter, padding 2) incl. the fused activation backward of the producing layer;
@@ -167,6 +168,7 @@ def test_conv_winograd_f44_fwd_dgrad_wgrad(case):
     from the all-ones point of the transformed dy.  Tolerances 2e-5 / 3e-5: the transforms cost ~15x the rounding error of
     the direct fp32 form (4.6e-6 against 3e-7 measured against fp64)."""
     ops = _ops()
+    monkeypatch.setattr(ops, "WINOGRAD", True)               # whatever ITG_WINOGRAD says: this test is about that path
     name, n, size, cin, cout = case
     g = _gen(zlib.crc32(name.encode()) % 1000)
     x = torch.randn(n, cin, size, size, generator=g)
@@ -196,7 +198,8 @@ def test_conv_winograd_f44_fwd_dgrad_wgrad(case):
     # the direct weight-gradient kernel on the same operands: another algorithm, same result
     pre0 = ops.to_nchw(ops.conv(gx, wg, bg, 4, 4, 1, 1, ops.PAD_ZERO), merged=True)
     dw0, db0 = torch.autograd.grad(pre0, (wg, bg), dyl.to(cuda))
-    assert 1e-7 < rel_l2(dwg.cpu(), dw0.cpu()) < 3e-5, rel_l2(dwg.cpu(), dw0.cpu())
+    lo = 1e-7 if os.environ.get("ITG_WINOGRAD_WGRAD", "1") == "1" else -1.0     # the library reads that switch itself
+    assert lo < rel_l2(dwg.cpu(), dw0.cpu()) < 3e-5, rel_l2(dwg.cpu(), dw0.cpu())
     assert float((dbg - db0).abs().max()) <= 2e-6 * float(dyl.abs().sum((0, 2, 3)).max())
 
 
@@ -774,6 +777,7 @@ def test_conv_winograd_f43_on_patch_grids_fwd_dgrad_wgrad(case, monkeypatch):
     statistics on the way out; the input gradient on the padded extent with the replicated frame folded onto the border;
     the weight gradient in the transformed domain.  Against F.conv2d on the merged image and against the direct kernels."""
     ops = _ops()
+    monkeypatch.setattr(ops, "WINOGRAD", True)
     monkeypatch.setattr(ops, "WINOGRAD_G", True)             # opt-in path (ITG_WINOGRAD_G=1): measured neutral on the train step
     name, n, (gh, gw), P, cin, cout, mode, resk = case
     g = _gen(zlib.crc32(name.encode()) % 1000)
