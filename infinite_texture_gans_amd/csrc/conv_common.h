@@ -189,6 +189,8 @@ int launch_zero_border(const GridT& g, hipStream_t s);
 int launch_zero_frames(const itg_tensor* t, int n, hipStream_t s);
 // conv_nt_fused.hip
 int launch_nt_fused(int mode, int bco, int bpix, const ConvP& p, int k, hipStream_t s);
+// conv_nt_w64.hip
+int launch_nt_w64(int bco, int bpix, const ConvP& p, int k, hipStream_t s);
 // conv_wgrad.hip
 TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g);
 TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec = ITG_PREC_F32, int ncls = 1);

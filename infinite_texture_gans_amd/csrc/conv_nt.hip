@@ -333,8 +333,11 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
             pl.bco, pl.bpix, pl.ksplit, pl.kchunks);
   // plain kernels here; the loader-transform (forward of a normalised input) and BatchNorm-backward-sums (input gradient)
   // forms are instantiated in conv_nt_fused.hip
-  const int mode = p.in_ab ? NT_XF : (p.bn_sums ? NT_BNS : NT_PLAIN);
-  int rc = mode == NT_PLAIN ? launch_nt_shape<NT_PLAIN>(pl.bco, pl.bpix, p, k, s) : launch_nt_fused(mode, pl.bco, pl.bpix, p, k, s);
+  // uniform-class launches (the Winograd GEMMs) with fp32 operands accumulate blockwise in fp64 (NT_W64, conv_nt_w64.hip)
+  static const int w64 = env_int("ITG_WINO_ACC64", 1);
+  const int mode = p.in_ab ? NT_XF : (p.bn_sums ? NT_BNS : ((p.ucls && k == 16 && w64) ? NT_W64 : NT_PLAIN));
+  int rc = mode == NT_PLAIN ? launch_nt_shape<NT_PLAIN>(pl.bco, pl.bpix, p, k, s)
+           : mode == NT_W64 ? launch_nt_w64(pl.bco, pl.bpix, p, k, s) : launch_nt_fused(mode, pl.bco, pl.bpix, p, k, s);
   if (rc) return rc;
   if (!second_stage) return (want_stats && !p.stats) ? stats_after(p, want_stats, s) : ITG_OK;   // (bn_sums: taken by the epilogue)
   {

@@ -5,7 +5,19 @@
 
 namespace itgk {
 
-enum { NT_PLAIN = 0, NT_XF = 1, NT_BNS = 2 };
+enum { NT_PLAIN = 0, NT_XF = 1, NT_BNS = 2, NT_W64 = 3 };
+
+// NT_W64 (fp32 operands): blocked accumulation for the Winograd GEMMs.  v_mfma_f32_16x16x4_f32 adds its products to the
+// accumulator one after the other, so a K loop of length L is ONE chain of L fp32 roundings: error ~ eps * sqrt(L / 2) of the
+// result.  A direct convolution does not care (3e-7 at L = 4096), but the Winograd output transform A^T M A amplifies the
+// error of M ~16 x (cancellation between the 49 classes): 4.6e-6 per layer, which flips the LeakyReLU behind D's 256 -> 512
+// layer on 15 x as many activations (tools/wino_error_study.py reproduces the number on the CPU: the transforms' own
+// rounding is 8 x smaller).  Here every K stage (16 values = 4 MFMAs) starts from a zero accumulator and the stage sums are
+// added in fp64 on the vector ALU (v_cvt_f64_f32 + v_add_f64 per element and stage, in the shadow of the next stage's MFMAs):
+// the chain is 16 long whatever L is.
+#ifndef ITG_W64_BLOCK
+#define ITG_W64_BLOCK 16
+#endif
 
 
 // DEPTH = number of K stages whose global loads are in flight while one stage is computed.
@@ -15,7 +27,8 @@ enum { NT_PLAIN = 0, NT_XF = 1, NT_BNS = 2 };
 // Either way a tile row occupies 16 dwords of a 20-dword LDS row and lane group g reads dwords 4g..4g+3.
 // Workgroups per CU the register budget is pinned to: 3 (168 VGPRs) for the wide tiles, 5 (96) for the
 // medium fp32 tiles, 4 (128) for the medium bf16 tiles (their stage holds twice the prefetch registers).
-constexpr int nt_min_blocks(int bco, int bpix, int wco, int wpix, int tbk) {
+constexpr int nt_min_blocks(int bco, int bpix, int wco, int wpix, int tbk, int mode = 0) {
+  if (mode == 3) return (wco / 16) * (wpix / 16) <= 4 ? 3 : 2;       // NT_W64: fp64 accumulators (2 registers per element)
   return ((wco / 16) * (wpix / 16) <= 8 && (bco + bpix) <= 192) ? 4 : 3;
 }
 
@@ -23,7 +36,7 @@ constexpr int nt_min_blocks(int bco, int bpix, int wco, int wpix, int tbk) {
 // upsample in the loader), NT_BNS = the BatchNorm backward sums in the epilogue (bn_sums); separate instantiations, so that
 // the plain kernels are exactly the round-2 code (as run-time branches the two cost them 2-20 %).
 template <int BCO, int BPIX, int WCO, int WPIX, int TBK, int DEPTH, bool TAB, int MODE>
-__global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void conv_nt_kernel(const ConvP p) {
+__global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK, MODE)) void conv_nt_kernel(const ConvP p) {
   // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share an L2): hand every XCD one contiguous run of
   // tile ids instead, so that an L2 serves neighbouring pixel tiles (shared halo rows, all output-channel tiles of a
   // pixel tile) and not a 1-in-8 sample of the whole image.  Bijective for any grid size; speed only.
@@ -227,6 +240,15 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
   for (int i = 0; i < FI; ++i)
 #pragma unroll
     for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr bool W64 = MODE == NT_W64;
+  static_assert(!W64 || !BF, "blocked fp64 accumulation is an fp32-operand mode");
+  f64x4 acc64[W64 ? FI : 1][W64 ? FJ : 1];
+  if constexpr (W64) {
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) acc64[i][j] = f64x4{0., 0., 0., 0.};
+  }
 
   const int frow = lane & 15, fk = ((lane >> 4) ^ (((lane >> 3) & 1) << 1)) * 4;   // swizzled slot of K group lane >> 4 in row frow
   auto compute = [&](int buf) {
@@ -245,6 +267,30 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
           for (int j = 0; j < FJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]),
                                                                 __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+      } else if constexpr (W64) {
+        // chains of ITG_W64_BLOCK / 4 MFMAs from a zero accumulator, summed in fp64; two fragments' chains are written
+        // side by side so that consecutive MFMAs are independent, and only their 8 temporaries are live
+        constexpr int CH = ITG_W64_BLOCK / 4;
+        static_assert(CH == 1 || CH == 2 || CH == 4, "ITG_W64_BLOCK is 4, 8 or 16");
+        static_assert(FJ % 2 == 0 || FJ == 1, "fragment columns are paired");
+        constexpr int JP = FJ == 1 ? 1 : 2;
+#pragma unroll
+        for (int s0 = 0; s0 < 4; s0 += CH)
+#pragma unroll
+          for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int j0 = 0; j0 < FJ; j0 += JP) {
+              f32x4 t[JP];
+#pragma unroll
+              for (int s = s0; s < s0 + CH; ++s)
+#pragma unroll
+                for (int jj = 0; jj < JP; ++jj)
+                  t[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j0 + jj][s], s == s0 ? f32x4{0.f, 0.f, 0.f, 0.f} : t[jj], 0, 0, 0);
+#pragma unroll
+              for (int jj = 0; jj < JP; ++jj)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc64[i][j0 + jj][e] += (double)t[jj][e];
+            }
       } else {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -286,6 +332,14 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK)) void
     }
   }
 
+  if constexpr (W64) {
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = (float)acc64[i][j][e];
+  }
   // ---- epilogue: lane holds 4 consecutive output channels of one pixel per fragment
   const int cq = (lane >> 4) * 4;
   if (p.ksplit > 1) {
@@ -469,7 +523,7 @@ int launch_nt(const ConvP& p, int tbk, hipStream_t s) {
   snprintf(g_last_launch, sizeof(g_last_launch), "conv_nt_kernel<%d, %d, %d, %d, %d, %d, %s, %d>", BCO, BPIX, WCO, WPIX, tbk,
            tbk == 32 ? D32 : D16, q.use_tab ? "true" : "false", MODE);
   if (tbk == 32) {
-    if constexpr (MODE != NT_PLAIN) return ITG_ERR_ARG;      // the fused forms exist for fp32 operands only
+    if constexpr (MODE != NT_PLAIN) return ITG_ERR_ARG;      // the fused / blocked-accumulation forms exist for fp32 operands only
     else {
     if (q.use_tab) hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 32, D32, true, MODE>), grid, dim3(256), tab_bytes, s, q);
     else hipLaunchKernelGGL((conv_nt_kernel<BCO, BPIX, WCO, WPIX, 32, D32, false, MODE>), grid, dim3(256), tab_bytes, s, q);
@@ -497,6 +551,26 @@ int launch_nt_shape(int bco, int bpix, const ConvP& p, int k, hipStream_t s) {
   if (bco == 112) return bpix == 128 ? launch_nt<112, 128, 112, 32, MODE>(p, k, s) : launch_nt<112, 64, 112, 16, MODE>(p, k, s);
   return bpix == 128 ? launch_nt<128, 128, 64, 64, MODE>(p, k, s)
          : bpix == 96 ? launch_nt<128, 96, 64, 48, MODE>(p, k, s) : launch_nt<128, 64, 64, 32, MODE>(p, k, s);
+}
+
+// NT_W64: tile shapes with <= 8 fragments per wave (fp64 accumulators take two registers per element)
+inline int w64_bpix(int bco, int bpix) {
+  if (bco >= 112) return 64;
+  if (bco == 64) return bpix > 128 ? 128 : bpix;
+  return bpix;
+}
+inline int launch_nt_shape_w64(int bco, int bpix, const ConvP& p, int k, hipStream_t s) {
+  constexpr int MODE = NT_W64;
+  bpix = w64_bpix(bco, bpix);
+  if (bco == 16)
+    return bpix == 256 ? launch_nt<16, 256, 16, 64, MODE>(p, k, s) : bpix == 128 ? launch_nt<16, 128, 16, 32, MODE>(p, k, s)
+                                                                                 : launch_nt<16, 64, 16, 16, MODE>(p, k, s);
+  if (bco == 32)
+    return bpix == 256 ? launch_nt<32, 256, 32, 64, MODE>(p, k, s) : bpix == 128 ? launch_nt<32, 128, 32, 32, MODE>(p, k, s)
+                                                                                 : launch_nt<32, 64, 32, 16, MODE>(p, k, s);
+  if (bco == 64) return bpix == 128 ? launch_nt<64, 128, 64, 32, MODE>(p, k, s) : launch_nt<64, 64, 32, 32, MODE>(p, k, s);
+  if (bco == 112) return launch_nt<112, 64, 112, 16, MODE>(p, k, s);
+  return launch_nt<128, 64, 64, 32, MODE>(p, k, s);
 }
 
 }  // namespace itgk

@@ -11,6 +11,7 @@
   } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // Device-side view of an itg_tensor with the derived merged-image extent.
 struct GridT {

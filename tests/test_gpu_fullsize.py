@@ -189,7 +189,7 @@ def test_config2_full_size_train_step_matches_cpu_oracle_within_1e3(winograd, mo
     import bench
     from infinite_texture_gans_amd import ops as _ops_mod
     # both algorithms of the discriminator's 256 -> 512 layer: the direct implicit GEMM and (the default) Winograd
-    # F(4 x 4, 4 x 4), whose transforms cost ~15x the rounding error of the direct fp32 form (4.6e-6 against 3e-7 rel-L2)
+    # F(4 x 4, 4 x 4) with blocked fp64 accumulation (1.4e-6 against the direct form's 1.1e-6 rel-L2 vs fp64, tools/wino_accuracy.py)
     monkeypatch.setattr(_ops_mod, "WINOGRAD", bool(winograd))
     o = _fullsize_step(bench.FLAGS, 6, False, 192, "f32", fp64_truth=True)
     got, want = o["losses"]
@@ -213,18 +213,14 @@ def test_config2_full_size_train_step_matches_cpu_oracle_within_1e3(winograd, mo
           "median %.2e max %.2e | HIP vs fp32 oracle: %.0f%% within 1e-3, max %.2e" % (
               len(rows), sorted(r[1] for r in rows)[len(rows) // 2], max(r[1] for r in rows),
               sorted(r[2] for r in rows)[len(rows) // 2], max(r[2] for r in rows), 100 * inside, max(r[3] for r in rows)))
-    # direct kernels: <= 2x the fp32 oracle's own distance to the truth (measured 0.6x).  Winograd: the layer's output
-    # carries ~5e-6 instead of ~3e-7 of rounding, which flips the LeakyReLU behind it on ~15x as many of its 9 M activations;
-    # every flip moves all upstream gradients (F10): measured median 2.0e-3 / max 2.9e-3 against the truth (the fp32 CPU
-    # oracle itself: 1.2e-3 / 1.6e-3) - bar 5e-3 per tensor, 3e-3 for the median
+    # ONE bar for both algorithms: <= 2x the fp32 oracle's own distance to the truth + 1e-4 per tensor (direct kernels: measured
+    # 0.6x).  Round 3's Winograd GEMMs accumulated K in one fp32 chain, which the output transform amplified to 4.1e-6 per
+    # layer (direct 1.1e-6 on the same data): ~4x the LeakyReLU flips behind the layer, G's gradients 2.0e-3 / 2.9e-3 from
+    # the truth and a wider bar here.  Round 4: blocked fp64 accumulation (conv_nt_kernel.h NT_W64) brings the layer to
+    # 1.4e-6 and the wider bar is gone.
     for k, e_hip, e_cpu, e_rel in rows:
-        if winograd:
-            assert e_hip < 5e-3, (k, e_hip, e_cpu)
-        else:
-            assert e_hip <= 2 * e_cpu + 1e-4, (k, e_hip, e_cpu)
+        assert e_hip <= 2 * e_cpu + 1e-4, (k, e_hip, e_cpu)
         assert e_rel < 1e-2, (k, e_rel)
-    if winograd:
-        assert sorted(r[1] for r in rows)[len(rows) // 2] < 3e-3
     # D's first-step gradients (real + fake passes accumulated, as Adam(D) consumed them) against the oracle's: D has
     # one LeakyReLU per layer on far fewer, larger activations than G's backward chain, measured ~1e-5; bar 1e-3
     errs = {k: _rel(o["gradD"][k], ref) for k, ref in o["gradD_ref"].items()}
