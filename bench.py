@@ -145,6 +145,12 @@ def gpu_leg(a):
     dt = float(t)
     losses = [float(v) for v in losses]
 
+    # ---- the same workload with the reference's DIRECT algorithm for every convolution the headline runs through Winograd
+    # (same process, same box, same streams): the number the Winograd path has to be read against
+    direct = None
+    if rank == 0 and world == 1 and a.workload == "config1" and ops.WINOGRAD and not args.bf16 and not a.no_direct:
+        direct = direct_leg(a, args, dev, reals, zs, use_graph)
+
     # ---- per-kernel launch durations (HIP events on the launching stream), one extra step
     # (every rank runs this iteration: it contains the sync-BN / gradient collectives)
     roof = None
@@ -194,6 +200,7 @@ def gpu_leg(a):
                 # direct implementation would have to sustain to match this step time - an equivalence figure, not a utilisation
                 "step_reference_equivalent_tflops": round(nec_gf / (dt / a.steps) / 1e3, 1),
                 "algorithms": _algorithms_note(),
+                "direct_algorithm": direct,
                 "traffic_source": traffic_note,
                 "streams": dict(ops.STREAM_PLACEMENT),
                 "membound": membound_leg(dev)}
@@ -201,6 +208,37 @@ def gpu_leg(a):
         dist.barrier()
     _PAR[0] = exchange_desc(tr)
     return rank, world, dt, args, losses, roof
+
+
+def direct_leg(a, args, dev, reals, zs, use_graph):
+    """crops/s of the same step with ops.WINOGRAD off (a second engine on freshly initialised models: the panels a layer
+    packs are decided at construction), timed exactly like the headline."""
+    from infinite_texture_gans_amd import ops, utils as U
+    from infinite_texture_gans_amd.engine import Trainer
+    keep = ops.WINOGRAD
+    ops.WINOGRAD = False
+    try:
+        torch.manual_seed(args.seed)
+        netG, netD = U.prepare_models(args, dev)
+        netG.train(), netD.train()
+        tr = Trainer(netG, netD, args, dev)
+        if use_graph:
+            tr.capture(reals[0], zs[0], warmup=max(1, a.warmup))
+            step = tr.step_graphed
+        else:
+            for i in range(a.warmup):
+                tr.step(reals[i % 2], zs[i])
+            step = tr.step
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(reals[i % 2], zs[a.warmup + i])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"crops_per_s": round(args.batch_size * a.steps / dt, 3), "ms_per_step": round(dt / a.steps * 1e3, 3),
+                "steps": a.steps, "note": "every convolution direct except the folded upsample (ITG_WINOGRAD=0), same process and streams"}
+    finally:
+        ops.WINOGRAD = keep
 
 
 _PAR = [""]
@@ -576,6 +614,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-direct", dest="no_direct", action="store_true",
+                    help="config1: skip the second timed leg with the direct algorithm instead of Winograd (roofline.direct_algorithm)")
     ap.add_argument("--reference_rng", action="store_true",
                     help="config5: every rank draws the reference's FULL-grid CPU latents (seed-identical images) instead of only "
                          "the rows of its own band on the device")

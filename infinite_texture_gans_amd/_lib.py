@@ -166,8 +166,14 @@ def load():
     return lib
 
 
+CAPTURE_LOG = None      # a set while an engine records a hipGraph: raw handles of the streams that received a launch (ops.capture_rule)
+
+
 def call(name, *args):
     """Invoke an int-returning entry point and raise on a non-zero status."""
+    if CAPTURE_LOG is not None and args:
+        st = args[-1]          # every launching entry point takes its stream last
+        CAPTURE_LOG.add(getattr(st, "value", st) or 0)
     rc = getattr(load(), name)(*args)
     if rc != 0:
         raise ItgError("%s failed: %s" % (name, _ERR.get(rc, rc)))

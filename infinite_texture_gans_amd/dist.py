@@ -29,6 +29,7 @@ def _active(sync):
 
 import os as _os
 _FORCE = _os.environ.get("ITG_FORCE_COLLECTIVES", "0") == "1"
+_HALO_STREAM = _os.environ.get("ITG_HALO_STREAM", "0") == "1"      # halo rows on a communication stream (RowHalo.exchange)
 
 
 class SyncGroup:
@@ -112,12 +113,14 @@ class RowHalo:
                     dist.P2POp(dist.irecv, bottom, self.rank + 1, self.group)]
         if not ops:
             return top, bottom
-        if first_row.is_cuda:
-            # Device rows (RCCL): the four transfers are posted as one group on a communication stream of this object and
-            # the CONSUMER stream waits for that stream - the host never blocks (ProcessGroupNCCL's Work.wait() is a
-            # stream-level wait as well, but it is taken on whatever stream is current; an explicit communication stream
-            # keeps the transfers off the compute queue and lets whatever the caller issues before it needs the rows run
-            # beside them).  The rows are kept referenced until the consumer has waited.
+        if first_row.is_cuda and _HALO_STREAM:
+            # Device rows (RCCL), OPT-IN (ITG_HALO_STREAM=1) until it has run on a real multi-rank RCCL group once (ADVICE r3:
+            # no gloo test can take this branch): the four transfers are posted as one group on a communication stream of
+            # this object and the CONSUMER stream waits for that stream - the host never blocks (ProcessGroupNCCL's
+            # Work.wait() is a stream-level wait as well, but it is taken on whatever stream is current; an explicit
+            # communication stream keeps the transfers off the compute queue and lets whatever the caller issues before it
+            # needs the rows run beside them).  The rows are kept referenced until the consumer has waited.
+            # Default: the plain form below on the current stream - the same calls the gloo tests execute.
             cur = torch.cuda.current_stream(first_row.device)
             comm = self._comm_stream(first_row.device)
             comm.wait_stream(cur)                          # the rows to send are produced on the compute stream
@@ -206,8 +209,11 @@ class BandComm(RowHalo):
             sizes = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(self.world)]
             self.dist.all_gather(sizes, torch.tensor([t.shape[-2]], dtype=torch.int64, device=t.device), group=self.group)
             heights = [int(s) for s in sizes]
-        if heights[self.rank] != t.shape[-2]:
-            raise ValueError("band of %d rows announced as %d" % (t.shape[-2], heights[self.rank]))
+        bad = heights[self.rank] != t.shape[-2]
+        if bad:
+            # a rank that raised here would leave the others blocked inside the collective: take part with a
+            # correctly shaped stand-in, then fail - the launcher tears the job down from this rank's error
+            mine, t = t.shape[-2], t.new_zeros(t.shape[:-2] + (heights[self.rank], t.shape[-1]))
         outs = [torch.empty(t.shape[:-2] + (h, t.shape[-1]), dtype=t.dtype, device=t.device) for h in heights]
         if all(h == t.shape[-2] for h in heights):
             self.dist.all_gather(outs, t.contiguous(), group=self.group)
@@ -216,6 +222,8 @@ class BandComm(RowHalo):
                 if r == self.rank:
                     outs[r].copy_(t)
                 self.dist.broadcast(outs[r], src=r, group=self.group)
+        if bad:
+            raise ValueError("rank %d: band of %d rows announced as %d" % (self.rank, mine, heights[self.rank]))
         return outs
 
     def reduce_scatter_rows(self, g, heights):
@@ -228,7 +236,7 @@ class BandComm(RowHalo):
             return g[..., lo:lo + h, :].contiguous()
         if g.is_cuda and self.dist.get_backend(self.group) == "gloo":
             return self.reduce_scatter_rows(g.cpu(), heights).to(g.device)
-        if len(set(heights)) == 1 and self.dist.get_backend(self.group) != "gloo":
+        if len(set(heights)) == 1:          # (gloo implements reduce_scatter too: the CPU tests take this very branch)
             chunks, o = [], 0
             for hr in heights:
                 chunks.append(g[..., o:o + hr, :].contiguous())

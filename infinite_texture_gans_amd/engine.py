@@ -450,7 +450,7 @@ class Trainer:
             ops.WGRAD_STREAM = keep
             fake = self.sample_fake(z, maps)
             self._mark("G forward (beside D(real) fwd+bwd)")
-            main.wait_stream(self.side)                        # D(fake) continues D's spectral-norm state and .grad
+            ops.join_stream(self.side, "D(real) branch join", main)      # D(fake) continues D's spectral-norm state and .grad
         else:
             d_real = self._d_loss(self._d_real_logits(real_x), True)
             d_real.backward(self._one)
@@ -560,9 +560,33 @@ class Trainer:
             for _ in range(warmup):
                 self.step(self._g_real, self._g_z, self._g_maps)
         torch.cuda.current_stream().wait_stream(side)
+        # The recording itself, by hand instead of `with torch.cuda.graph(...)`: between the step and capture_end the capture
+        # rule is checked (ops.capture_rule: on ROCm 7.2 hipStreamEndCapture segfaults when a forked stream without a node of
+        # the capture was waited for; such a wait is skipped while recording and reported here as a Python error, after the
+        # capture has been closed cleanly).
+        import gc
+        from . import _lib
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._g_out = self.step(self._g_real, self._g_z, self._g_maps)
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        del ops.CAPTURE_ERRORS[:]
+        with torch.cuda.stream(cap):
+            _lib.CAPTURE_LOG = {cap.cuda_stream}
+            self.graph.capture_begin()
+            try:
+                self._g_out = self.step(self._g_real, self._g_z, self._g_maps)
+            finally:
+                _lib.CAPTURE_LOG = None
+                self.graph.capture_end()
+        torch.cuda.current_stream().wait_stream(cap)
+        if ops.CAPTURE_ERRORS:
+            errs, self.graph = list(ops.CAPTURE_ERRORS), None
+            del ops.CAPTURE_ERRORS[:]
+            raise RuntimeError("Trainer.capture: the step's stream schedule breaks the capture rule (the recorded graph would have "
+                               "crashed hipStreamEndCapture and was discarded): " + "; ".join(errs))
         self.optD.t -= 1      # capture only records: undo the host-side counters of the recorded call
         self.optG.t -= 1
         return self

@@ -395,6 +395,8 @@ class _Conv(torch.autograd.Function):
             side = None
             if not ((need_w and wsink is None) or (need_b and bsink is None)):
                 side = wgrad_stream_for((wsink if wsink is not None else bsink).data_ptr())
+            if side is not None and _lib.CAPTURE_LOG is not None and not capture_rule(torch.cuda.current_stream(), "weight-gradient fork"):
+                side = None                # (recording) the forking stream holds no node yet: run the weight gradient in line
             if side is not None:
                 ev = torch.cuda.Event()
                 ev.record()
@@ -677,6 +679,9 @@ def concurrent_streams(device, want, spin_us=150, candidates=12):
     GPU_MAX_HW_QUEUES=5..12).  If fewer than ``want`` concurrent streams exist the last ones repeat (correct, just
     in order)."""
     cur = torch.cuda.current_stream(device)
+    ckey = (str(torch.device(device)), cur.cuda_stream, int(want))
+    if ckey in _PLACED:            # a second engine of the process (bench.py's direct-algorithm leg) gets the same queues
+        return list(_PLACED[ckey])
 
     def spin(st):
         _lib.call("itg_stream_spin", int(spin_us), C.c_void_p(st.cuda_stream))
@@ -721,13 +726,39 @@ def concurrent_streams(device, want, spin_us=150, candidates=12):
         import sys
         print("[itg] stream placement: only %d of %d side streams run concurrently with the main stream "
               "(ITG_STREAM_DEBUG=1 prints the probe timings)" % (found, min(want, 3)), file=sys.stderr, flush=True)
+    else:
+        _PLACED[ckey] = list(chosen)
     return chosen
 
 
+_PLACED = {}               # (device, origin stream, want) -> the streams a successful probe chose
 STREAM_PLACEMENT = {"want": 0, "concurrent": 0, "probed": False}    # what the last probe found (bench.py reports it)
 
 
 _wgrad_dirty = []          # weight-gradient streams that carry forked work nobody has waited for yet
+
+# ---- the capture rule (ROCm 7.2): hipStreamEndCapture segfaults when a forked stream that holds NO node of the capture yet
+# (it entered only by waiting) is itself waited for (tools/capture_nested_fork.py; rounds 1 and 3 both hit it through a
+# schedule change: a join of the weight-gradient streams into the D(real) branch while they were idle, 82b2aa7).  While an
+# engine records (engine.Trainer.capture sets _lib.CAPTURE_LOG to the streams that received a launch, seeded with the origin),
+# every cross-stream wait of the package asks capture_rule() first; an illegal wait is NOT recorded (the capture stays
+# valid) and is reported as a Python error after the capture has been closed cleanly.
+CAPTURE_ERRORS = []
+
+
+def capture_rule(waited, what):
+    """True if waiting for ``waited`` (a torch stream) may be recorded.  Outside an engine capture: always."""
+    log = _lib.CAPTURE_LOG
+    if log is None or (waited.cuda_stream or 0) in log:
+        return True
+    CAPTURE_ERRORS.append("%s: stream %#x is waited for but holds no node of this capture" % (what, waited.cuda_stream))
+    return False
+
+
+def join_stream(waited, what, waiter=None):
+    """``waiter`` (default: the current stream) waits for everything queued on ``waited`` - subject to the capture rule."""
+    if capture_rule(waited, what):
+        (waiter if waiter is not None else torch.cuda.current_stream()).wait_stream(waited)
 
 
 def wgrad_streams_join():
@@ -742,7 +773,7 @@ def wgrad_streams_join():
         return
     cur = torch.cuda.current_stream()
     for s_ in _wgrad_dirty:
-        cur.wait_stream(s_)
+        join_stream(s_, "wgrad_streams_join", cur)
     del _wgrad_dirty[:]
 
 
@@ -1025,6 +1056,8 @@ class _BNConv(torch.autograd.Function):
             side = None
             if not ((need_w and wsink is None) or (need_b and bsink is None)):
                 side = wgrad_stream_for((wsink if wsink is not None else bsink).data_ptr())
+            if side is not None and _lib.CAPTURE_LOG is not None and not capture_rule(torch.cuda.current_stream(), "weight-gradient fork"):
+                side = None
             if side is not None:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())

@@ -63,6 +63,17 @@ def test_rejected_calls_return_error_codes_not_crashes(lib):
     assert so.itg_local_pad_fwd(None, None, 1, 1, 3, 3, 4, 1, 0, None) < 0
     t = lib.Tensor(None, 1, 1, 1, 4, 4, 3, 4)
     assert so.itg_bn_stats(ctypes.byref(t), None, None) < 0
+    # the conv family with null tensors / panels / geometry, and a tensor whose pointer is null (the no-gradient-requested
+    # shapes a caller can produce: bias None, no weight gradient, no act_out) - VERDICT r3 item 2a
+    f0 = ctypes.c_float(0.0)
+    assert so.itg_conv2d_fwd(None, None, None, None, None, None, None, 0, f0, None, 0, None) < 0
+    assert so.itg_conv2d_dgrad(None, None, None, None, None, 0, f0, None, None, 0, None) < 0
+    assert so.itg_conv2d_dgrad(ctypes.byref(t), None, None, ctypes.byref(t), None, 0, f0, None, None, 0, None) < 0
+    assert so.itg_conv2d_wgrad(None, None, None, None, None, 0, None, 0, None) < 0
+    assert so.itg_conv2d_wgrad(ctypes.byref(t), ctypes.byref(t), None, None, None, 0, None, 0, None) < 0
+    ok = lib.Tensor(ctypes.c_void_p(64), 1, 1, 1, 4, 4, 3, 4)           # a well-formed descriptor (never dereferenced: the
+    assert so.itg_conv2d_dgrad(ctypes.byref(ok), None, None, ctypes.byref(ok), None, 0, f0, None, None, 0, None) < 0   # panel is null)
+    assert so.itg_conv2d_wgrad(ctypes.byref(ok), ctypes.byref(ok), None, None, None, 0, None, 0, None) < 0               # geometry is null
     bad_ld = lib.Tensor(ctypes.c_void_p(64), 1, 1, 1, 4, 4, 3, 3)      # ld not a multiple of 4
     assert so.itg_act_fwd(ctypes.byref(bad_ld), ctypes.byref(bad_ld), 1, ctypes.c_float(0.2), None) == -2
 

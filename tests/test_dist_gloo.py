@@ -147,7 +147,7 @@ def _band_net(x, w1, w2, halo=None):
     return h
 
 
-def band_worker(rank, world, port, out):
+def band_worker(rank, world, port, out, total_rows=7):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -156,17 +156,19 @@ def band_worker(rank, world, port, out):
         torch.set_num_threads(1)
         comm = BandComm(rank, world, dist.group.WORLD)
         g = torch.Generator().manual_seed(11)
-        x = torch.randn(3, 2, 14, 6, generator=g)
+        H = 2 * total_rows
+        x = torch.randn(world, 2, H, 6, generator=g)
         w1 = (torch.randn(4, 2, 3, 3, generator=g) * 0.4).requires_grad_(True)
         w2 = (torch.randn(1, 4, 3, 3, generator=g) * 0.4).requires_grad_(True)
-        a, b = comm.band(7)                                   # ragged: 3 + 2 + 2 patch rows of 2 pixels
-        sync = comm.band_sync(7)
-        assert sync.global_count(3 * (b - a) * 2 * 6) == 3 * 14 * 6
+        a, b = comm.band(total_rows)                          # 7 rows on 3 ranks: ragged, 3 + 2 + 2 patch rows of 2 pixels
+        sync = comm.band_sync(total_rows)
+        assert sync.global_count(world * (b - a) * 2 * 6) == world * H * 6
         band = _band_net(x[:, :, 2 * a:2 * b], w1, w2, comm)
-        full = ops.gather_rows(band, comm)                    # whole images on every rank
-        assert full.shape == (3, 1, 14, 6)
+        # static heights: equal bands take the reduce-scatter branch of the gather's backward, ragged ones all-reduce + slice
+        full = ops.gather_rows(band, comm, comm.band_heights(total_rows, 2))      # whole images on every rank
+        assert full.shape == (world, 1, H, 6)
         mine = full[rank:rank + 1]                            # "D" scores one image per rank
-        loss = (mine * torch.linspace(-1, 1, 14 * 6).reshape(1, 1, 14, 6)).sum() + (mine ** 2).mean()
+        loss = (mine * torch.linspace(-1, 1, H * 6).reshape(1, 1, H, 6)).sum() + (mine ** 2).mean()
         flat = torch.cat([t.reshape(-1) for t in torch.autograd.grad(loss, (w1, w2))])
         average_flat_gradient(flat, comm)
         if rank == 0:
@@ -175,23 +177,57 @@ def band_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_band_sharded_forward_backward_matches_single_process(tmp_path):
-    """Three ranks with ragged bands: differentiable halo exchange (halo gradients travel back),
-    band gather with summed band gradients, flat gradient averaging == the unsharded computation."""
+@pytest.mark.parametrize("world,total_rows", [(3, 7), (2, 8)], ids=["3_ragged_bands", "2_equal_bands_reduce_scatter"])
+def test_band_sharded_forward_backward_matches_single_process(tmp_path, world, total_rows):
+    """Ranks with ragged (3 + 2 + 2) or equal (4 + 4) bands: differentiable halo exchange (halo gradients travel back),
+    band gather with summed band gradients (equal bands: the reduce-scatter branch of dist.BandComm.reduce_scatter_rows, the
+    one an RCCL group takes too; ragged: all-reduce + slice), flat gradient averaging == the unsharded computation."""
     out = str(tmp_path / "r0.pt")
-    mp.spawn(band_worker, args=(3, free_port(), out), nprocs=3, join=True)
+    mp.spawn(band_worker, args=(world, free_port(), out, total_rows), nprocs=world, join=True)
     got = torch.load(out)
     g = torch.Generator().manual_seed(11)
-    x = torch.randn(3, 2, 14, 6, generator=g)
+    H = 2 * total_rows
+    x = torch.randn(world, 2, H, 6, generator=g)
     w1 = (torch.randn(4, 2, 3, 3, generator=g) * 0.4).requires_grad_(True)
     w2 = (torch.randn(1, 4, 3, 3, generator=g) * 0.4).requires_grad_(True)
     full = _band_net(x, w1, w2)
     assert torch.allclose(got["full"], full.detach(), atol=1e-6)
-    loss = sum((full[i:i + 1] * torch.linspace(-1, 1, 14 * 6).reshape(1, 1, 14, 6)).sum() + (full[i:i + 1] ** 2).mean()
-               for i in range(3)) / 3
+    loss = sum((full[i:i + 1] * torch.linspace(-1, 1, H * 6).reshape(1, 1, H, 6)).sum() + (full[i:i + 1] ** 2).mean()
+               for i in range(world)) / world
     flat = torch.cat([t.reshape(-1) for t in torch.autograd.grad(loss, (w1, w2))])
     err = float((got["flat"] - flat).norm() / flat.norm())
     assert err < 1e-5, err
+
+
+def heights_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from infinite_texture_gans_amd.dist import BandComm
+        comm = BandComm(rank, world, dist.group.WORLD)
+        t = torch.full((1, 1, 4 if rank == 0 else 6, 3), float(rank))       # rank 1 holds 6 rows but 4 are announced
+        res = "ok"
+        try:
+            outs = comm.all_gather(t, heights=[4, 4])
+            res = "ok %s" % [tuple(o.shape) for o in outs]
+        except ValueError as e:
+            res = "ValueError: %s" % e
+        # both ranks are still in step: one more collective completes
+        z = torch.ones(1)
+        dist.all_reduce(z)
+        torch.save((res, float(z)), out + str(rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_gather_with_wrong_static_heights_fails_on_the_bad_rank_without_hanging_the_others(tmp_path):
+    """a rank whose band does not have the announced height used to raise BEFORE the collective and left the
+    other ranks blocked in it.  Now it takes part with a correctly shaped stand-in and raises afterwards."""
+    out = str(tmp_path / "h")
+    mp.spawn(heights_worker, args=(2, free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + "0"), torch.load(out + "1")
+    assert r0[0].startswith("ok") and r0[1] == 2.0
+    assert r1[0].startswith("ValueError") and "announced as 4" in r1[0] and r1[1] == 2.0
 
 
 # ------------------------------------------------------------------------------- two-bucket gradient exchange

@@ -383,6 +383,43 @@ def test_graph_replay_equals_eager_step():
             assert rel_l2(a_, b_) < 1e-4, k
 
 
+def test_capture_reports_an_illegal_stream_wait_as_a_python_error(monkeypatch):
+    """ROCm 7.2's hipStreamEndCapture segfaults when a forked stream that holds no node of the capture is waited for (the
+    crash records of rounds 1 and 3: r3i_pytest.log).  Trainer.capture checks every cross-stream wait of the step against
+    that rule while it records (ops.capture_rule), leaves an illegal wait out of the graph, closes the capture cleanly and
+    raises.  Here the round-1 schedule is put back (join EVERY weight-gradient stream, idle or not): a RuntimeError, not a
+    crash; the same trainer then captures fine with the real schedule."""
+    from infinite_texture_gans_amd.engine import Trainer
+    from infinite_texture_gans_amd import ops, utils as U
+    fx = load("train_bn_nl4_sn")
+    a = parse_flags(fx["argv"])
+    real, z = torch.from_numpy(fx["real_x0"]).to(cuda), torch.from_numpy(fx["z0"]).to(cuda)
+    G, D = build(a, state(fx, "G0/"), state(fx, "D0/"))
+    G.train(), D.train()
+    args = U.prepare_parser().parse_args(["--smooth"])
+    args.beta1 = 0.0
+    tr = Trainer(G, D, args, cuda)
+    if not tr.overlap:
+        pytest.skip("stream overlap disabled by the environment")
+    good = ops.wgrad_streams_join
+
+    def join_all():
+        cur = torch.cuda.current_stream()
+        for s_ in tr._wstream:
+            ops.join_stream(s_, "join of every weight-gradient stream", cur)
+        del ops._wgrad_dirty[:]
+
+    monkeypatch.setattr(ops, "wgrad_streams_join", join_all)
+    with pytest.raises(RuntimeError, match="capture rule"):
+        tr.capture(real, z, warmup=1)
+    assert tr.graph is None
+    monkeypatch.setattr(ops, "wgrad_streams_join", good)
+    tr.capture(real, z, warmup=1)
+    l = tr.step_graphed(real, z)
+    torch.cuda.synchronize()
+    assert all(np.isfinite(float(v)) for v in l)
+
+
 @pytest.mark.parametrize("tag,world", [("bn_nl4", 2), ("bn_nl4", 3), ("ssm_nl4", 2)])
 def test_row_sharded_generation_equals_unsharded(tag, world):
     """Patch grid sharded by patch rows with halo exchange == the single-device one-shot result.

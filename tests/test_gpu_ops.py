@@ -1,5 +1,6 @@
 """GPU parity, op level: every C-ABI kernel family against the CPU oracle (torch-CPU primitives
 + oracle.patches) on the same seeded inputs.  fp32 tolerances are written at each check."""
+import ctypes
 import os
 import zlib
 
@@ -201,6 +202,69 @@ def test_conv_winograd_f44_fwd_dgrad_wgrad(case, monkeypatch):
     lo = 1e-7 if os.environ.get("ITG_WINOGRAD_WGRAD", "1") == "1" else -1.0     # the library reads that switch itself
     assert lo < rel_l2(dwg.cpu(), dw0.cpu()) < 3e-5, rel_l2(dwg.cpu(), dw0.cpu())
     assert float((dbg - db0).abs().max()) <= 2e-6 * float(dyl.abs().sum((0, 2, 3)).max())
+
+
+@pytest.mark.parametrize("ci,co,P", [(26, 26, 64), (26, 13, 128)], ids=["26_26_P64", "26_13_P128"])
+def test_input_gradient_only_call_on_the_halo_tile_path_eager_and_captured(ci, co, P):
+    """The call of round 3's crash record (gpurun_out/r3al.log): torch.autograd.grad(conv(GT(xg), w, None, 3x3, replicate).t,
+    xg, dy) - bias None, a raw 6-D leaf as the grid tensor, only the input gradient requested, the halo-tile kernels
+    (reference layers.py:25-34 behind LocalPadder :145-173).  The record's segfault was in hipStreamEndCapture and not in
+    the library: the probe kept an autograd graph of xg alive that was built on the default stream, so torch's engine
+    synchronised xg's stale AccumulateGrad stream (the default stream) with the capturing stream
+    (tools/probes/capture_stale_graph.py reproduces all three outcomes).  Checked here: the call is right when run eagerly
+    (against F.conv2d on the CPU) and identical when recorded into a hipGraph with no stale graph alive."""
+    ops = _ops()
+    g = _gen(11)
+    x = torch.zeros(2, 3, 3, P, P, ops.ld_for(ci))
+    x[..., :ci] = torch.randn(2, 3, 3, P, P, ci, generator=g)
+    w = (torch.randn(co, ci, 3, 3, generator=g) / (9 * ci) ** 0.5)
+    xg = x.to(cuda).requires_grad_(True)
+    wg = w.to(cuda)
+    y = ops.conv(ops.GT(xg, ci), wg, None, 3, 3, 1, 1, ops.PAD_REPLICATE)
+    dy = torch.zeros(y.t.shape)
+    dy[..., :co] = torch.randn(*y.t.shape[:-1], co, generator=g)
+    dyg = dy.to(cuda)
+    (dx,) = torch.autograd.grad(y.t, xg, dyg)
+    assert ops._lib.fn("itg_last_conv_kernel")().decode().startswith("conv_tile_kernel")
+    del y
+    xm = ops.to_nchw(ops.GT(xg.detach(), ci), merged=True).cpu().double().requires_grad_(True)
+    yr = F.conv2d(F.pad(xm, (1, 1, 1, 1), mode="replicate"), w.double())
+    (dxr,) = torch.autograd.grad(yr, xm, ops.to_nchw(ops.GT(dyg, co), merged=True).cpu().double())
+    assert rel_l2(ops.to_nchw(ops.GT(dx, ci), merged=True).cpu(), dxr) < 5e-6
+    # recorded: warm-up on a side stream, then the same call under capture, replayed
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        torch.autograd.grad(ops.conv(ops.GT(xg, ci), wg, None, 3, 3, 1, 1, ops.PAD_REPLICATE).t, xg, dyg)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        (dxc,) = torch.autograd.grad(ops.conv(ops.GT(xg, ci), wg, None, 3, 3, 1, 1, ops.PAD_REPLICATE).t, xg, dyg)
+    dxc.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(dxc, dx)
+
+
+def test_capture_rule_bookkeeping():
+    """ops.capture_rule / join_stream: while an engine records, a stream may only be waited for once it has received a
+    launch of this capture (_lib.call logs the stream argument); an illegal wait is skipped and reported."""
+    ops = _ops()
+    from infinite_texture_gans_amd import _lib
+    cur, s1 = torch.cuda.current_stream(), torch.cuda.Stream()
+    assert ops.capture_rule(s1, "outside a capture")            # no log: everything goes
+    _lib.CAPTURE_LOG = {cur.cuda_stream}
+    try:
+        del ops.CAPTURE_ERRORS[:]
+        ops.join_stream(s1, "idle stream")
+        assert len(ops.CAPTURE_ERRORS) == 1 and "idle stream" in ops.CAPTURE_ERRORS[0]
+        _lib.call("itg_stream_spin", 1, ctypes.c_void_p(s1.cuda_stream))
+        ops.join_stream(s1, "busy stream")
+        assert len(ops.CAPTURE_ERRORS) == 1
+    finally:
+        _lib.CAPTURE_LOG = None
+        del ops.CAPTURE_ERRORS[:]
+    torch.cuda.synchronize()
 
 
 UP2_CASES = [
