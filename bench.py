@@ -402,12 +402,24 @@ def membound_leg(dev):
     rows = []
 
     def timeit(fn, iters=10):
+        """GPU time per call: the calls are recorded into a hipGraph and the replay is timed with HIP events, so that the host's
+        launch cost (30 us for a BatchNorm forward, 85 us for its autograd backward - more than the kernels take) stays out."""
         fn()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                fn()
+        g.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(iters):
-            fn()
+        g.replay()
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters * 1e-3
@@ -425,14 +437,16 @@ def membound_leg(dev):
     numel = xg.t.numel()
     gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
     rm, rv, nbt = torch.zeros(c, device=dev), torch.ones(c, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
-    row("BatchNorm train fwd + LeakyReLU C=13 P=128", 4 * numel * 3,
-        timeit(lambda: ops.bn_act(xg, gamma, beta, rm, rv, nbt, True, 1e-5, 0.1, ops.ACT_LRELU, 0.02, False)))
-    xr = ops.GT(xg.t.clone().requires_grad_(True), c)
+    # backward: forward + backward recorded together (a backward alone would run on an autograd graph built outside the capture,
+    # whose stale default-stream AccumulateGrad nodes break hipStreamEndCapture - DESIGN section 3), the forward's time subtracted
+    t_f = timeit(lambda: ops.bn_act(xg, gamma, beta, rm, rv, nbt, True, 1e-5, 0.1, ops.ACT_LRELU, 0.02, False))
+    row("BatchNorm train fwd + LeakyReLU C=13 P=128", 4 * numel * 3, t_f)
+    xr = xg.t.clone().requires_grad_(True)
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
-    y = ops.bn_act(xr, gr, br, rm, rv, nbt, True, 1e-5, 0.1, ops.ACT_LRELU, 0.02, False)
-    dy = torch.randn_like(y.t)
-    row("BatchNorm train bwd C=13 P=128", 4 * numel * 5,
-        timeit(lambda: torch.autograd.grad(y.t, (xr.t, gr, br), dy, retain_graph=True)))
+    dy = torch.randn_like(xg.t)
+    t_fb = timeit(lambda: torch.autograd.grad(ops.bn_act(ops.GT(xr, c), gr, br, rm, rv, nbt, True, 1e-5, 0.1, ops.ACT_LRELU, 0.02, False).t,
+                                              (xr, gr, br), dy))
+    row("BatchNorm train bwd C=13 P=128", 4 * numel * 5, t_fb - t_f)
     row("LeakyReLU C=13 P=128", 8 * numel, timeit(lambda: ops.act(xg, ops.ACT_LRELU, 0.2)))
     xs = ops.GT(torch.randn(8, 3, 3, 64, 64, 28, device=dev), 26)
     row("nearest x2 upsample C=26 P=64", 4 * xs.t.numel() * 5, timeit(lambda: ops.upsample2x(xs)))

@@ -13,7 +13,7 @@ import sys
 
 def short(name):
     name = re.sub(r"^void ", "", name)
-    name = re.sub(r"itgk::", "", name)
+    name = re.sub(r"itgk::|\(anonymous namespace\)::", "", name)
     name = re.sub(r"\(.*$", "", name)
     return name[:64]
 
