@@ -28,10 +28,9 @@ sys.path.insert(0, ROOT)
 # (measured 1 / 2 / 3 / 4 queues: 679 / 763 / 722 / 749 crops/s on config 1).  Must be set before HIP initialises.
 if "config3" in sys.argv or os.environ.get("ITG_GRAPH") == "1":
     os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")
-if "config3" in sys.argv:
-    # config 3 is launch- and latency-bound (450 launches of ~9 us): the deferred weight-gradient reduce (one launch per backward
-    # pass instead of 2-5 per layer) is worth +4 % there (2 103 -> 2 189 crops/s); config 1 is bound by kernel work and loses 2 %
-    os.environ.setdefault("ITG_DEFER_REDUCE", "1")
+# (config 3 is launch- and latency-bound - 300 launches of ~9 us: the deferred weight-gradient reduce, one launch per backward pass
+# instead of 2-5 per layer, is worth +4 % there; config 1 is bound by kernel work and loses 2 %.  The decision is train.py's
+# launch_plan - the CLI and the bench run the same schedule - and is recorded in the line's config block.)
 
 import torch  # noqa: E402
 
@@ -101,7 +100,11 @@ def gpu_leg(a):
                  for _ in range(2)]
         zs = [torch.randn(args.num_images, args.z_dim, 18, 18, generator=g).to(dev) for _ in range(n_in)]
     else:
-        tr = Trainer(netG, netD, args, dev, dist_group=group)
+        from infinite_texture_gans_amd.train import launch_plan
+        args.launch_mode = "graph" if graph_mode() else "eager"
+        _, defer = launch_plan(args, world, False)
+        _LAUNCH.update(defer_reduce=bool(defer))
+        tr = Trainer(netG, netD, args, dev, dist_group=group, defer_reduce=defer)
         g = torch.Generator().manual_seed(args.seed + 1 + rank)
         reals = [(torch.rand(args.batch_size, 3, crop, crop, generator=g) * 2 - 1).to(dev) for _ in range(2)]
         zs = [torch.randn(args.num_images, args.z_dim, 14, 14, generator=g).to(dev) for _ in range(n_in)]
@@ -241,6 +244,7 @@ def direct_leg(a, args, dev, reals, zs, use_graph):
         ops.WINOGRAD = keep
 
 
+_LAUNCH = {"defer_reduce": False}      # what bench.py's trainer was built with (recorded in the line's config block)
 _PAR = [""]
 _RANKS = {"ranks": 1, "backend": "none"}      # what the process group reports once initialised (not the environment)
 
@@ -276,6 +280,13 @@ def _algorithms_note():
     if up2_fold_enabled():
         parts.append("nearest-x2 upsample folded into the generator blocks' first conv (4 of 9 taps' multiply-adds)")
     return "; ".join(parts + ["every other convolution direct"]) if parts else "direct convolutions throughout"
+
+
+def _env_defaults():
+    """Every ITG_* / HIP switch this process ran under that bench.py itself injected or that differs from unset (ADVICE r3:
+    a committed number must say what configuration it measured)."""
+    keys = sorted(k for k in os.environ if k.startswith("ITG_") or k in ("DEBUG_HIP_FORCE_GRAPH_QUEUES", "GPU_MAX_HW_QUEUES"))
+    return {k: os.environ[k] for k in keys}
 
 
 def graph_mode():
@@ -664,7 +675,10 @@ def main():
                           "global_batch": args.batch_size * world, "g_patches_per_sec": round(72 * world * a.steps / dt, 1),
                           "parallelism": "dp%d (%s BatchNorm statistics, %s)" % (
                           world, "all-reduced" if os.environ.get("ITG_SYNC_BN", "0") == "1" else "per-rank", _PAR[0]), "last_losses": losses,
-                          "launch": "hipGraph replay" if graph_mode() else "eager"},
+                          "launch": "hipGraph replay" if graph_mode() else "eager",
+                          "wgrad_reduce": "deferred (one launch per backward pass)" if _LAUNCH["defer_reduce"] else "per layer",
+                          "env_defaults": _env_defaults(),
+                          "cli_equivalent": "train.py --launch_mode auto --wgrad_reduce auto runs this schedule (train.launch_plan)"},
                "roofline": roof}
         out["config"].update(ranks)
         if world == 1 and not a.no_cpu_baseline:
@@ -698,7 +712,9 @@ def main():
                       "global_batch": args.batch_size * world, "g_patches_per_sec": round(72 * world * a.steps / dt, 1),
                       "parallelism": "dp%d (%s BatchNorm statistics, %s)" % (
                           world, "all-reduced" if os.environ.get("ITG_SYNC_BN", "0") == "1" else "per-rank", _PAR[0]), "last_losses": losses,
-                      "launch": "hipGraph replay" if graph_mode() else "eager"},
+                      "launch": "hipGraph replay" if graph_mode() else "eager",
+                      "wgrad_reduce": "deferred (one launch per backward pass)" if _LAUNCH["defer_reduce"] else "per layer",
+                      "env_defaults": _env_defaults()},
            "roofline": roof}
     out["config"].update(ranks)
     if world == 1 and not a.no_cpu_baseline:

@@ -205,7 +205,7 @@ class PackSet:
 class Trainer:
     """One G+D iteration of reference train.py:122-180 on the HIP kernels."""
 
-    def __init__(self, netG, netD, args, device, netG_ema=None, dist_group=None, sync_bn=None):
+    def __init__(self, netG, netD, args, device, netG_ema=None, dist_group=None, sync_bn=None, defer_reduce=None):
         """``dist_group``: data parallel over its ranks (one flat gradient all-reduce per model and step).
         ``sync_bn``: False (default, ITG_SYNC_BN=0) = every rank normalises with the statistics of its own batch,
         which is what the reference's nn.DataParallel does (train.py:74-77); True = BatchNorm sums are all-reduced
@@ -224,6 +224,7 @@ class Trainer:
                 for m in netD.modules():
                     if isinstance(m, _BNParams):
                         m.sync = sync
+        self._check_switches_agree()
         self.flatG, self.flatD = FlatParams(netG), FlatParams(netD)
         from .models.layers import _ConvParams
         for net in (netG, netD):        # backward kernels accumulate straight into the flat .grad buffers
@@ -264,14 +265,17 @@ class Trainer:
         # step, but 765 vs 780 crops/s: the per-layer reduce launches run on the weight-gradient streams in the shadow of the
         # input-gradient chain, which is the critical path; the single reduce at the join - ~50 MB of slabs per wide layer,
         # bandwidth-bound at ~150 us per pass - is ON that path.)
-        self.defer_reduce = os.environ.get("ITG_DEFER_REDUCE", "0") == "1"
+        # (``defer_reduce`` argument: train.py / bench.py decide per workload - on for the launch-bound config 3 under graph replay)
+        self.defer_reduce = (os.environ.get("ITG_DEFER_REDUCE", "0") == "1") if defer_reduce is None else bool(defer_reduce)
         self._defer = []
         self.set_overlap(self.overlap)
         from .dist import _active
         # two-bucket exchange: default on for the rehearsal backends (gloo / one-rank RCCL, where it is tested), opt-in on a
         # real multi-rank RCCL group until it has run there once
-        multi_rccl = (dist_group is not None and self.world > 1 and torch.device(device).type == "cuda"
-                      and os.environ.get("ITG_DIST_BACKEND", "nccl") == "nccl")
+        multi_rccl = False
+        if dist_group is not None and self.world > 1 and torch.device(device).type == "cuda":
+            import torch.distributed as _dist
+            multi_rccl = _dist.get_backend(dist_group) == "nccl"      # the backend of the group that was passed, not the environment
         if self.sync is not None and _active(self.sync) and os.environ.get("ITG_BUCKETS", "0" if multi_rccl else "1") == "1":
             # the early buckets travel on the D(real) branch stream: idle during both backward passes that are exchanged
             issue = self.side if self.overlap else None
@@ -283,6 +287,23 @@ class Trainer:
             }
 
         self._warm_collectives()
+
+    def _check_switches_agree(self):
+        """The per-process switches that decide WHICH collectives a rank issues (bucketed exchange, warm-up, sync-BN, deferred
+        reduces, stream overlap) must be equal on all ranks, or the collective sequences diverge and the job hangs in the
+        constructor.  One unconditional all-reduce of their values; a mismatch raises on every rank."""
+        if self.sync is None or self.sync.world <= 1:
+            return
+        names = ("ITG_BUCKETS", "ITG_BUCKET_HEAD", "ITG_WARM_COLLECTIVES", "ITG_SYNC_BN", "ITG_DEFER_REDUCE", "ITG_OVERLAP")
+        mine = [float(sum(ord(c) * (i + 1) for i, c in enumerate(os.environ.get(n, "")))) for n in names] + [float(self.sync_bn)]
+        dev = self.device if torch.device(self.device).type == "cuda" else "cpu"
+        t = torch.tensor(mine + [v * v for v in mine], dtype=torch.float64, device=dev)
+        self.sync.dist.all_reduce(t, op=self.sync.dist.ReduceOp.SUM, group=self.sync.group)
+        k, w = len(mine), float(self.sync.world)
+        for i, n in enumerate(names + ("sync_bn",)):
+            mean, msq = float(t[i]) / w, float(t[k + i]) / w
+            if abs(msq - mean * mean) > 1e-6 * max(1.0, msq):      # variance over ranks != 0
+                raise RuntimeError("the ranks of this job disagree on %s: set it identically on every rank" % n)
 
     def _warm_collectives(self):
         """RCCL sets up channels, proxy threads and per-size algorithm state lazily inside the first collectives of a process

@@ -431,12 +431,19 @@ class _Conv(torch.autograd.Function):
                     nws = _WS_SIZE.get(key)
                     if nws is None:
                         nws = _WS_SIZE[key] = _lib.fn("itg_conv2d_wgrad_workspace")(C.byref(dxd), C.byref(ddy), C.byref(g))
-                    ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+                    # every tensor the side-stream kernels of this layer touch that torch allocated HERE (main stream) goes
+                    # through `scratch`, which also puts it on the keep-alive list below (one place, not per branch)
+                    keep = []
+
+                    def scratch(t):
+                        keep.append(t)
+                        return t
+
+                    ws = scratch(torch.empty(nws, device=x.device, dtype=torch.float32))
                     direct_w = wsink is not None and ctx.sn is None and need_w
                     direct_b = bsink is not None and need_b
-                    gw_ = wsink if direct_w else torch.empty_like(w)
-                    gb = bsink if direct_b else (torch.empty_like(w[:, 0, 0, 0]) if need_b else None)
-                    keep = [ws, gw_, gb]            # scratch of this layer's side-stream kernels (see above)
+                    gw_ = wsink if direct_w else scratch(torch.empty_like(w))
+                    gb = bsink if direct_b else (scratch(torch.empty_like(w[:, 0, 0, 0])) if need_b else None)
                     npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
                     wino_wg = bool(g.flags & _lib.GEOM_WINO) and WINOGRAD_WGRAD
                     with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1,
@@ -449,13 +456,12 @@ class _Conv(torch.autograd.Function):
                     if ctx.sn is not None and need_w:
                         _, u, v = ctx.sn
                         rows, cols = co, w.numel() // co
-                        d_orig = wsink if wsink is not None else torch.empty_like(w)
+                        d_orig = wsink if wsink is not None else scratch(torch.empty_like(w))
                         # the <G, W> accumulator: a slice of the step's zeroed arena when there is one (no memset launch)
                         ws2 = ARENA.take(1) if ARENA is not None and ARENA.buf.device == x.device else None
                         zeroed = ws2 is not None
                         if ws2 is None:
-                            ws2 = torch.empty(2, device=x.device, dtype=torch.float64)
-                        keep += [d_orig, ws2]
+                            ws2 = scratch(torch.empty(2, device=x.device, dtype=torch.float64))
                         _lib.call("itg_spectral_norm_bwd", _ptr(gw_), _ptr(w), _ptr(u), _ptr(v), _ptr(inv_sigma), rows, cols,
                                   _ptr(d_orig), (ACC_DW if wsink is not None else 0) | (WS_ZEROED if zeroed else 0), _ptr(ws2), st)
                         gw_ = None if wsink is not None else d_orig
@@ -585,6 +591,12 @@ def _queue_wgrad(x, dxd, dy, ddy, gwg, w, wsink, bsink, need_w, need_b, sn, st, 
     if gwg.up2:           # folded-upsample layers reduce their class slabs through a kernel of their own
         return False
     key = ((wsink if wsink is not None else bsink).data_ptr(), tuple(x.shape), tuple(dy.shape))
+    pending = WGRAD_DEFER if queue is None else queue
+    if any(j[3] == key for j in pending):
+        # the same layer queued twice before a flush (a weight-shared conv, a module applied twice in one backward pass): its
+        # persistent slab workspace is still waiting for the reduce and a second contraction would overwrite it (ADVICE r3;
+        # itg.h: two jobs of one launch must not share dw / db) - this call takes the direct path
+        return False
     nws = _lib.fn("itg_conv2d_wgrad_workspace")(C.byref(dxd), C.byref(ddy), C.byref(gwg))
     ws = _persistent(("ws",) + key, nws, x.device)
     job = _lib.WgradJob()
@@ -593,6 +605,8 @@ def _queue_wgrad(x, dxd, dy, ddy, gwg, w, wsink, bsink, need_w, need_b, sn, st, 
     with _Prof(_nt_tag(co).replace("nt", "tn"), 1,
                2.0 * (dy.numel() // dy.shape[5]) * co * ci * ((kh + 3) ** 2 / 16.0 if wino_wg else kh * kw),
                4 * (x.numel() + dy.numel() + w.numel())):
+        if _lib.CAPTURE_LOG is not None:          # (this entry point is called through fn(): its error code is inspected below)
+            _lib.CAPTURE_LOG.add(getattr(st, "value", st) or 0)
         rc = _lib.fn("itg_conv2d_wgrad_slabs")(C.byref(dxd), C.byref(ddy), C.byref(gwg), _ptr(ws), nws, C.byref(job), st)
     if rc == -1:                    # ITG_ERR_ARG: a path without slabs (single-output-channel taps-as-rows layer)
         return False
@@ -616,7 +630,7 @@ def _queue_wgrad(x, dxd, dy, ddy, gwg, w, wsink, bsink, need_w, need_b, sn, st, 
         job.accumulate = (ACC_DW if need_w else 0) | (ACC_DB if need_b else 0)
         keep = ()
     job.db = bsink.data_ptr() if (need_b and bsink is not None) else None
-    (WGRAD_DEFER if queue is None else queue).append((job, snjob, (ws, x, dy) + keep))
+    pending.append((job, snjob, (ws, x, dy) + keep, key))
     return True
 
 

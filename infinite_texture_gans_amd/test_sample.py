@@ -45,16 +45,25 @@ def main(argv=None):
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     halo = None
-    if world > 1:
-        # torch.distributed.run --nproc-per-node N test_sample.py ...: the patch grid is sharded by patch rows,
-        # one band per GPU, with a halo-row exchange (RCCL send/recv) before every 3x3 conv
-        import torch.distributed as dist
-        from .dist import RowHalo
-        dist.init_process_group("nccl", device_id=device)
-        halo = RowHalo(rank, world, dist.group.WORLD)
     folder = os.path.dirname(a.model_path)
     ckpt = torch.load(a.model_path, map_location='cpu', weights_only=False)   # args is a pickled Namespace
     args = ckpt['args']
+    # N ranks (torch.distributed.run --nproc-per-node N test_sample.py ...):
+    #  * generators without attention: ONE image, its patch grid sharded by patch rows, one band per GPU, with a halo-row
+    #    exchange (RCCL send/recv) before every 3x3 conv;
+    #  * attention checkpoints (and padding_mode != local) stream their sub-images with carried state - a sequential
+    #    dependency that does not shard (SURVEY.md 8e "replicas only"): REPLICA mode, rank r generates its own image from
+    #    seed + r into <output_name stem>_rank<r><ext>, no collective at all.
+    replicas = world > 1 and (bool(args.attention) or args.padding_mode != 'local')
+    if world > 1 and not replicas:
+        import torch.distributed as dist
+        from .dist import RowHalo
+        backend = os.environ.get("ITG_DIST_BACKEND", "nccl")      # gloo: several ranks on one GPU (rehearsal)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+        halo = RowHalo(rank, world, dist.group.WORLD)
     netG = generators.ResidualPatchGenerator(
         z_dim=args.z_dim, G_ch=args.G_ch, base_res=args.base_res, n_layers_G=args.n_layers_G,
         attention=args.attention, img_ch=args.img_ch, leak=args.leak_G, SN=False, type_norm=args.type_norm_G,
@@ -63,19 +72,30 @@ def main(argv=None):
     netG = load_G(ckpt['netG_state_dict'], netG).to(device)
     if rank == 0:
         print(args)
+    if world == 1 and "ITG_SAMPLE_SEED" in os.environ:
+        torch.manual_seed(int(os.environ["ITG_SAMPLE_SEED"]))      # reproducible single-process images (tests)
+    if replicas:
+        base = int(os.environ.get("ITG_SAMPLE_SEED", 1234))
+        torch.manual_seed(base + rank)                   # a different image per rank
+        stem, ext = os.path.splitext(a.output_name)
+        a.output_name = "%s_rank%d%s" % (stem, rank, ext)
     with torch.no_grad():
         if args.padding_mode == 'local' and halo is not None:
             seed = int(os.environ.get("ITG_SAMPLE_SEED", torch.seed() if world == 1 else 1234))
             torch.manual_seed(seed)                      # every rank draws the SAME full-grid latents
             strip = U.sample_from_gen_PatchByPatch_test(
                 netG, z_dim=args.z_dim, num_images=1, output_resolution_height=a.output_resolution_height,
-                output_resolution_width=a.output_resolution_width, device=device, halo=halo)
+                output_resolution_width=a.output_resolution_width, device=device, halo=halo, strip_on_device=True)
+            g_ = U._unwrap(netG)
+            _, _, t_h, _, p_ = U.tiling_plan(g_.n_layers_G, args.base_res, 3, 3, a.output_resolution_height,
+                                             a.output_resolution_width)
+            img = U.gather_strips(strip, halo, U.strip_rows(halo, t_h, p_, a.output_resolution_height))
             import torch.distributed as dist
-            strips = [None] * world if rank == 0 else None
-            dist.gather_object(strip, strips, dst=0)
+            dist.barrier()
+            dist.destroy_process_group()
             if rank != 0:
                 return
-            img = torch.cat(strips, -2)
+            img = img.cpu()
         elif args.padding_mode == 'local':
             img = U.sample_from_gen_PatchByPatch_test(
                 netG, z_dim=args.z_dim, num_images=1, output_resolution_height=a.output_resolution_height,

@@ -53,6 +53,34 @@ def argparse_copy(args, **kw):
     return a
 
 
+def launch_plan(args, world, band):
+    """(use_graph, defer_reduce) of this run from --launch_mode / --wgrad_reduce (the same rule bench.py applies):
+    hipGraph replay needs one rank and --disc_iters 1 (one latent set per step); the deferred weight-gradient reduce pays
+    where the step is launch-bound - under replay with crops of at most 128 pixels (BASELINE config 3: +4 %), not on
+    config 1 (-2 %: its one big reduce lands on the critical path)."""
+    mode = getattr(args, "launch_mode", "auto")
+    if mode not in ("auto", "eager", "graph"):
+        raise ValueError("--launch_mode must be auto, eager or graph")
+    can = world == 1 and not band and args.disc_iters == 1
+    if mode == "graph" and not can:
+        raise ValueError("--launch_mode graph needs a single rank, --disc_iters 1 and no --shard_patch_rows")
+    env = os.environ.get("ITG_GRAPH")
+    # auto: "probe" - train() times its first eager iterations and switches to replay only if the host is the bottleneck
+    # (issue time > 90 % of the synchronised step time).  Measured on MI355X: config 1 issues a step in 5.6 ms against 7.4 ms
+    # of GPU time (eager 1 069 vs replay 1 050 crops/s through this CLI), config 3 in ~7 ms against 3.4 ms (replay 2x).
+    use_graph = can and (mode == "graph" or (mode == "auto" and env == "1"))
+    if can and mode == "auto" and env is None:
+        use_graph = "probe"
+    wr = getattr(args, "wgrad_reduce", "auto")
+    if wr not in ("auto", "layer", "deferred"):
+        raise ValueError("--wgrad_reduce must be auto, layer or deferred")
+    crop = args.center_crop or args.random_crop or 1 << 30
+    defer = wr == "deferred" or (wr == "auto" and bool(use_graph) and crop <= 128)
+    if "ITG_DEFER_REDUCE" in os.environ and wr == "auto":
+        defer = os.environ["ITG_DEFER_REDUCE"] == "1"
+    return use_graph, defer
+
+
 def train(args):
     device = U.prepare_device(args)
     seed = U.prepare_seed(args)
@@ -91,11 +119,16 @@ def train(args):
         print("# Params. G: ", sum(p.numel() for p in netG.parameters()))
         print("# Params. D: ", sum(p.numel() for p in netD.parameters()))
     netG.train(), netD.train()
+    use_graph, defer = launch_plan(args, world, band)
     if band:      # one batch, patch rows of every fake image spread over the ranks (BASELINE config 4)
         from .dist import BandComm
         tr = BandTrainer(netG, netD, args, device, BandComm(rank, world, group), netG_ema=netG_ema)
     else:
-        tr = Trainer(netG, netD, args, device, netG_ema=netG_ema, dist_group=group)
+        tr = Trainer(netG, netD, args, device, netG_ema=netG_ema, dist_group=group, defer_reduce=defer)
+    if rank == 0:
+        print("launch: %s, weight-gradient reduce: %s" % ({True: "hipGraph replay", False: "eager", "probe": "auto (decided after 4 iterations)"}[use_graph],
+                                                           "deferred" if defer else "per layer"))
+    probe = {"n": 0, "issue": 0.0, "start": 0.0}      # auto: host issue time of the first full-batch eager iterations
     filename = U.prepare_filename(args)
     start = time.time()
     G_losses, D_losses = [], []
@@ -108,6 +141,8 @@ def train(args):
                                           args.num_patches_height, args.num_patches_width, device, merged_maps=band)
         return U.sample_latents_zeros(netG, args.z_dim, args.base_res, args.map_dim, args.num_images, device)
 
+    recorded_lr = None          # (lr_D, lr_G) the recorded graph was captured with: the learning rates are kernel arguments
+
     print("Starting Training Loop...")
     for epoch in range(args.epochs):
         d_run = torch.zeros((), device=device)
@@ -118,7 +153,42 @@ def train(args):
             b = real_x.shape[0]
             # --disc_iters D updates with fresh latents each, then ONE G update on the last fake (train.py:124-169)
             lat = [sample() for _ in range(args.disc_iters)]
-            _, _, g_loss = tr.step(real_x, [l[0] for l in lat], [l[1] for l in lat])
+            if use_graph == "probe" and b == args.batch_size:
+                # auto launch mode: 1 untimed + 4 timed eager iterations, host issue time against synchronised time
+                if probe["n"] == 1:
+                    torch.cuda.synchronize()
+                    probe["start"] = time.perf_counter()
+                t0 = time.perf_counter()
+                _, _, g_loss = tr.step(real_x, [l[0] for l in lat], [l[1] for l in lat])
+                if probe["n"] >= 1:
+                    probe["issue"] += time.perf_counter() - t0
+                probe["n"] += 1
+                if probe["n"] == 5:
+                    torch.cuda.synchronize()
+                    wall = time.perf_counter() - probe["start"]
+                    use_graph = probe["issue"] > 0.9 * wall
+                    if rank == 0:
+                        print("launch (auto): the host issues an iteration in %.2f ms, the GPU finishes one every %.2f ms -> %s"
+                              % (probe["issue"] / 4 * 1e3, wall / 4 * 1e3, "hipGraph replay" if use_graph else "eager"))
+            elif use_graph is True and b == args.batch_size:
+                # the first full batch runs eagerly (every lazily created buffer then exists) and is recorded afterwards
+                # (recording does not train); later batches replay.  A decayed learning rate re-records; a short last
+                # batch of an epoch (another shape) runs eagerly.
+                z0, m0 = lat[0]
+                if recorded_lr is None:
+                    _, _, g_loss = tr.step(real_x, z0, m0)
+                    losses = list(tr.d_losses)
+                    tr.capture(real_x, z0, m0, warmup=0)
+                    recorded_lr, graph_losses = (tr.optD.lr, tr.optG.lr), tr.d_losses      # the graph's static loss tensors
+                    tr.d_losses = losses                      # this iteration's losses are the eager step's
+                else:
+                    if recorded_lr != (tr.optD.lr, tr.optG.lr):
+                        tr.capture(real_x, z0, m0, warmup=0)
+                        recorded_lr, graph_losses = (tr.optD.lr, tr.optG.lr), tr.d_losses
+                    _, _, g_loss = tr.step_graphed(real_x, z0, m0)
+                    tr.d_losses = graph_losses
+            else:
+                _, _, g_loss = tr.step(real_x, [l[0] for l in lat], [l[1] for l in lat])
             for d_real, d_fake in tr.d_losses:
                 d_run += d_fake * args.num_images + d_real * b
             g_run += g_loss * args.num_images

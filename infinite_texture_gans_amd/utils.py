@@ -70,6 +70,11 @@ _FLAGS = [
                             "accumulation; BASELINE config 3)"),
     ("sync_bn", "flag", False, "build-side extra: all-reduce the BatchNorm statistics over the data-parallel ranks "
                                "(default: per-rank statistics, as the reference's nn.DataParallel)"),
+    ("launch_mode", str, "auto", "build-side extra: eager | graph | auto.  graph = the whole iteration is recorded once into a "
+                                 "hipGraph and replayed (host cost ~0; single rank, --disc_iters 1); auto = graph where that applies"),
+    ("wgrad_reduce", str, "auto", "build-side extra: layer | deferred | auto.  deferred = one weight-gradient reduce launch per "
+                                  "backward pass instead of 2-5 per layer (pays when the step is launch-bound: auto turns it on "
+                                  "under graph replay for crops <= 128)"),
     ("shard_patch_rows", "flag", False, "build-side extra: multi-GPU runs shard the patch grid of ONE batch by patch "
                                         "rows (halo exchange) instead of replicating the batch per GPU"),
 ]
@@ -331,7 +336,7 @@ def tiling_plan(n_layers_G, base_res, num_patches_height, num_patches_width, out
 def sample_from_gen_PatchByPatch_test(netG, z_dim=128, base_res=4, map_dim=1, num_images=1, num_patches_height=3,
                                       num_patches_width=3, device="cpu", output_resolution_height=384,
                                       output_resolution_width=384, z_full=None, maps_full=None,
-                                      one_shot=None, halo=None):
+                                      one_shot=None, halo=None, strip_on_device=False):
     """Generate one large image (reference utils.py:258-397).
 
     Default (``one_shot=None``): generators without attention run ONE forward over the whole
@@ -361,7 +366,7 @@ def sample_from_gen_PatchByPatch_test(netG, z_dim=128, base_res=4, map_dim=1, nu
             if g.attention:
                 raise ValueError("row-sharded generation needs a generator without attention (SURVEY.md F7)")
             return _generate_row_sharded(g, z_full, maps_full, t_h, t_w, base_res, device, halo, p,
-                                         output_resolution_height, output_resolution_width)
+                                         output_resolution_height, output_resolution_width, on_device=strip_on_device)
         if one_shot:
             return _generate_one_shot(g, z_full, maps_full, t_h, t_w, base_res, device)[
                 :, :, :output_resolution_height, :output_resolution_width]
@@ -464,15 +469,62 @@ def generate_band(g, z_loc, maps_loc, t_w, base_res, halo):
             m.halo = None
 
 
-def _generate_row_sharded(g, z_full, maps_full, t_h, t_w, base_res, device, halo, p, out_h, out_w):
+def _generate_row_sharded(g, z_full, maps_full, t_h, t_w, base_res, device, halo, p, out_h, out_w, on_device=False):
     """One-shot generation with the T_h x T_w patch grid split by patch rows over the ranks of ``halo``
     (dist.RowHalo): every 3x3 conv exchanges one pixel row with each neighbour.  Latents are the SAME
-    full-grid tensors on every rank (same seed); each rank cuts out its band (+ the latent's own halo)."""
+    full-grid tensors on every rank (same seed); each rank cuts out its band (+ the latent's own halo).
+    ``on_device``: the strip stays in HBM (gather_strips collects the strips over the process group)."""
     a, b = halo.band(t_h)
     z_loc, maps_loc = band_latents(g, t_h, t_w, base_res, halo, device, z_full=z_full, maps_full=maps_full)
-    strip = _to_host(generate_band(g, z_loc, maps_loc, t_w, base_res, halo))
+    strip = generate_band(g, z_loc, maps_loc, t_w, base_res, halo)
+    if not on_device:
+        strip = _to_host(strip)
     lo, hi = a * p, min(b * p, out_h)
     return strip[:, :, :max(0, hi - lo), :out_w]
+
+
+def strip_rows(halo, t_h, p, out_h):
+    """[lo, hi) output pixel rows of every rank's strip (static: band() x patch height, cropped to the requested height)."""
+    out = []
+    for r in range(halo.world):
+        a, b = type(halo).band(_RankView(r, halo.world), t_h)
+        out.append((min(a * p, out_h), min(b * p, out_h)))
+    return out
+
+
+class _RankView:
+    """band() of another rank (RowHalo.band only reads rank / world)."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+
+def gather_strips(strip, halo, rows, dst=0):
+    """The strips (1, c, h_r, W) of a row-sharded generation -> the whole image on rank ``dst`` (None elsewhere), moved as
+    tensors into ONE preallocated image: rank r sends its strip, ``dst`` receives every strip into a staging buffer and
+    copies it into its rows (strips are ragged, so this is point-to-point, not dist.gather; round 3 pickled the strips
+    with gather_object).  Device strips travel over RCCL; under gloo (several ranks on one GPU, rehearsal) through the host."""
+    import torch.distributed as dist
+    if halo.world == 1:
+        return strip
+    via_host = strip.is_cuda and dist.get_backend(halo.group) == "gloo"
+    mine = strip.contiguous().cpu() if via_host else strip.contiguous()
+    if halo.rank != dst:
+        if mine.shape[-2] > 0:
+            dist.send(mine, dst, group=halo.group)
+        return None
+    n, c, _, w = strip.shape
+    img = torch.empty((n, c, rows[-1][1], w), dtype=strip.dtype, device=strip.device)
+    for r, (lo, hi) in enumerate(rows):
+        if hi <= lo:
+            continue
+        if r == dst:
+            img[:, :, lo:hi] = strip
+            continue
+        buf = torch.empty((n, c, hi - lo, w), dtype=strip.dtype, device=mine.device)
+        dist.recv(buf, r, group=halo.group)
+        img[:, :, lo:hi] = buf.to(strip.device)
+    return img
 
 
 def _generate_streamed(g, z_full, maps_full, steps_h, steps_w, p, base_res, nph, npw, device):

@@ -105,3 +105,96 @@ def test_reference_style_caller_runs_on_the_drop_in_module_names():
     sd = netD.state_dict()
     for k, v in state(fx, "D1/").items():
         assert rel_l2(sd[k].double().cpu(), v.double()) < 2e-3, k
+
+
+def test_single_image_loader_on_the_device_returns_exact_windows(tmp_path):
+    """f1 on the GPU (reference datasets/datasets_classes.py:12-51 behind utils.prepare_data :158-191): the decoded texture
+    lives in HBM as ToTensor -> Normalize(0.5, 0.5) bit for bit; a batch of random crops is cut on the device and every
+    item is an exact window of it at the offsets the generator drew (torch.randint order: all rows, then all columns);
+    center_crop wins over random_crop and uses torchvision's rounded offsets; the loader yields {0: batch} with a short
+    last batch (DataLoader(drop_last=False)); the batch feeds the train step unchanged."""
+    from PIL import Image
+    from infinite_texture_gans_amd.data import single_image, CropLoader
+    from infinite_texture_gans_amd import utils as U
+    rng = np.random.RandomState(5)
+    a = rng.randint(0, 256, (75, 91, 3), dtype=np.uint8)
+    path = str(tmp_path / "tex.png")
+    Image.fromarray(a).save(path)
+    want = (torch.from_numpy(a).permute(2, 0, 1).float() / 255.0 - 0.5) / 0.5
+    ds = single_image(path, "png", random_crop=32, sampling=20, device="cuda")
+    assert ds.img.is_cuda and torch.equal(ds.img.cpu(), want)
+    g = torch.Generator().manual_seed(11)
+    b = ds.crop_batch(6, g)
+    assert b.is_cuda and b.shape == (6, 3, 32, 32) and b.is_contiguous()
+    g2 = torch.Generator().manual_seed(11)
+    ys = torch.randint(0, 75 - 32 + 1, (6,), generator=g2).tolist()
+    xs = torch.randint(0, 91 - 32 + 1, (6,), generator=g2).tolist()
+    for i, (y, x) in enumerate(zip(ys, xs)):
+        assert torch.equal(b[i].cpu(), want[:, y:y + 32, x:x + 32]), i
+    dc = single_image(path, "png", center_crop=40, random_crop=32, device="cuda")
+    t, l = int(round((75 - 40) / 2.0)), int(round((91 - 40) / 2.0))
+    cb = dc.crop_batch(3)
+    assert cb.is_cuda and all(torch.equal(cb[i].cpu(), want[:, t:t + 40, l:l + 40]) for i in range(3))
+    assert torch.equal(dc[0][0].cpu(), want[:, t:t + 40, l:l + 40])
+    batches = list(CropLoader(ds, 8, seed=3))
+    assert [set(d) for d in batches] == [{0}] * 3 and [d[0].shape[0] for d in batches] == [8, 8, 4]
+    assert all(d[0].is_cuda and d[0].dtype == torch.float32 for d in batches)
+    # utils.prepare_data's (loader, dataset) pair on the device, as train.py uses it
+    args = U.prepare_parser().parse_args(["--data_path", path, "--data_ext", "png", "--random_crop", "32", "--sampling", "10",
+                                          "--batch_size", "4"])
+    loader, dset = U.prepare_data(args, device="cuda", seed=1)
+    first = next(iter(loader))[0]
+    assert first.is_cuda and first.shape == (4, 3, 32, 32) and len(dset) == 10
+    hits = [(y, x) for y in range(75 - 31) for x in range(91 - 31) if torch.equal(want[:, y:y + 32, x:x + 32], first[0].cpu())]
+    assert hits
+
+
+def _sample_worker(rank, world, port, ckpt, name, seed):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      ITG_DIST_BACKEND="gloo", ITG_SAMPLE_SEED=str(seed))
+    from infinite_texture_gans_amd import test_sample as S
+    S.main(["--model_path", ckpt, "--output_resolution_height", "150", "--output_resolution_width", "100", "--output_name", name])
+
+
+def _checkpoint(tmp_path, attention):
+    """A reference-format generator checkpoint with random-init weights (what test_sample.py reads: args + netG_state_dict)."""
+    from infinite_texture_gans_amd import utils as U
+    flags = ["--padding_mode", "local", "--type_norm", "BN", "--G_ch", "4", "--z_dim", "8", "--n_layers_G", "4", "--leak_G", "0.02"]
+    args = U.prepare_parser().parse_args(flags + (["--attention"] if attention else []))
+    torch.manual_seed(5)
+    netG, _ = U.prepare_models(args, "cpu")
+    d = tmp_path / ("att" if attention else "bn")
+    d.mkdir()
+    torch.save({"args": args, "netG_state_dict": netG.state_dict()}, d / "g.pth")
+    return str(d / "g.pth"), d
+
+
+def test_sample_cli_on_two_ranks_row_sharded_and_replica_mode(tmp_path):
+    """test_sample.py under a 2-rank launch (two processes on this one GPU over gloo; a real launch is one rank per GPU over
+    RCCL): a BN generator shards the ONE image by patch rows and rank 0 collects the strips as tensors (utils.gather_strips;
+    round 3 pickled them) - the image equals the single-process one from the same seed; an attention checkpoint streams with
+    carried state and does not shard: replica mode, rank r writes its own image <stem>_rank<r> from seed + r."""
+    import torch.multiprocessing as mp
+    from PIL import Image
+    from test_gpu_model import free_port
+    from infinite_texture_gans_amd import test_sample as S
+    ckpt, d = _checkpoint(tmp_path, attention=False)
+    os.environ["ITG_SAMPLE_SEED"] = "7"
+    try:
+        S.main(["--model_path", ckpt, "--output_resolution_height", "150", "--output_resolution_width", "100", "--output_name", "one.png"])
+    finally:
+        del os.environ["ITG_SAMPLE_SEED"]
+    mp.spawn(_sample_worker, args=(2, free_port(), ckpt, "two.png", 7), nprocs=2, join=True)
+    one, two = np.asarray(Image.open(d / "one.png")).astype(int), np.asarray(Image.open(d / "two.png")).astype(int)
+    assert one.shape == two.shape == (150, 100, 3)
+    assert np.abs(one - two).max() <= 1, np.abs(one - two).max()            # 8-bit rounding of equal-to-1e-6 floats
+    ckpt, d = _checkpoint(tmp_path, attention=True)
+    mp.spawn(_sample_worker, args=(2, free_port(), ckpt, "att.png", 11), nprocs=2, join=True)
+    r0, r1 = np.asarray(Image.open(d / "att_rank0.png")).astype(int), np.asarray(Image.open(d / "att_rank1.png")).astype(int)
+    assert r0.shape == r1.shape == (150, 100, 3) and np.abs(r0 - r1).max() > 8      # two different images
+    os.environ["ITG_SAMPLE_SEED"] = "11"
+    try:
+        S.main(["--model_path", ckpt, "--output_resolution_height", "150", "--output_resolution_width", "100", "--output_name", "att_one.png"])
+    finally:
+        del os.environ["ITG_SAMPLE_SEED"]
+    assert np.abs(np.asarray(Image.open(d / "att_one.png")).astype(int) - r0).max() <= 1      # rank 0's replica = the seed-11 image

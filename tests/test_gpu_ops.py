@@ -917,3 +917,23 @@ def test_pack_multi_panels_equal_the_single_panel_entry_points_bit_exact():
     torch.cuda.synchronize()
     for (job, ref) in zip(jobs, want):
         assert torch.equal(job[1], ref), (job[2:], (job[1] != ref).sum().item())
+
+
+def test_public_current_stream_fallback_gives_the_same_result(monkeypatch):
+    """ops._stream() uses torch's private raw-stream getter for speed; the public torch.cuda.current_stream() path behind it
+    must stay usable: same conv, same bits, also on a non-default stream."""
+    ops = _ops()
+    g = _gen(21)
+    x = ops.to_grid(torch.randn(2, 8, 12, 12, generator=g).to(cuda), 1, 1, merged=True)
+    w = torch.randn(16, 8, 3, 3, generator=g).to(cuda) * 0.1
+    y0 = ops.conv(x, w, None, 3, 3, 1, 1, ops.PAD_REPLICATE).t.clone()
+    monkeypatch.setattr(ops, "_raw_stream", None)
+    y1 = ops.conv(x, w, None, 3, 3, 1, 1, ops.PAD_REPLICATE).t.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        assert ops._stream().value == side.cuda_stream
+        y2 = ops.conv(x, w, None, 3, 3, 1, 1, ops.PAD_REPLICATE).t.clone()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(y0, y2)

@@ -21,7 +21,7 @@ with tempfile.TemporaryDirectory() as d:
     Image.fromarray(rng.randint(0, 255, (768, 1024, 3), dtype=np.uint8)).save(os.path.join(d, "tex.jpg"))
     flags = [f for f in bench.FLAGS]
     argv = flags + ["--data_path", os.path.join(d, "tex.jpg"), "--sampling", str(sampling), "--epochs", "3",
-                    "--fname", os.path.join(d, "cp")]
+                    "--fname", os.path.join(d, "cp")] + sys.argv[2:]          # e.g. --launch_mode eager
     t = []
     real_print = print
 
