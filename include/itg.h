@@ -91,6 +91,10 @@ typedef struct {
   const itg_in_norm* in_norm; /* NULL, or the input transform described above */
   int32_t flags;     /* ITG_GEOM_*; zero-initialise the struct */
   int32_t reserved;  /* 0 */
+  const float* wino_v; /* itg_conv2d_wgrad / itg_conv2d_wgrad_slabs of an ITG_GEOM_WINO layer only, or NULL: the transformed
+                      * input V = B^T d B of the SAME x, as itg_conv2d_fwd left it in the first 49 (36) * tiles * x.ld floats of
+                      * its workspace - the weight gradient then skips its own input transform (the caller keeps the forward's
+                      * workspace alive until the backward pass; round 4) */
 } itg_conv_geom;
 /* itg_conv2d_dgrad with ITG_PAD_REPLICATE folds the gradients of the replicated frame onto the 1-pixel border of dx
  * with atomics and zeroes that border first (one small launch per call).  ITG_GEOM_FRAME_ZEROED: the caller has zeroed

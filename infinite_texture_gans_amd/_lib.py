@@ -34,11 +34,13 @@ class InNorm(C.Structure):
 class ConvGeom(C.Structure):
     _fields_ = [("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("pad_mode", C.c_int32), ("pad_h", C.c_int32), ("precision", C.c_int32), ("up2", C.c_int32),
-                ("out_stats", C.c_void_p), ("in_norm", C.POINTER(InNorm)), ("flags", C.c_int32), ("reserved", C.c_int32)]
+                ("out_stats", C.c_void_p), ("in_norm", C.POINTER(InNorm)), ("flags", C.c_int32), ("reserved", C.c_int32),
+                ("wino_v", C.c_void_p)]
 
-    def __init__(self, kh, kw, stride, pad, pad_mode, pad_h=-1, precision=0, out_stats=None, in_norm=None, up2=0, flags=0):
+    def __init__(self, kh, kw, stride, pad, pad_mode, pad_h=-1, precision=0, out_stats=None, in_norm=None, up2=0, flags=0,
+                 wino_v=None):
         super().__init__(kh, kw, stride, pad, pad_mode, pad_h, precision, int(up2), out_stats,
-                         C.pointer(in_norm) if in_norm is not None else None, int(flags), 0)
+                         C.pointer(in_norm) if in_norm is not None else None, int(flags), 0, wino_v)
         self._in_norm = in_norm      # keep it alive
 
 

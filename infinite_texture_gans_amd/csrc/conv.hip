@@ -518,7 +518,7 @@ inline int up2_check(const itg_conv_geom* g, const itg_tensor* lo, const itg_ten
   return ITG_OK;
 }
 inline void clear_xf(ConvP& p) {
-  p.ucls = 0; p.u_in = p.u_w = p.u_out = 0;
+  p.ucls = 0; p.u_in = p.u_w = p.u_out = 0; p.u_dgrad = 0;
   p.in_ab = nullptr; p.in_act = ITG_ACT_NONE; p.in_slope = 0.f; p.in_ups = 0;
   p.bnx = null_grid(); p.bn_ab = nullptr; p.bn_mr = nullptr; p.bn_act = ITG_ACT_NONE; p.bn_slope = 0.f; p.bn_ups = 0;
   p.bn_sums = nullptr;
@@ -838,7 +838,7 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
     const int fold = wino_fold(g);
     if (fold && !(g->flags & ITG_GEOM_FRAME_ZEROED) && (rc = launch_zero_border(make_grid(dx), s))) return rc;
     return wino_conv(dy, w_packed_dgrad, nullptr, out_scale, r, 0, r ? act : 0, slope, dx, g->kh, g->kh - 2 + fold, ITG_PAD_ZERO, fold,
-                     ITG_ACT_NONE, 0.f, prec_of(g), workspace, workspace_floats, s);
+                     ITG_ACT_NONE, 0.f, prec_of(g), workspace, workspace_floats, s, true);
   }
   if (g->up2) {
     // dx(z) = sum_t W4(t) dy(2 z + t - 1): the 4 x 4 stride-2 conv of dy with the phase-summed taps (itg_pack_up2_dgrad).
@@ -1125,7 +1125,7 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
   if (wino_wgrad_ok(x, dy, g)) {
     const WinoWgPlan w = plan_wino_wgrad(x, dy, g->kh);
     if (workspace_floats < w.ws_floats) return ITG_ERR_WORKSPACE;
-    if ((rc = wino_wgrad_slabs(x, dy, g->pad, g->pad_mode, prec_of(g), w, workspace, db != nullptr, s))) return rc;
+    if ((rc = wino_wgrad_slabs(x, dy, g->pad, g->pad_mode, prec_of(g), w, workspace, db != nullptr, s, g->wino_v))) return rc;
     return launch_wgrad_reduce(workspace + w.slab_off, 1, workspace + w.db_off, w.Rr, dw, db, dy->c, x->c, x->ld, g->kh, g->kw, w.co_rows,
                                w.Kpad, accumulate, s);
   }
@@ -1149,7 +1149,7 @@ int itg_conv2d_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, const itg_
   if (wino_wgrad_ok(x, dy, g)) {
     const WinoWgPlan w = plan_wino_wgrad(x, dy, g->kh);
     if (workspace_floats < w.ws_floats) return ITG_ERR_WORKSPACE;
-    if ((rc = wino_wgrad_slabs(x, dy, g->pad, g->pad_mode, prec_of(g), w, workspace, true, (hipStream_t)stream))) return rc;
+    if ((rc = wino_wgrad_slabs(x, dy, g->pad, g->pad_mode, prec_of(g), w, workspace, true, (hipStream_t)stream, g->wino_v))) return rc;
     job->slab = workspace + w.slab_off; job->dbslab = workspace + w.db_off;
     job->splits = 1; job->dbsplits = w.Rr;
     job->co = dy->c; job->ci = x->c; job->ci_ld = x->ld; job->kh = g->kh; job->kw = g->kw;

@@ -61,6 +61,7 @@ struct ConvP {
   // p.out.p + c * u_out (floats); no split-K.  The class is the SLOWEST index of the tile id (classes share nothing).
   int ucls;
   unsigned u_in, u_w, u_out;
+  int u_dgrad;         // the uniform-class launch is an input gradient (blocked fp64 accumulation only with ITG_WINO_ACC64=2)
   // stride-2 input-gradient: the 4 output-parity classes run as ONE grid (blockIdx.y = class)
   int ncls;
   int cMT[4], cMU[4], cM[4], cioy[4], ciox[4], cooy[4], coox[4];
@@ -181,7 +182,7 @@ int try_conv_up2_tile(const ConvP& p, hipStream_t s, int* rc);
 int64_t wino_workspace_floats(const itg_tensor* in, const itg_tensor* out, int R, int fold);
 int wino_conv(const itg_tensor* in, const float* u_panel, const float* bias, const float* out_scale, const itg_tensor* res, int res_ups,
               int res_mode, float res_slope, const itg_tensor* out, int R, int pad, int pad_mode, int fold, int act, float slope,
-              int prec, float* workspace, int64_t workspace_floats, hipStream_t s);
+              int prec, float* workspace, int64_t workspace_floats, hipStream_t s, bool input_gradient = false);
 // conv_nt.hip
 NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = ITG_PREC_F32);
 int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s);
@@ -207,7 +208,7 @@ int launch_wgrad_reduce(const float* slab, int splits, const float* dbslab, int 
 struct WinoWgPlan { int R, Ty, Tx, Rr, co_rows, Kpad; int64_t tiles, v_off, m_off, u_off, slab_off, db_off, ws_floats; TnPlan tn; };
 WinoWgPlan plan_wino_wgrad(const itg_tensor* x, const itg_tensor* dy, int R);
 int wino_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, int pad, int pad_mode, int prec, const WinoWgPlan& w, float* workspace,
-                     bool want_db, hipStream_t s);
+                     bool want_db, hipStream_t s, const float* v_fwd = nullptr);
 int launch_reduce_multi(const itg_wgrad_job* jobs, int n, hipStream_t s);
 
 }  // namespace itgk

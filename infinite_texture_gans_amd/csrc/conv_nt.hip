@@ -41,90 +41,108 @@ __global__ void zero_border_kernel(GridT g) {
 // split-K second stage: out = act(sum_z partial[z] + bias [+ residual]) with the same output mapping
 // (blockIdx.y = parity class of a multi-class launch: one second-stage launch for all of them; the kernel argument stays
 // read-only - a modified copy of the struct would live in scratch memory)
-// STATS: also the consumer BatchNorm's statistics of the values as stored (p.stats) - its own instantiation (as a run-time
-// branch it slowed the launches that do not need them); the grid's thread count is then a multiple of ld / 4, so a thread
-// keeps one channel group and its fp64 partials go thread -> LDS -> one global atomic per channel and workgroup (norm.hip)
-template <bool STATS>
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvP p) {
-  __shared__ double lstat[STATS ? 2 * 512 : 2];
-  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-  if constexpr (STATS) {
-    for (int i = threadIdx.x; i < 2 * p.out.ld; i += 256) lstat[i] = 0.0;
-    __syncthreads();
+// one output element group (4 channels of pixel m of class cls): slab sum in a fixed order, epilogue, store; returns the values
+__device__ __forceinline__ f32x4 splitk_finish(const ConvP& p, const float* __restrict__ partial, int M, int MT, int MU, int ooy, int oox,
+                                               int m, int co) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  {
+    const float* q = partial + (size_t)m * p.co_rows + co;
+    const size_t zs = (size_t)M * p.co_rows;
+    f32x4 v1 = v, v2 = v, v3 = v;                       // four slab loads in flight, fixed summation order
+    int z = 0;
+    for (; z + 4 <= p.ksplit; z += 4) {
+      v += *reinterpret_cast<const f32x4*>(q + (size_t)z * zs);
+      v1 += *reinterpret_cast<const f32x4*>(q + (size_t)(z + 1) * zs);
+      v2 += *reinterpret_cast<const f32x4*>(q + (size_t)(z + 2) * zs);
+      v3 += *reinterpret_cast<const f32x4*>(q + (size_t)(z + 3) * zs);
+    }
+    for (; z < p.ksplit; ++z) v += *reinterpret_cast<const f32x4*>(q + (size_t)z * zs);
+    v = (v + v1) + (v2 + v3);
   }
+  if (p.scale) v *= *p.scale;
+  int n, t, u;
+  decode_m(m, MT, MU, n, t, u);
+  int oy = t * p.osy + ooy, ox = u * p.osx + oox;
+  bool border = false;
+  if (p.out_mode == 1) {
+    int ty = min(max(oy, 0), p.out.H - 1), tx = min(max(ox, 0), p.out.W - 1);
+    border = (ty == 0) | (ty == p.out.H - 1) | (tx == 0) | (tx == p.out.W - 1);
+    oy = ty; ox = tx;
+  }
+  const int off = grid_off(p.out, n, oy, ox);
+  if (p.bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (co + e < p.out.c) v[e] += p.bias[co + e];
+  }
+  if (p.res.p) {
+    f32x4 r = *reinterpret_cast<const f32x4*>(p.res.p + grid_off(p.res, n, oy >> p.res_ups, ox >> p.res_ups) + co);
+    if (p.res_mode == 0) v += r;
+    else v *= act_deriv(r, p.res_mode, p.res_slope);
+  }
+  if (p.act != ITG_ACT_NONE) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act, p.slope);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (co + e >= p.out.c) v[e] = 0.f;
+  float* dst = p.out.p + off + co;
+  if (border) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(dst + e, v[e]);
+  } else {
+    *reinterpret_cast<f32x4*>(dst) = v;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvP p) {
   const int q4 = p.out.ld >> 2;
   const int cls = blockIdx.y;
   const int M = p.cM[cls], MT = p.cMT[cls], MU = p.cMU[cls], ooy = p.cooy[cls], oox = p.coox[cls];
   const float* const partial = p.partial + p.cpoff[cls];
   int64_t total = (int64_t)M * q4;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int c4 = (int)(i % q4);
-    int m = (int)(i / q4);
-    int co = c4 * 4;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    {
-      const float* q = partial + (size_t)m * p.co_rows + co;
-      const size_t zs = (size_t)M * p.co_rows;
-      f32x4 v1 = v, v2 = v, v3 = v;                       // four slab loads in flight, fixed summation order
-      int z = 0;
-      for (; z + 4 <= p.ksplit; z += 4) {
-        v += *reinterpret_cast<const f32x4*>(q + (size_t)z * zs);
-        v1 += *reinterpret_cast<const f32x4*>(q + (size_t)(z + 1) * zs);
-        v2 += *reinterpret_cast<const f32x4*>(q + (size_t)(z + 2) * zs);
-        v3 += *reinterpret_cast<const f32x4*>(q + (size_t)(z + 3) * zs);
-      }
-      for (; z < p.ksplit; ++z) v += *reinterpret_cast<const f32x4*>(q + (size_t)z * zs);
-      v = (v + v1) + (v2 + v3);
-    }
-    if (p.scale) v *= *p.scale;
-    int n, t, u;
-    decode_m(m, MT, MU, n, t, u);
-    int oy = t * p.osy + ooy, ox = u * p.osx + oox;
-    bool border = false;
-    if (p.out_mode == 1) {
-      int ty = min(max(oy, 0), p.out.H - 1), tx = min(max(ox, 0), p.out.W - 1);
-      border = (ty == 0) | (ty == p.out.H - 1) | (tx == 0) | (tx == p.out.W - 1);
-      oy = ty; ox = tx;
-    }
-    const int off = grid_off(p.out, n, oy, ox);
-    if (p.bias) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (co + e < p.out.c) v[e] += p.bias[co + e];
-    }
-    if (p.res.p) {
-      f32x4 r = *reinterpret_cast<const f32x4*>(p.res.p + grid_off(p.res, n, oy >> p.res_ups, ox >> p.res_ups) + co);
-      if (p.res_mode == 0) v += r;
-      else v *= act_deriv(r, p.res_mode, p.res_slope);
-    }
-    if (p.act != ITG_ACT_NONE) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act, p.slope);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (co + e >= p.out.c) v[e] = 0.f;
-    float* dst = p.out.p + off + co;
-    if (border) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(dst + e, v[e]);
-    } else {
-      *reinterpret_cast<f32x4*>(dst) = v;
-    }
-    if constexpr (STATS) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    splitk_finish(p, partial, M, MT, MU, ooy, oox, (int)(i / q4), (int)(i % q4) * 4);
+}
+
+// ... and the consumer BatchNorm's statistics of the values as stored (p.stats).  Round 4: a workgroup OWNS 64 channels (16
+// lanes x 4) of a range of pixels - blockIdx.x = (channel group, pixel range) - so the per-channel sums of a workgroup meet in
+// LDS by plain stores and a fixed-order sum, and a channel receives one global fp64 atomic per PIXEL RANGE (tens) instead of one
+// per workgroup of a channel-agnostic sweep (round 3: ~58 workgroups of 8 sequential elements per thread with ds_add_f64
+// scatter, 20 us per launch on the generator's 4 x 4 ... 16 x 16 layers); one pixel group per thread keeps the slab loads wide.
+__global__ __launch_bounds__(256) void splitk_epilogue_stats_kernel(const ConvP p, int ngroups, int nranges) {
+  __shared__ double lst[8][256];
+  const int q4 = p.out.ld >> 2;
+  const int cls = blockIdx.y;
+  const int M = p.cM[cls], MT = p.cMT[cls], MU = p.cMU[cls], ooy = p.cooy[cls], oox = p.coox[cls];
+  const float* const partial = p.partial + p.cpoff[cls];
+  const int grp = blockIdx.x % ngroups, rng = blockIdx.x / ngroups;
+  const int lane16 = threadIdx.x & 15, prow = threadIdx.x >> 4;
+  const int c4 = grp * 16 + lane16;
+  const int per = (M + nranges - 1) / nranges;
+  const int m0 = rng * per, m1 = min(M, m0 + per);
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (c4 < q4) {
+    for (int m = m0 + prow; m < m1; m += 16) {
+      const f32x4 v = splitk_finish(p, partial, M, MT, MU, ooy, oox, m, c4 * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const double d = v[e]; s1[e] += d; s2[e] += d * d; }
     }
   }
-  if constexpr (STATS) {
-    const int cg = (int)((blockIdx.x * 256 + threadIdx.x) % q4);       // fixed: gridDim.x * 256 is a multiple of q4
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      atomicAdd(&lstat[cg * 4 + e], s1[e]);
-      atomicAdd(&lstat[p.out.ld + cg * 4 + e], s2[e]);
+  for (int e = 0; e < 4; ++e) { lst[e][threadIdx.x] = s1[e]; lst[4 + e][threadIdx.x] = s2[e]; }
+  __syncthreads();
+  if (threadIdx.x < 128) {                 // (which, lane16, e): the 16 pixel rows of the workgroup in a fixed order
+    const int which = threadIdx.x >> 6, l = (threadIdx.x >> 2) & 15, e = threadIdx.x & 3;
+    const int ch = (grp * 16 + l) * 4 + e;
+    if (ch < p.out.ld) {
+      double t = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += lst[which * 4 + e][r * 16 + l];
+      atomicAdd(&p.stats[which * p.out.ld + ch], t);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * p.out.ld; i += 256) atomicAdd(&p.stats[i], lstat[i]);
   }
 }
 
@@ -333,9 +351,13 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
             pl.bco, pl.bpix, pl.ksplit, pl.kchunks);
   // plain kernels here; the loader-transform (forward of a normalised input) and BatchNorm-backward-sums (input gradient)
   // forms are instantiated in conv_nt_fused.hip
-  // uniform-class launches (the Winograd GEMMs) with fp32 operands accumulate blockwise in fp64 (NT_W64, conv_nt_w64.hip)
+  // uniform-class launches (the Winograd GEMMs) with fp32 operands accumulate blockwise in fp64 (NT_W64, conv_nt_w64.hip):
+  // ITG_WINO_ACC64 = 1 (default) the FORWARD GEMMs - their rounding decides which LeakyReLU inputs change sign, and every flip
+  // moves all upstream gradients by ~1e-3 - 2 = the input-gradient GEMMs as well (their 6.6e-6 against 1.6e-6
+  // enters the gradients linearly: invisible next to the flips; 23 us per launch saved), 0 = off
   static const int w64 = env_int("ITG_WINO_ACC64", 1);
-  const int mode = p.in_ab ? NT_XF : (p.bn_sums ? NT_BNS : ((p.ucls && k == 16 && w64) ? NT_W64 : NT_PLAIN));
+  const bool acc64 = p.ucls && k == 16 && (w64 >= 2 || (w64 == 1 && !p.u_dgrad));
+  const int mode = p.in_ab ? NT_XF : (p.bn_sums ? NT_BNS : (acc64 ? NT_W64 : NT_PLAIN));
   int rc = mode == NT_PLAIN ? launch_nt_shape<NT_PLAIN>(pl.bco, pl.bpix, p, k, s)
            : mode == NT_W64 ? launch_nt_w64(pl.bco, pl.bpix, p, k, s) : launch_nt_fused(mode, pl.bco, pl.bpix, p, k, s);
   if (rc) return rc;
@@ -348,21 +370,17 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
     int per = 8192 / ncls;
     int blocks = (int)((total + 255) / 256 < per ? (total + 255) / 256 : per);
     if (blocks > 0 && stats_in_stage2) {
-      // thread count a multiple of ld / 4 (a thread then owns one channel group); ~8 elements per thread keeps the global
-      // fp64 atomics (2 ld per workgroup) rare
+      // (channel group of 64, pixel range) workgroups: enough ranges for ~2 workgroups per CU, at least 16 pixels each
       const int q4 = p.out.ld >> 2;
-      int g0 = q4, a = 256;
-      while (a) { int t = g0 % a; g0 = a; a = t; }           // gcd(256, q4)
-      g0 = q4 / g0;
-      int want = (int)((total + 2047) / 2048);
-      if (want > 1024 / ncls) want = 1024 / ncls;
-      if (want < 1) want = 1;
-      blocks = (want + g0 - 1) / g0 * g0;
+      const int ngroups = (q4 + 15) / 16;
+      int nranges = (512 / ncls + ngroups - 1) / ngroups;
+      if (nranges > (mmax + 15) / 16) nranges = (mmax + 15) / 16;
+      if (nranges < 1) nranges = 1;
       p.stats = want_stats;
-      hipLaunchKernelGGL(splitk_epilogue_kernel<true>, dim3(blocks, ncls), dim3(256), 0, s, p);
+      hipLaunchKernelGGL(splitk_epilogue_stats_kernel, dim3(ngroups * nranges, ncls), dim3(256), 0, s, p, ngroups, nranges);
       ITG_CHECK_LAUNCH();
     } else if (blocks > 0) {
-      hipLaunchKernelGGL(splitk_epilogue_kernel<false>, dim3(blocks, ncls), dim3(256), 0, s, p);
+      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks, ncls), dim3(256), 0, s, p);
       ITG_CHECK_LAUNCH();
     }
   }

@@ -303,7 +303,7 @@ int64_t wino_workspace_floats(const itg_tensor* in, const itg_tensor* out, int R
 // with pad = R - 1 and its frame folded onto out's border pixels, whose 1-pixel frame the caller has zeroed.
 int wino_conv(const itg_tensor* in, const float* u_panel, const float* bias, const float* out_scale, const itg_tensor* res, int res_ups,
               int res_mode, float res_slope, const itg_tensor* out, int R, int pad, int pad_mode, int fold, int act, float slope,
-              int prec, float* workspace, int64_t workspace_floats, hipStream_t s) {
+              int prec, float* workspace, int64_t workspace_floats, hipStream_t s, bool input_gradient) {
   const int H = in->gh * in->ph, W = in->gw * in->pw, Ho = out->gh * out->ph, Wo = out->gw * out->pw;
   if (in->n != out->n || (R != 3 && R != 4)) return ITG_ERR_ARG;
   const int He = Ho + 2 * fold, We = Wo + 2 * fold;
@@ -343,6 +343,7 @@ int wino_conv(const itg_tensor* in, const float* u_panel, const float* bias, con
     p.prec = prec;
     p.ncls = 1;
     p.ucls = NC;
+    p.u_dgrad = input_gradient ? 1 : 0;
     p.u_in = (unsigned)(tiles * in->ld); p.u_out = (unsigned)(tiles * out->ld); p.u_w = (unsigned)((size_t)p.co_rows * p.Kpad);
     int rc = dispatch_nt(p, nullptr, 0, s);
     if (rc) return rc;
@@ -396,20 +397,20 @@ WinoWgPlan plan_wino_wgrad(const itg_tensor* x, const itg_tensor* dy, int R) {
 }
 
 int wino_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, int pad, int pad_mode, int prec, const WinoWgPlan& w, float* workspace,
-                     bool want_db, hipStream_t s) {
+                     bool want_db, hipStream_t s, const float* v_fwd) {
   const int H = x->gh * x->ph, W = x->gw * x->pw, Ho = dy->gh * dy->ph, Wo = dy->gw * dy->pw;
   const int R = w.R, NP = 4 + R - 1, NC = NP * NP;
   if (x->n != dy->n || (R != 3 && R != 4)) return ITG_ERR_ARG;
   if (Ho != H + 2 * pad - (R - 1) || Wo != W + 2 * pad - (R - 1) || (x->ld & 15) || (dy->ld & 15) || prec != ITG_PREC_F32) return ITG_ERR_ARG;
   if (w.tiles * std::max(x->ld, dy->ld) * 4 >= 0xFFFF0000LL || w.tn.ngroups > 0) return ITG_ERR_ARG;
-  float* V = workspace + w.v_off;
+  const float* V = v_fwd ? v_fwd : workspace + w.v_off;       // v_fwd: the forward's transformed input (itg_conv_geom.wino_v)
   float* dM = workspace + w.m_off;
   float* dU = workspace + w.u_off;
-  {
+  if (!v_fwd) {
     const int64_t th = w.tiles * (x->ld >> 1);
     const dim3 grid((unsigned)((th + 255) / 256));
-    if (R == 4) hipLaunchKernelGGL(wino_in_kernel<4>, grid, dim3(256), 0, s, make_grid(x), pad, pad_mode, w.Ty, w.Tx, V);
-    else hipLaunchKernelGGL(wino_in_kernel<3>, grid, dim3(256), 0, s, make_grid(x), pad, pad_mode, w.Ty, w.Tx, V);
+    if (R == 4) hipLaunchKernelGGL(wino_in_kernel<4>, grid, dim3(256), 0, s, make_grid(x), pad, pad_mode, w.Ty, w.Tx, workspace + w.v_off);
+    else hipLaunchKernelGGL(wino_in_kernel<3>, grid, dim3(256), 0, s, make_grid(x), pad, pad_mode, w.Ty, w.Tx, workspace + w.v_off);
     ITG_CHECK_LAUNCH();
   }
   {
@@ -429,7 +430,7 @@ int wino_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, int pad, int pad
     // `tiles` pixels), one uniform class per transformed point
     WgP p;
     memset(&p, 0, sizeof(p));
-    itg_tensor vx = {V, 1, 1, 1, 1, (int)w.tiles, x->c, x->ld};
+    itg_tensor vx = {const_cast<float*>(V), 1, 1, 1, 1, (int)w.tiles, x->c, x->ld};
     itg_tensor vdy = {dM, 1, 1, 1, 1, (int)w.tiles, dy->c, dy->ld};
     p.x = make_grid(&vx); p.dy = make_grid(&vdy);
     p.slab = dU; p.dbslab = nullptr;

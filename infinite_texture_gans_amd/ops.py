@@ -318,6 +318,9 @@ class _Conv(torch.autograd.Function):
         # gradient w.r.t. that layer's PRE-activation; defer = the consumer of this layer's output does the same
         # for us, so our own activation backward is skipped.  The two always come in pairs (see callers).
         ctx.in_act, ctx.defer_act = fuse
+        # Winograd layers: the transformed input V sits at the start of the forward's workspace; the weight gradient of the
+        # same x takes it from there instead of transforming x again (itg_conv_geom.wino_v) - kept only when w takes a gradient
+        ctx.wino_ws = ws if (wino and WINO_KEEP_V and w.requires_grad and torch.is_grad_enabled()) else None
         ctx.save_for_backward(x, w, out if act != ACT_NONE else None)
         return out
 
@@ -389,6 +392,8 @@ class _Conv(torch.autograd.Function):
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if need_w or need_b:
+            if ctx.wino_ws is not None:       # a geometry of its own for the weight gradient: + the forward's V
+                g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, None, None, up2, _lib.GEOM_WINO, ctx.wino_ws.data_ptr())
             wsink, bsink = ctx.sinks if ctx.sinks is not None else (None, None)
             # Everything below only writes into the flat gradient buffers when sinks cover the requested
             # gradients: such a weight-gradient can run on the side stream, next to the input-gradient chain.
@@ -403,7 +408,7 @@ class _Conv(torch.autograd.Function):
                 # the operands were allocated on the main stream: keep them referenced until the owner of the side
                 # stream has joined it (engine.Trainer._join clears the list), so the allocator cannot hand their
                 # memory to a later main-stream kernel while the weight-gradient still reads it
-                WGRAD_KEEPALIVE.append((x, dy, inv_sigma))
+                WGRAD_KEEPALIVE.append((x, dy, inv_sigma, ctx.wino_ws))
                 side.wait_event(ev)
                 if side not in _wgrad_dirty:
                     _wgrad_dirty.append(side)
@@ -483,6 +488,7 @@ WINOGRAD = os.environ.get("ITG_WINOGRAD", "1") == "1"
 # three to five dependent launches of 8-20 us where the direct path has one or two - these layers are launch-latency-bound.  Opt-in.
 WINOGRAD_G = os.environ.get("ITG_WINOGRAD_G", "0") == "1"
 WINOGRAD_WGRAD = os.environ.get("ITG_WINOGRAD_WGRAD", "1") == "1"     # read by the library itself; here for the flop accounting
+WINO_KEEP_V = os.environ.get("ITG_WINO_KEEP_V", "1") == "1"           # the weight gradient re-uses the forward's transformed input
 
 
 def wino_applicable(x, kh, kw, stride, pad, pad_h, pad_mode, prec, up2=False, out_stats=False, out=None, co=None):
