@@ -128,18 +128,12 @@ def gpu_leg(a):
         for i in range(a.warmup):
             tr.step(reals[i % 2], zs[i])
         step = tr.step
-    # ITG_LOOKAHEAD=1: hand the step the NEXT real batch as well, so that D(real) of iteration k+1 runs beside the generator
-    # backward of iteration k (engine.Trainer.step(next_real=...)).  Measured neutral on one MI355X (772 vs 770 crops/s): the
-    # step is bound by the sum of the kernels' work, not by idle gaps - off by default (768 vs 785 with the measured
-    # stream placement of round 2; issued AFTER the backward, beside the head bucket's all-reduce, it costs 5 %).
-    ahead = not use_graph and os.environ.get("ITG_LOOKAHEAD", "0") == "1" and not band
+    # (handing the step the NEXT real batch so that its D(real) pass runs beside this iteration's generator backward -
+    # engine.Trainer.step(next_real=...) - measured neutral to -2 %: the bench does not use it)
     sync()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        if ahead:
-            losses = step(reals[i % 2], zs[a.warmup + i], None, reals[(i + 1) % 2] if i + 1 < a.steps else None)
-        else:
-            losses = step(reals[i % 2], zs[a.warmup + i])
+        losses = step(reals[i % 2], zs[a.warmup + i])
     sync()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], device=dev, dtype=torch.float64)

@@ -54,7 +54,6 @@ struct ConvP {
   GridT bnx; const float* bn_ab; const float* bn_mr; int bn_act; float bn_slope; int bn_ups; double* bn_sums;
   int prec;                     // ITG_PREC_F32 | ITG_PREC_BF16
   float* partial;      // split-K slabs [ksplit][M][co_rows] (ksplit > 1)
-  unsigned* tickets;   // split-K, in-launch combine: one zeroed word per (class, workgroup of a split), or null = second-stage launch
   int ksplit, kchunks; // K chunks (of BK) per split
   // uniform classes (ucls > 0; the 49 GEMMs of a Winograd-domain convolution, conv_wino.hip): ucls independent problems of
   // the geometry in slot 0 in ONE grid, class c on the input at p.in.p + c * u_in, the panel at p.w + c * u_w, the output at
@@ -167,10 +166,7 @@ constexpr int BKP = 16;  // pixels per pipeline stage (fp32 operands; 32 with bf
 struct TileWgPlan { int ok, mf, nld, cpt, tiles_x, tiles_y, blocks, thin, gpp, coef_off; int64_t ntiles; size_t lds; };
 struct TnPlan { int bcol, bco, splits, chunks_per_split, nchunks, co_rows, Kpad, ngroups; int64_t slab_floats, ws_floats; };
 
-inline int red_group() {       // slabs summed per thread in either weight-gradient reduce stage (>= 2: it is a divisor)
-  static const int v = env_int("ITG_RED_GROUP", 16) < 2 ? 2 : env_int("ITG_RED_GROUP", 16);
-  return v;
-}
+inline int red_group() { return 16; }       // slabs summed per thread in either weight-gradient reduce stage (64: neutral)
 
 // conv_tile.hip
 int try_conv_valu(const ConvP& p, hipStream_t s, int* rc);

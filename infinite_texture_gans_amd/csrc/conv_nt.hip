@@ -7,7 +7,6 @@
 // The pixel operand is gathered in merged-image coordinates from a patch-grid NHWC tensor, so the LocalPadder halo
 // (reference models/layers.py:145-173) is a neighbour-patch read and the outer replicate / zero padding (layers.py:82)
 // a clamp / predicate; nothing is materialised.
-#include <atomic>
 #include "conv_nt_kernel.h"
 
 namespace itgk {
@@ -190,21 +189,6 @@ int launch_zero_frames(const itg_tensor* t, int n, hipStream_t s) {
   return ITG_OK;
 }
 
-// ---- split-K ticket words (in-launch combine)
-constexpr int TICKET_SLOT = 1024, TICKET_SLOTS = 256;
-__device__ unsigned g_ticket_words[TICKET_SLOT * TICKET_SLOTS];      // zero at load; every use leaves its words zero again
-
-unsigned* next_ticket_slot() {
-  static unsigned* base = nullptr;
-  static std::atomic<unsigned> next{0};
-  if (!base) {
-    void* ptr = nullptr;
-    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_ticket_words)) != hipSuccess) return nullptr;
-    base = static_cast<unsigned*>(ptr);
-  }
-  return base + (size_t)(next.fetch_add(1) % TICKET_SLOTS) * TICKET_SLOT;
-}
-
 int launch_zero_border(const GridT& gx, hipStream_t s) {
   int64_t tot = (int64_t)gx.n * (2 * gx.W + 2 * gx.H) * (gx.ld >> 2);
   int blocks = (int)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048);
@@ -237,21 +221,18 @@ NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls, int prec) {
   //   fill          < 2 workgroups per CU leaves the MFMA pipe idle between phases
   //   split cost    the second stage's slab round trip ~ ks * 100 / K of the kernel's own time
   //   tile penalty  narrower tiles re-read the weight panel more often and carry more issue overhead
-  static const double split_cost = (double)env_int("ITG_SPLIT_COST", 200);
+  constexpr double split_cost = 200.0;
   pl.bpix = 128; pl.ksplit = 1;
   double best_eff = 0.0;
   const int cands_big[4] = {256, 128, 96, 64};
   const int cand_ks[13] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16};
-  static const int fill_env = env_int("ITG_FILL_MIN", 0);      // workgroups per CU below which a launch counts as under-filled
-  const double fill_min = (fill_env ? fill_env : (prec == ITG_PREC_BF16 ? 200 : 300)) / 100.0;   // bf16 stages are short: 2 (config 3 +1 %)
-  static const int allow96 = env_int("ITG_NT_96", 1);
-  static const double pen96 = env_int("ITG_PEN96", 104) / 100.0;
-  static const int force_bp = env_int("ITG_NT_BPIX", 0);       // experiments: pin the pixel-tile width of the <= 64-row tiles
+  // workgroups per CU below which a launch counts as under-filled (bf16 stages are short: 2, config 3 +1 %)
+  const double fill_min = prec == ITG_PREC_BF16 ? 2.0 : 3.0;
+  constexpr double pen96 = 1.04;
   for (int ci = 0; ci < 4; ++ci) {
     int bp = cands_big[ci];
-    if (force_bp && pl.bco <= 64 && bp != force_bp) continue;
     if (pl.bco >= 112 && bp == 256) continue;              // 128x256 / 112x256 are not instantiated
-    if (bp == 96 && (pl.bco != 128 || !allow96 || pl.tbk != 16)) continue;   // 128x96 (fp32): 3 workgroups per CU exactly on M = 73728
+    if (bp == 96 && (pl.bco != 128 || pl.tbk != 16)) continue;   // 128x96 (fp32): 3 workgroups per CU exactly on M = 73728
     int64_t blocks = ((M + bp - 1) / bp) * nco * ncls;
     double pen = bp >= 256 ? 1.0 : (bp == 128 ? (pl.bco >= 112 ? 1.0 : 1.04) : bp == 96 ? pen96 : (pl.bco >= 112 ? 1.08 : 1.12));
     for (int i = 0; i < 13; ++i) {
@@ -319,21 +300,11 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
     pl.ksplit = 1; pl.kchunks = (p.Kpad + pl.tbk - 1) / pl.tbk; pl.ws_floats = 0;
     // 49 classes x (tiles / bpix) x (co / 128) workgroups: the 64-pixel tile quantises best on 256 CUs x 4 resident
     // workgroups (forward GEMM of the generated batch 206 -> 186 us, the real batch's 74 -> 70; 96 / 128 are slower)
-    static const int wbp = env_int("ITG_WINO_BPIX", 64);
-    if (wbp && pl.bco == 128) pl.bpix = wbp;
+    if (pl.bco == 128) pl.bpix = 64;
   }
   if (pl.ws_floats > workspace_floats || (pl.ws_floats && !workspace)) return ITG_ERR_WORKSPACE;
   p.ksplit = pl.ksplit; p.kchunks = pl.kchunks; p.partial = workspace;
-  p.tickets = nullptr;
-  if (pl.ksplit > 1) {
-    // in-launch combine: ticket words from a static device array, handed out in slots of TICKET_SLOT words round-robin
-    // per launch (a slot is reused TICKET_SLOTS split-K launches later - streams are joined every train step, far fewer
-    // launches apart - and every word is reset to zero by the workgroup that draws the last ticket)
-    static const int inl = env_int("ITG_SPLITK_INLAUNCH", 0);   // measured: b1 forward 59 -> 93 us, step 778 -> 736 crops/s (229 KB of slabs per tile: the release / acquire pair costs more than the second-stage launch)
-    const int64_t words = (((int64_t)p.M + pl.bpix - 1) / pl.bpix) * ((p.co_rows + pl.bco - 1) / pl.bco) * ncls_;
-    if (inl && words <= TICKET_SLOT) p.tickets = next_ticket_slot();
-  }
-  const bool second_stage = pl.ksplit > 1 && !p.tickets;
+  const bool second_stage = pl.ksplit > 1;      // (an in-launch combine - agent-scope release / ticket / acquire - measured slower: DESIGN section 3)
   const bool stats_in_stage2 = second_stage && p.stats && (stats_paths & 4) && p.out_mode == 0 && p.out.ld <= 512;
   if (second_stage || !(stats_paths & 2)) p.stats = nullptr;
   if (second_stage) p.bn_sums = nullptr;                     // the second stage does not take them: separate reduce launch

@@ -354,44 +354,7 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK, MODE)
         if (co < p.co_rows) *reinterpret_cast<f32x4*>(slab + (size_t)m * p.co_rows + co) = acc[i][j];
       }
     }
-    if (!p.tickets) return;                 // two-launch form: splitk_epilogue_kernel sums the slabs
-    // In-launch combine (MI355X guide, split-K recipe): every wave drains its slab stores, the workgroup meets, one lane
-    // releases at agent scope and draws a ticket; the workgroup whose ticket is the last of its tile acquires and sums ALL
-    // slabs of the tile in slab order (fixed order: deterministic, whichever split arrives last) and runs the ordinary
-    // epilogue.  Correct for any placement of a tile's splits over XCDs.  The ticket word is reset by the last arriver.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int* const flag = reinterpret_cast<int*>(smem);          // the K loop ended with a barrier: its buffers are free
-    if (tid == 0) {
-      unsigned* const tk = p.tickets + blockIdx.x;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool last = t == (unsigned)(gridDim.z - 1);
-      if (last) {
-        __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      flag[0] = last ? 1 : 0;
-    }
-    __syncthreads();
-    if (!flag[0]) return;
-    const size_t zs = (size_t)cM * p.co_rows;
-#pragma unroll
-    for (int j = 0; j < FJ; ++j) {
-      const int m = m0 + wpix0 + 16 * j + (lane & 15);
-#pragma unroll
-      for (int i = 0; i < FI; ++i) {
-        const int co = co0 + wco0 + 16 * i + cq;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m < cM && co < p.co_rows) {
-          const float* q = cpartial + (size_t)m * p.co_rows + co;
-          for (int z = 0; z < (int)gridDim.z; ++z) v += *reinterpret_cast<const f32x4*>(q + (size_t)z * zs);
-        }
-        acc[i][j] = v;
-      }
-    }
+    return;                 // splitk_epilogue_kernel (conv_nt.hip) sums the slabs and runs the epilogue
   }
   if (p.scale) {          // 1/sigma of an unscaled panel (two-launch split-K: applied by the second stage)
     const float osc = *p.scale;
@@ -512,8 +475,7 @@ int launch_nt(const ConvP& p, int tbk, hipStream_t s) {
   dim3 grid((unsigned)gx, 1, (unsigned)p.ksplit);
   size_t tab_bytes = (size_t)BPIX * (p.ntaps + 1) * sizeof(unsigned);
   q.use_tab = (p.cin_ld < 64 && tab_bytes <= 24 * 1024) ? 1 : 0;
-  static const int xcd = env_int("ITG_NT_XCD", 1);
-  q.xcd_remap = xcd;
+  q.xcd_remap = 1;
   if (!q.use_tab) tab_bytes = 0;
   if (MODE == NT_XF) tab_bytes += (size_t)2 * p.cin_ld * sizeof(float);      // alpha | beta' of the input transform behind the tap table
   // two K stages in flight except for the medium fp32 tiles, whose 96-register budget has no room for

@@ -358,8 +358,7 @@ int try_conv_valu(const ConvP& p, hipStream_t s, int* rc) {
   const int ci4 = p.cin_ld >> 2, co4 = p.out.ld >> 2;
   // (4 input groups, 1 output group) = the forward of `final`: 44 us against 68 us on the halo-tile MFMA kernel; its
   // input gradient (1, 4) measured slower here (61 vs 41 us) and stays on the tile kernel
-  static const int dgrad_too = env_int("ITG_CONV_VALU_DGRAD", 0);
-  if (!((ci4 == 4 && co4 == 1) || (dgrad_too && ci4 == 1 && (co4 == 4 || co4 == 1)))) return 0;
+  if (!(ci4 == 4 && co4 == 1)) return 0;
   if ((int64_t)p.MT * p.MU < 64 * 64) return 0;
   ConvP q = p;
   int64_t ib = (int64_t)p.in.n * p.in.gh * p.in.gw * p.in.ph * p.in.pw * p.in.ld * 4;
@@ -693,9 +692,7 @@ int try_conv_up2_tile(const ConvP& p, hipStream_t s, int* rc) {
     }
   }
   int per_cu = (int)((160 * 1024) / lds);
-  static const int cu_env = env_int("ITG_UP2_TILE_CU", 0);
   if (per_cu > 2) per_cu = 2;
-  if (cu_env > 0) per_cu = cu_env;
   if (per_cu < 1) per_cu = 1;
   const int64_t want = 256 * (int64_t)per_cu;
   const unsigned blocks = (unsigned)(ntiles < want ? ntiles : want);
@@ -723,20 +720,13 @@ int try_conv_s2k4(const ConvP& p, hipStream_t s, int* rc) {
   if (ntiles > 0x7fffffff) return 0;
   const int FI = p.co_rows / 16;
   const size_t lds = ((size_t)4 * p.co_rows * 20 + p.co_rows + (size_t)S2_PIX * 4) * sizeof(float);
-  static const int nw = env_int("ITG_S2K4_WAVES", 8) == 8 ? 8 : 4;         // 8 waves per tile: 43.9 -> 41.0 us on D's first layer
-  static const int per_cu_env = env_int("ITG_S2K4_CU", 0);
-  const int64_t want = 256 * (int64_t)(per_cu_env > 0 ? per_cu_env : (nw == 8 ? 2 : 3));
+  constexpr int nw = 8;         // 8 waves per tile: 43.9 -> 41.0 us on D's first layer (1 / 3 / 4 workgroups per CU instead of 2: worse)
+  const int64_t want = 256 * 2;
   const unsigned blocks = (unsigned)(ntiles < want ? ntiles : want);
   snprintf(g_last_launch, sizeof(g_last_launch), "conv_s2k4_kernel<%d, %d>", FI, nw);
-  if (nw == 8) {
-    if (FI == 4) hipLaunchKernelGGL((conv_s2k4_kernel<4, 8>), dim3(blocks), dim3(512), lds, s, q, tiles_x, tiles_y, (int)ntiles);
-    else if (FI == 2) hipLaunchKernelGGL((conv_s2k4_kernel<2, 8>), dim3(blocks), dim3(512), lds, s, q, tiles_x, tiles_y, (int)ntiles);
-    else hipLaunchKernelGGL((conv_s2k4_kernel<1, 8>), dim3(blocks), dim3(512), lds, s, q, tiles_x, tiles_y, (int)ntiles);
-  } else {
-    if (FI == 4) hipLaunchKernelGGL((conv_s2k4_kernel<4, 4>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles);
-    else if (FI == 2) hipLaunchKernelGGL((conv_s2k4_kernel<2, 4>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles);
-    else hipLaunchKernelGGL((conv_s2k4_kernel<1, 4>), dim3(blocks), dim3(256), lds, s, q, tiles_x, tiles_y, (int)ntiles);
-  }
+  if (FI == 4) hipLaunchKernelGGL((conv_s2k4_kernel<4, 8>), dim3(blocks), dim3(512), lds, s, q, tiles_x, tiles_y, (int)ntiles);
+  else if (FI == 2) hipLaunchKernelGGL((conv_s2k4_kernel<2, 8>), dim3(blocks), dim3(512), lds, s, q, tiles_x, tiles_y, (int)ntiles);
+  else hipLaunchKernelGGL((conv_s2k4_kernel<1, 8>), dim3(blocks), dim3(512), lds, s, q, tiles_x, tiles_y, (int)ntiles);
   *rc = hipGetLastError() == hipSuccess ? ITG_OK : ITG_ERR_LAUNCH;
   return 1;
 }
@@ -749,8 +739,7 @@ int try_conv_tile(ConvP& p, hipStream_t s, int* rc) {
   if (p.prec != ITG_PREC_F32 || p.cin_ld > 32 || p.co_rows > 32) return 0;
   if ((int64_t)p.MT * p.MU < 64 * 64) return 0;          // tiny images: the gather kernel with split-K wins
   const int FI = p.co_rows / 16;
-  static const int stats2 = env_int("ITG_TILE_STATS2", 0);
-  if (FI == 2 && !stats2) { p.stats = nullptr; p.bn_sums = nullptr; }   // two row tiles + statistics spill (17-24 VGPRs): the caller runs the separate pass
+  if (FI == 2) { p.stats = nullptr; p.bn_sums = nullptr; }   // two row tiles + statistics spill (17-24 VGPRs): the caller runs the separate pass
   ConvP q = p;
   int64_t ib = (int64_t)p.in.n * p.in.gh * p.in.gw * p.in.ph * p.in.pw * p.in.ld * 4;
   if (ib >= 0xFFFF0000LL) return 0;
@@ -792,14 +781,11 @@ int try_conv_tile(ConvP& p, hipStream_t s, int* rc) {
   }
   // persistent grid = what is resident at once (register budget: 4 workgroups per CU with 6 loads, 3 with 11)
   int per_cu = (int)((160 * 1024) / lds);
-  static const int tile_cu = env_int("ITG_TILE_CU", 0);       // tuning override of the persistent workgroups per CU
-  const int reg_cu = tile_cu > 0 ? tile_cu : (nld <= 6 ? 4 : 3);
+  const int reg_cu = nld <= 6 ? 4 : 3;
   if (per_cu > reg_cu) per_cu = reg_cu;
   if (per_cu < 1) per_cu = 1;
   const int64_t want = 256 * (int64_t)per_cu;
-  static const int even = env_int("ITG_TILE_EVEN", 0);      // equal tile counts per persistent workgroup: measured worse (b6c2 forward 69 -> 76 us)
-  const int64_t per_wg = (ntiles + want - 1) / want;
-  const unsigned blocks = (unsigned)(even ? (ntiles + per_wg - 1) / per_wg : (ntiles < want ? ntiles : want));
+  const unsigned blocks = (unsigned)(ntiles < want ? ntiles : want);      // (equal tile counts per workgroup measured worse: b6c2 forward 69 -> 76 us)
   snprintf(g_last_launch, sizeof(g_last_launch), "conv_tile_kernel<%d, %d, %d, %s>", FI, nld <= 6 ? 6 : 11, stm, xfm ? "true" : "false");
   int a_tx = tiles_x, a_ty = tiles_y, a_nt = (int)ntiles, a_cpt = cpt, a_nch = nch;
   void* args[] = {(void*)&q, &a_tx, &a_ty, &a_nt, &a_cpt, &a_nch};

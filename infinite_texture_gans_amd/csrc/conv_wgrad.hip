@@ -951,10 +951,8 @@ TileWgPlan plan_wgrad_up2_tile(const itg_tensor* x, const itg_tensor* dy, const 
   if (red > fl) fl = red;
   t.lds = fl * sizeof(float);
   if (t.lds > 80 * 1024 || t.ntiles > 0x7fffffff) return t;
-  static const int cu_env = env_int("ITG_UP2_WTILE_CU", 0);
   int per_cu = (int)((160 * 1024) / t.lds);
   if (per_cu > 2) per_cu = 2;
-  if (cu_env > 0) per_cu = cu_env;
   if (per_cu < 1) per_cu = 1;
   const int64_t want = 256 * (int64_t)per_cu;
   t.blocks = (int)(t.ntiles < want ? t.ntiles : want);
@@ -1029,10 +1027,8 @@ TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_
   if (t.lds > 64 * 1024 || t.ntiles > 0x7fffffff) return t;
   // one persistent workgroup per CU: alone the kernel is 13 % faster with two, but it runs beside the input-gradient chain
   // of the same backward pass and two would crowd that out of LDS (step: 780 vs 774 crops/s)
-  static const int wtile_cu = env_int("ITG_WTILE_CU", 1);
-  static const int wthin_cu = env_int("ITG_WTHIN_CU", 1);
   int per_cu = (int)((160 * 1024) / t.lds);
-  if (per_cu > (t.thin ? wthin_cu : wtile_cu)) per_cu = t.thin ? wthin_cu : wtile_cu;
+  if (per_cu > 1) per_cu = 1;
   int64_t want = 256 * (int64_t)(per_cu < 1 ? 1 : per_cu);
   t.blocks = (int)(t.ntiles < want ? t.ntiles : want);
   t.ok = 1;
@@ -1204,8 +1200,7 @@ int launch_tn(WgP p, int splits, int prec, hipStream_t s) {
   const int otp = taps_tile + 1;
   // long per-workgroup pixel loops run best with the occupancy of the single-prefetch variant (4 waves per SIMD), short
   // ones with two stages in flight (measured on D's 256->512 layer vs its 64->128 / 128->256 layers)
-  static const int depth_env = env_int("ITG_TN_DEPTH", 0);
-  const int depth = depth_env ? depth_env : (p.chunks_per_split >= 128 ? 1 : 2);
+  const int depth = p.chunks_per_split >= 128 ? 1 : 2;
   const int kp = prec == ITG_PREC_BF16 ? 32 : BKP;
   static const int flat_env = env_int("ITG_TN_FLAT", 1);
   const bool flat = flat_env && !p.in_ab && prec != ITG_PREC_BF16 && !p.up2 && p.x.gh == 1 && p.x.gw == 1 && p.dy.gh == 1 &&
@@ -1250,8 +1245,7 @@ TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec, int ncls) {
   t.nchunks = (int)((M + kp - 1) / kp);
   // workgroup target: ~3 per CU; with bf16 operands a split's MFMA work is a quarter as long and the slab round trip
   // weighs more: 2 per CU (config 3: 1996 -> 2026 crops/s; config 1 loses 1 % with it)
-  static const int want_env = env_int("ITG_TN_BLOCKS", 0);
-  const int want_blocks = want_env ? want_env : (prec == ITG_PREC_BF16 ? 512 : 768);
+  const int want_blocks = prec == ITG_PREC_BF16 ? 512 : 768;        // (384 / 512 / 1024 with fp32 operands: -3.8 / -0.8 / -1.1 %)
   int want = (want_blocks / ncls + tiles - 1) / tiles;      // ncls grids of (tiles x splits) workgroups run as one launch
   int max_splits = (t.nchunks + 7) / 8;             // at least 8 chunks per split
   int splits = want < max_splits ? want : max_splits;

@@ -375,9 +375,8 @@ WinoWgPlan plan_wino_wgrad(const itg_tensor* x, const itg_tensor* dy, int R) {
   w.tn = plan_tn(w.tiles, dy->ld, x->ld, ITG_PREC_F32, NC);
   // pixel-range splits of the NP^2 contractions: 49 classes x 8 tiles fill the chip on their own, and every split is one
   // more slab for the output transform to read (256 -> 512 layer: 274 -> 258 us on the generated batch, 120 -> 107 on the real one)
-  static const int force_splits = env_int("ITG_WINO_TN_SPLITS", 1);
-  if (force_splits > 0) {
-    int sp = std::min(force_splits, std::max(1, w.tn.nchunks / 8));
+  {
+    const int sp = 1;
     w.tn.chunks_per_split = (w.tn.nchunks + sp - 1) / sp;
     w.tn.splits = (w.tn.nchunks + w.tn.chunks_per_split - 1) / w.tn.chunks_per_split;
     w.tn.slab_floats = (int64_t)w.tn.splits * NC * w.tn.co_rows * w.tn.Kpad;

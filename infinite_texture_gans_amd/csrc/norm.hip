@@ -494,8 +494,7 @@ int itg_bn_finalize_apply(const itg_tensor* x, const double* sums, double count,
   int64_t npix = grid_pixels(x);
   int q4 = x->ld >> 2;
   if (x->ld > MAX_LD) return ITG_ERR_ARG;
-  static const int cap = env_i("ITG_BN_APPLY_BLOCKS", 2048);
-  int blocks = sweep_blocks(npix * q4, q4, 8, cap);
+  int blocks = sweep_blocks(npix * q4, q4, 8, 2048);
   const size_t lds = (size_t)2 * x->ld * sizeof(float);
   if (ups)
     hipLaunchKernelGGL(bn_finalize_apply_kernel<true>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, (const float*)x->ptr,
@@ -516,8 +515,7 @@ int itg_bn_apply(const itg_tensor* x, const float* ab, const itg_tensor* y, int 
   if (!ab || (rc = ups_mode(x, y, &ups))) return rc ? rc : ITG_ERR_ARG;
   int64_t npix = grid_pixels(x);
   int q4 = x->ld >> 2;
-  static const int cap = env_i("ITG_BN_APPLY_BLOCKS", 2048);
-  int blocks = sweep_blocks(npix * q4, q4, 8, cap);
+  int blocks = sweep_blocks(npix * q4, q4, 8, 2048);
   if (ups)
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr,
                        (float*)y->ptr, ab, npix, x->ld, x->ph, x->pw, act, slope);

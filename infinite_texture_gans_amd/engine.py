@@ -254,7 +254,7 @@ class Trainer:
         # queue behind the kernels of the side streams (one-rank RCCL rehearsal: 12.07 ms with vs 12.13 ms without
         # overlap, against 10.86 ms without the collectives).  The two gradient all-reduces come after the joins.
         self.overlap = os.environ.get("ITG_OVERLAP", "0" if self.sync_bn else "1") == "1"
-        self.side, self._wstream, self.wstream, self.sc_stream = None, None, None, None
+        self.side, self._wstream, self.wstream = None, None, None
         # D(real)'s weight gradients may leave their branch stream for the weight-gradient streams (a fork of a fork;
         # also under hipGraph capture - what used to crash there was a wait for an idle forked stream, see
         # ops.wgrad_streams_join)
@@ -333,9 +333,6 @@ class Trainer:
             nws = max(1, min(2, int(os.environ.get("ITG_WGRAD_STREAMS", "2"))))
             picked = ops.concurrent_streams(self.device, 1 + nws)
             self.side, self._wstream = picked[0], picked[1:]
-            # the generator blocks' 1x1 shortcut on a stream of its own is worth nothing measurable (784 vs 785 crops/s);
-            # ITG_SC_STREAM=1 runs it on the second weight-gradient stream, which is idle during the forward pass
-            self.sc_stream = self._wstream[-1] if os.environ.get("ITG_SC_STREAM", "0") == "1" else None
         self.wstream = self._wstream if on else None
 
     def repack(self):
@@ -408,7 +405,6 @@ class Trainer:
         ops.ARENA = self.arena
         ops.WGRAD_STREAM = self.wstream
         ops.WGRAD_DEFER = self._defer if self.defer_reduce else None
-        ops.SHORTCUT_STREAM = self.sc_stream if self.overlap else None
         try:
             zs = list(z) if isinstance(z, (list, tuple)) else [z]
             ms = list(maps) if isinstance(maps, (list, tuple)) and isinstance(z, (list, tuple)) else [maps] * len(zs)
@@ -424,7 +420,6 @@ class Trainer:
             ops.ARENA = None
             ops.WGRAD_STREAM = None
             ops.WGRAD_DEFER = None
-            ops.SHORTCUT_STREAM = None
             ops.BACKWARD_ENTRY_HOOK = None
             if self.wstream is not None and not torch.cuda.is_current_stream_capturing():
                 ops.WGRAD_KEEPALIVE.clear()

@@ -614,16 +614,7 @@ class ResBlockGenerator(nn.Module):
             if upsample_input:
                 x = ops.upsample2x(x)
                 upsample_input = False
-        # The learnable 1x1 shortcut depends only on the block input: inside a Trainer step it runs on its own HIP stream
-        # beside bn1 -> conv1 -> bn2 (small latency-bound launches on both sides); autograd runs its backward there too.
-        side = ops.SHORTCUT_STREAM
-        forked = (self.learnable_sc and side is not None and self.type_norm == "BN" and x.t.is_cuda
-                  and not torch.cuda.is_current_stream_capturing())
-        if forked:
-            main = torch.cuda.current_stream()
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                sc = self._shortcut(x, map, upsample_input)
+        # (the learnable 1x1 shortcut on a HIP stream of its own measured 784 vs 785 crops/s: dropped in round 4)
         if self.type_norm == "SSM":
             out = self.bn1.run(x, map, act=A, slope=s)
             out = self.conv1.forward_grid(out, image_location, out_stats=fuse)
@@ -631,15 +622,12 @@ class ResBlockGenerator(nn.Module):
         else:
             # BatchNorm-apply + LeakyReLU (+ the x2 upsample) happen in conv1's / conv2's tile loaders where the conv path
             # gathers its halo itself (conv2d_lp.forward_grid); otherwise as their own pass
-            fo = [] if (_ENV_BN_FORK and not forked and self.training and torch.is_grad_enabled()) else None
+            fo = [] if (_ENV_BN_FORK and self.training and torch.is_grad_enabled()) else None
             out = self.conv1.forward_grid(x, image_location, out_stats=fuse, bn=self.bn1, bn_act=(A, s), upsample=upsample_input,
                                           fork_out=fo)
             if fo:
                 x = fo[0]          # the shortcut below reads the block input through bn1's alias (its gradient joins bn1's)
-        if forked:
-            main.wait_stream(side)
-            sc.t.record_stream(main)                 # allocated on the side stream, read by conv2's epilogue on this one
-        elif self.learnable_sc:
+        if self.learnable_sc:
             sc = self._shortcut(x, map, upsample_input)
         else:
             sc = ops.upsample2x(x) if (upsample_input and not res_upsample_enabled()) else x

@@ -538,7 +538,6 @@ BACKWARD_ENTRY_HOOK = None   # callable((weight.grad, bias.grad)) at the entry o
                              # (engine.GradExchange: the first layer of the model's head starting its backward means the
                              # gradients of everything behind it are enqueued)
 ACC_DW, ACC_DB, WS_ZEROED = 1, 2, 4      # include/itg.h: ITG_ACC_DW, ITG_ACC_DB, ITG_WS_ZEROED
-SHORTCUT_STREAM = None       # stream of the generator blocks' 1x1 shortcut branch (set by engine.Trainer for a step), or None
 WGRAD_STREAM = None          # one stream or a list of streams used round-robin (consecutive layers overlap each other too)
 WGRAD_KEEPALIVE = []
 _wgrad_rr = [0]

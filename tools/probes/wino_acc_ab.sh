@@ -8,5 +8,4 @@ echo "== ACC64 off"; ITG_WINO_ACC64=0 python tools/wino_accuracy.py
 echo "== ACC64 b16 (default)"; python tools/wino_accuracy.py
 echo "== ACC64 b8"; ITG_LIB=$GRAFT_REPO_ROOT/ab_libs/libitg_b8.so python tools/wino_accuracy.py
 echo "== ACC64 b4"; ITG_LIB=$GRAFT_REPO_ROOT/ab_libs/libitg_b4.so python tools/wino_accuracy.py
-echo "== ACC64 b16 bpix128"; ITG_WINO_BPIX=128 python tools/wino_accuracy.py
 } > gpurun_out/r4a_wino_acc.log 2>&1

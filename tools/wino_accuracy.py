@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rounding error and time of D's 256 -> 512 4 x 4 stride-1 layer (reference models/discriminators.py:196-206) on the GPU:
 direct kernel vs Winograd F(4 x 4, 4 x 4), each against F.conv2d in fp64 on the CPU.  The switches of the Winograd GEMMs
-(ITG_WINO_ACC64, ITG_WINO_BPIX) are read once per process: run the tool once per variant.
+(ITG_WINO_ACC64) are read once per process: run the tool once per variant.
 Usage (GPU box):  python tools/wino_accuracy.py [n_images=8] [size=48]"""
 import os
 import sys
@@ -33,7 +33,7 @@ def main():
     dy = torch.randn(n, cout, size - 1, size - 1, generator=g)
     dxref = torch.autograd.functional.vjp(lambda t: F.conv2d(t, w.double(), None, padding=1), x[:1].double(), dy[:1].double())[1]
     xg, wg, bg = x.to(dev), w.to(dev), b.to(dev)
-    print("switches: ITG_WINO_ACC64=%s ITG_WINO_BPIX=%s" % (os.environ.get("ITG_WINO_ACC64", "default"), os.environ.get("ITG_WINO_BPIX", "default")))
+    print("switches: ITG_WINO_ACC64=%s" % os.environ.get("ITG_WINO_ACC64", "default"))
     for wino in (False, True):
         ops.WINOGRAD = wino
         gx = ops.to_grid(xg, 1, 1, merged=True)
