@@ -266,11 +266,14 @@ int bn_reduce_after(const ConvP& p, double* sums, hipStream_t s) {
 }
 
 int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s) {
-  // ITG_STATS_PATHS: bit 0 halo-tile kernel, bit 1 implicit-GEMM epilogue take the consumer BatchNorm's statistics
-  // themselves; a cleared bit - and always the split-K second stage, where fusing them measured slower - runs the
-  // separate statistics launch over the finished output instead.  (Measured neutral on the step: 764.9 vs 764.3 crops/s;
-  // it removes 8 of the 13 statistics launches of a generator forward.)
-  static const int stats_paths = env_int("ITG_STATS_PATHS", 7);      // bit 2: the split-K second stage takes them (its own instantiation)
+  // ITG_STATS_PATHS: bit 0 halo-tile kernels, bit 1 implicit-GEMM epilogue, bit 2 split-K second stage take the consumer
+  // BatchNorm's statistics themselves; a cleared bit runs the separate statistics launch over the finished output instead.
+  // Default 5 since round 4: the implicit-GEMM epilogue's flush is one fp64 atomic per channel and WORKGROUP onto the same
+  // 2 * ld doubles, thousands of workgroups deep on the generator's 32 x 32 ... 64 x 64 layers, and those serialise at
+  // ~13 ns each (norm.hip) - with bn_stats at 4.9 TB/s the separate pass is cheaper: 1 095 (7) / 1 097 (6) / 1 101 (5) /
+  // 1 101 (4) crops/s in one call.  The persistent halo-tile kernels (<= 1 024 workgroups) and the split-K second stage
+  // (channel-owning workgroups) keep theirs.
+  static const int stats_paths = env_int("ITG_STATS_PATHS", 5);
   double* const want_stats = p.stats;
   double* const want_bn = p.bn_sums;
   {
