@@ -91,8 +91,20 @@ class RowHalo:
         a = self.rank * base + min(self.rank, extra)
         return a, a + base + (1 if self.rank < extra else 0)
 
-    def exchange(self, first_row, last_row):
-        """-> (top, bottom): the row above this band / below it, or None at the grid's outer border."""
+    _pending = None        # (consumer stream, communication stream) of an exchange posted with defer_wait
+
+    def wait(self):
+        """The consumer stream waits for the exchange posted with ``defer_wait`` (no-op otherwise)."""
+        if self._pending is not None:
+            cur, comm = self._pending
+            self._pending = None
+            cur.wait_stream(comm)
+
+    def exchange(self, first_row, last_row, defer_wait=False):
+        """-> (top, bottom): the row above this band / below it, or None at the grid's outer border.
+        ``defer_wait`` (with the communication stream, ITG_HALO_STREAM=1): the transfers are posted but the consumer stream
+        does not wait yet - the caller launches what needs no halo row and then calls wait().  Without a communication
+        stream (default, gloo, host staging) the exchange is complete on return and wait() is a no-op."""
         import torch.distributed as dist
         if self.world == 1:
             return None, None
@@ -127,7 +139,10 @@ class RowHalo:
             with torch.cuda.stream(comm):
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()                             # stream-level: orders `comm` behind the transfer
-            cur.wait_stream(comm)
+            if defer_wait:
+                self._pending = (cur, comm)
+            else:
+                cur.wait_stream(comm)
             for t in (first_row, last_row, top, bottom):
                 if t is not None:
                     t.record_stream(comm)
@@ -160,7 +175,7 @@ class ThreadRowHalo(RowHalo):
         super().__init__(rank, shared.world)
         self.shared = shared
 
-    def exchange(self, first_row, last_row):
+    def exchange(self, first_row, last_row, defer_wait=False):
         s = self.shared
         s.first[self.rank], s.last[self.rank] = first_row, last_row
         torch.cuda.synchronize() if first_row.is_cuda else None

@@ -28,6 +28,7 @@ _ENV_BN_LOADER = os.environ.get("ITG_BN_LOADER", "0") == "1"
 _ENV_RES_UPS = os.environ.get("ITG_RES_UPS", "1") == "1"
 _ENV_BN_FUSE = os.environ.get("ITG_BN_FUSE", "1") == "1"
 _ENV_UP2_FOLD = os.environ.get("ITG_UP2_FOLD", "1") == "1"
+_ENV_HALO_INTERIOR = os.environ.get("ITG_HALO_INTERIOR", "0") == "1"      # band training: interior rows first, border rows after the exchange
 _ENV_BN_FORK = os.environ.get("ITG_BN_FORK", "1") == "1"      # the shortcut's gradient is added inside bn1's backward kernel
 
 
@@ -377,14 +378,46 @@ class conv2d_lp(nn.Module):
             raise ValueError("band training expects the image layout (1x1 grid), got %r" % (x,))
         rows = t[:, 0, 0]
         first, last = rows[:, 0], rows[:, H - 1]
-        top, bottom = ops.halo_exchange(first, last, lp.halo)
+        interior_first = _ENV_HALO_INTERIOR and lp.halo.world > 1 and H >= 3
+        top, bottom = ops.halo_exchange(first, last, lp.halo, defer_wait=interior_first)
         if top is None:
             top = first if outer == "replicate" else torch.zeros_like(first)
         if bottom is None:
             bottom = last if outer == "replicate" else torch.zeros_like(last)
-        ext = torch.cat((top.unsqueeze(1), rows, bottom.unsqueeze(1)), 1).reshape(n, 1, 1, H + 2, W, ld)
-        return self.conv.run(GT(ext, x.c), pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope,
-                             residual=residual, pad_h=0, up2=up2)
+        if not interior_first:
+            ext = torch.cat((top.unsqueeze(1), rows, bottom.unsqueeze(1)), 1).reshape(n, 1, 1, H + 2, W, ld)
+            return self.conv.run(GT(ext, x.c), pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope,
+                                 residual=residual, pad_h=0, up2=up2)
+        # Interior first (ITG_HALO_INTERIOR=1, SURVEY section 7 / VERDICT r3 item 7): the exchange has been POSTED (on the halo's
+        # communication stream with ITG_HALO_STREAM=1); the output rows that need no neighbour row - all but the first and the
+        # last k (k = 1, or 2 behind the folded upsample) - are convolved from the band itself while the rows travel, then this
+        # stream waits for them and the 2 k border rows follow as ONE small conv over [top, row 0, row 1] and
+        # [row H-2, row H-1, bottom] of every image.  Three differentiable pieces, concatenated.
+        k = 2 if up2 else 1
+        r_full = None
+        if residual is not None:
+            r_full = residual.t[:, 0, 0]
+            if r_full.shape[1] * 2 == (2 * H if up2 else H) and not up2:
+                r_full = ops.upsample2x(residual).t[:, 0, 0]      # a half-size shortcut cannot be cut at single output rows
+        def res_rows(a, b):             # output rows [a, b) of the residual (read through the x2 upsample when it is half-size)
+            if r_full is None:
+                return None
+            half = r_full.shape[1] * 2 == (2 * H if up2 else H)
+            ra, rb = (a // 2, b // 2) if half else (a, b)
+            return GT(r_full[:, ra:rb].contiguous().unsqueeze(1).unsqueeze(1), residual.c)
+        Hout = 2 * H if up2 else H
+        y_int = self.conv.run(GT(rows.reshape(n, 1, 1, H, W, ld), x.c), pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope,
+                              residual=res_rows(k, Hout - k), pad_h=0, up2=up2)
+        lp.halo.wait()                  # the neighbours' rows are needed from here on
+        b_in = torch.cat((torch.stack((top, rows[:, 0], rows[:, 1]), 1), torch.stack((rows[:, H - 2], rows[:, H - 1], bottom), 1)), 0)
+        r_b = None
+        if r_full is not None:
+            rt, rb_ = res_rows(0, k), res_rows(Hout - k, Hout)
+            r_b = GT(torch.cat((rt.t, rb_.t), 0), residual.c)
+        y_b = self.conv.run(GT(b_in.reshape(2 * n, 1, 1, 3, W, ld), x.c), pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope,
+                            residual=r_b, pad_h=0, up2=up2)
+        yt = torch.cat((y_b.t[:n], y_int.t, y_b.t[n:]), 3)
+        return GT(yt, y_int.c)
 
     def _forward_row_sharded(self, x, lp, outer, act, slope, residual):
         """This rank owns a band of patch rows: fetch the neighbours' boundary pixel rows (RCCL send/recv),

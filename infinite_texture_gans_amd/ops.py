@@ -1412,9 +1412,12 @@ class _HaloExchange(torch.autograd.Function):
     the upper neighbour's bottom-halo gradient, and vice versa."""
 
     @staticmethod
-    def forward(ctx, first, last, comm):
+    def forward(ctx, first, last, comm, defer_wait=False):
         ctx.comm = comm
-        top, bottom = comm.exchange(first.contiguous(), last.contiguous())
+        if defer_wait:      # the consumer calls comm.wait() before it reads the rows (interior-first convs)
+            top, bottom = comm.exchange(first.contiguous(), last.contiguous(), defer_wait=True)
+        else:
+            top, bottom = comm.exchange(first.contiguous(), last.contiguous())
         ctx.has = (top is not None, bottom is not None)
         ctx.shape = tuple(first.shape)
         return (top if top is not None else first.new_zeros(0), bottom if bottom is not None else first.new_zeros(0))
@@ -1425,12 +1428,13 @@ class _HaloExchange(torch.autograd.Function):
         up = dtop.contiguous() if ctx.has[0] else z()
         down = dbottom.contiguous() if ctx.has[1] else z()
         from_above, from_below = ctx.comm.exchange(up, down)
-        return (from_above if from_above is not None else z(), from_below if from_below is not None else z(), None)
+        return (from_above if from_above is not None else z(), from_below if from_below is not None else z(), None, None)
 
 
-def halo_exchange(first, last, comm):
-    """-> (top, bottom) with None at the grid's outer border; differentiable."""
-    top, bottom = _HaloExchange.apply(first, last, comm)
+def halo_exchange(first, last, comm, defer_wait=False):
+    """-> (top, bottom) with None at the grid's outer border; differentiable.  ``defer_wait``: the transfers are only posted;
+    the caller runs whatever does not need the rows and then calls ``comm.wait()``."""
+    top, bottom = _HaloExchange.apply(first, last, comm, defer_wait)
     return (top if top.numel() else None), (bottom if bottom.numel() else None)
 
 

@@ -496,8 +496,10 @@ def free_port():
         return s_.getsockname()[1]
 
 
-@pytest.mark.parametrize("tag,world", [("bn_nl4_sn", 2), ("bn_nl4_g44", 2), ("bn_nl4_g44", 4)])
-def test_band_sharded_train_step_matches_reference_golden(tag, world, tmp_path):
+@pytest.mark.parametrize("tag,world,interior", [("bn_nl4_sn", 2, False), ("bn_nl4_g44", 2, False), ("bn_nl4_g44", 4, False),
+                                                ("bn_nl4_g44", 2, True)],
+                         ids=["bn_nl4_sn-2", "bn_nl4_g44-2", "bn_nl4_g44-4", "bn_nl4_g44-2-interior_first"])
+def test_band_sharded_train_step_matches_reference_golden(tag, world, interior, tmp_path, monkeypatch):
     """BASELINE config 4's protocol (patch rows of every fake image sharded over ranks, halo rows
     exchanged per conv in forward AND backward, sync-BN, D data-parallel over gathered images) must
     reproduce the single-process reference step.  Ranks are separate processes sharing the one GPU of
@@ -505,6 +507,9 @@ def test_band_sharded_train_step_matches_reference_golden(tag, world, tmp_path):
     config 4's workload shape (4x4 patch grid, 4 images) on 2 and on 4 ranks (one patch row per rank)."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "band")
+    # interior_first (ITG_HALO_INTERIOR=1, read at import by the spawned ranks): every band conv posts its halo exchange,
+    # convolves the rows that need no neighbour row, waits, and convolves the 2 (4 behind the folded upsample) border rows
+    monkeypatch.setenv("ITG_HALO_INTERIOR", "1" if interior else "0")
     mp.spawn(_band_worker, args=(world, free_port(), tag, out), nprocs=world, join=True)
     res = [torch.load("%s.%d" % (out, r)) for r in range(world)]
     fx = load("train_" + tag)

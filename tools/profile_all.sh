@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 export ITG_OVERLAP=0
-CMD="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-direct"
+CMD="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-direct --no-membound"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- $CMD > $OUT/${TAG}_stats.log 2>&1
 echo stats done
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -- $CMD > $OUT/${TAG}_fetch.log 2>&1
