@@ -320,7 +320,7 @@ class _Conv(torch.autograd.Function):
         ctx.in_act, ctx.defer_act = fuse
         # Winograd layers: the transformed input V sits at the start of the forward's workspace; the weight gradient of the
         # same x takes it from there instead of transforming x again (itg_conv_geom.wino_v) - kept only when w takes a gradient
-        ctx.wino_ws = ws if (wino and WINO_KEEP_V and w.requires_grad and torch.is_grad_enabled()) else None
+        ctx.wino_ws = ws if (wino and WINO_KEEP_V and w.requires_grad) else None       # (grad mode reads off inside forward())
         ctx.save_for_backward(x, w, out if act != ACT_NONE else None)
         return out
 
