@@ -268,6 +268,10 @@ class Trainer:
         # (``defer_reduce`` argument: train.py / bench.py decide per workload - on for the launch-bound config 3 under graph replay)
         self.defer_reduce = (os.environ.get("ITG_DEFER_REDUCE", "0") == "1") if defer_reduce is None else bool(defer_reduce)
         self._defer = []
+        # spectrally normalised layers that are not deferred finish their weight gradient through the job reduce (dot in the
+        # reduce launch + one apply launch): -10 launches; pays where the step is launch-bound (config 3 under replay: 2 473 ->
+        # 2 497 crops/s), costs 0.2 % on config 1 - so it follows the deferred reduce unless ITG_SN_FUSED_REDUCE says otherwise
+        self.sn_fused = (os.environ["ITG_SN_FUSED_REDUCE"] == "1") if "ITG_SN_FUSED_REDUCE" in os.environ else self.defer_reduce
         self.set_overlap(self.overlap)
         from .dist import _active
         # two-bucket exchange: default on for the rehearsal backends (gloo / one-rank RCCL, where it is tested), opt-in on a
@@ -405,6 +409,7 @@ class Trainer:
         ops.ARENA = self.arena
         ops.WGRAD_STREAM = self.wstream
         ops.WGRAD_DEFER = self._defer if self.defer_reduce else None
+        sn_keep, ops.SN_FUSED_REDUCE = ops.SN_FUSED_REDUCE, self.sn_fused
         try:
             zs = list(z) if isinstance(z, (list, tuple)) else [z]
             ms = list(maps) if isinstance(maps, (list, tuple)) and isinstance(z, (list, tuple)) else [maps] * len(zs)
@@ -420,6 +425,7 @@ class Trainer:
             ops.ARENA = None
             ops.WGRAD_STREAM = None
             ops.WGRAD_DEFER = None
+            ops.SN_FUSED_REDUCE = sn_keep
             ops.BACKWARD_ENTRY_HOOK = None
             if self.wstream is not None and not torch.cuda.is_current_stream_capturing():
                 ops.WGRAD_KEEPALIVE.clear()
