@@ -551,8 +551,9 @@ class Trainer:
         """The weight-gradient streams have to drain before gradients are exchanged / consumed by Adam; the queued reduces of
         this backward pass run behind them, in one launch."""
         if self.wstream is not None:
+            ops.flush_deferred(per_stream=True)      # each weight-gradient stream reduces its own layers, then is joined
             ops.wgrad_streams_join()
-            ops.flush_deferred()
+            ops.flush_deferred()                     # (ITG_DEFER_STREAMS=0: the single reduce behind the join)
             ops.WGRAD_KEEPALIVE.clear()
         else:
             ops.flush_deferred()
@@ -561,6 +562,7 @@ class Trainer:
         """End of D(real)'s backward on whatever stream it ran: its queued weight gradients are reduced THERE (D(fake)'s
         pass accumulates into the same .grad afterwards and is ordered behind this stream)."""
         if ops.WGRAD_DEFER:
+            ops.flush_deferred(per_stream=True)
             ops.wgrad_streams_join()
             ops.flush_deferred()
 

@@ -635,7 +635,7 @@ def _queue_wgrad(x, dxd, dy, ddy, gwg, w, wsink, bsink, need_w, need_b, sn, st, 
         job.accumulate = (ACC_DW if need_w else 0) | (ACC_DB if need_b else 0)
         keep = ()
     job.db = bsink.data_ptr() if (need_b and bsink is not None) else None
-    pending.append((job, snjob, (ws, x, dy) + keep, key))
+    pending.append((job, snjob, (ws, x, dy) + keep, key, getattr(st, "value", st) or 0))
     return True
 
 
@@ -652,13 +652,28 @@ def _finish_jobs(jobs, st):
         _lib.call("itg_spectral_norm_bwd_multi", (_lib.SnJob * len(chunk))(*chunk), len(chunk), st)
 
 
-def flush_deferred():
-    """Finish every queued weight gradient on the CURRENT stream (which must have been ordered behind the streams the
-    slabs were computed on: wgrad_streams_join)."""
+DEFER_PER_STREAM = os.environ.get("ITG_DEFER_STREAMS", "1") == "1"
+
+
+def flush_deferred(per_stream=False):
+    """Finish every queued weight gradient.  Default: on the CURRENT stream, which must have been ordered behind the streams
+    the slabs were computed on (wgrad_streams_join).  ``per_stream`` (call it BEFORE the join): every stream finishes the
+    layers whose slabs it computed itself - one reduce (+ one spectral-norm) launch per weight-gradient stream and backward
+    pass, issued behind that stream's last contraction, so the reduces run beside the tail of the input-gradient chain
+    instead of behind the join (round 3's single reduce at the join sat on the critical path: 765 vs 780 crops/s)."""
     jobs = WGRAD_DEFER
     if not jobs:
         return
-    _finish_jobs(jobs, _stream())
+    if per_stream and not DEFER_PER_STREAM:
+        return                           # the plain flush behind the join finishes them
+    if per_stream:
+        by = {}
+        for j in jobs:
+            by.setdefault(j[4], []).append(j)
+        for handle, group in by.items():
+            _finish_jobs(group, C.c_void_p(handle))
+    else:
+        _finish_jobs(jobs, _stream())
     if not torch.cuda.is_current_stream_capturing():
         WGRAD_KEEPALIVE.append(tuple(j[2] for j in jobs))       # operands stay referenced until the owner's join clears the list
     del jobs[:]
