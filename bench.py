@@ -636,8 +636,8 @@ def cpu_infer_leg():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)      # 0.7 s of config 1 (20 steps = 0.15 s was a short sample)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-membound", dest="no_membound", action="store_true",
                     help="skip the memory-bound operator probes (roofline.membound): profiler runs, so that the kernel statistics "
