@@ -597,10 +597,11 @@ def _queue_wgrad(x, dxd, dy, ddy, gwg, w, wsink, bsink, need_w, need_b, sn, st, 
         return False
     key = ((wsink if wsink is not None else bsink).data_ptr(), tuple(x.shape), tuple(dy.shape))
     pending = WGRAD_DEFER if queue is None else queue
-    if any(j[3] == key for j in pending):
-        # the same layer queued twice before a flush (a weight-shared conv, a module applied twice in one backward pass): its
-        # persistent slab workspace is still waiting for the reduce and a second contraction would overwrite it (ADVICE r3;
-        # itg.h: two jobs of one launch must not share dw / db) - this call takes the direct path
+    if any(j[3][0] == key[0] for j in pending):
+        # the same gradient sink queued twice before a flush (a weight-shared conv, a module applied twice in one backward
+        # pass - e.g. the interior and border pieces of an interior-first band conv): two jobs of one reduce launch must not
+        # share dw / db (itg.h: they would read-modify-write the same words concurrently), and with equal shapes the second
+        # contraction would also overwrite the first one's persistent slabs - this call takes the direct path
         return False
     nws = _lib.fn("itg_conv2d_wgrad_workspace")(C.byref(dxd), C.byref(ddy), C.byref(gwg))
     ws = _persistent(("ws",) + key, nws, x.device)

@@ -789,6 +789,8 @@ def test_bucketed_gradient_exchange_with_lookahead_equals_the_plain_exchange(tmp
     the next iteration issued beside the head bucket's all-reduce.  Same arithmetic, so the same losses and parameters
     (up to the summation order of the atomics in the BatchNorm statistics)."""
     import torch.multiprocessing as mp
+    if os.environ.get("ITG_DEFER_REDUCE", "0") == "1":
+        pytest.skip("deferred weight-gradient reduces finish the tail's gradients only at the join: single bucket by design")
     tag, world = "bn_nl4_sn", 2
     res = {}
     for name, env, ahead in (("plain", {"ITG_BUCKETS": "0", "ITG_OVERLAP": "0"}, False),
