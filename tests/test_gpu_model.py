@@ -5,6 +5,8 @@ Gradient methodology: forward tensors at <= 1e-4 rel-L2 (fp3
 post-step parameters at 2e-3 on tiny models (flip-free seeds); conv biases that feed a BatchNorm
 have mathematically zero gradient and are only required to stay within the +-lr drift Adam(beta1=0)
 gives them."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -877,9 +879,10 @@ def test_one_rank_rccl_collectives_leave_the_step_unchanged(tmp_path, sync_bn):
     schedule of a data-parallel rank - stream overlap, the tail bucket's asynchronous all-reduce on the communication
     stream under the backward, D(real) of the next iteration beside G's head bucket."""
     import json
-    import os
     import subprocess
     import sys
+    if os.environ.get("ITG_DEFER_REDUCE", "0") == "1":
+        pytest.skip("deferred weight-gradient reduces: single bucket by design (the script asserts the two-bucket exchange)")
     env = dict(os.environ, ITG_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY="0", ITG_TEST_SYNC_BN=sync_bn)
     out = str(tmp_path / "nccl1.pt")
