@@ -230,6 +230,77 @@ def test_all_gather_with_wrong_static_heights_fails_on_the_bad_rank_without_hang
     assert r1[0].startswith("ValueError") and "announced as 4" in r1[0] and r1[1] == 2.0
 
 
+def switches_worker(rank, world, port, out, differ):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if differ and rank == 1:
+        os.environ["ITG_BUCKETS"] = "1"            # only this rank would issue the two-bucket exchange
+    else:
+        os.environ.pop("ITG_BUCKETS", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from infinite_texture_gans_amd.dist import SyncGroup
+        from infinite_texture_gans_amd.engine import Trainer
+
+        class Stub:                                  # what Trainer._check_switches_agree reads of a trainer
+            sync, sync_bn, device = SyncGroup(dist.group.WORLD), False, "cpu"
+        res = "agree"
+        try:
+            Trainer._check_switches_agree(Stub())
+        except RuntimeError as e:
+            res = str(e)
+        z = torch.ones(1)
+        dist.all_reduce(z)                           # the ranks are still in step
+        torch.save((res, float(z)), out + str(rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("differ", [False, True], ids=["same_switches", "one_rank_differs"])
+def test_ranks_that_disagree_on_a_collective_switch_fail_together_instead_of_hanging(tmp_path, differ):
+    """ITG_BUCKETS / ITG_WARM_COLLECTIVES / ... decide WHICH collectives a rank issues; if they differ between ranks
+    the sequences diverge and the job hangs in Trainer's constructor.  One unconditional all-reduce of their values makes a
+    mismatch a RuntimeError on EVERY rank."""
+    out = str(tmp_path / "sw")
+    mp.spawn(switches_worker, args=(2, free_port(), out, differ), nprocs=2, join=True)
+    r0, r1 = torch.load(out + "0"), torch.load(out + "1")
+    assert r0[1] == 2.0 and r1[1] == 2.0
+    if differ:
+        assert "ITG_BUCKETS" in r0[0] and "ITG_BUCKETS" in r1[0], (r0, r1)
+    else:
+        assert r0[0] == "agree" and r1[0] == "agree"
+
+
+def strips_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from infinite_texture_gans_amd.dist import RowHalo
+        from infinite_texture_gans_amd import utils as U
+        halo = RowHalo(rank, world, dist.group.WORLD)
+        t_h, p, out_h, w = 7, 4, 26, 5                    # 7 patch rows of 4 pixels on 3 ranks (3 + 2 + 2), cropped to 26 rows
+        rows = U.strip_rows(halo, t_h, p, out_h)
+        lo, hi = rows[rank]
+        full = torch.arange(1 * 2 * 28 * w, dtype=torch.float32).reshape(1, 2, 28, w)
+        img = U.gather_strips(full[:, :, lo:hi].clone(), halo, rows)
+        if rank == 0:
+            torch.save({"rows": rows, "img": img}, out)
+        else:
+            assert img is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ragged_strips_of_a_row_sharded_image_are_gathered_as_tensors(tmp_path):
+    """utils.gather_strips (test_sample.py on N ranks): rank r's strip of output rows - ragged bands, the last one cropped to the
+    requested height - lands in rank 0's preallocated image by point-to-point tensor transfers (round 3: gather_object)."""
+    out = str(tmp_path / "strips.pt")
+    mp.spawn(strips_worker, args=(3, free_port(), out), nprocs=3, join=True)
+    got = torch.load(out)
+    assert got["rows"] == [(0, 12), (12, 20), (20, 26)]
+    full = torch.arange(1 * 2 * 28 * 5, dtype=torch.float32).reshape(1, 2, 28, 5)
+    assert torch.equal(got["img"], full[:, :, :26])
+
+
 # ------------------------------------------------------------------------------- two-bucket gradient exchange
 class _Flat:
     """What engine.GradExchange needs of engine.FlatParams: the flat gradient buffer."""
