@@ -173,6 +173,8 @@ int try_conv_valu(const ConvP& p, hipStream_t s, int* rc);
 int try_conv_tile(ConvP& p, hipStream_t s, int* rc);
 int try_conv_s2k4(const ConvP& p, hipStream_t s, int* rc);
 int try_conv_up2_tile(const ConvP& p, hipStream_t s, int* rc);
+// conv_strip.hip
+int try_conv_strip(const ConvP& p, hipStream_t s, int* rc);
 // conv_wino.hip: Winograd F(4 x 4, R x R) for wide stride-1 layers (R = 4: the discriminator's 256 -> 512 layer; R = 3: the
 // generator's wide blocks)
 int64_t wino_workspace_floats(const itg_tensor* in, const itg_tensor* out, int R, int fold);

@@ -281,6 +281,7 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
     if (try_conv_valu(p, s, &rc_v)) return rc_v;
     if (try_conv_s2k4(p, s, &rc_v)) return rc_v;
     if (p.ncls == 4 && try_conv_up2_tile(p, s, &rc_v)) return rc_v;
+    if (try_conv_strip(p, s, &rc_v)) return rc_v;
   }
   {
     int rc_tile = ITG_OK;

@@ -92,6 +92,13 @@ CONV_CASES = [
     ("tile3x3_rep_3_13", 1, (3, 3), 32, 3, 13, 3, 1, 1, "replicate"),                # cin_ld 4: four taps per K chunk
     ("tile3x3_zero_7_2_thin", 2, (2, 3), 36, 7, 2, 3, 1, 1, "constant"),             # <= 4 outputs: 4x4x1-MFMA weight gradient, 16 groups / pass
     ("tile3x3_rep_16_4_thin", 1, (2, 2), 40, 16, 4, 3, 1, 1, "replicate"),           # all four output rows live
+    # ... on power-of-two patches >= 32 wide: the barrier-free strip kernels (forward; input gradient with the replicate frame
+    # folded in register), every (input chunks, output row tiles) instantiation
+    ("strip3x3_rep_13_13", 2, (3, 3), 32, 13, 13, 3, 1, 1, "replicate"),             # 96x96: segments end inside the image
+    ("strip3x3_zero_26_26", 1, (2, 3), 32, 26, 26, 3, 1, 1, "constant"),             # two chunks x two row tiles, zero frame
+    ("strip3x3_rep_26_13", 1, (3, 3), 32, 26, 13, 3, 1, 1, "replicate"),             # 2 x 1 forward, 1 x 2 input gradient
+    ("strip3x3_rep_8_16_p64", 1, (1, 2), 64, 8, 16, 3, 1, 1, "replicate"),           # one patch row, 8-float pixels
+    ("strip3x3_rep_16_20_tall", 1, (2, 1), 128, 16, 20, 3, 1, 1, "replicate"),       # 256 x 128: one strip column of patches
     # 4x4 stride-2 layers with <= 4 input channels on images >= 128^2 (the discriminator's first layer): stride-2 halo-tile kernel
     ("d4x4_s2_3_64_tile", 1, (3, 3), 48, 3, 64, 4, 2, 1, "zeros"),                    # patch-grid input, 72x72 out: partial tiles
     ("d4x4_s2_3_24_tile", 2, (1, 1), 130, 3, 24, 4, 2, 1, "zeros"),                   # 32 filter rows, odd tile counts
@@ -150,6 +157,62 @@ def test_conv_fwd_dgrad_wgrad(case, prec):
     # a bias gradient is one fp32 sum per channel: bound the error by the magnitude of the summed terms
     # (with one output channel the rel-L2 of a single cancelling sum is not a meaningful measure)
     assert float((dbg.cpu() - dbr).abs().max()) <= tol_b * float(dyl.abs().sum((0, 2, 3)).max())
+
+
+STRIP_CASES = [
+    # name, n, (gh, gw), P, cin, cout, mode, residual (None | "same" | "half"), act, stats
+    ("b6c2_fwd_13_13_half_res_stats", 2, (3, 3), 64, 13, 13, "replicate", "half", "none", True),     # the generator's conv2: + shortcut through the upsample, BatchNorm sums
+    ("b5c2_fwd_26_26_same_res_lrelu", 1, (2, 3), 32, 26, 26, "replicate", "same", "lrelu", True),
+    ("zero_frame_13_26_tanh", 1, (3, 2), 32, 13, 26, "constant", None, "tanh", False),
+    ("many_units_per_wave_16_16", 5, (4, 4), 128, 16, 16, "replicate", None, "lrelu", True),         # 512^2 x 5: persistent waves take several units
+]
+
+
+@pytest.mark.parametrize("case", STRIP_CASES, ids=[c[0] for c in STRIP_CASES])
+def test_conv_strip_kernel_epilogues_and_fold(case):
+    """conv_strip.hip (reference models/layers.py:25-34 behind LocalPadder :145-173, the residual sum of :313-322): the
+    barrier-free strip kernel with its whole epilogue - bias, same-size or half-size residual, activation, BatchNorm sums -
+    against F.conv2d on the merged image, and its input gradient (the replicate frame folded in register, the activation
+    derivative of the producing layer multiplied in) against autograd.  2e-6 / 5e-6 rel-L2: the conv tests' fp32 bounds."""
+    ops = _ops()
+    from oracle import patches as P
+    name, n, (gh, gw), p, cin, cout, mode, residual, act, stats = case
+    g = _gen(zlib.crc32(name.encode()) % 1000)
+    x = torch.randn(n * gh * gw, cin, p, p, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    rp = p if residual == "same" else p // 2
+    r = torch.randn(n * gh * gw, cout, rp, rp, generator=g) if residual else None
+    xr, wr = x.clone().requires_grad_(True), w.clone()
+    m = P.merge(xr, gh, gw)
+    pre = F.conv2d(F.pad(m, (1,) * 4, mode="replicate"), wr, b) if mode == "replicate" else F.conv2d(m, wr, b, padding=1)
+    if residual:
+        rm = P.merge(r, gh, gw)
+        pre = pre + (rm if residual == "same" else F.interpolate(rm, scale_factor=2, mode="nearest"))
+    yr = {"none": lambda t: t, "lrelu": lambda t: F.leaky_relu(t, 0.2), "tanh": torch.tanh}[act](pre)
+    xg = x.to(cuda).requires_grad_(True)
+    gx = ops.to_grid(xg, gh, gw, merged=False)
+    gr = ops.to_grid(r.to(cuda), gh, gw, merged=False) if residual else None
+    pm = ops.PAD_REPLICATE if mode == "replicate" else ops.PAD_ZERO
+    a = {"none": ops.ACT_NONE, "lrelu": ops.ACT_LRELU, "tanh": ops.ACT_TANH}[act]
+    y = ops.conv(gx, w.to(cuda), b.to(cuda), 3, 3, 1, 1, pm, a, 0.2, residual=gr, out_stats=stats)
+    assert ops._lib.fn("itg_last_conv_kernel")().decode().startswith("conv_strip_kernel")
+    yg = ops.to_nchw(y, merged=True)
+    assert rel_l2(yg.detach().cpu(), yr.detach()) < 2e-6, rel_l2(yg.detach().cpu(), yr.detach())
+    if y.t.shape[-1] > cout:
+        assert float(y.t.detach()[..., cout:].abs().max()) == 0.0      # pad channels stay zero
+    if stats:
+        t = y.t.detach().double().reshape(-1, y.t.shape[-1])
+        assert rel_l2(y.stats.cpu(), torch.cat((t.sum(0), (t * t).sum(0))).cpu()) < 1e-6
+    dy = torch.randn(yr.shape, generator=g)
+    # reference gradient through the activation pattern of the output under test (SURVEY F10: among 10^7 pre-activations a
+    # few sit within rounding of 0, and a flipped LeakyReLU derivative is not a kernel error)
+    yc = yg.detach().cpu()
+    dpre = dy * (torch.where(yc > 0, 1.0, 0.2) if act == "lrelu" else (1 - yc * yc) if act == "tanh" else 1.0)
+    (dxr,) = torch.autograd.grad(pre, xr, dpre)
+    (dxg,) = torch.autograd.grad(yg, xg, dy.to(cuda))
+    assert ops._lib.fn("itg_last_conv_kernel")().decode().startswith("conv_strip_kernel")
+    assert rel_l2(dxg.cpu(), dxr) < 5e-6, rel_l2(dxg.cpu(), dxr)
 
 
 WINO_CASES = [
@@ -225,7 +288,7 @@ def test_input_gradient_only_call_on_the_halo_tile_path_eager_and_captured(ci, c
     dy[..., :co] = torch.randn(*y.t.shape[:-1], co, generator=g)
     dyg = dy.to(cuda)
     (dx,) = torch.autograd.grad(y.t, xg, dyg)
-    assert ops._lib.fn("itg_last_conv_kernel")().decode().startswith("conv_tile_kernel")
+    assert ops._lib.fn("itg_last_conv_kernel")().decode().startswith(("conv_strip_kernel", "conv_tile_kernel"))
     del y
     xm = ops.to_nchw(ops.GT(xg.detach(), ci), merged=True).cpu().double().requires_grad_(True)
     yr = F.conv2d(F.pad(xm, (1, 1, 1, 1), mode="replicate"), w.double())
