@@ -224,7 +224,6 @@ class Trainer:
                 for m in netD.modules():
                     if isinstance(m, _BNParams):
                         m.sync = sync
-        self._check_switches_agree()
         self.flatG, self.flatD = FlatParams(netG), FlatParams(netD)
         from .models.layers import _ConvParams
         for net in (netG, netD):        # backward kernels accumulate straight into the flat .grad buffers
@@ -280,7 +279,9 @@ class Trainer:
         if dist_group is not None and self.world > 1 and torch.device(device).type == "cuda":
             import torch.distributed as _dist
             multi_rccl = _dist.get_backend(dist_group) == "nccl"      # the backend of the group that was passed, not the environment
-        if self.sync is not None and _active(self.sync) and os.environ.get("ITG_BUCKETS", "0" if multi_rccl else "1") == "1":
+        buckets = os.environ.get("ITG_BUCKETS", "0" if multi_rccl else "1") == "1"
+        self._check_switches_agree(buckets)
+        if self.sync is not None and _active(self.sync) and buckets:
             # the early buckets travel on the D(real) branch stream: idle during both backward passes that are exchanged
             issue = self.side if self.overlap else None
             early = not self.defer_reduce      # deferred reduces finish the tail's gradients only at the join: single bucket
@@ -292,22 +293,37 @@ class Trainer:
 
         self._warm_collectives()
 
-    def _check_switches_agree(self):
-        """The per-process switches that decide WHICH collectives a rank issues (bucketed exchange, warm-up, sync-BN, deferred
-        reduces, stream overlap) must be equal on all ranks, or the collective sequences diverge and the job hangs in the
-        constructor.  One unconditional all-reduce of their values; a mismatch raises on every rank."""
+    def _check_switches_agree(self, buckets):
+        """The RESOLVED per-process decisions about which collectives a rank issues (bucketed exchange and its head share,
+        warm-up, sync-BN, deferred reduces - constructor argument, --wgrad_reduce or environment -, the spectral-norm reduce that
+        follows them, stream overlap) must be equal on all ranks, or the collective sequences diverge and the job hangs
+        (ADVICE r3 / r4).  Called once every decision is taken and before the first conditional collective; two unconditional
+        integer all-reduces (MIN, MAX) and exact equality: a mismatch raises on every rank."""
         if self.sync is None or self.sync.world <= 1:
             return
-        names = ("ITG_BUCKETS", "ITG_BUCKET_HEAD", "ITG_WARM_COLLECTIVES", "ITG_SYNC_BN", "ITG_DEFER_REDUCE", "ITG_OVERLAP")
-        mine = [float(sum(ord(c) * (i + 1) for i, c in enumerate(os.environ.get(n, "")))) for n in names] + [float(self.sync_bn)]
+        names = ("bucketed gradient exchange (ITG_BUCKETS)", "head bucket share (ITG_BUCKET_HEAD)", "collective warm-up (ITG_WARM_COLLECTIVES)",
+                 "sync-BN (--sync_bn / ITG_SYNC_BN)", "deferred weight-gradient reduce (--wgrad_reduce / ITG_DEFER_REDUCE)",
+                 "fused spectral-norm reduce (ITG_SN_FUSED_REDUCE)", "stream overlap (ITG_OVERLAP)")
+        mine = [int(bool(buckets)), int(round(float(os.environ.get("ITG_BUCKET_HEAD", "0.2")) * 1e6)),
+                int(os.environ.get("ITG_WARM_COLLECTIVES", "1") == "1"), int(self.sync_bn), int(self.defer_reduce), int(self.sn_fused),
+                int(self.overlap)]
         dev = self.device if torch.device(self.device).type == "cuda" else "cpu"
-        t = torch.tensor(mine + [v * v for v in mine], dtype=torch.float64, device=dev)
-        self.sync.dist.all_reduce(t, op=self.sync.dist.ReduceOp.SUM, group=self.sync.group)
-        k, w = len(mine), float(self.sync.world)
-        for i, n in enumerate(names + ("sync_bn",)):
-            mean, msq = float(t[i]) / w, float(t[k + i]) / w
-            if abs(msq - mean * mean) > 1e-6 * max(1.0, msq):      # variance over ranks != 0
-                raise RuntimeError("the ranks of this job disagree on %s: set it identically on every rank" % n)
+        lo = torch.tensor(mine, dtype=torch.int64, device=dev)
+        hi = lo.clone()
+        self.sync.dist.all_reduce(lo, op=self.sync.dist.ReduceOp.MIN, group=self.sync.group)
+        self.sync.dist.all_reduce(hi, op=self.sync.dist.ReduceOp.MAX, group=self.sync.group)
+        bad = [n for n, a, b in zip(names, lo.tolist(), hi.tolist()) if a != b]
+        if bad:
+            raise RuntimeError("the ranks of this job disagree on %s: set it identically on every rank" % ", ".join(bad))
+
+    def set_defer_reduce(self, on):
+        """Switch the deferred weight-gradient reduce between steps (train.py --launch_mode auto decides it with the launch
+        mode, after its probe).  Single-rank engines only: the gradient exchange fixed its bucket plan at construction."""
+        if self._exchange:
+            raise RuntimeError("the deferred reduce of a data-parallel engine is fixed at construction")
+        self.defer_reduce = bool(on)
+        if "ITG_SN_FUSED_REDUCE" not in os.environ:
+            self.sn_fused = self.defer_reduce
 
     def _warm_collectives(self):
         """RCCL sets up channels, proxy threads and per-size algorithm state lazily inside the first collectives of a process
@@ -574,6 +590,7 @@ class Trainer:
         state and step counters, BN/SN buffers all live in device memory, nothing is read back."""
         self._g_real, self._g_z = real_x.clone(), z.clone()
         self._g_maps = None if maps is None or maps[0] is None else [m.clone() for m in maps]
+        keep_fork = self.nested_fork
         if "ITG_NESTED_FORK" not in os.environ:
             # a replayed graph places its branches itself: D(real)'s weight gradients leaving their branch stream help the
             # eager queues (+1 %) and cost the replay 5 % (config 1: 1 047 vs 1 101 crops/s, the eager number; config 3 neutral)
@@ -597,22 +614,28 @@ class Trainer:
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
         del ops.CAPTURE_ERRORS[:]
-        with torch.cuda.stream(cap):
-            _lib.CAPTURE_LOG = {cap.cuda_stream}
-            self.graph.capture_begin()
-            try:
-                self._g_out = self.step(self._g_real, self._g_z, self._g_maps)
-            finally:
-                _lib.CAPTURE_LOG = None
-                self.graph.capture_end()
-        torch.cuda.current_stream().wait_stream(cap)
-        if ops.CAPTURE_ERRORS:
-            errs, self.graph = list(ops.CAPTURE_ERRORS), None
-            del ops.CAPTURE_ERRORS[:]
-            raise RuntimeError("Trainer.capture: the step's stream schedule breaks the capture rule (the recorded graph would have "
-                               "crashed hipStreamEndCapture and was discarded): " + "; ".join(errs))
-        self.optD.t -= 1      # capture only records: undo the host-side counters of the recorded call
-        self.optG.t -= 1
+        t_before = (self.optD.t, self.optG.t)      # recording does not train: the host-side step counters are put back
+        try:
+            with torch.cuda.stream(cap):
+                _lib.CAPTURE_LOG = {cap.cuda_stream}
+                self.graph.capture_begin()
+                try:
+                    self._g_out = self.step(self._g_real, self._g_z, self._g_maps)
+                finally:
+                    _lib.CAPTURE_LOG = None
+                    self.graph.capture_end()
+            torch.cuda.current_stream().wait_stream(cap)
+            if ops.CAPTURE_ERRORS:
+                errs = list(ops.CAPTURE_ERRORS)
+                del ops.CAPTURE_ERRORS[:]
+                raise RuntimeError("Trainer.capture: the step's stream schedule breaks the capture rule (the recorded graph would have "
+                                   "crashed hipStreamEndCapture and was discarded): " + "; ".join(errs))
+        except BaseException:
+            # whatever failed, the engine stays usable for eager steps (train.py --launch_mode auto falls back to them)
+            self.graph, self.nested_fork = None, keep_fork
+            self.optD.t, self.optG.t = t_before
+            raise
+        self.optD.t, self.optG.t = t_before
         return self
 
     def step_graphed(self, real_x, z, maps=None):

@@ -320,7 +320,9 @@ class _Conv(torch.autograd.Function):
         ctx.in_act, ctx.defer_act = fuse
         # Winograd layers: the transformed input V sits at the start of the forward's workspace; the weight gradient of the
         # same x takes it from there instead of transforming x again (itg_conv_geom.wino_v) - kept only when w takes a gradient
-        ctx.wino_ws = ws if (wino and WINO_KEEP_V and w.requires_grad) else None       # (grad mode reads off inside forward())
+        # (only where the weight gradient can consume it - fp32 operands, Winograd weight gradient on; the workspace
+        # is V followed by the GEMM result M, one allocation behind one C-ABI pointer: M's ~40 MB per pass stay alive with V)
+        ctx.wino_ws = ws if (wino and WINO_KEEP_V and WINOGRAD_WGRAD and prec == PREC_F32 and w.requires_grad) else None       # (grad mode reads off inside forward())
         ctx.save_for_backward(x, w, out if act != ACT_NONE else None)
         return out
 
@@ -597,7 +599,10 @@ def _queue_wgrad(x, dxd, dy, ddy, gwg, w, wsink, bsink, need_w, need_b, sn, st, 
         return False
     key = ((wsink if wsink is not None else bsink).data_ptr(), tuple(x.shape), tuple(dy.shape))
     pending = WGRAD_DEFER if queue is None else queue
-    if any(j[3][0] == key[0] for j in pending):
+    # (a private queue - the spectral-norm fused reduce - shares the persistent slabs with the step's deferred queue: a sink
+    # that is still pending THERE must not have its slabs overwritten either)
+    also = WGRAD_DEFER if (queue is not None and WGRAD_DEFER is not None and WGRAD_DEFER is not queue) else ()
+    if any(j[3][0] == key[0] for j in pending) or any(j[3][0] == key[0] for j in also):
         # the same gradient sink queued twice before a flush (a weight-shared conv, a module applied twice in one backward
         # pass - e.g. the interior and border pieces of an interior-first band conv): two jobs of one reduce launch must not
         # share dw / db (itg.h: they would read-modify-write the same words concurrently), and with equal shapes the second

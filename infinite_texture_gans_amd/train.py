@@ -75,10 +75,18 @@ def launch_plan(args, world, band):
     if wr not in ("auto", "layer", "deferred"):
         raise ValueError("--wgrad_reduce must be auto, layer or deferred")
     crop = args.center_crop or args.random_crop or 1 << 30
-    defer = wr == "deferred" or (wr == "auto" and bool(use_graph) and crop <= 128)
+    # "probe": the engine starts with per-layer reduces (the eager schedule) and train() switches the deferred form on together
+    # with the replay if the probe picks it (Trainer.set_defer_reduce)
+    defer = wr == "deferred" or (wr == "auto" and use_graph is True and crop <= 128)
     if "ITG_DEFER_REDUCE" in os.environ and wr == "auto":
         defer = os.environ["ITG_DEFER_REDUCE"] == "1"
     return use_graph, defer
+
+
+def defer_with_replay(args):
+    """Does --wgrad_reduce auto pick the deferred reduce once --launch_mode auto has decided for replay?"""
+    crop = args.center_crop or args.random_crop or 1 << 30
+    return getattr(args, "wgrad_reduce", "auto") == "auto" and "ITG_DEFER_REDUCE" not in os.environ and crop <= 128
 
 
 def train(args):
@@ -142,12 +150,32 @@ def train(args):
         return U.sample_latents_zeros(netG, args.z_dim, args.base_res, args.map_dim, args.num_images, device)
 
     recorded_lr = None          # (lr_D, lr_G) the recorded graph was captured with: the learning rates are kernel arguments
+    fatal_capture = getattr(args, "launch_mode", "auto") == "graph"      # auto falls back to eager launches, graph does not
+
+    def record(real_x, z0, m0):
+        """Record the step; returns False (and says why, once) when the capture fails and the run is to go on eagerly in
+        this process (an op that cannot be captured, the capture rule of ops.capture_rule, an out-of-memory on the
+        graph's private pool during a re-record must not end a training that runs eagerly) - never by restarting: the GPU is
+        initialised."""
+        try:
+            tr.capture(real_x, z0, m0, warmup=0)
+            return True
+        except Exception as e:      # noqa: BLE001 - whatever the capture raised, eager launches still work
+            if fatal_capture:
+                raise
+            tr.graph = None
+            if rank == 0:
+                print("launch (auto): recording the step failed (%s: %s) - continuing with eager launches" % (type(e).__name__, e))
+            return False
 
     print("Starting Training Loop...")
     for epoch in range(args.epochs):
         d_run = torch.zeros((), device=device)
         g_run = torch.zeros((), device=device)
         n_d = n_g = 0
+        if use_graph == "probe":
+            # the probe's five iterations lie inside ONE epoch: the epoch-end host sync, checkpoint and print stay out of its clock
+            probe = {"n": 0, "issue": 0.0, "start": 0.0}
         for data_b in data:
             real_x = data_b[0]
             b = real_x.shape[0]
@@ -167,6 +195,8 @@ def train(args):
                     torch.cuda.synchronize()
                     wall = time.perf_counter() - probe["start"]
                     use_graph = probe["issue"] > 0.9 * wall
+                    if use_graph and defer_with_replay(args):
+                        tr.set_defer_reduce(True)          # the schedule that pays under replay (launch_plan)
                     if rank == 0:
                         print("launch (auto): the host issues an iteration in %.2f ms, the GPU finishes one every %.2f ms -> %s"
                               % (probe["issue"] / 4 * 1e3, wall / 4 * 1e3, "hipGraph replay" if use_graph else "eager"))
@@ -178,15 +208,22 @@ def train(args):
                 if recorded_lr is None:
                     _, _, g_loss = tr.step(real_x, z0, m0)
                     losses = list(tr.d_losses)
-                    tr.capture(real_x, z0, m0, warmup=0)
-                    recorded_lr, graph_losses = (tr.optD.lr, tr.optG.lr), tr.d_losses      # the graph's static loss tensors
+                    if record(real_x, z0, m0):
+                        recorded_lr, graph_losses = (tr.optD.lr, tr.optG.lr), tr.d_losses      # the graph's static loss tensors
+                    else:
+                        use_graph = False
                     tr.d_losses = losses                      # this iteration's losses are the eager step's
                 else:
                     if recorded_lr != (tr.optD.lr, tr.optG.lr):
-                        tr.capture(real_x, z0, m0, warmup=0)
-                        recorded_lr, graph_losses = (tr.optD.lr, tr.optG.lr), tr.d_losses
-                    _, _, g_loss = tr.step_graphed(real_x, z0, m0)
-                    tr.d_losses = graph_losses
+                        if record(real_x, z0, m0):
+                            recorded_lr, graph_losses = (tr.optD.lr, tr.optG.lr), tr.d_losses
+                        else:
+                            use_graph = False
+                    if use_graph:
+                        _, _, g_loss = tr.step_graphed(real_x, z0, m0)
+                        tr.d_losses = graph_losses
+                    else:
+                        _, _, g_loss = tr.step(real_x, z0, m0)
             else:
                 _, _, g_loss = tr.step(real_x, [l[0] for l in lat], [l[1] for l in lat])
             for d_real, d_fake in tr.d_losses:

@@ -232,20 +232,24 @@ def test_all_gather_with_wrong_static_heights_fails_on_the_bad_rank_without_hang
 
 def switches_worker(rank, world, port, out, differ):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    if differ and rank == 1:
-        os.environ["ITG_BUCKETS"] = "1"            # only this rank would issue the two-bucket exchange
-    else:
-        os.environ.pop("ITG_BUCKETS", None)
+    os.environ.pop("ITG_BUCKETS", None)
+    os.environ.pop("ITG_BUCKET_HEAD", None)
+    if differ == "bucket_head_last_digit" and rank == 1:
+        os.environ["ITG_BUCKET_HEAD"] = "0.21"       # a value whose hash differs by little (the float-variance test of r4 missed those)
+    if differ == "explicit_default" and rank == 1:
+        os.environ["ITG_BUCKET_HEAD"] = "0.2"        # the default written out: NOT a disagreement (r4 raised a false mismatch)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from infinite_texture_gans_amd.dist import SyncGroup
         from infinite_texture_gans_amd.engine import Trainer
 
-        class Stub:                                  # what Trainer._check_switches_agree reads of a trainer
+        class Stub:                                  # what Trainer._check_switches_agree reads of a trainer: RESOLVED decisions
             sync, sync_bn, device = SyncGroup(dist.group.WORLD), False, "cpu"
+            overlap, sn_fused = True, False
+            defer_reduce = differ == "defer_reduce_argument" and rank == 1     # --wgrad_reduce deferred on one rank only
         res = "agree"
         try:
-            Trainer._check_switches_agree(Stub())
+            Trainer._check_switches_agree(Stub(), buckets=(differ == "buckets" and rank == 1))
         except RuntimeError as e:
             res = str(e)
         z = torch.ones(1)
@@ -255,19 +259,21 @@ def switches_worker(rank, world, port, out, differ):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("differ", [False, True], ids=["same_switches", "one_rank_differs"])
+@pytest.mark.parametrize("differ", [None, "explicit_default", "buckets", "defer_reduce_argument", "bucket_head_last_digit"])
 def test_ranks_that_disagree_on_a_collective_switch_fail_together_instead_of_hanging(tmp_path, differ):
-    """ITG_BUCKETS / ITG_WARM_COLLECTIVES / ... decide WHICH collectives a rank issues; if they differ between ranks
-    the sequences diverge and the job hangs in Trainer's constructor.  One unconditional all-reduce of their values makes a
-    mismatch a RuntimeError on EVERY rank."""
+    """the bucketed exchange, the deferred reduce (constructor argument / --wgrad_reduce as much as the
+    environment), sync-BN ... decide WHICH collectives a rank issues; if they differ between ranks the sequences diverge and
+    the job hangs.  Trainer compares the RESOLVED decisions with two integer all-reduces (MIN, MAX) once they are all taken: a
+    mismatch is a RuntimeError on EVERY rank, an explicitly written default is not a mismatch."""
     out = str(tmp_path / "sw")
     mp.spawn(switches_worker, args=(2, free_port(), out, differ), nprocs=2, join=True)
     r0, r1 = torch.load(out + "0"), torch.load(out + "1")
     assert r0[1] == 2.0 and r1[1] == 2.0
-    if differ:
-        assert "ITG_BUCKETS" in r0[0] and "ITG_BUCKETS" in r1[0], (r0, r1)
+    word = {"buckets": "ITG_BUCKETS", "defer_reduce_argument": "--wgrad_reduce", "bucket_head_last_digit": "ITG_BUCKET_HEAD"}.get(differ)
+    if word:
+        assert word in r0[0] and word in r1[0], (r0, r1)
     else:
-        assert r0[0] == "agree" and r1[0] == "agree"
+        assert r0[0] == "agree" and r1[0] == "agree", (r0, r1)
 
 
 def strips_worker(rank, world, port, out):

@@ -115,6 +115,9 @@ def _rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
+_ORACLE_RUNS = {}
+
+
 def _fullsize_step(flags, nl_G, attention, crop, prec, fp64_truth=False, grid=3, band=False):
     """One train iteration at a BASELINE configuration on identical seeded state / real_x / z: HIP Trainer vs the
     CPU oracle's train_step.  Returns the comparison numbers."""
@@ -138,15 +141,22 @@ def _fullsize_step(flags, nl_G, attention, crop, prec, fp64_truth=False, grid=3,
     real = torch.rand(8, 3, crop, crop, generator=g) * 2 - 1
     z = torch.randn(8, 128, 4 * grid + 2, 4 * grid + 2, generator=g)
     torch.set_num_threads(16)
-    truth = None
-    if fp64_truth:      # the same step in fp64 on the same initial state: the yardstick for gradient errors (F10)
-        g64 = ostep.as_leaf_params({k: (v.detach().double() if v.is_floating_point() else v.clone()) for k, v in gsd.items()})
-        d64 = ostep.as_leaf_params({k: (v.detach().double() if v.is_floating_point() else v.clone()) for k, v in dsd.items()})
-        o64D = ostep.Adam([d64[k] for k in ostep.trainable(d64)])
-        o64G = ostep.Adam([g64[k] for k in ostep.trainable(g64)])
-        ostep.train_step(g64, d64, gcfg, dcfg, o64G, o64D, real.double(), z.double(), None, smooth=True)
-        truth = {k: g64[k].grad for k in ostep.trainable(g64)}
-    r = ostep.train_step(gsd, dsd, gcfg, dcfg, optG, optD, real, z, None, smooth=True)
+    # ONE oracle run per configuration and session (_ORACLE_RUNS): oneDNN's threaded summation order moves the fp32 oracle's
+    # own distance to its fp64 run by up to 40 % between runs, so every parametrisation of a test is held to
+    # the yardstick of the same run
+    key = (tuple(flags), nl_G, attention, crop, bool(fp64_truth), grid)
+    if key not in _ORACLE_RUNS:
+        truth = None
+        if fp64_truth:      # the same step in fp64 on the same initial state: the yardstick for gradient errors (F10)
+            g64 = ostep.as_leaf_params({k: (v.detach().double() if v.is_floating_point() else v.clone()) for k, v in gsd.items()})
+            d64 = ostep.as_leaf_params({k: (v.detach().double() if v.is_floating_point() else v.clone()) for k, v in dsd.items()})
+            o64D = ostep.Adam([d64[k] for k in ostep.trainable(d64)])
+            o64G = ostep.Adam([g64[k] for k in ostep.trainable(g64)])
+            ostep.train_step(g64, d64, gcfg, dcfg, o64G, o64D, real.double(), z.double(), None, smooth=True)
+            truth = {k: g64[k].grad for k in ostep.trainable(g64)}
+        r = ostep.train_step(gsd, dsd, gcfg, dcfg, optG, optD, real, z, None, smooth=True)
+        _ORACLE_RUNS[key] = (gsd, dsd, r, truth)
+    gsd, dsd, r, truth = _ORACLE_RUNS[key]
     netG, netD = netG.to(cuda).train(), netD.to(cuda).train()
     with ops.mfma_precision(prec):
         tr = BandTrainer(netG, netD, args, cuda, BandComm(0, 1, None)) if band else Trainer(netG, netD, args, cuda)
@@ -221,6 +231,11 @@ def test_config2_full_size_train_step_matches_cpu_oracle_within_1e3(winograd, mo
     for k, e_hip, e_cpu, e_rel in rows:
         assert e_hip <= 2 * e_cpu + 1e-4, (k, e_hip, e_cpu)
         assert e_rel < 1e-2, (k, e_rel)
+    # ... and a bar that does not move with the oracle's run: the HIP gradients against the fp64 truth directly.  Every fp32
+    # implementation sits a handful of LeakyReLU sign flips (~1e-3 each, F10) from the truth, and WHICH flips depends on its
+    # summation orders: measured r4 direct median 0.65e-3 / max 0.86e-3, Winograd 1.03e-3 / 1.36e-3; r5 (strip kernels in the
+    # generator's last blocks: another order) direct 1.30e-3 / 1.81e-3; the fp32 CPU oracle itself 0.8-1.4e-3 / 1.1-3.1e-3.
+    assert sorted(r[1] for r in rows)[len(rows) // 2] <= 2e-3 and max(r[1] for r in rows) <= 4e-3
     # D's first-step gradients (real + fake passes accumulated, as Adam(D) consumed them) against the oracle's: D has
     # one LeakyReLU per layer on far fewer, larger activations than G's backward chain, measured ~1e-5; bar 1e-3
     errs = {k: _rel(o["gradD"][k], ref) for k, ref in o["gradD_ref"].items()}

@@ -330,6 +330,29 @@ def test_capture_rule_bookkeeping():
     torch.cuda.synchronize()
 
 
+def test_winograd_weight_gradient_with_the_forwards_transformed_input_is_bit_exact(monkeypatch):
+    """the Winograd weight gradient that takes the forward's V from the retained workspace (itg_conv_geom.wino_v,
+    ops.WINO_KEEP_V) runs the same transform kernel on the same x as the one that transforms x again: weight and bias
+    gradients are bit-identical (reference layer: models/discriminators.py:196-206)."""
+    ops = _ops()
+    if not (ops.WINOGRAD_WGRAD and os.environ.get("ITG_WINOGRAD_WGRAD", "1") == "1"):
+        pytest.skip("Winograd weight gradient switched off by the environment")
+    monkeypatch.setattr(ops, "WINOGRAD", True)
+    g = _gen(17)
+    x = torch.randn(2, 64, 22, 22, generator=g).to(cuda)
+    w = (torch.randn(96, 64, 4, 4, generator=g) / 32).to(cuda)
+    b = (torch.randn(96, generator=g) * 0.1).to(cuda)
+    grads = {}
+    for keep in (True, False):
+        monkeypatch.setattr(ops, "WINO_KEEP_V", keep)
+        wq, bq = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = ops.conv(ops.to_grid(x, 1, 1, merged=True), wq, bq, 4, 4, 1, 1, ops.PAD_ZERO, ops.ACT_LRELU, 0.2, wino=True)
+        dy = torch.randn(y.t.shape, generator=torch.Generator(device="cuda").manual_seed(5), device=cuda)
+        dy[..., 96:] = 0
+        grads[keep] = torch.autograd.grad(y.t, (wq, bq), dy)
+    assert torch.equal(grads[True][0], grads[False][0]) and torch.equal(grads[True][1], grads[False][1])
+
+
 def test_winograd_layer_rounding_against_fp64_is_at_the_direct_kernels_level():
     """the discriminator's 256 -> 512 layer (reference models/discriminators.py:196-206) through Winograd
     F(4 x 4, 4 x 4), measured against F.conv2d in fp64 on the operand distribution the layer really sees (the previous
@@ -359,6 +382,26 @@ def test_winograd_layer_rounding_against_fp64_is_at_the_direct_kernels_level():
     # Winograd 1.4e-6 on both; round 3's plain fp32 chain: 4.1e-6
     assert errs[False] < 1.5e-6, errs
     assert errs[True] < 2e-6, errs
+    # The INPUT gradient of the same layer.  "At the direct kernels' level" is a forward-only claim: by default
+    # (ITG_WINO_ACC64=1) only the forward GEMMs accumulate blockwise in fp64 - their rounding decides LeakyReLU signs - while the
+    # input-gradient GEMMs stay on the plain fp32 chain (its error enters the gradients linearly): measured 6.6e-6 against the
+    # direct kernel's 4.1e-7, bound 8e-6; with ITG_WINO_ACC64=2 they are blocked as well: bound 2e-6.
+    dy = torch.randn(ref.shape, generator=g)
+    wd = w.double()
+    dx_ref = torch.nn.grad.conv2d_input(x.shape, wd, dy.double(), padding=1)
+    gerrs = {}
+    try:
+        for wino in (False, True):
+            ops.WINOGRAD = wino
+            xq = xg.clone().requires_grad_(True)
+            yq = ops.to_nchw(ops.conv(ops.to_grid(xq, 1, 1, merged=True), wg, bg, 4, 4, 1, 1, ops.PAD_ZERO, wino=wino), merged=True)
+            (dx,) = torch.autograd.grad(yq, xq, dy.to(cuda))
+            gerrs[wino] = float((dx.cpu().double() - dx_ref).norm() / dx_ref.norm())
+    finally:
+        ops.WINOGRAD = keep
+    print("256->512 layer input gradient rel-L2 vs fp64: direct %.2e, Winograd %.2e" % (gerrs[False], gerrs[True]))
+    assert gerrs[False] < 1.5e-6, gerrs
+    assert gerrs[True] < (2e-6 if os.environ.get("ITG_WINO_ACC64", "1") == "2" else 8e-6), gerrs
 
 
 UP2_CASES = [
