@@ -258,6 +258,22 @@ int itg_local_pad_nhwc_fwd(const itg_tensor* x, const itg_tensor* y, int pad_mod
 int itg_local_pad_stream_fwd(const itg_tensor* x, const float* left, const float* top, const float* bottom,
                              const itg_tensor* y, int pad_mode, void* stream);
 
+/* ---- halo rows of a row-sharded band (training; reference models/layers.py:145-173 LocalPadder.forward, with the patch
+ * grid sharded by patch rows over ranks: SURVEY 8e / BASELINE config 4) -------------------------------------------------
+ * ext = (n, 1, 1, H + 2, W, ld): a rank's band in image layout with ONE HALO ROW above and below every image.  Rows
+ * 1 .. H are written by the producer (itg_bn_finalize_apply / itg_bn_apply with y.ph == x.ph + 2 write exactly those rows;
+ * itg_band_interior_copy for producers that cannot), rows 0 / H + 1 by itg_band_halo_fill; the conv then reads ext with
+ * itg_conv_geom.pad_h = 0, and its input gradient has the same layout: itg_band_halo_grad folds the halo rows' gradients
+ * (their own, at a replicate border; the neighbour's, arrived over RCCL) onto rows 1 / H, and itg_bn_bwd_* with
+ * dy.ph == x.ph + 2 read rows 1 .. H of it.  No concatenated copy of the band exists in either direction.
+ * mode_*: 0 = the (n, W, ld) buffer `top` / `bottom` (`above` / `below`), 1 = replicate border, 2 = zero border.        */
+int itg_band_halo_fill(const itg_tensor* ext, const float* top, const float* bottom, int mode_top, int mode_bottom, void* stream);
+int itg_band_halo_grad(const itg_tensor* gext, const float* above, const float* below, int mode_top, int mode_bottom, void* stream);
+/* rows r0 / r1 of every image -> compact (n, W, ld) buffers (what the halo exchange sends); either output may be NULL */
+int itg_band_rows_get(const itg_tensor* ext, int r0, int r1, float* out0, float* out1, void* stream);
+/* to_ext != 0: rows 1 .. H of ext = band; else band = rows 1 .. H of ext (band: (n, 1, 1, H, W, ld))                      */
+int itg_band_interior_copy(const itg_tensor* band, const itg_tensor* ext, int to_ext, void* stream);
+
 /* ---- stream placement probe ---------------------------------------------------------------
  * One wave that occupies `stream`'s hardware queue for `microseconds` (<= 100000) and exits.  No reference counterpart
  * (the reference runs one CUDA stream, train.py:122-171); the step engine overlaps D(real) with the generator forward

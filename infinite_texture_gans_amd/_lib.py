@@ -103,6 +103,10 @@ SIGNATURES = {
     "itg_local_pad_bwd": (_i, [_P, _P, _i, _i, _i, _i, _i, _i, _i, _P]),
     "itg_local_pad_nhwc_fwd": (_i, [_TP, _TP, _i, _P]),
     "itg_local_pad_stream_fwd": (_i, [_TP, _P, _P, _P, _TP, _i, _P]),
+    "itg_band_halo_fill": (_i, [_TP, _P, _P, _i, _i, _P]),
+    "itg_band_halo_grad": (_i, [_TP, _P, _P, _i, _i, _P]),
+    "itg_band_rows_get": (_i, [_TP, _i, _i, _P, _P, _P]),
+    "itg_band_interior_copy": (_i, [_TP, _TP, _i, _P]),
     "itg_nchw_to_grid": (_i, [_P, _TP, _i, _P]),
     "itg_grid_to_nchw": (_i, [_TP, _P, _i, _P]),
     "itg_bn_stats": (_i, [_TP, _P, _P]),

@@ -30,22 +30,26 @@ struct StripP {
   int nstrips;      // 32-pixel strips per image row
   int nseg, L;      // row segments per image, rows per segment
   int units;        // n * nseg * nstrips
-  int lph, lpw;     // log2 of the patch extent (powers of two)
-  int fold;         // input gradient of a replicate-padded layer: frame terms folded in register
-  int H, W;         // merged image extent
+  int lpw;          // log2 of the patch width (a power of two >= 32); patch heights: powers of two, or any height on 1 x 1 grids
+  int fold_v, fold_h;   // input gradient of a replicate-padded layer: frame rows / columns folded in register
+  int rep_v;        // the rows above / below the image are the clamped edge rows (replicate padding with implicit halo rows)
+  int rsh;          // output row t reads input rows t + ky + rsh - 1: 0 with one implicit padding row (the standard layer), 1 for a
+                    // row-sharded band whose input carries its halo rows (pad_h = 0), -1 for that band's input gradient
+  int H, Hin, W;    // output rows, input rows, width of the merged image
   int res_half;     // residual has half the patch extent (read through a nearest x2 upsample)
   unsigned long long* ts;   // ITG_STRIP_DEBUG & 64: cycle stamps of two workgroups' waves (printed by the host)
   int dbg;          // timing experiments (ITG_STRIP_DEBUG; results wrong): 1 no stores, 2 no MFMAs, 4 no loads after the first rows
 };
 
 // pixel index of the first pixel of merged row Y of image n (column 0 of patch column 0)
-__device__ __forceinline__ int strip_rowpix(const GridT& g, int lph, int lpw, int n, int Y) {
-  const int R = Y >> lph, y = Y & (g.ph - 1);
-  return ((((n * g.gh + R) * g.gw) << lph) + y) << lpw;
+__device__ __forceinline__ int strip_rowpix(const GridT& g, int lpw, int n, int Y) {
+  int R = 0, y = Y;
+  if (g.gh > 1) { const int lph = 31 - __clz(g.ph); R = Y >> lph; y = Y & (g.ph - 1); }      // (power-of-two patch height)
+  return (((n * g.gh + R) * g.gw) * g.ph + y) << lpw;
 }
 // ... plus this for merged column X
-__device__ __forceinline__ int strip_colpix(const GridT& g, int lph, int lpw, int X) {
-  return ((X >> lpw) << (lph + lpw)) + (X & (g.pw - 1));
+__device__ __forceinline__ int strip_colpix(const GridT& g, int lpw, int X) {
+  return (X >> lpw) * (g.ph << lpw) + (X & (g.pw - 1));
 }
 
 template <int CTRL>
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
   const unsigned res_bytes = has_res ? (unsigned)((size_t)p.res.n * p.res.gh * p.res.gw * p.res.ph * p.res.pw * p.res.ld * 4) : 0u;
   const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(has_res ? p.res.p : p.out.p), 0, res_bytes, 0x00020000);
   const bool replicate = p.pad_mode == ITG_PAD_REPLICATE;
-  const int H = sp.H, W = sp.W, lph = sp.lph, lpw = sp.lpw;
+  const int H = sp.H, Hin = sp.Hin, W = sp.W, lpw = sp.lpw;
   const unsigned ild4 = (unsigned)p.in.ld * 4u, old4 = (unsigned)p.out.ld * 4u, rld4 = (unsigned)p.res.ld * 4u;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -149,14 +153,14 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
     const int n = unit / (sp.nstrips * sp.nseg);
     const int X0 = xs * 32, y0 = seg * sp.L, y1 = min(H, y0 + sp.L);
     // ---- lane byte offsets of this strip (the row's offset is added as the scalar operand of every access)
-    const int cpix = strip_colpix(p.in, lph, lpw, X0);
+    const int cpix = strip_colpix(p.in, lpw, X0);
     const unsigned vc0 = (unsigned)(cpix + nl) * ild4 + (unsigned)g * 16u, vc1 = vc0 + 16u * ild4;
     unsigned ved = p.in_bytes;                            // lanes 0 / 15: the pixel left / right of the strip
     {
       int XE = nl == 0 ? X0 - 1 : X0 + 32;
       bool ok = nl == 0 || nl == 15;
       if (replicate) XE = min(max(XE, 0), W - 1); else ok = ok && (unsigned)XE < (unsigned)W;
-      if (ok) ved = (unsigned)strip_colpix(p.in, lph, lpw, XE) * ild4 + (unsigned)g * 16u;
+      if (ok) ved = (unsigned)strip_colpix(p.in, lpw, XE) * ild4 + (unsigned)g * 16u;
     }
     unsigned vo[FI][2], vr[FI][2];
 #pragma unroll
@@ -164,23 +168,23 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         const int co = 16 * i + 4 * g;
-        vo[i][f] = co < p.out.ld ? (unsigned)(cpix + 16 * f + nl) * old4 + (unsigned)co * 4u : out_bytes;
+        vo[i][f] = co < p.out.ld ? (unsigned)(strip_colpix(p.out, lpw, X0) + 16 * f + nl) * old4 + (unsigned)co * 4u : out_bytes;
         vr[i][f] = res_bytes;
         if (has_res && co < p.res.ld) {
-          const int rp = sp.res_half ? strip_colpix(p.res, lph - 1, lpw - 1, X0 >> 1) + ((16 * f + nl) >> 1) : cpix + 16 * f + nl;
+          const int rp = sp.res_half ? strip_colpix(p.res, lpw - 1, X0 >> 1) + ((16 * f + nl) >> 1) : strip_colpix(p.res, lpw, X0) + 16 * f + nl;
           vr[i][f] = (unsigned)rp * rld4 + (unsigned)co * 4u;
         }
       }
-    const bool foldl = sp.fold && X0 == 0, foldr = sp.fold && X0 + 32 == W;
+    const bool foldl = sp.fold_h && X0 == 0, foldr = sp.fold_h && X0 + 32 == W;
 
     f32x4 c0[3][KC], c1[3][KC], ed[3][KC];                // three rows in flight: row Yv lives in set (Yv - y0 + 1) % 3
     auto load_row = [&](int Yv, f32x4 (&a0)[KC], f32x4 (&a1)[KC], f32x4 (&ae)[KC]) {
-      int Yc = Yv;
+      int Yc = Yv + sp.rsh;                               // the input row behind virtual row Yv
       bool ok = Yv <= y1;
-      if (replicate) Yc = min(max(Yv, 0), H - 1); else ok = ok && (unsigned)Yv < (unsigned)H;
+      if (sp.rep_v) Yc = min(max(Yc, 0), Hin - 1); else ok = ok && (unsigned)Yc < (unsigned)Hin;
       if (!ok) return;                                    // wave-uniform: a row outside a zero-padded image is never used
       if ((sp.dbg & 4) && Yv > y0 + 1) return;
-      const unsigned rb = (unsigned)strip_rowpix(p.in, lph, lpw, n, Yc) * ild4;
+      const unsigned rb = (unsigned)strip_rowpix(p.in, lpw, n, Yc) * ild4;
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
         a0[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, vc0 + 64u * c, rb, 0));
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
     };
     // finished output row t: epilogue + store
     auto finish = [&](f32x4 (&acc)[FI][2], int t, const f32x4 (&rv)[FI][2]) {
-      const unsigned ob = (unsigned)strip_rowpix(p.out, lph, lpw, n, t) * old4;
+      const unsigned ob = (unsigned)strip_rowpix(p.out, lpw, n, t) * old4;
 #pragma unroll
       for (int i = 0; i < FI; ++i) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(biasl + 16 * i + 4 * g);
@@ -290,13 +294,13 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
       const bool done2 = t2 >= y0 && t2 < y1;
       f32x4 rv[FI][2];
       if (has_res && done2) {
-        const unsigned rb = (unsigned)(sp.res_half ? strip_rowpix(p.res, lph - 1, lpw - 1, n, t2 >> 1) : strip_rowpix(p.res, lph, lpw, n, t2)) * rld4;
+        const unsigned rb = (unsigned)(sp.res_half ? strip_rowpix(p.res, lpw - 1, n, t2 >> 1) : strip_rowpix(p.res, lpw, n, t2)) * rld4;
 #pragma unroll
         for (int i = 0; i < FI; ++i)
 #pragma unroll
           for (int f = 0; f < 2; ++f) rv[i][f] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, vr[i][f], rb, 0));
       }
-      const bool rowok = replicate || (unsigned)Yv < (unsigned)H;
+      const bool rowok = sp.rep_v || (unsigned)(Yv + sp.rsh) < (unsigned)Hin;
       if (rowok && !(sp.dbg & 2)) {
         f32x4 bl[2][KC], br[2][KC];
         if (sp.dbg & 8) {
@@ -324,10 +328,10 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
           mfma_row3(A0, A1, A2, bl, s0, s1, br);
         } else {                                                                         // first / last rows of a segment
           if (d0) mfma_ky(A0, 0, bl, s0, s1, br);
-          else if (sp.fold && Yv == H - 1 && d1) mfma_ky(A1, 0, bl, s0, s1, br);         // row H's gradient folds onto row H - 1
+          else if (sp.fold_v && Yv == H - 1 && d1) mfma_ky(A1, 0, bl, s0, s1, br);         // row H's gradient folds onto row H - 1
           if (d1) mfma_ky(A1, 1, bl, s0, s1, br);
           if (done2) mfma_ky(A2, 2, bl, s0, s1, br);
-          else if (sp.fold && Yv == 0 && d1) mfma_ky(A1, 2, bl, s0, s1, br);             // row -1's gradient folds onto row 0
+          else if (sp.fold_v && Yv == 0 && d1) mfma_ky(A1, 2, bl, s0, s1, br);             // row -1's gradient folds onto row 0
         }
       }
       if (done2) finish(A2, t2, rv);
@@ -399,23 +403,40 @@ int try_conv_strip(const ConvP& p, hipStream_t s, int* rc) {
   if (p.prec != ITG_PREC_F32 || p.cin_ld > 32 || p.cin_ld < 8 || p.co_rows > 32 || p.in_ab || p.bn_sums) return 0;      // (4-float pixels: a chunk would be 3/4 padding - the halo-tile kernel packs four taps into one)
   const GridT& gi = p.in;
   const GridT& go = p.out;
-  if (gi.n != go.n || gi.gh != go.gh || gi.gw != go.gw || gi.ph != go.ph || gi.pw != go.pw) return 0;
-  const int lph = ilog2_exact(gi.ph), lpw = ilog2_exact(gi.pw);
-  if (lph < 1 || lpw < 5) return 0;                           // 32-pixel strips stay inside a patch; a half-size residual needs ph >= 2
-  int fold = 0;
-  if (p.out_mode == 0) {
-    if (p.ioy != -1 || p.iox != -1 || p.ooy != 0 || p.oox != 0 || p.MT != gi.H || p.MU != gi.W) return 0;
+  if (gi.n != go.n || gi.gh != go.gh || gi.gw != go.gw || gi.pw != go.pw) return 0;
+  const int lpw = ilog2_exact(gi.pw);
+  if (lpw < 5) return 0;                                      // 32-pixel strips stay inside a patch
+  if (gi.gh > 1 && (ilog2_exact(gi.ph) < 1 || gi.ph != go.ph)) return 0;      // (a half-size residual needs ph >= 2)
+  int fold_v = 0, fold_h = 0, rsh = 0, rep_v = 0;
+  if (gi.ph == go.ph) {
+    if (p.out_mode == 0) {
+      if (p.ioy != -1 || p.iox != -1 || p.ooy != 0 || p.oox != 0 || p.MT != gi.H || p.MU != gi.W) return 0;
+      rep_v = p.pad_mode == ITG_PAD_REPLICATE;
+    } else {
+      // the padded-extent input gradient of a replicate-padded layer (itg_conv2d_dgrad): same result, folded in register
+      if (p.ioy != -2 || p.iox != -2 || p.ooy != -1 || p.oox != -1 || p.MT != go.H + 2 || p.MU != go.W + 2 || p.pad_mode != ITG_PAD_ZERO) return 0;
+      fold_v = fold_h = 1;
+    }
+  } else if (gi.gh == 1 && gi.ph == go.ph + 2) {
+    // a row-sharded band whose input carries its halo rows (itg_conv_geom.pad_h = 0): every input row exists
+    if (p.out_mode != 0 || p.ioy != 0 || p.iox != -1 || p.ooy != 0 || p.oox != 0 || p.MT != go.H || p.MU != go.W) return 0;
+    rsh = 1;
+  } else if (gi.gh == 1 && gi.ph + 2 == go.ph) {
+    // ... and its input gradient: dx has the halo rows (their gradients travel back to the neighbours), dy rows outside the band
+    // are zero; the left / right frame of a replicate-padded layer is folded as above
+    if (p.ioy != -2 || p.ooy != 0 || p.MT != go.H || p.pad_mode != ITG_PAD_ZERO) return 0;
+    if (p.out_mode == 0) { if (p.iox != -1 || p.oox != 0 || p.MU != go.W) return 0; }
+    else { if (p.iox != -2 || p.oox != -1 || p.MU != go.W + 2) return 0; fold_h = 1; }
+    rsh = -1;
   } else {
-    // the padded-extent input gradient of a replicate-padded layer (itg_conv2d_dgrad): same result, folded in register
-    if (p.ioy != -2 || p.iox != -2 || p.ooy != -1 || p.oox != -1 || p.MT != go.H + 2 || p.MU != go.W + 2 || p.pad_mode != ITG_PAD_ZERO) return 0;
-    fold = 1;
+    return 0;
   }
-  if ((int64_t)gi.H * gi.W < 64 * 64) return 0;
+  if ((int64_t)go.H * go.W < 64 * 64) return 0;
   int res_half = 0;
   if (p.res.p) {
     const GridT& gr = p.res;
     if (gr.n != go.n || gr.gh != go.gh || gr.gw != go.gw || gr.ld != go.ld) return 0;
-    if (p.res_ups) { if (2 * gr.ph != go.ph || 2 * gr.pw != go.pw) return 0; res_half = 1; }
+    if (p.res_ups) { if (2 * gr.ph != go.ph || 2 * gr.pw != go.pw || (gr.gh > 1 && ilog2_exact(gr.ph) < 0)) return 0; res_half = 1; }
     else if (gr.ph != go.ph || gr.pw != go.pw) return 0;
   }
   const int64_t ib = (int64_t)gi.n * gi.gh * gi.gw * gi.ph * gi.pw * gi.ld * 4, ob = (int64_t)go.n * go.gh * go.gw * go.ph * go.pw * go.ld * 4;
@@ -425,15 +446,16 @@ int try_conv_strip(const ConvP& p, hipStream_t s, int* rc) {
   ConvP q = p;
   q.in_bytes = (unsigned)ib;
   StripP sp;
-  sp.nstrips = gi.W / 32; sp.lph = lph; sp.lpw = lpw; sp.fold = fold; sp.H = gi.H; sp.W = gi.W; sp.res_half = res_half;
+  sp.nstrips = go.W / 32; sp.lpw = lpw; sp.fold_v = fold_v; sp.fold_h = fold_h; sp.rep_v = rep_v; sp.rsh = rsh;
+  sp.H = go.H; sp.Hin = gi.H; sp.W = go.W; sp.res_half = res_half;
   // rows per segment: every wave slot of the chip (1 024 SIMDs x resident waves) gets one unit if the image allows it; a
   // segment re-loads two halo rows, so short segments cost loads (not MFMAs)
   const int occ = KC * FI == 1 ? 3 : 2;
   const int64_t slots = 1024LL * occ;
-  int bestL = gi.H;
+  int bestL = go.H;
   double best = 1e30;
-  for (int L = 4; L <= gi.H && L <= 128; ++L) {
-    const int nseg = (gi.H + L - 1) / L;
+  for (int L = 4; L <= go.H && L <= 128; ++L) {
+    const int nseg = (go.H + L - 1) / L;
     const int64_t units = (int64_t)gi.n * nseg * sp.nstrips;
     const int64_t rounds = (units + slots - 1) / slots;
     const double cost = (double)rounds * (L + 0.35 * 2 + 1.0);      // rows of MFMA work per slot + halo loads + prologue
@@ -448,7 +470,7 @@ int try_conv_strip(const ConvP& p, hipStream_t s, int* rc) {
     if (!tsbuf) { if (hipMalloc(&tsbuf, 8 * 40 * 8) != hipSuccess) tsbuf = nullptr; }
     if (tsbuf) { (void)hipMemsetAsync(tsbuf, 0, 8 * 40 * 8, s); sp.ts = tsbuf; }
   }
-  sp.nseg = (gi.H + sp.L - 1) / sp.L;
+  sp.nseg = (go.H + sp.L - 1) / sp.L;
   const int64_t units = (int64_t)gi.n * sp.nseg * sp.nstrips;
   if (units > 0x7fffffff) return 0;
   sp.units = (int)units;

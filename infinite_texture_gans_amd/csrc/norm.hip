@@ -151,10 +151,19 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   ab[i] = a; ab[ld + i] = b;
 }
 
-// store one normalised pixel group; UPS: y has 2x the patch extent (nearest)
-template <bool UPS>
+// store one normalised pixel group; UPS = 1: y has 2x the patch extent (nearest); UPS = 2 (BN_PADROWS): y is a row-sharded
+// band in image layout with ONE HALO ROW above and below every image ((ph + 2) x pw pixels per image, rows 1 .. ph written:
+// the halo rows are the neighbour ranks' pixels, reference models/layers.py:145-173, filled by itg_band_halo_fill)
+constexpr int BN_PADROWS = 2;
+__device__ __forceinline__ int64_t padrows_pix(int64_t pix, int ph, int pw) {
+  const int64_t img = pix / ((int64_t)ph * pw);
+  return pix + (2 * img + 1) * pw;
+}
+template <int UPS>
 __device__ __forceinline__ void store_y(float* __restrict__ y, int64_t pix, int ld, int cg, int ph, int pw, f32x4 v) {
-  if (!UPS) {
+  if (UPS == BN_PADROWS) {
+    *reinterpret_cast<f32x4*>(y + padrows_pix(pix, ph, pw) * ld + cg * 4) = v;
+  } else if (!UPS) {
     *reinterpret_cast<f32x4*>(y + pix * ld + cg * 4) = v;
   } else {
     int64_t blk = pix / (ph * pw);
@@ -169,7 +178,7 @@ __device__ __forceinline__ void store_y(float* __restrict__ y, int64_t pix, int 
 }
 
 // the sweep y = act(a * x + b) of a thread's channel group: four 16-byte loads in flight
-template <bool UPS>
+template <int UPS>
 __device__ __forceinline__ void apply_sweep(const float* __restrict__ x, float* __restrict__ y, f32x4 a, f32x4 b, int64_t pix,
                                             int64_t step, int64_t npix, int ld, int cg, int ph, int pw, int act, float slope) {
   constexpr int UN = 4;
@@ -193,7 +202,7 @@ __device__ __forceinline__ void apply_sweep(const float* __restrict__ x, float* 
 }
 
 // y = act(alpha*x + beta); ups: y has 2x the patch extent (nearest)
-template <bool UPS>
+template <int UPS>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        const float* __restrict__ ab, int64_t npix, int ld, int ph,
                                                        int pw, int act, float slope) {
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // bn_finalize + bn_apply in one launch (training): every WORKGROUP derives the affine coefficients of all channels from the
 // fp64 sums once, into LDS (one thread per channel); workgroup 0 also publishes mean / rstd / (a, b) for the backward and
 // updates the running statistics.
-template <bool UPS>
+template <int UPS>
 __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                 const double* __restrict__ sums, double count,
                                                                 double count_scale, const float* __restrict__ gamma,
@@ -254,8 +263,9 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __r
   apply_sweep<UPS>(x, y, a, b, gt / q4, T / q4, npix, ld, cg, ph, pw, act, slope);
 }
 
-template <bool UPS>
+template <int UPS>
 __device__ __forceinline__ f32x4 load_dy(const float* __restrict__ dy, int64_t pix, int ld, int cg, int ph, int pw) {
+  if (UPS == BN_PADROWS) return *reinterpret_cast<const f32x4*>(dy + padrows_pix(pix, ph, pw) * ld + cg * 4);
   if (!UPS) return *reinterpret_cast<const f32x4*>(dy + pix * ld + cg * 4);
   int64_t blk = pix / (ph * pw);
   int r = (int)(pix - blk * ph * pw);
@@ -274,7 +284,7 @@ __device__ __forceinline__ float act_grad(float pre, int act, float slope) {
   return 1.f;
 }
 
-template <bool UPS, int NT>
+template <int UPS, int NT>
 __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            const float* __restrict__ ab,
                                                            const float* __restrict__ mean_rstd, int64_t npix, int ld,
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const float* __restri
   const f32x4 rs = *reinterpret_cast<const f32x4*>(mean_rstd + ld + cg * 4);
   double s[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0};
   int64_t pix = gt / q4;
-  constexpr int UN = UPS ? 2 : 4;                            // pixels in flight per thread (an upsampled dy is 4 loads per pixel)
+  constexpr int UN = UPS == 1 ? 2 : 4;                            // pixels in flight per thread (an upsampled dy is 4 loads per pixel)
   for (; pix + (UN - 1) * step < npix; pix += UN * step) {
     f32x4 v[UN], g[UN];
 #pragma unroll
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const float* __restri
 
 // ADD: dx also takes a second gradient of the BatchNorm's input (`addend`, x's shape): the tensor feeds the residual
 // shortcut as well (reference models/layers.py:313-322), and the sum of its two gradients is otherwise a launch of its own
-template <bool UPS, bool ADD>
+template <int UPS, bool ADD>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            const float* __restrict__ ab,
                                                            const float* __restrict__ mean_rstd,
@@ -474,12 +484,15 @@ int itg_bn_finalize(const double* sums, double count, double count_scale, const 
   return ITG_OK;
 }
 
-static int ups_mode(const itg_tensor* small, const itg_tensor* big, bool* ups) {
+// 0: same extent, 1: `big` has twice the patch extent (nearest x2 upsample), 2 (BN_PADROWS): `big` is the image-layout band
+// with one halo row above and below (ph + 2 rows)
+static int ups_mode(const itg_tensor* small, const itg_tensor* big, int* ups) {
   if (small->n != big->n || small->gh != big->gh || small->gw != big->gw || small->c != big->c ||
       small->ld != big->ld)
     return ITG_ERR_ARG;
-  if (small->ph == big->ph && small->pw == big->pw) { *ups = false; return ITG_OK; }
-  if (2 * small->ph == big->ph && 2 * small->pw == big->pw) { *ups = true; return ITG_OK; }
+  if (small->ph == big->ph && small->pw == big->pw) { *ups = 0; return ITG_OK; }
+  if (2 * small->ph == big->ph && 2 * small->pw == big->pw) { *ups = 1; return ITG_OK; }
+  if (small->gh == 1 && small->gw == 1 && small->ph + 2 == big->ph && small->pw == big->pw) { *ups = BN_PADROWS; return ITG_OK; }
   return ITG_ERR_ARG;
 }
 
@@ -489,19 +502,23 @@ int itg_bn_finalize_apply(const itg_tensor* x, const double* sums, double count,
                           void* stream) {
   int rc;
   if ((rc = check_tensor(x)) || (rc = check_tensor(y))) return rc;
-  bool ups;
+  int ups;
   if (!sums || !mean_rstd || !ab || count <= 0 || (rc = ups_mode(x, y, &ups))) return rc ? rc : ITG_ERR_ARG;
   int64_t npix = grid_pixels(x);
   int q4 = x->ld >> 2;
   if (x->ld > MAX_LD) return ITG_ERR_ARG;
   int blocks = sweep_blocks(npix * q4, q4, 8, 2048);
   const size_t lds = (size_t)2 * x->ld * sizeof(float);
-  if (ups)
-    hipLaunchKernelGGL(bn_finalize_apply_kernel<true>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, (const float*)x->ptr,
+  if (ups == BN_PADROWS)
+    hipLaunchKernelGGL(bn_finalize_apply_kernel<BN_PADROWS>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, (const float*)x->ptr,
+                       (float*)y->ptr, sums, count, count_scale, gamma, beta, eps, momentum, running_mean, running_var, nbt,
+                       mean_rstd, ab, npix, x->c, x->ld, x->ph, x->pw, act, slope);
+  else if (ups)
+    hipLaunchKernelGGL(bn_finalize_apply_kernel<1>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, (const float*)x->ptr,
                        (float*)y->ptr, sums, count, count_scale, gamma, beta, eps, momentum, running_mean, running_var, nbt,
                        mean_rstd, ab, npix, x->c, x->ld, x->ph, x->pw, act, slope);
   else
-    hipLaunchKernelGGL(bn_finalize_apply_kernel<false>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, (const float*)x->ptr,
+    hipLaunchKernelGGL(bn_finalize_apply_kernel<0>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, (const float*)x->ptr,
                        (float*)y->ptr, sums, count, count_scale, gamma, beta, eps, momentum, running_mean, running_var, nbt,
                        mean_rstd, ab, npix, x->c, x->ld, x->ph, x->pw, act, slope);
   ITG_CHECK_LAUNCH();
@@ -511,16 +528,19 @@ int itg_bn_finalize_apply(const itg_tensor* x, const double* sums, double count,
 int itg_bn_apply(const itg_tensor* x, const float* ab, const itg_tensor* y, int act, float slope, void* stream) {
   int rc;
   if ((rc = check_tensor(x)) || (rc = check_tensor(y))) return rc;
-  bool ups;
+  int ups;
   if (!ab || (rc = ups_mode(x, y, &ups))) return rc ? rc : ITG_ERR_ARG;
   int64_t npix = grid_pixels(x);
   int q4 = x->ld >> 2;
   int blocks = sweep_blocks(npix * q4, q4, 8, 2048);
-  if (ups)
-    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr,
+  if (ups == BN_PADROWS)
+    hipLaunchKernelGGL(bn_apply_kernel<BN_PADROWS>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr,
+                       (float*)y->ptr, ab, npix, x->ld, x->ph, x->pw, act, slope);
+  else if (ups)
+    hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr,
                        (float*)y->ptr, ab, npix, x->ld, x->ph, x->pw, act, slope);
   else
-    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr,
+    hipLaunchKernelGGL(bn_apply_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr,
                        (float*)y->ptr, ab, npix, x->ld, x->ph, x->pw, act, slope);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
@@ -530,17 +550,17 @@ int itg_bn_bwd_reduce(const itg_tensor* x, const itg_tensor* dy, const float* ab
                       float slope, double* sums, void* stream) {
   int rc;
   if ((rc = check_tensor(x)) || (rc = check_tensor(dy))) return rc;
-  bool ups;
+  int ups;
   if (!ab || !mean_rstd || !sums || x->ld > MAX_LD) return ITG_ERR_ARG;
   if ((rc = ups_mode(x, dy, &ups))) return rc;
   int64_t npix = grid_pixels(x);
   int q4 = x->ld >> 2;
-  const RedPlan rp = plan_reduce(npix * q4, q4, ups ? 4 : 8);
+  const RedPlan rp = plan_reduce(npix * q4, q4, ups == 1 ? 4 : 8);
 #define ITG_BWD_RED(U, N)                                                                                              \
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<U, N>), dim3(rp.blocks), dim3(N), rp.lds, (hipStream_t)stream,               \
                      (const float*)x->ptr, (const float*)dy->ptr, ab, mean_rstd, npix, x->ld, x->ph, x->pw, act, slope, sums)
-  if (rp.nt == 1024) { if (ups) ITG_BWD_RED(true, 1024); else ITG_BWD_RED(false, 1024); }
-  else { if (ups) ITG_BWD_RED(true, 256); else ITG_BWD_RED(false, 256); }
+  if (rp.nt == 1024) { if (ups == BN_PADROWS) ITG_BWD_RED(BN_PADROWS, 1024); else if (ups) ITG_BWD_RED(1, 1024); else ITG_BWD_RED(0, 1024); }
+  else { if (ups == BN_PADROWS) ITG_BWD_RED(BN_PADROWS, 256); else if (ups) ITG_BWD_RED(1, 256); else ITG_BWD_RED(0, 256); }
 #undef ITG_BWD_RED
   ITG_CHECK_LAUNCH();
   return ITG_OK;
@@ -553,7 +573,7 @@ int itg_bn_bwd_apply_add(const itg_tensor* x, const itg_tensor* dy, const float*
   if (!sums_local) sums_local = sums;
   int rc;
   if ((rc = check_tensor(x)) || (rc = check_tensor(dy)) || (rc = check_tensor(dx))) return rc;
-  bool ups;
+  int ups;
   if (!ab || !mean_rstd || !sums || count <= 0 || !same_shape(x, dx)) return ITG_ERR_ARG;
   if ((rc = ups_mode(x, dy, &ups))) return rc;
   const float* ad = nullptr;
@@ -570,8 +590,9 @@ int itg_bn_bwd_apply_add(const itg_tensor* x, const itg_tensor* dy, const float*
   hipLaunchKernelGGL((bn_bwd_apply_kernel<U, A>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr,        \
                      (const float*)dy->ptr, ab, mean_rstd, sums, sums_local, 1.0 / count, npix, x->ld, x->c, x->ph, x->pw, act, \
                      slope, (float*)dx->ptr, dgamma, dbeta, accumulate, ad)
-  if (ups) { if (ad) ITG_BWD_APPLY(true, true); else ITG_BWD_APPLY(true, false); }
-  else { if (ad) ITG_BWD_APPLY(false, true); else ITG_BWD_APPLY(false, false); }
+  if (ups == BN_PADROWS) { if (ad) ITG_BWD_APPLY(BN_PADROWS, true); else ITG_BWD_APPLY(BN_PADROWS, false); }
+  else if (ups) { if (ad) ITG_BWD_APPLY(1, true); else ITG_BWD_APPLY(1, false); }
+  else { if (ad) ITG_BWD_APPLY(0, true); else ITG_BWD_APPLY(0, false); }
 #undef ITG_BWD_APPLY
   ITG_CHECK_LAUNCH();
   return ITG_OK;

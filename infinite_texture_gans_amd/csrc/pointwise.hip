@@ -443,6 +443,87 @@ __global__ void stream_spin_kernel(long long ticks, unsigned* sink) {
   if (sink && threadIdx.x == 0) *sink = n;
 }
 
+// ------------------------------------------------------------------------------- halo rows of a row-sharded band (training)
+// A rank of a patch grid sharded by patch ROWS holds its band in image layout with one halo row above and below every image:
+// ext = (n, 1, 1, H + 2, W, ld), rows 1 .. H its own pixels (written there by the producing BatchNorm, norm.hip BN_PADROWS),
+// rows 0 and H + 1 what LocalPadder (reference models/layers.py:145-173) puts around them: the neighbour rank's boundary row
+// (arrived over RCCL as an (n, W, ld) buffer), or at the image's outer border the replicate / zero padding of layers.py:82.
+enum { BAND_FROM_BUFFER = 0, BAND_REPLICATE = 1, BAND_ZERO = 2 };
+
+__global__ void band_halo_fill_kernel(float* __restrict__ ext, const float* __restrict__ top, const float* __restrict__ bottom, int n,
+                                      int H2, int W, int ld, int mode_top, int mode_bottom) {
+  const int q4 = ld >> 2;
+  const int64_t total = (int64_t)n * 2 * W * q4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % q4);
+    int64_t r = i / q4;
+    const int x = (int)(r % W); r /= W;
+    const int which = (int)(r & 1), img = (int)(r >> 1);
+    const int mode = which ? mode_bottom : mode_top;
+    float* const row0 = ext + (((int64_t)img * H2) * W + x) * ld + c4 * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (mode == BAND_FROM_BUFFER) v = *reinterpret_cast<const f32x4*>((which ? bottom : top) + ((int64_t)img * W + x) * ld + c4 * 4);
+    else if (mode == BAND_REPLICATE) v = *reinterpret_cast<const f32x4*>(row0 + (int64_t)(which ? H2 - 2 : 1) * W * ld);
+    *reinterpret_cast<f32x4*>(row0 + (int64_t)(which ? H2 - 1 : 0) * W * ld) = v;
+  }
+}
+
+// backward of the fill on the gradient of ext: the halo rows' gradients belong to the rows they were copies of.  Row 1 takes
+// what came back from the rank above (`above`: the gradient that rank found in ITS bottom halo row), or - replicate border -
+// this tensor's own row 0; row H likewise from below.  (One thread handles both ends of a column: with H = 1 they are one row.)
+__global__ void band_halo_grad_kernel(float* __restrict__ g, const float* __restrict__ above, const float* __restrict__ below, int n,
+                                      int H2, int W, int ld, int mode_top, int mode_bottom) {
+  const int q4 = ld >> 2;
+  const int64_t total = (int64_t)n * W * q4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % q4);
+    int64_t r = i / q4;
+    const int x = (int)(r % W);
+    const int img = (int)(r / W);
+    float* const col = g + (((int64_t)img * H2) * W + x) * ld + c4 * 4;
+    const int64_t rs = (int64_t)W * ld;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const int mode = which ? mode_bottom : mode_top;
+      if (mode == BAND_ZERO) continue;
+      f32x4 a;
+      if (mode == BAND_FROM_BUFFER) a = *reinterpret_cast<const f32x4*>((which ? below : above) + ((int64_t)img * W + x) * ld + c4 * 4);
+      else a = *reinterpret_cast<const f32x4*>(col + (which ? H2 - 1 : 0) * rs);
+      float* const dst = col + (which ? H2 - 2 : 1) * rs;
+      *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(dst) + a;
+    }
+  }
+}
+
+// rows r0 and r1 of every image -> two compact (n, W, ld) buffers (what the exchange sends: forward rows 1 / H, backward 0 / H + 1)
+__global__ void band_rows_get_kernel(const float* __restrict__ ext, float* __restrict__ out0, float* __restrict__ out1, int n, int H2,
+                                     int W, int ld, int r0, int r1) {
+  const int q4 = ld >> 2;
+  const int64_t total = (int64_t)n * 2 * W * q4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % q4);
+    int64_t r = i / q4;
+    const int x = (int)(r % W); r /= W;
+    const int which = (int)(r & 1), img = (int)(r >> 1);
+    float* const out = which ? out1 : out0;
+    if (!out) continue;
+    *reinterpret_cast<f32x4*>(out + ((int64_t)img * W + x) * ld + c4 * 4) =
+        *reinterpret_cast<const f32x4*>(ext + (((int64_t)img * H2 + (which ? r1 : r0)) * W + x) * ld + c4 * 4);
+  }
+}
+
+// rows 1 .. H of ext <-> a compact band (producers that cannot write the padded layout themselves, e.g. SSM modulation)
+template <bool TO_EXT>
+__global__ void band_interior_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int H, int W, int ld) {
+  const int q4 = ld >> 2;
+  const int64_t per = (int64_t)H * W * q4, total = (int64_t)n * per;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t img = i / per, w = i - img * per;
+    const int64_t compact = i * 4, padded = (img * (H + 2) * W * q4 + (int64_t)W * q4 + w) * 4;
+    *reinterpret_cast<f32x4*>(dst + (TO_EXT ? padded : compact)) = *reinterpret_cast<const f32x4*>(src + (TO_EXT ? compact : padded));
+  }
+}
+
 extern "C" {
 
 static int flat_check(const itg_tensor* a, const itg_tensor* b) {
@@ -609,6 +690,65 @@ int itg_local_pad_stream_fwd(const itg_tensor* x, const float* left, const float
   int64_t total = grid_pixels(y) * (y->ld >> 2);
   hipLaunchKernelGGL(local_pad_nhwc_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, s, d, left, top,
                      bottom, pad_mode);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+static int band_check(const itg_tensor* ext) {
+  int rc = check_tensor(ext);
+  if (rc) return rc;
+  if (ext->gh != 1 || ext->gw != 1 || ext->ph < 3) return ITG_ERR_ARG;      // image layout, at least one own row
+  return ITG_OK;
+}
+
+int itg_band_halo_fill(const itg_tensor* ext, const float* top, const float* bottom, int mode_top, int mode_bottom, void* stream) {
+  int rc = band_check(ext);
+  if (rc) return rc;
+  if (mode_top < 0 || mode_top > 2 || mode_bottom < 0 || mode_bottom > 2) return ITG_ERR_ARG;
+  if ((mode_top == BAND_FROM_BUFFER && !top) || (mode_bottom == BAND_FROM_BUFFER && !bottom)) return ITG_ERR_ARG;
+  const int64_t total = (int64_t)ext->n * 2 * ext->pw * (ext->ld >> 2);
+  hipLaunchKernelGGL(band_halo_fill_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (float*)ext->ptr, top, bottom,
+                     ext->n, ext->ph, ext->pw, ext->ld, mode_top, mode_bottom);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_band_halo_grad(const itg_tensor* gext, const float* above, const float* below, int mode_top, int mode_bottom, void* stream) {
+  int rc = band_check(gext);
+  if (rc) return rc;
+  if (mode_top < 0 || mode_top > 2 || mode_bottom < 0 || mode_bottom > 2) return ITG_ERR_ARG;
+  if ((mode_top == BAND_FROM_BUFFER && !above) || (mode_bottom == BAND_FROM_BUFFER && !below)) return ITG_ERR_ARG;
+  const int64_t total = (int64_t)gext->n * gext->pw * (gext->ld >> 2);
+  hipLaunchKernelGGL(band_halo_grad_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (float*)gext->ptr, above, below,
+                     gext->n, gext->ph, gext->pw, gext->ld, mode_top, mode_bottom);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_band_rows_get(const itg_tensor* ext, int r0, int r1, float* out0, float* out1, void* stream) {
+  int rc = band_check(ext);
+  if (rc) return rc;
+  if (r0 < 0 || r0 >= ext->ph || r1 < 0 || r1 >= ext->ph || (!out0 && !out1)) return ITG_ERR_ARG;
+  const int64_t total = (int64_t)ext->n * 2 * ext->pw * (ext->ld >> 2);
+  hipLaunchKernelGGL(band_rows_get_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)ext->ptr, out0, out1,
+                     ext->n, ext->ph, ext->pw, ext->ld, r0, r1);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int itg_band_interior_copy(const itg_tensor* band, const itg_tensor* ext, int to_ext, void* stream) {
+  int rc = band_check(ext);
+  if (rc || (rc = check_tensor(band))) return rc;
+  if (band->gh != 1 || band->gw != 1 || band->n != ext->n || band->ph + 2 != ext->ph || band->pw != ext->pw || band->ld != ext->ld ||
+      band->c != ext->c)
+    return ITG_ERR_ARG;
+  const int64_t total = grid_pixels(band) * (band->ld >> 2);
+  if (to_ext)
+    hipLaunchKernelGGL(band_interior_copy_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)band->ptr,
+                       (float*)ext->ptr, band->n, band->ph, band->pw, band->ld);
+  else
+    hipLaunchKernelGGL(band_interior_copy_kernel<false>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)ext->ptr,
+                       (float*)band->ptr, band->n, band->ph, band->pw, band->ld);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }

@@ -316,8 +316,12 @@ class conv2d_lp(nn.Module):
         if bn is not None and not fused:
             # fork_out (a list): the caller reads the BatchNorm's input a second time (residual shortcut); it gets an alias of
             # it whose gradient the BatchNorm backward absorbs (ops.bn_act(fork=True))
+            # a row-sharded band (training): the BatchNorm writes straight into the halo-row layout the band conv reads
+            band = (lp_ is not None and lp_.merge_patches_into_image and lp_.halo is not None and lp_.training
+                    and not (upsample and not fold) and not (_ENV_HALO_INTERIOR and lp_.halo.world > 1)
+                    and x.t.shape[1] == 1 and x.t.shape[2] == 1)
             x = bn.run(x, act=bn_act[0], slope=bn_act[1], upsample=upsample and not fold, consumer_upsamples=fold,
-                       fork=fork_out is not None)
+                       fork=fork_out is not None, pad_rows=band)
             if fork_out is not None and x.fork is not None:
                 fork_out.append(x.fork)
         # a residual at half the output's patch extent (the un-upsampled shortcut) is read through the x2 upsample by the conv
@@ -376,18 +380,20 @@ class conv2d_lp(nn.Module):
         n, g1, g2, H, W, ld = t.shape
         if g1 != 1 or g2 != 1:
             raise ValueError("band training expects the image layout (1x1 grid), got %r" % (x,))
+        padded = getattr(x, "padded", False)
+        interior_first = _ENV_HALO_INTERIOR and lp.halo.world > 1 and H >= 3 and not padded
+        if not interior_first:
+            # the band in the halo-row layout (written there by the BatchNorm in front, or copied once for the producers that
+            # cannot), its two halo rows filled in place (ops.band_halo: exchange + itg_band_halo_fill), vertical padding 0
+            ext = ops.band_halo(x if padded else ops.band_extend(x), lp.halo, outer == "replicate")
+            return self.conv.run(ext, pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope, residual=residual, pad_h=0, up2=up2)
         rows = t[:, 0, 0]
         first, last = rows[:, 0], rows[:, H - 1]
-        interior_first = _ENV_HALO_INTERIOR and lp.halo.world > 1 and H >= 3
-        top, bottom = ops.halo_exchange(first, last, lp.halo, defer_wait=interior_first)
+        top, bottom = ops.halo_exchange(first, last, lp.halo, defer_wait=True)
         if top is None:
             top = first if outer == "replicate" else torch.zeros_like(first)
         if bottom is None:
             bottom = last if outer == "replicate" else torch.zeros_like(last)
-        if not interior_first:
-            ext = torch.cat((top.unsqueeze(1), rows, bottom.unsqueeze(1)), 1).reshape(n, 1, 1, H + 2, W, ld)
-            return self.conv.run(GT(ext, x.c), pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope,
-                                 residual=residual, pad_h=0, up2=up2)
         # Interior first (ITG_HALO_INTERIOR=1, SURVEY section 7 / VERDICT r3 item 7): the exchange has been POSTED (on the halo's
         # communication stream with ITG_HALO_STREAM=1); the output rows that need no neighbour row - all but the first and the
         # last k (k = 1, or 2 behind the folded upsample) - are convolved from the band itself while the rows travel, then this
@@ -473,11 +479,12 @@ class _BNParams(nn.BatchNorm2d):
         return (self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked, self.training,
                 self.eps, self.momentum, self.sync, self._sinks())
 
-    def run(self, x, act=ops.ACT_NONE, slope=0.0, upsample=False, consumer_upsamples=False, fork=False):
+    def run(self, x, act=ops.ACT_NONE, slope=0.0, upsample=False, consumer_upsamples=False, fork=False, pad_rows=False):
         sinks = self._sinks()
         return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked,
                           training=self.training, eps=self.eps, momentum=self.momentum, act=act, slope=slope,
-                          upsample=upsample, sync=self.sync, sinks=sinks, consumer_upsamples=consumer_upsamples, fork=fork)
+                          upsample=upsample, sync=self.sync, sinks=sinks, consumer_upsamples=consumer_upsamples, fork=fork,
+                          pad_rows=pad_rows)
 
     def forward(self, x):
         if isinstance(x, GT):

@@ -110,13 +110,14 @@ def _req_cuda(t, what):
 
 class GT:
     """Patch-grid NHWC activation: ``t`` is (n, gh, gw, ph, pw, ld), ``c`` logical channels."""
-    __slots__ = ("t", "c", "stats", "fork")
+    __slots__ = ("t", "c", "stats", "fork", "padded")
 
     def __init__(self, t, c, stats=None):
         # stats: fp64 [2 * ld] per-channel (sum, sum of squares) of ``t`` when the conv that produced it accumulated
         # them in its epilogue (conv(..., out_stats=True)); the BatchNorm that consumes ``t`` then skips its stats pass
         # fork: set by bn_act(fork=True): the alias of the BatchNorm's input whose gradient the BatchNorm backward absorbs
-        self.t, self.c, self.stats, self.fork = t, int(c), stats, None
+        # padded: ``t`` is a row-sharded band in the halo-row layout (n, 1, 1, H + 2, W, ld), rows 1 .. H written (bn_act(pad_rows=True))
+        self.t, self.c, self.stats, self.fork, self.padded = t, int(c), stats, None, False
 
     n = property(lambda s: s.t.shape[0])
     gh = property(lambda s: s.t.shape[1])
@@ -857,7 +858,7 @@ def _zeros_f64(n, device):
 class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, rm, rv, nbt, c, training, eps, momentum, act, slope, ups, sync, sinks=None, pre_sums=None,
-                virt_ups=False, fork=False):
+                virt_ups=False, fork=False, pad_rows=False):
         ctx.set_materialize_grads(False)
         x_in = x
         x = x.contiguous()
@@ -879,7 +880,14 @@ class _BNAct(torch.autograd.Function):
         stat = torch.empty(4 * ld, device=dev, dtype=torch.float32)
         mean_rstd, ab = stat[:2 * ld], stat[2 * ld:]
         s = 2 if ups else 1
-        y = torch.empty((n, gh, gw, ph * s, pw * s, ld), device=dev, dtype=torch.float32)
+        if pad_rows:
+            # the band layout of a row-sharded grid (include/itg.h "halo rows of a row-sharded band"): rows 1 .. ph are written
+            # here, rows 0 / ph + 1 by ops.band_halo; the backward receives the gradient in the same layout
+            if ups or gh != 1 or gw != 1:
+                raise _lib.ItgError("pad_rows: image-layout bands only, no materialised upsample")
+            y = torch.empty((n, 1, 1, ph + 2, pw, ld), device=dev, dtype=torch.float32)
+        else:
+            y = torch.empty((n, gh, gw, ph * s, pw * s, ld), device=dev, dtype=torch.float32)
         dy_ = _desc(y, c)
         if training:      # coefficients, running statistics and the normalised output in one launch
             _lib.call("itg_bn_finalize_apply", C.byref(dx_), _ptr(sums), count, 4.0 if (ups or virt_ups) else 1.0, _ptr(gamma), _ptr(beta),
@@ -903,7 +911,7 @@ class _BNAct(torch.autograd.Function):
     def backward(ctx, dy, g_alias=None):
         x, stat = ctx.saved_tensors
         if dy is None:          # only the alias was used downstream
-            return (g_alias,) + (None,) * 17
+            return (g_alias,) + (None,) * 18
         c, act, slope, count, sync, training, affine = ctx.meta
         if not training:
             raise _lib.ItgError("BatchNorm backward is only implemented for training-mode statistics")
@@ -943,11 +951,11 @@ class _BNAct(torch.autograd.Function):
                       count, act, float(slope), C.byref(dgx), _ptr(dg), _ptr(db), acc, st)
         if acc:
             dg = db = None
-        return gx, dg, db, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return gx, dg, db, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def bn_act(x, gamma, beta, rm, rv, nbt, training=True, eps=1e-5, momentum=0.1, act=ACT_NONE, slope=0.0,
-           upsample=False, sync=None, sinks=None, consumer_upsamples=False, fork=False):
+           upsample=False, sync=None, sinks=None, consumer_upsamples=False, fork=False, pad_rows=False):
     """y = act(BatchNorm(x)) [nearest-upsampled x2 when ``upsample``]: statistics are taken on x
     (identical to those of the upsampled tensor), the unbiased running_var uses the x4 count.
     ``consumer_upsamples``: y stays at x's size and the conv that reads it folds the x2 upsample into its filter
@@ -956,13 +964,16 @@ def bn_act(x, gamma, beta, rm, rv, nbt, training=True, eps=1e-5, momentum=0.1, a
         # ``fork``: the result carries ``.fork``, an alias of x; a consumer that reads x through it (the residual shortcut of
         # a generator block) gets its gradient summed into the BatchNorm's own input gradient by the backward kernel
         t, alias = _BNAct.apply(x.t, gamma, beta, rm, rv, nbt, x.c, training, eps, momentum, act, slope, upsample, sync, sinks,
-                                x.stats if training else None, bool(consumer_upsamples), True)
+                                x.stats if training else None, bool(consumer_upsamples), True, bool(pad_rows))
         y = GT(t, x.c)
         y.fork = GT(alias, x.c)
+        y.padded = bool(pad_rows)
         return y
     t = _BNAct.apply(x.t, gamma, beta, rm, rv, nbt, x.c, training, eps, momentum, act, slope, upsample, sync, sinks,
-                     x.stats if training else None, bool(consumer_upsamples))
-    return GT(t, x.c)
+                     x.stats if training else None, bool(consumer_upsamples), False, bool(pad_rows))
+    y = GT(t, x.c)
+    y.padded = bool(pad_rows)         # ``pad_rows``: y.t is (n, 1, 1, ph + 2, pw, ld) with its halo rows still to be filled (band_halo)
+    return y
 
 
 def bn_stats_only(x, rm, rv, nbt, training=True, eps=1e-5, momentum=0.1, sync=None):
@@ -1427,6 +1438,84 @@ def pack_sizes(co, ci, kh, kw, stride, up2=False, wino=False):
 
 
 # ------------------------------------------------------------------------------- row-sharded grids (training)
+class _BandHalo(torch.autograd.Function):
+    """In place: fill the two halo rows of a band in the padded image layout (n, 1, 1, H + 2, W, ld) - the neighbour ranks'
+    boundary rows over ``comm`` (dist.RowHalo), the replicate / zero padding at the image's outer border - reference
+    LocalPadder.forward, models/layers.py:145-173, for a patch grid sharded by patch rows.  Backward, in place on the gradient
+    of that tensor: the halo rows' gradients travel back the same way and are added onto rows 1 / H (itg_band_halo_grad).
+    One small launch each way on one rank, three with neighbours (rows out, exchange, rows in): no concatenated copy of the
+    band, no slicing of its gradient (the torch.cat path of rounds 2-4 spent 12.8 % of config 4's kernel time on both)."""
+
+    @staticmethod
+    def forward(ctx, ext, c, comm, replicate):
+        _req_cuda(ext, "ext")
+        n, _, _, H2, W, ld = ext.shape
+        st = _stream()
+        d = _desc(ext, c)
+        top = bottom = None
+        if comm is not None and comm.world > 1:
+            first, last = torch.empty((n, W, ld), device=ext.device), torch.empty((n, W, ld), device=ext.device)
+            _lib.call("itg_band_rows_get", C.byref(d), 1, H2 - 2, _ptr(first), _ptr(last), st)
+            top, bottom = comm.exchange(first, last)
+        border = 1 if replicate else 2
+        ctx.modes = (0 if top is not None else border, 0 if bottom is not None else border)
+        _lib.call("itg_band_halo_fill", C.byref(d), _ptr(top), _ptr(bottom), ctx.modes[0], ctx.modes[1], st)
+        ctx.comm, ctx.c = comm, c
+        ctx.mark_dirty(ext)
+        return ext
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        n, _, _, H2, W, ld = g.shape
+        st = _stream()
+        d = _desc(g, ctx.c)
+        above = below = None
+        if 0 in ctx.modes:
+            up, down = torch.zeros((n, W, ld), device=g.device), torch.zeros((n, W, ld), device=g.device)
+            _lib.call("itg_band_rows_get", C.byref(d), 0, H2 - 1, _ptr(up) if ctx.modes[0] == 0 else None,
+                      _ptr(down) if ctx.modes[1] == 0 else None, st)
+            above, below = ctx.comm.exchange(up, down)
+        _lib.call("itg_band_halo_grad", C.byref(d), _ptr(above), _ptr(below), ctx.modes[0], ctx.modes[1], st)
+        return g, None, None, None
+
+
+def band_halo(x, comm, replicate):
+    """x: GT whose tensor is a band in the padded layout with rows 1 .. H written (ops.bn_act(pad_rows=True), band_extend)."""
+    return GT(_BandHalo.apply(x.t, x.c, comm, bool(replicate)), x.c)
+
+
+class _BandExtend(torch.autograd.Function):
+    """(n, 1, 1, H, W, ld) -> the padded layout with rows 1 .. H copied (halo rows unwritten): for producers that cannot write
+    the padded layout themselves (SSM modulation, attention); BatchNorm writes it directly (bn_act(pad_rows=True))."""
+
+    @staticmethod
+    def forward(ctx, x, c):
+        _req_cuda(x, "x")
+        x = x.contiguous()
+        n, g1, g2, H, W, ld = x.shape
+        if g1 != 1 or g2 != 1:
+            raise _lib.ItgError("band_extend expects the image layout (1x1 grid)")
+        ext = torch.empty((n, 1, 1, H + 2, W, ld), device=x.device, dtype=torch.float32)
+        _lib.call("itg_band_interior_copy", C.byref(_desc(x, c)), C.byref(_desc(ext, c)), 1, _stream())
+        ctx.c = c
+        return ext
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        n, _, _, H2, W, ld = g.shape
+        gx = torch.empty((n, 1, 1, H2 - 2, W, ld), device=g.device, dtype=torch.float32)
+        _lib.call("itg_band_interior_copy", C.byref(_desc(gx, ctx.c)), C.byref(_desc(g, ctx.c)), 0, _stream())
+        return gx, None
+
+
+def band_extend(x):
+    y = GT(_BandExtend.apply(x.t, x.c), x.c)
+    y.padded = True
+    return y
+
+
 class _HaloExchange(torch.autograd.Function):
     """(first_row, last_row) of this rank's band -> (row above, row below).  The backward is the same
     exchange applied to the halo gradients: the gradient of the row this rank sent up comes back as

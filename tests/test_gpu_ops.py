@@ -725,6 +725,76 @@ def test_conv_with_separate_vertical_padding(mode):
     assert rel_l2(bg.grad.cpu(), b.grad) < 1e-5
 
 
+@pytest.mark.parametrize("mode,cin,cout,H,W,res", [("replicate", 13, 13, 70, 128, "same"), ("zeros", 26, 26, 96, 64, None),
+                                                   ("replicate", 16, 26, 64, 96, "half")])
+def test_band_conv_on_the_strip_kernels(mode, cin, cout, H, W, res):
+    """The conv of a row-sharded band whose input carries its halo rows (pad_h = 0; non-power-of-two heights, image layout) and
+    its input gradient - which has those halo rows, no vertical fold, the horizontal frame folded - on conv_strip.hip
+    (W = 96: 32-pixel strips need no power-of-two width on... they do: that case stays on the halo-tile kernels)."""
+    ops = _ops()
+    g = _gen(H + W)
+    n = 2
+    x = torch.randn(n, cin, H + 2, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64) * 0.2).requires_grad_(True)
+    b = torch.randn(cout, generator=g, dtype=torch.float64)
+    r = None
+    ref = F.conv2d(F.pad(x, (1, 1, 0, 0), mode="replicate" if mode == "replicate" else "constant"), w, b)
+    if res == "same":
+        r = torch.randn(n, cout, H, W, generator=g, dtype=torch.float64)
+        ref = ref + r
+    elif res == "half":
+        r = torch.randn(n, cout, H // 2, W // 2, generator=g, dtype=torch.float64)
+        ref = ref + F.interpolate(r, scale_factor=2, mode="nearest")
+    gy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    dxr, dwr = torch.autograd.grad(ref, (x, w), gy)
+    xg = x.detach().float().to(cuda).requires_grad_(True)
+    wg = w.detach().float().to(cuda).requires_grad_(True)
+    rg = ops.to_grid(r.float().to(cuda), 1, 1, merged=True) if r is not None else None
+    y = ops.conv(ops.to_grid(xg, 1, 1, merged=True), wg, b.float().to(cuda), stride=1, pad=1,
+                 pad_mode=ops.PAD_REPLICATE if mode == "replicate" else ops.PAD_ZERO, pad_h=0, residual=rg)
+    want = "conv_strip_kernel" if W & (W - 1) == 0 else "conv_tile_kernel"
+    assert ops._lib.fn("itg_last_conv_kernel")().decode().startswith(want)
+    out = ops.to_nchw(y, merged=True)
+    assert rel_l2(out.detach().cpu(), ref.detach()) < 2e-6
+    dxg, dwg = torch.autograd.grad(out, (xg, wg), gy.float().to(cuda))
+    assert rel_l2(dxg.cpu(), dxr) < 5e-6 and rel_l2(dwg.cpu(), dwr) < 5e-6
+
+
+@pytest.mark.parametrize("outer", ["replicate", "constant"])
+def test_band_halo_row_layout_equals_the_concatenated_form(outer):
+    """ops.bn_act(pad_rows=True) + ops.band_halo on one rank (the neighbours' rows are the outer padding then): the BatchNorm
+    writes rows 1 .. H of the (H + 2)-row band, the halo rows are filled in place, the conv reads it with pad_h = 0 - against
+    conv(pad(act(bn(x)))) under autograd (reference models/layers.py:145-173,279-280,301-311): output, input gradient, gamma /
+    beta gradients.  band_extend (the copy form for non-BatchNorm producers) must give the same."""
+    ops = _ops()
+    g = _gen(9)
+    n, c, co, H, W = 2, 13, 8, 12, 16
+    x = torch.randn(n, c, H, W, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    w = torch.randn(co, c, 3, 3, generator=g) * 0.2
+    xr, gr_, br_ = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    a = F.leaky_relu(F.batch_norm(xr, None, None, gr_, br_, training=True), 0.2)
+    ref = F.conv2d(F.pad(a, (1, 1, 1, 1), mode="replicate" if outer == "replicate" else "constant"), w)
+    dy = torch.randn(ref.shape, generator=g)
+    want = torch.autograd.grad(ref, (xr, gr_, br_), dy)
+    for producer in ("bn_pad_rows", "band_extend"):
+        xg, gg, bg = x.to(cuda).requires_grad_(True), gamma.to(cuda).requires_grad_(True), beta.to(cuda).requires_grad_(True)
+        rm, rv, nbt = torch.zeros(c, device=cuda), torch.ones(c, device=cuda), torch.zeros((), dtype=torch.int64, device=cuda)
+        gx = ops.to_grid(xg, 1, 1, merged=True)
+        if producer == "bn_pad_rows":
+            h = ops.bn_act(gx, gg, bg, rm, rv, nbt, True, 1e-5, 0.1, ops.ACT_LRELU, 0.2, pad_rows=True)
+            assert h.padded and h.t.shape[3] == H + 2
+        else:
+            h = ops.band_extend(ops.bn_act(gx, gg, bg, rm, rv, nbt, True, 1e-5, 0.1, ops.ACT_LRELU, 0.2))
+        ext = ops.band_halo(h, None, outer == "replicate")
+        y = ops.to_nchw(ops.conv(ext, w.to(cuda), None, 3, 3, 1, 1, ops.PAD_REPLICATE if outer == "replicate" else ops.PAD_ZERO, pad_h=0),
+                        merged=True)
+        assert rel_l2(y.detach().cpu(), ref.detach()) < 2e-6, producer
+        got = torch.autograd.grad(y, (xg, gg, bg), dy.to(cuda))
+        for a_, b_ in zip(got, want):
+            assert rel_l2(a_.cpu(), b_) < 1e-5, producer
+
+
 def test_conv_chain_with_activation_backward_fused_into_consumer_dgrad():
     """conv -> LeakyReLU -> conv (stride 2, 4 output-parity classes) -> tanh-less head: the first conv's
     activation backward runs in the second conv's input-gradient epilogue (itg_conv2d_dgrad act_out)."""
