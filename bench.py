@@ -306,6 +306,19 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def schedule_source_hash():
+    """sha256 over the host files that decide WHICH kernels a step launches, in what form and order (ops.py, engine.py,
+    models/layers.py, dist.py): a profile taken before a schedule change describes another step even when the kernel sources are
+    unchanged (the r04 set trailed two such commits)."""
+    import hashlib
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, "infinite_texture_gans_amd")
+    for f in ("ops.py", "engine.py", os.path.join("models", "layers.py"), "dist.py"):
+        h.update(f.encode())
+        h.update(open(os.path.join(pkg, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def hbm_traffic(kernel):
     """(HBM bytes per launch of ``kernel``, provenance note) from the committed PMC summary (separate rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied by tools/prof_summary.py).  The summary carries the hash
@@ -320,17 +333,21 @@ def hbm_traffic(kernel):
     try:
         js = json.load(open(files[-1]))
         meta = js.get("_meta", {})
-        here = kernel_source_hash()
+        here, sched = kernel_source_hash(), schedule_source_hash()
         if meta.get("kernel_source_sha16") != here:
             return None, ("profiles/%s was measured on kernel sources %s (git %s), this build is %s: traffic withheld; "
                           "re-run tools/profile_all.sh" % (name, meta.get("kernel_source_sha16", "unrecorded"),
                                                            meta.get("git_head", "?"), here))
+        if meta.get("schedule_source_sha16") != sched:
+            return None, ("profiles/%s was measured under the launch schedule %s (git %s), this tree's ops / engine / layers / dist "
+                          "hash to %s: traffic withheld; re-run tools/profile_all.sh" % (
+                              name, meta.get("schedule_source_sha16", "unrecorded"), meta.get("git_head", "?"), sched))
         t = js.get(kernel)
         if t is None:
             return None, "profiles/%s has no entry for this kernel" % name
         return int(t["fetch_bytes"] + t["write_bytes"]), (
-            "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of kernel sources %s = this build (git %s); "
-            "counters cannot be read from inside the timed process" % (name, here, meta.get("git_head", "?")))
+            "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of kernel sources %s and launch schedule %s = this build "
+            "(git %s); counters cannot be read from inside the timed process" % (name, here, sched, meta.get("git_head", "?")))
     except Exception as e:      # noqa: BLE001
         return None, "profiles/%s unreadable: %s" % (name, e)
 

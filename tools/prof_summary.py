@@ -92,7 +92,8 @@ def main():
                 head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
             except Exception:      # noqa: BLE001  (the GPU box has no .git)
                 head = os.environ.get("ITG_GIT_HEAD", "unknown")
-            traffic["_meta"] = {"kernel_source_sha16": bench.kernel_source_hash(), "git_head": head}
+            traffic["_meta"] = {"kernel_source_sha16": bench.kernel_source_hash(), "schedule_source_sha16": bench.schedule_source_hash(),
+                                "git_head": head}
             json.dump(traffic, open(os.path.join(ROOT, "profiles", "%s%s_hbm_traffic.json" % (a.round, a.suffix)), "w"), indent=0)
     print("wrote", out + ".md")
 
