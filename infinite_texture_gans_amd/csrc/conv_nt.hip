@@ -281,7 +281,11 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
     if (try_conv_valu(p, s, &rc_v)) return rc_v;
     if (try_conv_s2k4(p, s, &rc_v)) return rc_v;
     if (p.ncls == 4 && try_conv_up2_tile(p, s, &rc_v)) return rc_v;
-    if (try_conv_strip(p, s, &rc_v)) return rc_v;
+    {
+      ConvP ps = p;
+      ps.stats = nullptr;                                     // strip kernels: statistics by the separate pass (conv_strip.hip)
+      if (try_conv_strip(ps, s, &rc_v)) return (rc_v == ITG_OK && want_stats) ? stats_after(p, want_stats, s) : rc_v;
+    }
   }
   {
     int rc_tile = ITG_OK;

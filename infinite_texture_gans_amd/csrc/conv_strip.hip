@@ -15,7 +15,7 @@
 //     rotated in (row_ror), 6 DPP moves per register and row instead of two more LDS reads per tap;
 //   * the vertical taps are three ACCUMULATOR sets: input row Y feeds output rows Y + 1, Y, Y - 1 (ky = 0, 1, 2), row Y - 1
 //     is complete after it and leaves through the epilogue (1 / sigma, bias, residual or activation derivative, activation,
-//     BatchNorm sums in registers) as 1 KB contiguous stores; rows Y + 1 .. Y + 2 are in flight in two more register sets;
+//     ) as 1 KB contiguous stores; rows Y + 1 .. Y + 2 are in flight in two more register sets;
 //   * the filter bank sits in LDS once per workgroup (read-only afterwards): 9 x chunks x row tiles A fragments per row;
 //   * row addresses are scalar (the row's byte offset is the buffer load's soffset), lane offsets are fixed per strip.
 // Input gradients of replicate-padded layers (itg_conv2d_dgrad's padded-extent + atomic fold, conv.hip) are folded IN
@@ -76,7 +76,7 @@ __device__ __forceinline__ f32x4 dppmov4(f32x4 src) {
 constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHR1 = 0x111, DPP_ROW_ROR1 = 0x121, DPP_ROW_ROR15 = 0x12F;
 
 // KC = 16-channel chunks of an input pixel (1: cin_ld <= 16, 2: cin_ld <= 32), FI = 16-row tiles of output channels
-template <int KC, int FI, bool STATS>
+template <int KC, int FI>
 __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel(const ConvP p, const StripP sp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // filter bank: [9 taps][KC][FI] blocks of 16 rows x 16 k, unpadded, the four 16-byte k groups of a row XOR-swizzled with bit 3
@@ -84,7 +84,6 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
   // padded pitch-20 rows of the first version were 2-way conflicted - SQ_LDS_BANK_CONFLICT 47 % of the LDS cycles)
   float* Wl = lds;
   float* biasl = lds + 9 * KC * FI * 256;                 // [32]
-  float* lstat = biasl + 32;                              // [4 waves][2][16 * FI]
   const int tid = threadIdx.x, lane = tid & 63;
   // the wave index as an SGPR: everything a wave decides (its unit, rows, frame cases) is then provably uniform - scalar
   // branches and scalar row offsets instead of exec-mask regions and a waterfall loop around every buffer access (the first
@@ -142,10 +141,6 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
   const int H = sp.H, Hin = sp.Hin, W = sp.W, lpw = sp.lpw;
   const unsigned ild4 = (unsigned)p.in.ld * 4u, old4 = (unsigned)p.out.ld * 4u, rld4 = (unsigned)p.res.ld * 4u;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-  f32x4 ts1[FI], ts2[FI];                                 // BatchNorm sums of everything this wave stores (p.stats)
-#pragma unroll
-  for (int i = 0; i < FI; ++i) { ts1[i] = zero4; ts2[i] = zero4; }
 
   for (int unit = blockIdx.x * 4 + wave; unit < sp.units; unit += gridDim.x * 4) {
     const int xs = unit % sp.nstrips;
@@ -281,7 +276,6 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
           }
-          if constexpr (STATS) { ts1[i] += v; ts2[i] += v * v; }
           if (!(sp.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rout, vo[i][f], ob, 0);
           acc[i][f] = zero4;
         }
@@ -356,37 +350,6 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
 
   STAMP();
   if (tson && lane == 0) tsp[38] = __builtin_amdgcn_s_memrealtime();
-  if constexpr (STATS) {
-    // per-lane sums -> the 16 pixel lanes of a channel group -> the four waves in a fixed order -> one fp64 atomic per channel
-#pragma unroll
-    for (int i = 0; i < FI; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          ts1[i][e] += __shfl_xor(ts1[i][e], o, 64);
-          ts2[i][e] += __shfl_xor(ts2[i][e], o, 64);
-        }
-    if (nl == 0) {
-#pragma unroll
-      for (int i = 0; i < FI; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          lstat[(wave * 2 + 0) * 16 * FI + 16 * i + 4 * g + e] = ts1[i][e];
-          lstat[(wave * 2 + 1) * 16 * FI + 16 * i + 4 * g + e] = ts2[i][e];
-        }
-    }
-    __syncthreads();
-    if (tid < 32 * FI) {
-      const int which = tid / (16 * FI), ch = tid % (16 * FI);
-      if (ch < p.out.ld) {
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) t += (double)lstat[(w * 2 + which) * 16 * FI + ch];
-        atomicAdd(&p.stats[which * p.out.ld + ch], t);
-      }
-    }
-  }
 }
 
 static inline int ilog2_exact(int v) {
@@ -442,7 +405,8 @@ int try_conv_strip(const ConvP& p, hipStream_t s, int* rc) {
   const int64_t ib = (int64_t)gi.n * gi.gh * gi.gw * gi.ph * gi.pw * gi.ld * 4, ob = (int64_t)go.n * go.gh * go.gw * go.ph * go.pw * go.ld * 4;
   if (ib >= 0xFFFF0000LL || ob >= 0xFFFF0000LL) return 0;
   const int KC = p.cin_ld <= 16 ? 1 : 2, FI = p.co_rows / 16;
-  if (p.stats && go.ld > 32) return 0;
+  if (p.stats) return 0;      // the consumer BatchNorm's statistics: the caller's separate pass (dispatch_nt; in-kernel sums + 768 workgroups' closing
+                              // fp64 atomics measured 0.3 - 1.6 % slower per step than bn_stats at 4.9 TB/s)
   ConvP q = p;
   q.in_bytes = (unsigned)ib;
   StripP sp;
@@ -474,7 +438,7 @@ int try_conv_strip(const ConvP& p, hipStream_t s, int* rc) {
   const int64_t units = (int64_t)gi.n * sp.nseg * sp.nstrips;
   if (units > 0x7fffffff) return 0;
   sp.units = (int)units;
-  size_t lds = ((size_t)9 * KC * FI * 256 + 32 + 4 * 2 * 16 * FI) * sizeof(float);
+  size_t lds = ((size_t)9 * KC * FI * 256 + 32) * sizeof(float);
   // every CU gets the SAME number of workgroups: the kernel is MFMA-bound with all waves resident from the start, so a CU that
   // was handed four workgroups while its neighbour got two finishes a third later than the even deal (the dispatcher fills by
   // resources, not evenly: 2.5 resident waves per SIMD measured where 3 were launched).  LDS is what caps a CU at `occ`.
@@ -483,15 +447,14 @@ int try_conv_strip(const ConvP& p, hipStream_t s, int* rc) {
   int64_t blocks = (units + 3) / 4;
   const int64_t maxb = 256LL * occ;
   if (blocks > maxb) blocks = maxb;
-  const bool st = p.stats != nullptr;
   const void* kern = nullptr;
-#define ITG_STRIP_PICK(KC_, FI_) kern = st ? (const void*)&conv_strip_kernel<KC_, FI_, true> : (const void*)&conv_strip_kernel<KC_, FI_, false>
+#define ITG_STRIP_PICK(KC_, FI_) kern = (const void*)&conv_strip_kernel<KC_, FI_>
   if (KC == 1 && FI == 1) { ITG_STRIP_PICK(1, 1); }
   else if (KC == 1) { ITG_STRIP_PICK(1, 2); }
   else if (FI == 1) { ITG_STRIP_PICK(2, 1); }
   else { ITG_STRIP_PICK(2, 2); }
 #undef ITG_STRIP_PICK
-  snprintf(g_last_launch, sizeof(g_last_launch), "conv_strip_kernel<%d, %d, %s>", KC, FI, st ? "true" : "false");
+  snprintf(g_last_launch, sizeof(g_last_launch), "conv_strip_kernel<%d, %d>", KC, FI);
   if (lds > 48 * 1024) {
     static const void* attr_set[8] = {nullptr};
     bool seen = false;
