@@ -49,28 +49,6 @@ typedef struct {
 enum { ITG_PAD_ZERO = 0, ITG_PAD_REPLICATE = 1 };
 enum { ITG_ACT_NONE = 0, ITG_ACT_LRELU = 1, ITG_ACT_TANH = 2 };
 
-/* Input transform of a convolution (optional, itg_conv_geom.in_norm): the conv does not see the tensor `in` it is
- * handed but  u = up2x?( act( alpha * in + beta' ) ),  i.e. the BatchNorm-apply + LeakyReLU (+ nearest x2 upsample)
- * that precedes every generator conv (reference models/layers.py:301-311, generators.py:95-117) runs inside the
- * conv's tile loader and u is never written to memory; padding positions stay zero / replicate u.
- *   itg_conv2d_fwd / itg_conv2d_wgrad : `in` / `x` is the BatchNorm's INPUT (half the conv's input extent when
- *       upsample = 1); ab = alpha | beta' (2 * in.ld floats, itg_bn_finalize).
- *   itg_conv2d_dgrad : `dx` is the gradient w.r.t. u (u's extent).  With bwd_sums != NULL the epilogue also
- *       accumulates the BatchNorm backward sums over every element g of dx:  ge = g * act'(alpha x + beta'),
- *       bwd_sums[c] += ge, bwd_sums[ld + c] += ge * xhat  (x, mean_rstd: the BatchNorm's input and statistics;
- *       2 * ld zeroed doubles) - what itg_bn_bwd_reduce computes in a pass of its own; itg_bn_bwd_apply(x, dx, ...)
- *       then finishes the BatchNorm backward.  Kernel paths that cannot take the sums run that pass themselves.  */
-typedef struct {
-  const float* ab;          /* alpha | beta', 2 * ld floats */
-  int32_t act;              /* ITG_ACT_NONE | ITG_ACT_LRELU (0 <= slope <= 1) */
-  float slope;
-  int32_t upsample;         /* 0 | 1 */
-  int32_t reserved;
-  const itg_tensor* x;      /* dgrad + bwd_sums only: the BatchNorm's input */
-  const float* mean_rstd;   /* dgrad + bwd_sums only: mean | rstd, 2 * ld floats */
-  double* bwd_sums;         /* dgrad only, or NULL */
-} itg_in_norm;
-
 typedef struct {
   int32_t kh, kw, stride, pad;
   int32_t pad_mode; /* ITG_PAD_*: how reads outside the merged image resolve */
@@ -83,12 +61,13 @@ typedef struct {
                       * (reference models/generators.py:52 + layers.py:301-311: nn.Upsample in front of every block's first
                       * conv2d_lp).  3 x 3, stride 1, pad 1 only; panels from itg_pack_up2_fwd / itg_pack_up2_dgrad; the input
                       * gradient is the 4 x 4 stride-2 convolution of dy with the same phase sums and lands on the half-size
-                      * tensor (the upsample's backward included); no in_norm.                                              */
+                      * tensor (the upsample's backward included).                                                           */
   double* out_stats; /* itg_conv2d_fwd only, or NULL: 2 * out.ld doubles (sum | sum of squares per channel over every
                       * output pixel), ACCUMULATED into by the conv's epilogue - the BatchNorm statistics of the
                       * layer that consumes this output (nn.BatchNorm2d after every generator conv, reference
                       * models/layers.py:279-280,301-322) without a second pass over the tensor (out.ld <= 512) */
-  const itg_in_norm* in_norm; /* NULL, or the input transform described above */
+  const void* reserved_ptr;   /* NULL (rounds 3-4: an input transform - BatchNorm-apply inside the conv's tile loader - that was
+                               * measured slower in every configuration and removed; the slot keeps the struct layout) */
   int32_t flags;     /* ITG_GEOM_*; zero-initialise the struct */
   int32_t reserved;  /* 0 */
   const float* wino_v; /* itg_conv2d_wgrad / itg_conv2d_wgrad_slabs of an ITG_GEOM_WINO layer only, or NULL: the transformed

@@ -21,27 +21,15 @@ class Tensor(C.Structure):
 PREC_F32, PREC_BF16 = 0, 1      # itg.h ITG_PREC_*
 
 
-class InNorm(C.Structure):
-    """itg_in_norm: BatchNorm-apply + activation (+ nearest x2 upsample) done by the conv's tile loader."""
-    _fields_ = [("ab", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float), ("upsample", C.c_int32),
-                ("reserved", C.c_int32), ("x", C.POINTER(Tensor)), ("mean_rstd", C.c_void_p), ("bwd_sums", C.c_void_p)]
-
-    def __init__(self, ab, act, slope, upsample, x=None, mean_rstd=None, bwd_sums=None):
-        super().__init__(ab, act, slope, int(upsample), 0, C.pointer(x) if x is not None else None, mean_rstd, bwd_sums)
-        self._x = x      # keep the descriptor alive
-
-
 class ConvGeom(C.Structure):
     _fields_ = [("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("pad_mode", C.c_int32), ("pad_h", C.c_int32), ("precision", C.c_int32), ("up2", C.c_int32),
-                ("out_stats", C.c_void_p), ("in_norm", C.POINTER(InNorm)), ("flags", C.c_int32), ("reserved", C.c_int32),
+                ("out_stats", C.c_void_p), ("reserved_ptr", C.c_void_p), ("flags", C.c_int32), ("reserved", C.c_int32),
                 ("wino_v", C.c_void_p)]
 
-    def __init__(self, kh, kw, stride, pad, pad_mode, pad_h=-1, precision=0, out_stats=None, in_norm=None, up2=0, flags=0,
+    def __init__(self, kh, kw, stride, pad, pad_mode, pad_h=-1, precision=0, out_stats=None, _reserved=None, up2=0, flags=0,
                  wino_v=None):
-        super().__init__(kh, kw, stride, pad, pad_mode, pad_h, precision, int(up2), out_stats,
-                         C.pointer(in_norm) if in_norm is not None else None, int(flags), 0, wino_v)
-        self._in_norm = in_norm      # keep it alive
+        super().__init__(kh, kw, stride, pad, pad_mode, pad_h, precision, int(up2), out_stats, None, int(flags), 0, wino_v)
 
 
 GEOM_FRAME_ZEROED = 1

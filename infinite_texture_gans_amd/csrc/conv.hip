@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(GridT in, GridT out, con
 inline bool cin1_conv(const itg_tensor* in, const itg_tensor* out, const itg_conv_geom* g) {
   static const int enable = env_int("ITG_CIN1_CONV", 1);
   return enable && in->c == 1 && in->ld == 4 && g->kh == 3 && g->kw == 3 && g->stride == 1 && g->pad == 0 && pad_v_raw(g) == 0 &&
-         out->ld <= 128 && out->c >= 16 && g->precision != ITG_PREC_BF16 && !g->out_stats && !g->in_norm;
+         out->ld <= 128 && out->c >= 16 && g->precision != ITG_PREC_BF16 && !g->out_stats;
 }
 
 inline bool thin_in_conv(const itg_tensor* dy, const itg_tensor* dx, const itg_conv_geom* g) {
@@ -498,30 +498,17 @@ int conv_out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1;
 inline int pad_v(const itg_conv_geom* g) { return g->pad_h >= 0 ? g->pad_h : g->pad; }
 inline int prec_of(const itg_conv_geom* g) { return g->precision == ITG_PREC_BF16 ? ITG_PREC_BF16 : ITG_PREC_F32; }
 
-// itg_in_norm of a call (or none): validated against the tensor it transforms
-inline int in_norm_of(const itg_conv_geom* g, const itg_tensor* in, const itg_in_norm** out) {
-  *out = nullptr;
-  const itg_in_norm* n = g->in_norm;
-  if (!n) return ITG_OK;
-  if (!n->ab || (n->act != ITG_ACT_NONE && n->act != ITG_ACT_LRELU) || n->slope < 0.f || n->slope > 1.f) return ITG_ERR_ARG;
-  if ((n->upsample != 0 && n->upsample != 1) || (((uintptr_t)n->ab) & 15) || !in) return ITG_ERR_ARG;
-  *out = n;
-  return ITG_OK;
-}
 // itg_conv_geom.up2: 3x3, stride 1, pad 1 on the x2 upsample of `lo` (half the patch extent of `hi`, same grid).
 // pad_h = 0 (row-sharded bands, 1-row grids): `lo` carries one explicit halo row of SOURCE pixels above and below.
 inline int up2_check(const itg_conv_geom* g, const itg_tensor* lo, const itg_tensor* hi) {
   const int pv = pad_v_raw(g);
-  if (g->kh != 3 || g->kw != 3 || g->stride != 1 || g->pad != 1 || (pv != 0 && pv != 1) || g->in_norm) return ITG_ERR_ARG;
+  if (g->kh != 3 || g->kw != 3 || g->stride != 1 || g->pad != 1 || (pv != 0 && pv != 1)) return ITG_ERR_ARG;
   if (lo->n != hi->n || lo->gh != hi->gh || lo->gw != hi->gw || 2 * lo->pw != hi->pw) return ITG_ERR_ARG;
   if (pv == 1 ? 2 * lo->ph != hi->ph : (lo->gh != 1 || 2 * (lo->ph - 2) != hi->ph)) return ITG_ERR_ARG;
   return ITG_OK;
 }
 inline void clear_xf(ConvP& p) {
   p.ucls = 0; p.u_in = p.u_w = p.u_out = 0; p.u_dgrad = 0;
-  p.in_ab = nullptr; p.in_act = ITG_ACT_NONE; p.in_slope = 0.f; p.in_ups = 0;
-  p.bnx = null_grid(); p.bn_ab = nullptr; p.bn_mr = nullptr; p.bn_act = ITG_ACT_NONE; p.bn_slope = 0.f; p.bn_ups = 0;
-  p.bn_sums = nullptr;
 }
 
 
@@ -644,7 +631,7 @@ int itg_pack_multi(const int64_t* table_dev, int n, int64_t total, void* stream)
 // ITG_GEOM_WINO: geometry the Winograd pipeline takes (conv_wino.hip)
 // 4 x 4 stride 1 pad 1 with zero padding (R = 4), or 3 x 3 stride 1 pad 1 with zero or replicate padding (R = 3)
 static inline bool wino_geom(const itg_conv_geom* g) {
-  if (!(g->flags & ITG_GEOM_WINO) || g->kh != g->kw || g->stride != 1 || g->pad != 1 || pad_v_raw(g) != 1 || g->up2 || g->in_norm)
+  if (!(g->flags & ITG_GEOM_WINO) || g->kh != g->kw || g->stride != 1 || g->pad != 1 || pad_v_raw(g) != 1 || g->up2)
     return false;
   return (g->kh == 4 && g->pad_mode == ITG_PAD_ZERO) || (g->kh == 3 && (g->pad_mode == ITG_PAD_ZERO || g->pad_mode == ITG_PAD_REPLICATE));
 }
@@ -691,9 +678,7 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   int rc;
   if ((rc = check_tensor(in)) || (rc = check_tensor(out))) return rc;
   if (!w_packed || !g || g->kh <= 0 || g->kw <= 0 || g->stride <= 0 || g->pad < 0) return ITG_ERR_ARG;
-  const itg_in_norm* nin;
-  if (!w_packed || !g) return ITG_ERR_ARG;
-  if ((rc = in_norm_of(g, in, &nin))) return rc;
+  if (g->reserved_ptr) return ITG_ERR_ARG;
   if (g->flags & ITG_GEOM_WINO) {
     if (!wino_geom(g)) return ITG_ERR_ARG;
     const itg_tensor* r = (residual && residual->ptr) ? residual : nullptr;
@@ -758,7 +743,7 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
     ITG_CHECK_LAUNCH();
     return ITG_OK;
   }
-  if (thin_out_conv(in, out, g) && !(residual && residual->ptr) && !nin) {
+  if (thin_out_conv(in, out, g) && !(residual && residual->ptr)) {
     if (g->out_stats) return ITG_ERR_ARG;       // single-output-channel layers have no BatchNorm consumer on this path
     // taps-as-rows path (see tap_gather_fwd_kernel): a 1x1 conv into P[pixel][16], then the tap gather
     const int H = in->gh * in->ph, W = in->gw * in->pw;
@@ -786,8 +771,6 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   p.in = make_grid(in);
   p.out = make_grid(out);
   p.res = null_grid();
-  const int ups = nin ? nin->upsample : 0;
-  if (nin) { p.in_ab = nin->ab; p.in_act = nin->act; p.in_slope = nin->slope; p.in_ups = ups; }
   p.res_ups = 0;
   if (residual && residual->ptr) {
     if ((rc = check_tensor(residual))) return rc;
@@ -802,7 +785,7 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
     p.res = make_grid(residual);
   }
   if (in->n != out->n) return ITG_ERR_ARG;
-  int Ho = conv_out_dim(p.in.H << ups, g->kh, g->stride, pad_v(g)), Wo = conv_out_dim(p.in.W << ups, g->kw, g->stride, g->pad);
+  int Ho = conv_out_dim(p.in.H, g->kh, g->stride, pad_v(g)), Wo = conv_out_dim(p.in.W, g->kw, g->stride, g->pad);
   if (Ho != p.out.H || Wo != p.out.W) return ITG_ERR_ARG;
   if (g->pad_mode == ITG_PAD_REPLICATE && g->stride != 1) return ITG_ERR_ARG;
   p.w = w_packed; p.bias = bias; p.scale = out_scale; p.res_mode = 0; p.res_slope = 0.f;
@@ -876,7 +859,7 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
     p.M = (int)M;
     return dispatch_nt(p, workspace, workspace_floats, s);
   }
-  if (thin_in_conv(dy, dx, g) && !g->in_norm) {
+  if (thin_in_conv(dy, dx, g)) {
     const int Ho = dy->gh * dy->ph, Wo = dy->gw * dy->pw, H = dx->gh * dx->ph, W = dx->gw * dx->pw;
     if (conv_out_dim(H, 4, 2, 1) != Ho || conv_out_dim(W, 4, 2, 1) != Wo) return ITG_ERR_ARG;
     const int rows = 64;     // 4 parity classes x 4 taps x 4 (padded) input channels
@@ -915,20 +898,7 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
   p.prec = prec_of(g);
   p.in = make_grid(dy);
   p.out = make_grid(dx);
-  {
-    const itg_in_norm* nin;
-    if ((rc = in_norm_of(g, dx, &nin))) return rc;
-    if (nin && nin->bwd_sums) {
-      if (!nin->x || !nin->mean_rstd || (rc = check_tensor(nin->x))) return rc ? rc : ITG_ERR_ARG;
-      const itg_tensor* x = nin->x;
-      const int u = nin->upsample;
-      if (x->n != dx->n || x->gh != dx->gh || x->gw != dx->gw || (x->ph << u) != dx->ph || (x->pw << u) != dx->pw ||
-          x->c != dx->c || x->ld != dx->ld || dx->ld > 512)
-        return ITG_ERR_ARG;
-      p.bnx = make_grid(x); p.bn_ab = nin->ab; p.bn_mr = nin->mean_rstd; p.bn_act = nin->act; p.bn_slope = nin->slope;
-      p.bn_ups = u; p.bn_sums = nin->bwd_sums;
-    }
-  }
+  if (g->reserved_ptr) return ITG_ERR_ARG;
   p.res = null_grid();
   p.res_mode = 0; p.res_slope = 0.f; p.res_ups = 0;
   if (act_out && act_out->ptr && act != ITG_ACT_NONE) {
@@ -1008,7 +978,7 @@ static bool wino_wgrad_ok(const itg_tensor* x, const itg_tensor* dy, const itg_c
 int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g) {
   if (!x || !dy || !g) return 0;
   if (wino_wgrad_ok(x, dy, g)) return plan_wino_wgrad(x, dy, g->kh).ws_floats;
-  if (thin_out_conv(x, dy, g) && !g->in_norm) {
+  if (thin_out_conv(x, dy, g)) {
     int64_t Min = grid_pixels(x);
     TnPlan t = plan_tn(Min, 16, x->ld, prec_of(g));
     return Min * 16 + 16 * (int64_t)x->c + 16 + t.ws_floats + (int64_t)t.splits * t.co_rows;
@@ -1036,7 +1006,6 @@ static int wgrad_setup(const itg_tensor* x, const itg_tensor* dy, const itg_conv
     // conv3x3(up2x(x)): four output-parity classes of 2 x 2 taps over the SOURCE pixel domain (WgP.up2); the replicate
     // clamp of the gathered operand in source coordinates is the upsampled image's replicate padding
     if ((rc = up2_check(g, x, dy))) return rc;
-    p.in_ab = nullptr; p.in_act = ITG_ACT_NONE; p.in_slope = 0.f; p.in_ups = 0;
     p.up2 = 1;
     const int64_t M = grid_pixels(dy) / 4;              // source pixels that produce output (pad_h = 0: x carries 2 halo rows more)
     if (M >= ((int64_t)1 << 29)) return ITG_ERR_ARG;
@@ -1058,11 +1027,8 @@ static int wgrad_setup(const itg_tensor* x, const itg_tensor* dy, const itg_conv
     t_out = t; prec_out = prec;
     return ITG_OK;
   }
-  const itg_in_norm* nin;
-  if ((rc = in_norm_of(g, x, &nin))) return rc;
-  const int ups = nin ? nin->upsample : 0;
-  p.in_ab = nin ? nin->ab : nullptr; p.in_act = nin ? nin->act : ITG_ACT_NONE; p.in_slope = nin ? nin->slope : 0.f; p.in_ups = ups;
-  int Ho = conv_out_dim(p.x.H << ups, g->kh, g->stride, pad_v(g)), Wo = conv_out_dim(p.x.W << ups, g->kw, g->stride, g->pad);
+  if (g->reserved_ptr) return ITG_ERR_ARG;
+  int Ho = conv_out_dim(p.x.H, g->kh, g->stride, pad_v(g)), Wo = conv_out_dim(p.x.W, g->kw, g->stride, g->pad);
   if (Ho != p.dy.H || Wo != p.dy.W) return ITG_ERR_ARG;
   if (g->pad_mode == ITG_PAD_REPLICATE && g->stride != 1) return ITG_ERR_ARG;
   int64_t M = (int64_t)x->n * Ho * Wo;
@@ -1100,7 +1066,7 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
   if (x->n != dy->n) return ITG_ERR_ARG;
   if (accumulate & ~(ITG_ACC_DW | ITG_ACC_DB)) return ITG_ERR_ARG;     // a bit set, not a boolean (ABI note)
   hipStream_t s = (hipStream_t)stream;
-  if (thin_out_conv(x, dy, g) && !g->in_norm) {
+  if (thin_out_conv(x, dy, g)) {
     const int H = x->gh * x->ph, W = x->gw * x->pw;
     if (conv_out_dim(H, g->kh, 1, pad_v(g)) != dy->gh * dy->ph || conv_out_dim(W, g->kw, 1, g->pad) != dy->gw * dy->pw)
       return ITG_ERR_ARG;
@@ -1144,7 +1110,7 @@ int itg_conv2d_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, const itg_
   if ((rc = check_tensor(x)) || (rc = check_tensor(dy))) return rc;
   if (!g || !workspace || !job) return ITG_ERR_ARG;
   if (x->n != dy->n || g->kh * g->kw > 49) return ITG_ERR_ARG;
-  if (thin_out_conv(x, dy, g) && !g->in_norm) return ITG_ERR_ARG;      // taps-as-rows path: not deferrable
+  if (thin_out_conv(x, dy, g)) return ITG_ERR_ARG;      // taps-as-rows path: not deferrable
   if (g->up2) return ITG_ERR_ARG;                                       // folded-upsample layers reduce through their own kernel
   if (wino_wgrad_ok(x, dy, g)) {
     const WinoWgPlan w = plan_wino_wgrad(x, dy, g->kh);

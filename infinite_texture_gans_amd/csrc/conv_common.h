@@ -7,8 +7,6 @@
 #include "itg_common.h"
 
 extern "C" int itg_bn_stats(const itg_tensor* x, double* sums, void* stream);
-extern "C" int itg_bn_bwd_reduce(const itg_tensor* x, const itg_tensor* dy, const float* ab, const float* mean_rstd, int act,
-                                 float slope, double* sums, void* stream);
 
 namespace itgk {
 
@@ -42,16 +40,6 @@ struct ConvP {
   int use_tab;                  // per-row tap-offset table in LDS (narrow layers)
   int xcd_remap;                // deal contiguous runs of tiles to each XCD (its L2 then sees 1/8 of the pixel tiles)
   double* stats;                // fwd only, or null: [2][out.ld] per-channel sum / sum of squares of the stored output
-  // Input transform (itg_in_norm): the conv sees up2x?(act(alpha * in + beta')) of the tensor `in` it is handed, i.e. the
-  // BatchNorm-apply + LeakyReLU (+ nearest x2 upsample) of reference models/layers.py:301-311 / generators.py:95-117 is
-  // done by the tile loader; padding stays zero.  in_ab = [2][cin_ld] (alpha | beta'), or null.
-  const float* in_ab;
-  int in_act; float in_slope;
-  int in_ups;                   // 1: conv coordinates are those of the x2 upsampled image, `in` holds the half-size tensor
-  // BatchNorm backward statistics in the input-gradient epilogue: the output dx is the gradient w.r.t. u = up2x?(act(bn(x)));
-  // per output element g: ge = g * act'(alpha x + beta'), bn_sums[c] += ge, bn_sums[ld + c] += ge * xhat (x read at the
-  // source pixel).  bn_sums null = off.
-  GridT bnx; const float* bn_ab; const float* bn_mr; int bn_act; float bn_slope; int bn_ups; double* bn_sums;
   int prec;                     // ITG_PREC_F32 | ITG_PREC_BF16
   float* partial;      // split-K slabs [ksplit][M][co_rows] (ksplit > 1)
   int ksplit, kchunks; // K chunks (of BK) per split
@@ -151,7 +139,6 @@ struct WgP {
   int co_rows, ncol_tiles, nco_tiles;
   int chunks_per_split, nchunks;
   unsigned x_bytes, dy_bytes;
-  const float* in_ab; int in_act; float in_slope; int in_ups;     // input transform of x (see ConvP)
   // itg_conv_geom.up2 (conv_tn_kernel only): x is the half-size source tensor and blockIdx.y = output-parity class (ry, rx):
   // pixel (t, u) of the SOURCE domain pairs dY(2t + ry, 2u + rx) with the 2 x 2 taps at (t + ry - 1, u + rx - 1); slab and
   // bias partial of (split, class) sit at index split * 4 + class
@@ -186,8 +173,6 @@ NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = 
 int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s);
 int launch_zero_border(const GridT& g, hipStream_t s);
 int launch_zero_frames(const itg_tensor* t, int n, hipStream_t s);
-// conv_nt_fused.hip
-int launch_nt_fused(int mode, int bco, int bpix, const ConvP& p, int k, hipStream_t s);
 // conv_nt_w64.hip
 int launch_nt_w64(int bco, int bpix, const ConvP& p, int k, hipStream_t s);
 // conv_wgrad.hip

@@ -258,13 +258,6 @@ int stats_after(const ConvP& p, double* stats, hipStream_t s) {
   return itg_bn_stats(&t, stats, s);
 }
 
-// likewise the BatchNorm backward sums of an input-gradient call whose kernel path did not accumulate them
-int bn_reduce_after(const ConvP& p, double* sums, hipStream_t s) {
-  itg_tensor g = {p.out.p, p.out.n, p.out.gh, p.out.gw, p.out.ph, p.out.pw, p.out.c, p.out.ld};
-  itg_tensor x = {p.bnx.p, p.bnx.n, p.bnx.gh, p.bnx.gw, p.bnx.ph, p.bnx.pw, p.bnx.c, p.bnx.ld};
-  return itg_bn_bwd_reduce(&x, &g, p.bn_ab, p.bn_mr, p.bn_act, p.bn_slope, sums, s);
-}
-
 int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s) {
   // ITG_STATS_PATHS: bit 0 halo-tile kernels, bit 1 implicit-GEMM epilogue, bit 2 split-K second stage take the consumer
   // BatchNorm's statistics themselves; a cleared bit runs the separate statistics launch over the finished output instead.
@@ -275,7 +268,6 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
   // (channel-owning workgroups) keep theirs.
   static const int stats_paths = env_int("ITG_STATS_PATHS", 5);
   double* const want_stats = p.stats;
-  double* const want_bn = p.bn_sums;
   {
     int rc_v = ITG_OK;
     if (try_conv_valu(p, s, &rc_v)) return rc_v;
@@ -293,7 +285,6 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
     if (!(stats_paths & 1)) pt.stats = nullptr;
     if (try_conv_tile(pt, s, &rc_tile)) {
       if (rc_tile == ITG_OK && want_stats && !pt.stats) return stats_after(p, want_stats, s);
-      if (rc_tile == ITG_OK && want_bn && !pt.bn_sums) return bn_reduce_after(p, want_bn, s);
       return rc_tile;
     }
   }
@@ -315,7 +306,6 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
   const bool second_stage = pl.ksplit > 1;      // (an in-launch combine - agent-scope release / ticket / acquire - measured slower: DESIGN section 3)
   const bool stats_in_stage2 = second_stage && p.stats && (stats_paths & 4) && p.out_mode == 0 && p.out.ld <= 512;
   if (second_stage || !(stats_paths & 2)) p.stats = nullptr;
-  if (second_stage) p.bn_sums = nullptr;                     // the second stage does not take them: separate reduce launch
   for (int c = 0; c < 4; ++c) p.cpoff[c] = (unsigned)((size_t)c * pl.ksplit * p.M * p.co_rows);
   {
     int64_t ib = (int64_t)p.in.n * p.in.gh * p.in.gw * p.in.ph * p.in.pw * p.in.ld * 4;
@@ -328,19 +318,15 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
   if (plan_debug)
     fprintf(stderr, "[nt] M=%d x%d co_rows=%d Kpad=%d -> bco=%d bpix=%d ksplit=%d kchunks=%d\n", p.M, ncls_, p.co_rows, p.Kpad,
             pl.bco, pl.bpix, pl.ksplit, pl.kchunks);
-  // plain kernels here; the loader-transform (forward of a normalised input) and BatchNorm-backward-sums (input gradient)
-  // forms are instantiated in conv_nt_fused.hip
   // uniform-class launches (the Winograd GEMMs) with fp32 operands accumulate blockwise in fp64 (NT_W64, conv_nt_w64.hip):
   // ITG_WINO_ACC64 = 1 (default) the FORWARD GEMMs - their rounding decides which LeakyReLU inputs change sign, and every flip
   // moves all upstream gradients by ~1e-3 - 2 = the input-gradient GEMMs as well (their 6.6e-6 against 1.6e-6
   // enters the gradients linearly: invisible next to the flips; 23 us per launch saved), 0 = off
   static const int w64 = env_int("ITG_WINO_ACC64", 1);
   const bool acc64 = p.ucls && k == 16 && (w64 >= 2 || (w64 == 1 && !p.u_dgrad));
-  const int mode = p.in_ab ? NT_XF : (p.bn_sums ? NT_BNS : (acc64 ? NT_W64 : NT_PLAIN));
-  int rc = mode == NT_PLAIN ? launch_nt_shape<NT_PLAIN>(pl.bco, pl.bpix, p, k, s)
-           : mode == NT_W64 ? launch_nt_w64(pl.bco, pl.bpix, p, k, s) : launch_nt_fused(mode, pl.bco, pl.bpix, p, k, s);
+  int rc = acc64 ? launch_nt_w64(pl.bco, pl.bpix, p, k, s) : launch_nt_shape<NT_PLAIN>(pl.bco, pl.bpix, p, k, s);
   if (rc) return rc;
-  if (!second_stage) return (want_stats && !p.stats) ? stats_after(p, want_stats, s) : ITG_OK;   // (bn_sums: taken by the epilogue)
+  if (!second_stage) return (want_stats && !p.stats) ? stats_after(p, want_stats, s) : ITG_OK;
   {
     const int ncls = p.ncls > 1 ? p.ncls : 1;
     int mmax = 0;
@@ -363,7 +349,6 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
       ITG_CHECK_LAUNCH();
     }
   }
-  if (want_bn) return bn_reduce_after(p, want_bn, s);
   return (want_stats && !p.stats) ? stats_after(p, want_stats, s) : ITG_OK;
 }
 

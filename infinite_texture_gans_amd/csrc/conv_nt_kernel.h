@@ -5,7 +5,7 @@
 
 namespace itgk {
 
-enum { NT_PLAIN = 0, NT_XF = 1, NT_BNS = 2, NT_W64 = 3 };
+enum { NT_PLAIN = 0, NT_W64 = 3 };
 
 // NT_W64 (fp32 operands): blocked accumulation for the Winograd GEMMs.  v_mfma_f32_16x16x4_f32 adds its products to the
 // accumulator one after the other, so a K loop of length L is ONE chain of L fp32 roundings: error ~ eps * sqrt(L / 2) of the
@@ -32,9 +32,8 @@ constexpr int nt_min_blocks(int bco, int bpix, int wco, int wpix, int tbk, int m
   return ((wco / 16) * (wpix / 16) <= 8 && (bco + bpix) <= 192) ? 4 : 3;
 }
 
-// MODE (NT_PLAIN | NT_XF | NT_BNS): NT_XF = the input transform of ConvP (in_ab / in_ups: BatchNorm-apply + activation +
-// upsample in the loader), NT_BNS = the BatchNorm backward sums in the epilogue (bn_sums); separate instantiations, so that
-// the plain kernels are exactly the round-2 code (as run-time branches the two cost them 2-20 %).
+// MODE (NT_PLAIN | NT_W64).  (Round 3's NT_XF / NT_BNS - BatchNorm-apply in the loader, BatchNorm backward sums in the
+// input-gradient epilogue - were measured slower twice and removed in round 5.)
 template <int BCO, int BPIX, int WCO, int WPIX, int TBK, int DEPTH, bool TAB, int MODE>
 __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK, MODE)) void conv_nt_kernel(const ConvP p) {
   // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share an L2): hand every XCD one contiguous run of
@@ -136,23 +135,13 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK, MODE)
   extern __shared__ unsigned taptab[];
   const int TS = p.ntaps + 1;
   constexpr bool use_tab = TAB;               // narrow layers only: wide ones change tap rarely and need the LDS
-  // input transform (p.in_ab): alpha | beta' of the input's BatchNorm live in LDS behind the tap table; a stage's
-  // values pass through act(alpha * v + beta') on their way from the prefetch registers into LDS
-  constexpr bool xf = MODE == NT_XF;
-  float* const abt = reinterpret_cast<float*>(taptab + (use_tab ? BPIX * TS : 0));
-  if constexpr (xf) {
-    for (int t = tid; t < 2 * p.cin_ld; t += 256) abt[t] = p.in_ab[t];
-    if constexpr (!use_tab) __syncthreads();
-  }
-  const int ups = xf ? p.in_ups : 0;          // conv coordinates are those of the x2 upsampled input
   auto tap_offset = [&](int i, int tt) -> unsigned {
     const int tky = tt / p.kw, tkx = tt - tky * p.kw;
     int iy = py[i] + tky, ix = px[i] + tkx;
     bool ok = pv[i] && tt < p.ntaps;
-    const int Hv = p.in.H << ups, Wv = p.in.W << ups;
-    if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-    iy = min(max(iy, 0), Hv - 1) >> ups;
-    ix = min(max(ix, 0), Wv - 1) >> ups;
+    if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.in.H && (unsigned)ix < (unsigned)p.in.W;
+    iy = min(max(iy, 0), p.in.H - 1);
+    ix = min(max(ix, 0), p.in.W - 1);
     unsigned o = (unsigned)grid_off(p.in, pn[i], iy, ix) * 4u;
     return ok ? o : p.in_bytes;
   };
@@ -176,15 +165,7 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK, MODE)
   locate();
 
   f32x4 rp[DEPTH][PL], rw[DEPTH][WL];
-  int scc[DEPTH];                 // xf: channel of the stage held by a register set ...
-  unsigned sok[DEPTH];            // ... and which of its rows carry data (bit i; the others are padding and stay zero)
   auto load_tiles = [&](int kk, int set, f32x4 (&rp_)[PL], f32x4 (&rw_v)[WL]) {
-    if constexpr (xf) {
-      unsigned m = 0;
-#pragma unroll
-      for (int i = 0; i < PL; ++i) m |= (poff[i] != p.in_bytes ? 1u : 0u) << i;
-      scc[set] = cc; sok[set] = m;
-    }
 #pragma unroll
     for (int i = 0; i < PL; ++i)
       rp_[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, poff[i] + (unsigned)cc * 4u, 0, 0));
@@ -202,25 +183,11 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK, MODE)
     }
   };
   auto store_tiles = [&](int buf, int set, const f32x4 (&rp_)[PL], const f32x4 (&rw_v)[WL]) {
-    f32x4 xa = {1.f, 1.f, 1.f, 1.f}, xb = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (xf) {
-      xa = *reinterpret_cast<const f32x4*>(abt + scc[set]);
-      xb = *reinterpret_cast<const f32x4*>(abt + p.cin_ld + scc[set]);
-    }
 #pragma unroll
     for (int i = 0; i < PL; ++i) {
       if (BPIX % RPP != 0 && lrow + i * RPP >= BPIX) continue;
       float* dst = Ps + (buf * BPIX + lrow + i * RPP) * LDT + swz;
-      f32x4 v = rp_[i];
-      if constexpr (xf) {
-        const bool live = (sok[set] >> i) & 1u;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = fmaf(v[e], xa[e], xb[e]);
-          if (p.in_act == ITG_ACT_LRELU) t = fmaxf(t, t * p.in_slope);       // 0 <= slope <= 1
-          v[e] = live ? t : 0.f;
-        }
-      }
+      const f32x4 v = rp_[i];
       if constexpr (BF) *reinterpret_cast<uint2*>(dst) = pack_bf16x4(v);
       else *reinterpret_cast<f32x4*>(dst) = v;
     }
@@ -404,20 +371,7 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK, MODE)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (co + e >= p.out.c) v[e] = 0.f;
-      if constexpr (MODE == NT_BNS) {       // v is the gradient w.r.t. up2x?(act(bn(x))) at this pixel
-        const f32x4 xs = *reinterpret_cast<const f32x4*>(p.bnx.p + grid_off(p.bnx, n, oy >> p.bn_ups, ox >> p.bn_ups) + co);
-        const f32x4 ba = *reinterpret_cast<const f32x4*>(p.bn_ab + co), bb = *reinterpret_cast<const f32x4*>(p.bn_ab + p.out.ld + co);
-        const f32x4 bm = *reinterpret_cast<const f32x4*>(p.bn_mr + co), br = *reinterpret_cast<const f32x4*>(p.bn_mr + p.out.ld + co);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float pre = fmaf(xs[e], ba[e], bb[e]);
-          const float ge = v[e] * (p.bn_act == ITG_ACT_LRELU ? (pre > 0.f ? 1.f : p.bn_slope) : 1.f);
-          st1[i][e] += ge;
-          st2[i][e] += ge * ((xs[e] - bm[e]) * br[e]);
-        }
-      } else {
-        st1[i] += v; st2[i] += v * v;
-      }
+      st1[i] += v; st2[i] += v * v;
       float* dst = out_base + off + co;
       if (border) {
 #pragma unroll
@@ -427,7 +381,7 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK, MODE)
       }
     }
   }
-  double* const sums_out = MODE == NT_BNS ? p.bn_sums : p.stats;
+  double* const sums_out = p.stats;
   if (sums_out) {      // workgroup-uniform
     // lanes that share lane >> 4 hold the same 4 channels of different pixels: butterfly over the pixel lanes, then
     // fp64 per workgroup in LDS (the K loop's buffers are free: it ended with a barrier), one global atomic per channel
@@ -477,7 +431,6 @@ int launch_nt(const ConvP& p, int tbk, hipStream_t s) {
   q.use_tab = (p.cin_ld < 64 && tab_bytes <= 24 * 1024) ? 1 : 0;
   q.xcd_remap = 1;
   if (!q.use_tab) tab_bytes = 0;
-  if (MODE == NT_XF) tab_bytes += (size_t)2 * p.cin_ld * sizeof(float);      // alpha | beta' of the input transform behind the tap table
   // two K stages in flight except for the medium fp32 tiles, whose 96-register budget has no room for
   // the second prefetch set (it would spill into scratch inside the K loop)
   constexpr int D32 = (nt_min_blocks(BCO, BPIX, WCO, WPIX, 32) == 3 && BCO >= 64) ? 1 : 2;   // wide bf16 stages: 16 prefetch registers per set

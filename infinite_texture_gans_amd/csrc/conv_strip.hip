@@ -363,7 +363,7 @@ static inline int ilog2_exact(int v) {
 int try_conv_strip(const ConvP& p, hipStream_t s, int* rc) {
   static const int enable = env_int("ITG_CONV_STRIP", 1);
   if (!enable || p.ncls > 1 || p.ucls || p.ntaps != 9 || p.kw != 3 || p.isy != 1 || p.isx != 1 || p.osy != 1 || p.osx != 1) return 0;
-  if (p.prec != ITG_PREC_F32 || p.cin_ld > 32 || p.cin_ld < 8 || p.co_rows > 32 || p.in_ab || p.bn_sums) return 0;      // (4-float pixels: a chunk would be 3/4 padding - the halo-tile kernel packs four taps into one)
+  if (p.prec != ITG_PREC_F32 || p.cin_ld > 32 || p.cin_ld < 8 || p.co_rows > 32) return 0;      // (4-float pixels: a chunk would be 3/4 padding - the halo-tile kernel packs four taps into one)
   const GridT& gi = p.in;
   const GridT& go = p.out;
   if (gi.n != go.n || gi.gh != go.gh || gi.gw != go.gw || gi.pw != go.pw) return 0;

@@ -10,13 +10,12 @@ namespace itgk {
 // K index k = 16 q + 4 g + e maps to (tap, c) = divmod(k, cin_ld); cin_ld % 4 == 0 keeps the four e of a lane
 // in one tap, so lane group g of chunk q reads 16 B at pixel * cpt + koff[q][g].
 // NLD = b128 loads per thread and tile = ceil(340 * (cin_ld / 4) / 256): 6 up to cin_ld 16, 11 up to 32
-// ST: TS_STATS = also accumulate the consumer BatchNorm's statistics (p.stats), TS_BNS = an input gradient that accumulates
-// the BatchNorm backward sums of the layer in front (p.bn_sums); XF = the input transform of ConvP (BatchNorm-apply +
-// activation + nearest x2 upsample while the halo tile is written to LDS).  All separate instantiations, so that the plain
-// launches keep the register budget and the code they were tuned to.
-enum { TS_NONE = 0, TS_STATS = 1, TS_BNS = 2 };
+// ST: TS_STATS = also accumulate the consumer BatchNorm's statistics (p.stats); a separate instantiation, so that the plain
+// launches keep the register budget and the code they were tuned to.  (Round 3's loader-side BatchNorm - an XF / TS_BNS pair of
+// instantiations per kernel - was measured slower twice and removed in round 5.)
+enum { TS_NONE = 0, TS_STATS = 1 };
 
-template <int FI, int NLD, int ST, bool XF>
+template <int FI, int NLD, int ST>
 __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(const ConvP p, int tiles_x, int tiles_y, int ntiles, int cpt, int nch) {
   constexpr bool STATS = ST != TS_NONE;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -25,8 +24,7 @@ __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(cons
   int* koff = reinterpret_cast<int*>(lds + nch * co_rows * 20);
   float* biasl = lds + nch * co_rows * 20 + ((nch * 4 + 3) & ~3);       // [32] bias per output row (zero past out.c)
   double* lstat = reinterpret_cast<double*>(biasl + 32);                // [2][32] BatchNorm sums of this workgroup (p.stats)
-  float* coef = biasl + 32 + 128;                                       // [4][32]: XF alpha | beta';  TS_BNS alpha | beta' | mean | rstd
-  float* Xt = coef + 128;
+  float* Xt = biasl + 32 + 128 + 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = p.cin_ld >> 2;
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in.p, 0, p.in_bytes, 0x00020000);
@@ -57,55 +55,29 @@ __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(cons
     int ky = tap / 3, kx = tap - ky * 3;
     koff[e] = tap < 9 ? (ky * (TT_W + 2) + kx) * cpt + c : 0;      // K padding: weights are zero, read something finite
   }
-  if constexpr (XF) {
-    if (tid < 64) coef[tid] = (tid & 31) < p.cin_ld ? p.in_ab[(tid >> 5) * p.cin_ld + (tid & 31)] : 0.f;
-  }
-  if constexpr (ST == TS_BNS) {
-    if (tid < 128) {
-      const int c = tid & 31, w = tid >> 5;
-      coef[tid] = c < p.out.ld ? (w < 2 ? p.bn_ab[w * p.out.ld + c] : p.bn_mr[(w - 2) * p.out.ld + c]) : 0.f;
-    }
-  }
   // ---- tile loader (global -> registers -> LDS)
   f32x4 rt[NLD];
-  unsigned okmask = 0;                                // XF: which loads of the tile in flight carry data (padding stays zero)
-  const int ups = XF ? p.in_ups : 0;                  // conv coordinates are those of the x2 upsampled input
   auto load_tile = [&](int tile) {
     int b = tile;
     const int tx_i = b % tiles_x; b /= tiles_x;
     const int ty_i = b % tiles_y;
     const int n = b / tiles_y;
     const int y0 = ty_i * TT_H + p.ioy, x0 = tx_i * TT_W + p.iox;
-    unsigned m = 0;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       int iy = y0 + e_r[i], ix = x0 + e_c[i];
       bool ok = e_r[i] >= 0;
-      const int Hv = p.in.H << ups, Wv = p.in.W << ups;
-      if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-      iy = min(max(iy, 0), Hv - 1) >> ups; ix = min(max(ix, 0), Wv - 1) >> ups;
+      if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.in.H && (unsigned)ix < (unsigned)p.in.W;
+      iy = min(max(iy, 0), p.in.H - 1); ix = min(max(ix, 0), p.in.W - 1);
       unsigned o = (unsigned)grid_off(p.in, n, iy, ix) * 4u + e_cb[i];
       rt[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? o : p.in_bytes, 0, 0));
-      if constexpr (XF) m |= (ok ? 1u : 0u) << i;
     }
-    if constexpr (XF) okmask = m;
   };
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       if (e_r[i] < 0) continue;
-      f32x4 v = rt[i];
-      if constexpr (XF) {
-        const f32x4 xa = *reinterpret_cast<const f32x4*>(coef + (e_cb[i] >> 2)), xb = *reinterpret_cast<const f32x4*>(coef + 32 + (e_cb[i] >> 2));
-        const bool live = (okmask >> i) & 1u;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = fmaf(v[e], xa[e], xb[e]);
-          if (p.in_act == ITG_ACT_LRELU) t = fmaxf(t, t * p.in_slope);
-          v[e] = live ? t : 0.f;
-        }
-      }
-      *reinterpret_cast<f32x4*>(Xt + e_lds[i]) = v;
+      *reinterpret_cast<f32x4*>(Xt + e_lds[i]) = rt[i];
     }
   };
   const int fj = lane & 15, g = lane >> 4;
@@ -194,20 +166,6 @@ __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(cons
         const f32x4 v = store_out(p, n, t * p.osy + p.ooy, u * p.osx + p.oox, co, acc[i][f], osc,
                                   *reinterpret_cast<const f32x4*>(biasl + co), has_res, r);
         if constexpr (ST == TS_STATS) { ts1[i] += v; ts2[i] += v * v; }
-        if constexpr (ST == TS_BNS) {       // v = gradient w.r.t. up2x?(act(bn(x))) at this pixel: sums of ge = v act'(.) and ge xhat
-          int oy = t * p.osy + p.ooy, ox = u * p.osx + p.oox;
-          if (p.out_mode == 1) { oy = min(max(oy, 0), p.out.H - 1); ox = min(max(ox, 0), p.out.W - 1); }
-          const f32x4 xs = *reinterpret_cast<const f32x4*>(p.bnx.p + grid_off(p.bnx, n, oy >> p.bn_ups, ox >> p.bn_ups) + co);
-          const f32x4 ba = *reinterpret_cast<const f32x4*>(coef + co), bb = *reinterpret_cast<const f32x4*>(coef + 32 + co);
-          const f32x4 bm = *reinterpret_cast<const f32x4*>(coef + 64 + co), br = *reinterpret_cast<const f32x4*>(coef + 96 + co);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float pre = fmaf(xs[e], ba[e], bb[e]);
-            const float ge = v[e] * (p.bn_act == ITG_ACT_LRELU ? (pre > 0.f ? 1.f : p.bn_slope) : 1.f);
-            ts1[i][e] += ge;
-            ts2[i][e] += ge * ((xs[e] - bm[e]) * br[e]);
-          }
-        }
       }
     }
     if constexpr (STATS) {      // pixel lanes -> one lane per channel group -> fp64 in LDS
@@ -230,7 +188,7 @@ __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(cons
   }
   if constexpr (STATS) {
     __syncthreads();
-    double* const so = ST == TS_BNS ? p.bn_sums : p.stats;
+    double* const so = p.stats;
     if (tid < 32 && tid < p.out.ld) {
       atomicAdd(&so[tid], lstat[tid]);
       atomicAdd(&so[p.out.ld + tid], lstat[32 + tid]);
@@ -245,7 +203,7 @@ __global__ __launch_bounds__(256, (NLD <= 6 ? 4 : 3)) void conv_tile_kernel(cons
 // workgroup stages one (8+2) x (32+2) halo tile in LDS, every thread owns ONE output pixel and all its output
 // channels, reads its 9 neighbours as 16-byte LDS vectors and takes the filter taps through the scalar cache
 // (wave-uniform addresses -> s_load), i.e. <= 576 v_fma per pixel and nothing else in the loop: HBM-bound.
-template <int CI4, int CO4, bool XF>
+template <int CI4, int CO4>
 __global__ __launch_bounds__(256, 5) void conv_valu_kernel(const ConvP p, int tiles_x, int tiles_y, int cpt) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Xt = lds;
@@ -259,15 +217,6 @@ __global__ __launch_bounds__(256, 5) void conv_valu_kernel(const ConvP p, int ti
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in.p, 0, p.in_bytes, 0x00020000);
   const int y0 = t0 + p.ioy, x0 = u0 + p.iox;
   f32x4 rt[NLD];                                           // every load of the tile in flight before the first LDS store
-  // XF (input transform of ConvP): CI4 divides 256, so a thread's channel group - and its alpha / beta' - never changes
-  static_assert(256 % CI4 == 0, "fixed channel group per thread");
-  const int ups = XF ? p.in_ups : 0;
-  f32x4 xa = {1.f, 1.f, 1.f, 1.f}, xb = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (XF) {
-    xa = *reinterpret_cast<const f32x4*>(p.in_ab + (tid % CI4) * 4);
-    xb = *reinterpret_cast<const f32x4*>(p.in_ab + p.cin_ld + (tid % CI4) * 4);
-  }
-  unsigned okmask = 0;
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
     const int e = min(tid + i * 256, TT_PIX * CI4 - 1);
@@ -275,29 +224,17 @@ __global__ __launch_bounds__(256, 5) void conv_valu_kernel(const ConvP p, int ti
     const int r = pix / (TT_W + 2), c = pix - r * (TT_W + 2);
     int iy = y0 + r, ix = x0 + c;
     bool ok = true;
-    const int Hv = p.in.H << ups, Wv = p.in.W << ups;
-    if (p.pad_mode != ITG_PAD_REPLICATE) ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-    iy = min(max(iy, 0), Hv - 1) >> ups; ix = min(max(ix, 0), Wv - 1) >> ups;
+    if (p.pad_mode != ITG_PAD_REPLICATE) ok = (unsigned)iy < (unsigned)p.in.H && (unsigned)ix < (unsigned)p.in.W;
+    iy = min(max(iy, 0), p.in.H - 1); ix = min(max(ix, 0), p.in.W - 1);
     const unsigned o = (unsigned)grid_off(p.in, n, iy, ix) * 4u + (unsigned)c4 * 16u;
     rt[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? o : p.in_bytes, 0, 0));
-    if constexpr (XF) okmask |= (ok ? 1u : 0u) << i;
   }
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
     const int e = tid + i * 256;
     if (e < TT_PIX * CI4) {
       const int pix = e / CI4, c4 = e - pix * CI4;
-      f32x4 v = rt[i];
-      if constexpr (XF) {
-        const bool live = (okmask >> i) & 1u;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float t = fmaf(v[q], xa[q], xb[q]);
-          if (p.in_act == ITG_ACT_LRELU) t = fmaxf(t, t * p.in_slope);
-          v[q] = live ? t : 0.f;
-        }
-      }
-      *reinterpret_cast<f32x4*>(Xt + pix * cpt + c4 * 4) = v;
+      *reinterpret_cast<f32x4*>(Xt + pix * cpt + c4 * 4) = rt[i];
     }
   }
   __syncthreads();
@@ -354,7 +291,6 @@ int try_conv_valu(const ConvP& p, hipStream_t s, int* rc) {
   static const int enable = env_int("ITG_CONV_VALU", 1);
   if (!enable || p.ncls > 1 || p.ntaps != 9 || p.kw != 3 || p.isy != 1 || p.isx != 1 || p.osy != 1 || p.osx != 1) return 0;
   if (p.prec != ITG_PREC_F32 || p.stats || p.co_rows != 16) return 0;
-  if (p.bn_sums) return 0;
   const int ci4 = p.cin_ld >> 2, co4 = p.out.ld >> 2;
   // (4 input groups, 1 output group) = the forward of `final`: 44 us against 68 us on the halo-tile MFMA kernel; its
   // input gradient (1, 4) measured slower here (61 vs 41 us) and stays on the tile kernel
@@ -369,19 +305,11 @@ int try_conv_valu(const ConvP& p, hipStream_t s, int* rc) {
   const int64_t ntiles = (int64_t)p.in.n * tiles_x * tiles_y;
   if (ntiles > 0x7fffffff) return 0;
   const size_t lds = (size_t)TT_PIX * cpt * sizeof(float);
-  const bool xfm = p.in_ab != nullptr;
-  snprintf(g_last_launch, sizeof(g_last_launch), "conv_valu_kernel<%d, %d, %s>", ci4, co4, xfm ? "true" : "false");
+  snprintf(g_last_launch, sizeof(g_last_launch), "conv_valu_kernel<%d, %d>", ci4, co4);
   const dim3 grid((unsigned)ntiles);
-  if (ci4 == 4) {
-    if (xfm) hipLaunchKernelGGL((conv_valu_kernel<4, 1, true>), grid, dim3(256), lds, s, q, tiles_x, tiles_y, cpt);
-    else hipLaunchKernelGGL((conv_valu_kernel<4, 1, false>), grid, dim3(256), lds, s, q, tiles_x, tiles_y, cpt);
-  } else if (co4 == 4) {
-    if (xfm) hipLaunchKernelGGL((conv_valu_kernel<1, 4, true>), grid, dim3(256), lds, s, q, tiles_x, tiles_y, cpt);
-    else hipLaunchKernelGGL((conv_valu_kernel<1, 4, false>), grid, dim3(256), lds, s, q, tiles_x, tiles_y, cpt);
-  } else {
-    if (xfm) hipLaunchKernelGGL((conv_valu_kernel<1, 1, true>), grid, dim3(256), lds, s, q, tiles_x, tiles_y, cpt);
-    else hipLaunchKernelGGL((conv_valu_kernel<1, 1, false>), grid, dim3(256), lds, s, q, tiles_x, tiles_y, cpt);
-  }
+  if (ci4 == 4) hipLaunchKernelGGL((conv_valu_kernel<4, 1>), grid, dim3(256), lds, s, q, tiles_x, tiles_y, cpt);
+  else if (co4 == 4) hipLaunchKernelGGL((conv_valu_kernel<1, 4>), grid, dim3(256), lds, s, q, tiles_x, tiles_y, cpt);
+  else hipLaunchKernelGGL((conv_valu_kernel<1, 1>), grid, dim3(256), lds, s, q, tiles_x, tiles_y, cpt);
   *rc = hipGetLastError() == hipSuccess ? ITG_OK : ITG_ERR_LAUNCH;
   return 1;
 }
@@ -662,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void conv_up2_tile_kernel(const ConvP p, in
 int try_conv_up2_tile(const ConvP& p, hipStream_t s, int* rc) {
   static const int enable = env_int("ITG_UP2_TILE", 1);
   if (!enable || p.ncls != 4 || p.ntaps != 4 || p.kw != 2 || p.cioy[0] != -1 || p.ciox[0] != -1 || p.out_mode != 0) return 0;
-  if (p.prec != ITG_PREC_F32 || p.cin_ld > 32 || p.co_rows > 32 || p.res.p || p.in_ab || p.bn_sums) return 0;
+  if (p.prec != ITG_PREC_F32 || p.cin_ld > 32 || p.co_rows > 32 || p.res.p) return 0;
   if ((int64_t)p.MT * p.MU < 48 * 48) return 0;
   const int FI = p.co_rows / 16;
   if (FI == 2 && p.stats) return 0;                           // (two row tiles + statistics: register budget; separate pass by the caller)
@@ -708,7 +636,7 @@ int try_conv_s2k4(const ConvP& p, hipStream_t s, int* rc) {
   static const int enable = env_int("ITG_CONV_S2K4", 1);
   if (!enable || p.ncls > 1 || p.ntaps != 16 || p.kw != 4 || p.isy != 2 || p.isx != 2 || p.ioy != -1 || p.iox != -1) return 0;
   if (p.osy != 1 || p.osx != 1 || p.ooy != 0 || p.oox != 0 || p.out_mode != 0 || p.pad_mode != ITG_PAD_ZERO) return 0;
-  if (p.prec != ITG_PREC_F32 || p.cin_ld != 4 || p.stats || p.in_ab || p.bn_sums || p.res.p) return 0;
+  if (p.prec != ITG_PREC_F32 || p.cin_ld != 4 || p.stats || p.res.p) return 0;
   if (p.co_rows != 16 && p.co_rows != 32 && p.co_rows != 64) return 0;
   if ((int64_t)p.MT * p.MU < 64 * 64) return 0;
   ConvP q = p;
@@ -739,7 +667,7 @@ int try_conv_tile(ConvP& p, hipStream_t s, int* rc) {
   if (p.prec != ITG_PREC_F32 || p.cin_ld > 32 || p.co_rows > 32) return 0;
   if ((int64_t)p.MT * p.MU < 64 * 64) return 0;          // tiny images: the gather kernel with split-K wins
   const int FI = p.co_rows / 16;
-  if (FI == 2) { p.stats = nullptr; p.bn_sums = nullptr; }   // two row tiles + statistics spill (17-24 VGPRs): the caller runs the separate pass
+  if (FI == 2) p.stats = nullptr;   // two row tiles + statistics spill (17-24 VGPRs): the caller runs the separate pass
   ConvP q = p;
   int64_t ib = (int64_t)p.in.n * p.in.gh * p.in.gw * p.in.ph * p.in.pw * p.in.ld * 4;
   if (ib >= 0xFFFF0000LL) return 0;
@@ -753,17 +681,11 @@ int try_conv_tile(ConvP& p, hipStream_t s, int* rc) {
   const int nld = (TT_PIX * (p.cin_ld >> 2) + 255) / 256;
   static const int lds_cap = env_int("ITG_TILE_LDS_KB", 80) * 1024;       // 26 -> 26 channels (b5c2) needs 76 KB: two workgroups per CU
   if (ntiles > 0x7fffffff || lds > (size_t)lds_cap || nld > 11) return 0;
-  const int stm = p.bn_sums ? TS_BNS : (p.stats ? TS_STATS : TS_NONE);
-  const bool xfm = p.in_ab != nullptr;
-  if (xfm && stm == TS_BNS) return 0;
+  const int stm = p.stats ? TS_STATS : TS_NONE;
   const bool small = nld <= 6;
   const void* kern = nullptr;
 #define ITG_TILE_PICK(FI_, NLD_)                                                                                        \
-  kern = xfm ? (stm == TS_STATS ? (const void*)&conv_tile_kernel<FI_, NLD_, TS_STATS, true>                            \
-                                : (const void*)&conv_tile_kernel<FI_, NLD_, TS_NONE, true>)                             \
-             : (stm == TS_BNS ? (const void*)&conv_tile_kernel<FI_, NLD_, TS_BNS, false>                                \
-                : stm == TS_STATS ? (const void*)&conv_tile_kernel<FI_, NLD_, TS_STATS, false>                          \
-                                  : (const void*)&conv_tile_kernel<FI_, NLD_, TS_NONE, false>)
+  kern = stm == TS_STATS ? (const void*)&conv_tile_kernel<FI_, NLD_, TS_STATS> : (const void*)&conv_tile_kernel<FI_, NLD_, TS_NONE>
   if (FI == 1 && small) { ITG_TILE_PICK(1, 6); }
   else if (FI == 1) { ITG_TILE_PICK(1, 11); }
   else if (small) { ITG_TILE_PICK(2, 6); }
@@ -786,7 +708,7 @@ int try_conv_tile(ConvP& p, hipStream_t s, int* rc) {
   if (per_cu < 1) per_cu = 1;
   const int64_t want = 256 * (int64_t)per_cu;
   const unsigned blocks = (unsigned)(ntiles < want ? ntiles : want);      // (equal tile counts per workgroup measured worse: b6c2 forward 69 -> 76 us)
-  snprintf(g_last_launch, sizeof(g_last_launch), "conv_tile_kernel<%d, %d, %d, %s>", FI, nld <= 6 ? 6 : 11, stm, xfm ? "true" : "false");
+  snprintf(g_last_launch, sizeof(g_last_launch), "conv_tile_kernel<%d, %d, %d>", FI, nld <= 6 ? 6 : 11, stm);
   int a_tx = tiles_x, a_ty = tiles_y, a_nt = (int)ntiles, a_cpt = cpt, a_nch = nch;
   void* args[] = {(void*)&q, &a_tx, &a_ty, &a_nt, &a_cpt, &a_nch};
   (void)hipLaunchKernel(kern, dim3(blocks), dim3(256), args, lds, s);

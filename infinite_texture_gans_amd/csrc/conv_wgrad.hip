@@ -17,13 +17,11 @@ constexpr int tn_min_blocks(int bcol, int wcol, int wco, bool bf, int depth) {
   return depth == 2 ? 3 : (bf ? 2 : ((wcol / 16) * (wco / 16) >= 16 && bcol >= 256 ? 3 : 4));
 }
 
-// XF: the input transform of WgP (BatchNorm-apply + activation + upsample of x in the loader); its own instantiation so that
-// the plain kernel is exactly the round-2 code
 // FLAT: both tensors are plain images (1 x 1 patch grids: the discriminator's layers), zero padding, no parity classes, at
 // most 15 taps per column tile and MU >= the pixels of a stage: the offset producer is then straight-line code (no patch
 // arithmetic, no clamp, one pass, selects instead of branches) that the scheduler may place between the MFMAs of the stage
 // - the generic producer cost 10 % of D's weight-gradient time (timing experiment with the producer switched off after the pipeline had filled: D3 678 -> 608 us).
-template <int BCOL, int BCO, int WCOL, int WCO, bool BF, int DEPTH, bool XF, bool FLAT = false>
+template <int BCOL, int BCO, int WCOL, int WCO, bool BF, int DEPTH, bool FLAT = false>
 __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) void conv_tn_kernel(const WgP p, int otp) {
   constexpr int FI = WCOL / 16, FJ = WCO / 16;
   constexpr int WAVES_COL = BCOL / WCOL;
@@ -152,10 +150,8 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
       } else {
         int iy = pt_ * p.stride - p.pad_h + pky[i] + ry, ix = pu * p.stride - p.pad + pkx[i] + rx;
         bool ok = live;
-        const int ups = XF ? p.in_ups : 0;
-        const int Hv = p.x.H << ups, Wv = p.x.W << ups;      // conv coordinates: those of the (x2 upsampled) input
-        if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-        iy = min(max(iy, 0), Hv - 1) >> ups; ix = min(max(ix, 0), Wv - 1) >> ups;
+        if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.x.H && (unsigned)ix < (unsigned)p.x.W;
+        iy = min(max(iy, 0), p.x.H - 1); ix = min(max(ix, 0), p.x.W - 1);
         o = ok ? (unsigned)grid_off(p.x, live ? pn : 0, iy, ix) * 4u : p.x_bytes;
       }
       otab[(buf * KP + prow) * OTP + (pe0 + i * 256) / KP] = o;
@@ -165,26 +161,8 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
   };
 
   f32x4 rxs[DEPTH][XL], rys[DEPTH][YL];
-  // input transform (p.in_ab, see ConvP): alpha | beta' in LDS behind the offset table; a thread's column groups - hence its
-  // coefficients - never change, but XL x 8 registers for them would cost a workgroup per CU: two ds_read_b128 per store
-  constexpr bool xf = XF;
-  float* const abt = reinterpret_cast<float*>(otab + (DEPTH + 1) * KP * OTP);
-  if constexpr (xf) {
-    for (int t = tid; t < 2 * p.cin_ld; t += 256) abt[t] = p.in_ab[t];
-  }
-  unsigned sokx[DEPTH];          // xf: which X loads of the stage held by a register set carry data (the others stay zero)
   auto load_tiles = [&](int slot, int set, f32x4 (&rx)[XL], f32x4 (&ry)[YL]) {
-    if constexpr (xf) {
-      unsigned m = 0;
-#pragma unroll
-      for (int i = 0; i < XL; ++i) {
-        const unsigned ot = xok[i] ? otab[(slot * KP + xr[i]) * OTP + xj[i]] : p.x_bytes;
-        m |= (ot != p.x_bytes ? 1u : 0u) << i;
-        unsigned o = ot != p.x_bytes ? ot + xcb[i] : p.x_bytes;
-        rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxr, o, 0, 0));
-      }
-      sokx[set] = m;
-    } else {
+    {
 #pragma unroll
       for (int i = 0; i < XL; ++i) {
         // table read unconditional (clamped index), validity by select: no exec-mask branch around the ds_read
@@ -207,17 +185,6 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
     for (int i = 0; i < XL; ++i)
       if (XFULL || xr[i] < KP) {
         f32x4 v = rx[i];
-        if constexpr (xf) {
-          const int c = (int)(xcb[i] >> 2);
-          const f32x4 xa = *reinterpret_cast<const f32x4*>(abt + c), xb = *reinterpret_cast<const f32x4*>(abt + p.cin_ld + c);
-          const bool live = (sokx[set] >> i) & 1u;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float t = fmaf(v[e], xa[e], xb[e]);
-            if (p.in_act == ITG_ACT_LRELU) t = fmaxf(t, t * p.in_slope);
-            v[e] = live ? t : 0.f;
-          }
-        }
         if constexpr (BF) *reinterpret_cast<uint2*>(Xh + (buf * KP + xr[i]) * LHX + xcol[i]) = pack_bf16x4(v);
         else *reinterpret_cast<f32x4*>(Xs + (buf * KP + xr[i]) * LDX + xcol[i]) = v;
       }
@@ -367,8 +334,7 @@ __global__ __launch_bounds__(256, tn_min_blocks(BCOL, WCOL, WCO, BF, DEPTH)) voi
 // against ALL 9 * cin_ld (tap, c) rows: per 4 pixels MF ds_read_b32 + 1 and MF MFMAs, no address arithmetic.
 // The 4 waves' accumulators are summed in a fixed order through LDS; one slab per workgroup, reduced by the
 // same two-stage reduction as the generic path.
-// XF: the input transform of WgP (BatchNorm-apply + activation + upsample of x while its halo tile is written to LDS)
-template <int NJ, int NLD, bool XF>
+template <int NJ, int NLD>
 __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgP p, int tiles_x, int tiles_y, int ntiles, int cpt, int coef_off) {
   constexpr int MF = 4 * NJ;                               // 16-row MFMA tiles of the (tap, c) dimension
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -405,12 +371,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgP p, int til
     y_lds[i] = pix * CPD + (e % yq4) * 4;
   }
   for (int e = tid; e < TT_H * TT_W * CPD; e += 256) Yt[e] = 0.f;     // channel groups >= dy.ld stay zero
-  float* const coef = lds + coef_off;                                 // XF: alpha | beta' [2][32]
-  if constexpr (XF) {
-    if (tid < 64) coef[tid] = (tid & 31) < p.cin_ld ? p.in_ab[(tid >> 5) * p.cin_ld + (tid & 31)] : 0.f;
-  }
-  const int ups = XF ? p.in_ups : 0;
-  unsigned okmask = 0;
   f32x4 rt[NLD], ry[YLD];
   auto load_tile = [&](int tile) {
     int b = tile;
@@ -418,19 +378,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgP p, int til
     const int ty_i = b % tiles_y;
     const int n = b / tiles_y;
     const int t0 = ty_i * TT_H, u0 = tx_i * TT_W;
-    unsigned m = 0;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       int iy = t0 - p.pad_h + e_r[i], ix = u0 - p.pad + e_c[i];
       bool ok = e_r[i] >= 0;
-      const int Hv = p.x.H << ups, Wv = p.x.W << ups;
-      if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-      iy = min(max(iy, 0), Hv - 1) >> ups; ix = min(max(ix, 0), Wv - 1) >> ups;
+      if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.x.H && (unsigned)ix < (unsigned)p.x.W;
+      iy = min(max(iy, 0), p.x.H - 1); ix = min(max(ix, 0), p.x.W - 1);
       unsigned o = (unsigned)grid_off(p.x, n, iy, ix) * 4u + e_cb[i];
       rt[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxr, ok ? o : p.x_bytes, 0, 0));
-      if constexpr (XF) m |= (ok ? 1u : 0u) << i;
     }
-    if constexpr (XF) okmask = m;
 #pragma unroll
     for (int i = 0; i < YLD; ++i) {
       int t = t0 + y_r[i], u = u0 + y_c[i];
@@ -445,16 +401,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgP p, int til
     for (int i = 0; i < NLD; ++i) {
       if (e_r[i] < 0) continue;
       f32x4 v = rt[i];
-      if constexpr (XF) {
-        const f32x4 xa = *reinterpret_cast<const f32x4*>(coef + (e_cb[i] >> 2)), xb = *reinterpret_cast<const f32x4*>(coef + 32 + (e_cb[i] >> 2));
-        const bool live = (okmask >> i) & 1u;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = fmaf(v[e], xa[e], xb[e]);
-          if (p.in_act == ITG_ACT_LRELU) t = fmaxf(t, t * p.in_slope);
-          v[e] = live ? t : 0.f;
-        }
-      }
       *reinterpret_cast<f32x4*>(Xt + e_lds[i]) = v;
     }
 #pragma unroll
@@ -562,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgP p, int til
 // (tap, c4) groups with no padding, and a lane's registers are dW[co = 0..3][(tap, c)] of its own (tap, c).
 // Same persistent halo tiles, slabs and reduction as wgrad_tile_kernel.  The (tap, c4) groups are dealt GPP per
 // pass so that, with 16 channels, the three taps of a pass fall in different LDS banks (the pixel is shared).
-template <int NP, int NLD, bool XF>
+template <int NP, int NLD>
 __global__ __launch_bounds__(256, 2) void wgrad_thin_kernel(const WgP p, int tiles_x, int tiles_y, int ntiles, int gpp, int coef_off) {
   constexpr int cpt = 16;                                  // X tile pitch: compile-time, so that every LDS read below has an immediate offset
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -586,12 +532,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_kernel(const WgP p, int til
     e_cb[i] = (unsigned)c4 * 16u;
   }
   const int y_r = tid / TT_W, y_c = tid % TT_W;            // one dY pixel (4 channels) per thread
-  float* const coef = lds + coef_off;                      // XF: alpha | beta' [2][16]
-  if constexpr (XF) {
-    if (tid < 32) coef[tid] = (tid & 15) < p.cin_ld ? p.in_ab[(tid >> 4) * p.cin_ld + (tid & 15)] : 0.f;
-    __syncthreads();
-  }
-  const int ups = XF ? p.in_ups : 0;
   f32x4 rtA[NLD], rtB[NLD], ryA, ryB;                    // two tiles in flight: a tile's MFMA work is shorter than a load
   unsigned okA = 0, okB = 0;
   auto load_tile = [&](int tile, f32x4 (&rt)[NLD], f32x4& ry, unsigned& okm) {
@@ -600,19 +540,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_kernel(const WgP p, int til
     const int ty_i = b % tiles_y;
     const int n = b / tiles_y;
     const int t0 = ty_i * TT_H, u0 = tx_i * TT_W;
-    unsigned m = 0;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       int iy = t0 - p.pad_h + e_r[i], ix = u0 - p.pad + e_c[i];
       bool ok = e_r[i] >= 0;
-      const int Hv = p.x.H << ups, Wv = p.x.W << ups;
-      if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-      iy = min(max(iy, 0), Hv - 1) >> ups; ix = min(max(ix, 0), Wv - 1) >> ups;
+      if (p.pad_mode != ITG_PAD_REPLICATE) ok = ok && (unsigned)iy < (unsigned)p.x.H && (unsigned)ix < (unsigned)p.x.W;
+      iy = min(max(iy, 0), p.x.H - 1); ix = min(max(ix, 0), p.x.W - 1);
       unsigned o = (unsigned)grid_off(p.x, n, iy, ix) * 4u + e_cb[i];
       rt[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxr, ok ? o : p.x_bytes, 0, 0));
-      if constexpr (XF) m |= (ok ? 1u : 0u) << i;
     }
-    if constexpr (XF) okm = m;
     int t = t0 + y_r, u = u0 + y_c;
     bool ok = t < p.MT && u < p.MU;
     unsigned o = (unsigned)grid_off(p.dy, n, ok ? t : 0, ok ? u : 0) * 4u;
@@ -624,16 +560,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_kernel(const WgP p, int til
     for (int i = 0; i < NLD; ++i) {
       if (e_r[i] < 0) continue;
       f32x4 v = rt[i];
-      if constexpr (XF) {
-        const f32x4 xa = *reinterpret_cast<const f32x4*>(coef + (e_cb[i] >> 2)), xb = *reinterpret_cast<const f32x4*>(coef + 16 + (e_cb[i] >> 2));
-        const bool live = (okm >> i) & 1u;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = fmaf(v[e], xa[e], xb[e]);
-          if (p.in_act == ITG_ACT_LRELU) t = fmaxf(t, t * p.in_slope);
-          v[e] = live ? t : 0.f;
-        }
-      }
       *reinterpret_cast<f32x4*>(Xt + e_lds[i]) = v;
     }
 #pragma unroll
@@ -1039,26 +965,17 @@ template <int NJ, int NLD>
 void launch_wgrad_tile(const WgP& p, const TileWgPlan& t, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<NJ, NLD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<NJ, NLD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<NJ, NLD>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     attr_done = true;
   }
-  snprintf(g_last_launch, sizeof(g_last_launch), "wgrad_tile_kernel<%d, %d, %s>", NJ, NLD, p.in_ab ? "true" : "false");
-  if (p.in_ab)
-    hipLaunchKernelGGL((wgrad_tile_kernel<NJ, NLD, true>), dim3((unsigned)t.blocks), dim3(256), t.lds, s, p, t.tiles_x, t.tiles_y,
-                       (int)t.ntiles, t.cpt, t.coef_off);
-  else
-    hipLaunchKernelGGL((wgrad_tile_kernel<NJ, NLD, false>), dim3((unsigned)t.blocks), dim3(256), t.lds, s, p, t.tiles_x, t.tiles_y,
+  snprintf(g_last_launch, sizeof(g_last_launch), "wgrad_tile_kernel<%d, %d>", NJ, NLD);
+  hipLaunchKernelGGL((wgrad_tile_kernel<NJ, NLD>), dim3((unsigned)t.blocks), dim3(256), t.lds, s, p, t.tiles_x, t.tiles_y,
                        (int)t.ntiles, t.cpt, t.coef_off);
 }
 
 void launch_wgrad_thin(const WgP& p, const TileWgPlan& t, hipStream_t s) {
-  snprintf(g_last_launch, sizeof(g_last_launch), "wgrad_thin_kernel<3, 6, %s>", p.in_ab ? "true" : "false");
-  if (p.in_ab)
-    hipLaunchKernelGGL((wgrad_thin_kernel<3, 6, true>), dim3((unsigned)t.blocks), dim3(256), t.lds, s, p, t.tiles_x, t.tiles_y,
-                       (int)t.ntiles, t.gpp, t.coef_off);
-  else
-    hipLaunchKernelGGL((wgrad_thin_kernel<3, 6, false>), dim3((unsigned)t.blocks), dim3(256), t.lds, s, p, t.tiles_x, t.tiles_y,
+  snprintf(g_last_launch, sizeof(g_last_launch), "wgrad_thin_kernel<3, 6>");
+  hipLaunchKernelGGL((wgrad_thin_kernel<3, 6>), dim3((unsigned)t.blocks), dim3(256), t.lds, s, p, t.tiles_x, t.tiles_y,
                        (int)t.ntiles, t.gpp, t.coef_off);
 }
 
@@ -1203,29 +1120,21 @@ int launch_tn(WgP p, int splits, int prec, hipStream_t s) {
   const int depth = p.chunks_per_split >= 128 ? 1 : 2;
   const int kp = prec == ITG_PREC_BF16 ? 32 : BKP;
   static const int flat_env = env_int("ITG_TN_FLAT", 1);
-  const bool flat = flat_env && !p.in_ab && prec != ITG_PREC_BF16 && !p.up2 && p.x.gh == 1 && p.x.gw == 1 && p.dy.gh == 1 &&
+  const bool flat = flat_env && prec != ITG_PREC_BF16 && !p.up2 && p.x.gh == 1 && p.x.gw == 1 && p.dy.gh == 1 &&
                     p.dy.gw == 1 && p.pad_mode != ITG_PAD_REPLICATE && otp <= 16 && p.MU >= kp;
-  snprintf(g_last_launch, sizeof(g_last_launch), "conv_tn_kernel<%d, %d, %d, %d, %s, %d, %s, %s>", BCOL, BCO, WCOL, WCO,
-           prec == ITG_PREC_BF16 ? "true" : "false", prec == ITG_PREC_BF16 ? 1 : depth, p.in_ab ? "true" : "false",
-           flat ? "true" : "false");
-  const size_t abb = p.in_ab ? (size_t)2 * p.cin_ld * 4 : 0;      // alpha | beta' of the input transform behind the offset table
+  snprintf(g_last_launch, sizeof(g_last_launch), "conv_tn_kernel<%d, %d, %d, %d, %s, %d, %s>", BCOL, BCO, WCOL, WCO,
+           prec == ITG_PREC_BF16 ? "true" : "false", prec == ITG_PREC_BF16 ? 1 : depth, flat ? "true" : "false");
   if (flat) {                                                      // (+ the spare word inactive producer threads write to)
     if (depth == 2)
-      hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 2, false, true>), grid, dim3(256), (size_t)3 * kp * otp * 4 + 16, s, p, otp);
+      hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 2, true>), grid, dim3(256), (size_t)3 * kp * otp * 4 + 16, s, p, otp);
     else
-      hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 1, false, true>), grid, dim3(256), (size_t)2 * kp * otp * 4 + 16, s, p, otp);
-  } else if (p.in_ab) {
-    if (prec == ITG_PREC_BF16) return ITG_ERR_ARG;                 // the loader transform exists for fp32 operands
-    if (depth == 2)
-      hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 2, true>), grid, dim3(256), (size_t)3 * kp * otp * 4 + abb, s, p, otp);
-    else
-      hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 1, true>), grid, dim3(256), (size_t)2 * kp * otp * 4 + abb, s, p, otp);
+      hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 1, true>), grid, dim3(256), (size_t)2 * kp * otp * 4 + 16, s, p, otp);
   } else if (prec == ITG_PREC_BF16)
-    hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, true, 1, false>), grid, dim3(256), (size_t)2 * kp * otp * 4, s, p, otp);
+    hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, true, 1>), grid, dim3(256), (size_t)2 * kp * otp * 4, s, p, otp);
   else if (depth == 2)
-    hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 2, false>), grid, dim3(256), (size_t)3 * kp * otp * 4, s, p, otp);
+    hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 2>), grid, dim3(256), (size_t)3 * kp * otp * 4, s, p, otp);
   else
-    hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 1, false>), grid, dim3(256), (size_t)2 * kp * otp * 4, s, p, otp);
+    hipLaunchKernelGGL((conv_tn_kernel<BCOL, BCO, WCOL, WCO, false, 1>), grid, dim3(256), (size_t)2 * kp * otp * 4, s, p, otp);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }

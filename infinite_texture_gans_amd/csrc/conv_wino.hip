@@ -333,7 +333,7 @@ int wino_conv(const itg_tensor* in, const float* u_panel, const float* bias, con
     memset(&p, 0, sizeof(p));
     itg_tensor vin = {V, in->n, 1, 1, Ty, Tx, in->c, in->ld};
     itg_tensor vout = {Mm, in->n, 1, 1, Ty, Tx, out->c, out->ld};
-    p.in = make_grid(&vin); p.out = make_grid(&vout); p.res = null_grid(); p.bnx = null_grid();
+    p.in = make_grid(&vin); p.out = make_grid(&vout); p.res = null_grid();
     p.w = u_panel; p.bias = nullptr; p.scale = nullptr;
     p.ntaps = 1; p.kw = 1; p.cin_ld = in->ld; p.Kpad = round_up(in->ld, BK);
     p.MT = Ty; p.MU = Tx; p.M = (int)tiles;
@@ -439,7 +439,6 @@ int wino_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, int pad, int pad
     p.co_rows = w.tn.co_rows;
     p.chunks_per_split = w.tn.chunks_per_split; p.nchunks = w.tn.nchunks;
     p.x_bytes = (unsigned)(w.tiles * x->ld * 4); p.dy_bytes = (unsigned)(w.tiles * dy->ld * 4);
-    p.in_ab = nullptr; p.in_act = ITG_ACT_NONE;
     p.ucls = NC; p.u_x = (unsigned)(w.tiles * x->ld); p.u_dy = (unsigned)(w.tiles * dy->ld);
     TileWgPlan none;
     memset(&none, 0, sizeof(none));

@@ -82,11 +82,7 @@ __device__ __forceinline__ void block_flush(double* lds, const double (&a)[4], c
     int tt = t0;
     for (; tt + stride < NT; tt += 2 * stride) { s0 += row[tt]; s1 += row[tt + stride]; }
     if (tt < NT) s0 += row[tt];
-#ifdef ITG_EXPERIMENT_NOATOMIC            // timing experiment only (tools/probes/bn_prof2.sh): results are wrong
-    if (s0 == 12345.678) gsum[j] = s0 + s1;
-#else
     atomicAdd(&gsum[j], s0 + s1);
-#endif
   }
 }
 

@@ -24,20 +24,11 @@ def _pad_mode(outer_padding):
 
 
 # read once at import (an os.environ lookup per layer call is measurable in the 6.8 ms a step takes to issue)
-_ENV_BN_LOADER = os.environ.get("ITG_BN_LOADER", "0") == "1"
 _ENV_RES_UPS = os.environ.get("ITG_RES_UPS", "1") == "1"
 _ENV_BN_FUSE = os.environ.get("ITG_BN_FUSE", "1") == "1"
 _ENV_UP2_FOLD = os.environ.get("ITG_UP2_FOLD", "1") == "1"
 _ENV_HALO_INTERIOR = os.environ.get("ITG_HALO_INTERIOR", "0") == "1"      # band training: interior rows first, border rows after the exchange
 _ENV_BN_FORK = os.environ.get("ITG_BN_FORK", "1") == "1"      # the shortcut's gradient is added inside bn1's backward kernel
-
-
-def loader_norm_enabled():
-    """ITG_BN_LOADER=1: BatchNorm-apply + activation + upsample inside the conv kernels' tile loaders and the BatchNorm
-    backward sums in the input-gradient epilogues (itg_in_norm).  Off by default: measured on MI355X it removes 0.32 ms of
-    normalisation passes per step and adds 0.40 ms to the convolutions whose loaders / epilogues carry them (config 1:
-    765 vs 778 crops/s, profiles/r03_bn_loader_ab.txt)."""
-    return _ENV_BN_LOADER
 
 
 def up2_fold_enabled():
@@ -146,17 +137,6 @@ class _ConvParams(nn.Module):
         return ops.conv(x, w, self.bias, self.k, self.k, self.stride, p_,
                         pad_mode, act, slope, residual, sn, out_grid, self._sinks(w), pad_h, packed=packed,
                         in_act=in_act, defer_act_bwd=defer_act_bwd, out_stats=out_stats, out=out, up2=up2, wino=wino)
-
-    def run_bn(self, x, bn, in_act, in_slope, upsample=False, pad=None, pad_mode=ops.PAD_ZERO, act=ops.ACT_NONE, slope=0.0,
-               residual=None, out_grid=None, pad_h=-1, out_stats=False):
-        """conv(up2x?(in_act(bn(x)))): the BatchNorm ``bn`` (a _BNParams) is applied by the conv kernels' loaders."""
-        if self.SN:
-            raise ValueError("the loader-side BatchNorm is not combined with spectral norm")
-        w = self.weight
-        return ops.bn_conv(x, bn.as_tuple(), w, self.bias, self.k, self.k, self.stride, self.padding if pad is None else pad,
-                           pad_mode, act, slope, residual, out_grid, self._sinks(w), pad_h,
-                           packed=self._packed if self._packed_kind == "plain" else None,
-                           out_stats=out_stats, in_act=in_act, in_slope=in_slope, upsample=upsample)
 
     def forward(self, x):
         """Plain conv on an NCHW image batch (zero padding), as the reference's nn.Conv2d."""
@@ -301,19 +281,17 @@ class conv2d_lp(nn.Module):
         """x: GT patches (or, for the generator's ``start`` layer, the merged latent as a 1x1-grid GT).
         ``out_stats``: the output feeds a training-mode BatchNorm - its statistics are taken in this conv's epilogue.
         ``bn`` (a _BNParams) + ``bn_act`` = (activation, slope) + ``upsample``: the conv's input is
-        up2x?(act(bn(x))) (reference models/layers.py:301-311); on the paths that gather the halo inside the conv kernel the
-        normalisation runs in the kernel's tile loader, on the others (streamed / row-sharded halos) as its own pass."""
-        fused = (bn is not None and not self.conv.SN and loader_norm_enabled() and ops.MFMA_PRECISION == ops.PREC_F32
-                 and (self.padding_mode != "local" or (self.local_padder.halo is None and self.local_padder.merge_patches_into_image
-                                                       and (self.training or _whole_image(image_location)))))
+        up2x?(act(bn(x))) (reference models/layers.py:301-311): the normalisation runs as its own pass (at the block input's
+        resolution when the conv folds the upsample).  (A loader-side form - BatchNorm-apply inside the conv kernels' tile loaders,
+        `itg_in_norm` - was built in round 3, measured slower in every configuration and deleted in round 5: DESIGN section 3.)"""
         # the x2 upsample in front of a block's first conv is folded into the conv (ops.conv(up2=True)) on the paths that hand
         # the patch grid to the kernel as it is; the normalisation then stays at the block input's resolution
         lp_ = self.local_padder if self.padding_mode == "local" else None
         direct = (lp_ is None
                   or (lp_.merge_patches_into_image and lp_.halo is None and (self.training or _whole_image(image_location)))
                   or (lp_.merge_patches_into_image and lp_.halo is not None and lp_.training))      # band training: halo rows of SOURCE pixels
-        fold = bool(upsample) and bn is not None and not fused and up2_fold_enabled() and direct
-        if bn is not None and not fused:
+        fold = bool(upsample) and bn is not None and up2_fold_enabled() and direct
+        if bn is not None:
             # fork_out (a list): the caller reads the BatchNorm's input a second time (residual shortcut); it gets an alias of
             # it whose gradient the BatchNorm backward absorbs (ops.bn_act(fork=True))
             # a row-sharded band (training): the BatchNorm writes straight into the halo-row layout the band conv reads
@@ -326,7 +304,7 @@ class conv2d_lp(nn.Module):
                 fork_out.append(x.fork)
         # a residual at half the output's patch extent (the un-upsampled shortcut) is read through the x2 upsample by the conv
         # epilogue on the paths that hand the patch grid to the kernel as it is; the reshaping paths materialise it
-        out_ph = x.t.shape[3] * (2 if ((fused or fold) and upsample) else 1)
+        out_ph = x.t.shape[3] * (2 if (fold and upsample) else 1)
         half_res = residual is not None and residual.t.shape[3] * 2 == out_ph
         native = (self.padding_mode == "local" and self.local_padder.merge_patches_into_image
                   and (self.training or (_whole_image(image_location) and self.local_padder.halo is None)))
@@ -336,13 +314,9 @@ class conv2d_lp(nn.Module):
             # per-patch zero padding: every patch is an independent image
             n, gh, gw, ph, pw, ld = x.t.shape
             flat = GT(x.t.reshape(n * gh * gw, 1, 1, ph, pw, ld), x.c, x.stats)
-            s_ = 2 if ((fused or fold) and upsample) else 1
+            s_ = 2 if (fold and upsample) else 1
             r = None if residual is None else GT(residual.t.reshape(n * gh * gw, 1, 1, ph * s_, pw * s_, -1), residual.c)
-            if fused:
-                y = self.conv.run_bn(flat, bn, bn_act[0], bn_act[1], upsample, pad=1, pad_mode=ops.PAD_ZERO, act=act, slope=slope,
-                                     residual=r)
-            else:
-                y = self.conv.run(flat, pad=1, pad_mode=ops.PAD_ZERO, act=act, slope=slope, residual=r, up2=fold)
+            y = self.conv.run(flat, pad=1, pad_mode=ops.PAD_ZERO, act=act, slope=slope, residual=r, up2=fold)
             return GT(y.t.reshape(n, gh, gw, ph * s_, pw * s_, -1), y.c)
         lp = self.local_padder
         gh, gw, outer = lp.cfg()
@@ -353,9 +327,6 @@ class conv2d_lp(nn.Module):
             if lp.training:
                 return self._forward_band_train(x, lp, outer, act, slope, residual, up2=fold)
             return self._forward_row_sharded(x, lp, outer, act, slope, residual)
-        if fused:      # training, or ONE sub-image that is the whole picture (one-shot generation: no state is carried on)
-            return self.conv.run_bn(x, bn, bn_act[0], bn_act[1], upsample, pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope,
-                                    residual=residual, out_stats=out_stats)
         if lp.training or fold:     # (fold outside training: ONE sub-image that is the whole picture, no state is carried on)
             # halo + outer padding are resolved inside the conv's tile loader
             return self.conv.run(x, pad=1, pad_mode=_pad_mode(outer), act=act, slope=slope, residual=residual,
@@ -473,11 +444,6 @@ class _BNParams(nn.BatchNorm2d):
         if self.grad_sinks and self.weight is not None and self.weight.requires_grad and self.weight.grad is not None:
             return (self.weight.grad, self.bias.grad)
         return None
-
-    def as_tuple(self):
-        """What ops.bn_conv needs of this BatchNorm (parameters, buffers, mode, gradient sinks)."""
-        return (self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked, self.training,
-                self.eps, self.momentum, self.sync, self._sinks())
 
     def run(self, x, act=ops.ACT_NONE, slope=0.0, upsample=False, consumer_upsamples=False, fork=False, pad_rows=False):
         sinks = self._sinks()

@@ -996,194 +996,6 @@ def bn_stats_only(x, rm, rv, nbt, training=True, eps=1e-5, momentum=0.1, sync=No
     return stat, count
 
 
-class _BNConv(torch.autograd.Function):
-    """out = act(conv(u, w) + bias [+ residual]) with u = up2x?(in_act(BatchNorm(x))) never written to memory: the
-    BatchNorm apply, the activation and the nearest x2 upsample of reference models/layers.py:301-311 /
-    generators.py:95-117 run inside the tile loaders of the forward and weight-gradient kernels (itg_in_norm), and the
-    BatchNorm backward sums are accumulated by the input-gradient epilogue.  Replaces a _BNAct + _Conv pair."""
-
-    @staticmethod
-    def forward(ctx, x, gamma, beta, w, bias, residual, bnbuf, c_in, geom, bn_cfg, act, slope, out_grid, sinks, bn_sinks,
-                packed, pre_sums, stats, sync):
-        kh, kw, stride, pad, pad_mode, pad_h, prec = geom
-        training, eps, momentum, in_act, in_slope, ups = bn_cfg
-        rm, rv, nbt = bnbuf
-        x = x.contiguous()
-        n, gh, gw, ph, pw, ld = x.shape
-        dev = x.device
-        st = _stream()
-        dx_ = _desc(x, c_in)
-        count = float(x.numel() // ld)
-        sums = None
-        if training:
-            if pre_sums is not None:
-                sums = pre_sums
-            else:
-                sums = _zeros_f64(2 * ld, dev)
-                _lib.call("itg_bn_stats", C.byref(dx_), _ptr(sums), st)
-            if sync is not None and _active(sync):
-                sync.all_reduce(sums)
-                count = sync.global_count(count)
-        stat = torch.empty(4 * ld, device=dev, dtype=torch.float32)
-        mean_rstd, ab = stat[:2 * ld], stat[2 * ld:]
-        _lib.call("itg_bn_finalize", _ptr(sums), count, 4.0 if ups else 1.0, _ptr(gamma), _ptr(beta), float(eps),
-                  float(momentum), _ptr(rm), _ptr(rv), _ptr(nbt), _ptr(mean_rstd), _ptr(ab), c_in, ld, int(training), st)
-        co, ci = w.shape[0], w.shape[1]
-        s_ = 2 if ups else 1
-        pv = pad_h if pad_h >= 0 else pad
-        H, W = gh * ph * s_, gw * pw * s_
-        Ho, Wo = (H + 2 * pv - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
-        ogh, ogw = out_grid
-        if packed is not None:
-            wp = packed[0]
-        else:
-            wp = torch.empty(_lib.fn("itg_pack_fwd_size")(co, ld, kh, kw), device=dev, dtype=torch.float32)
-            _lib.call("itg_pack_fwd", _ptr(w), None, _ptr(wp), co, ci, ld, kh, kw, st)
-        out = torch.empty((n, ogh, ogw, Ho // ogh, Wo // ogw, ld_for(co)), device=dev, dtype=torch.float32)
-        do_ = _desc(out, co)
-        dr_ = _desc(residual, co) if residual is not None else _null_desc()
-        nin = _lib.InNorm(ab.data_ptr(), in_act, float(in_slope), ups)
-        g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, stats.data_ptr() if stats is not None else None, nin)
-        nws = _lib.fn("itg_conv2d_fwd_workspace")(C.byref(dx_), C.byref(do_), C.byref(g))
-        ws = torch.empty(nws, device=dev, dtype=torch.float32) if nws else None
-        with _Prof(_nt_tag(co), 1, 2.0 * n * Ho * Wo * co * ci * kh * kw, 4 * (x.numel() + out.numel() + wp.numel())):
-            _lib.call("itg_conv2d_fwd", C.byref(dx_), _ptr(wp), _ptr(bias), None, C.byref(dr_), C.byref(do_), C.byref(g),
-                      act, float(slope), _ptr(ws), nws, st)
-        ctx.geom, ctx.bn_cfg, ctx.act, ctx.slope, ctx.c_in, ctx.co = geom, bn_cfg, act, slope, c_in, co
-        ctx.count, ctx.sync, ctx.affine = count, sync, gamma is not None
-        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
-        ctx.res_ups = residual is not None and residual.shape[3] * 2 == out.shape[3]
-        ctx.sinks, ctx.bn_sinks, ctx.packed = sinks, bn_sinks, packed
-        ctx.save_for_backward(x, w, stat, out if act != ACT_NONE else None)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        x, w, stat, out = ctx.saved_tensors
-        kh, kw, stride, pad, pad_mode, pad_h, prec = ctx.geom
-        training, eps, momentum, in_act, in_slope, ups = ctx.bn_cfg
-        if not training:
-            raise _lib.ItgError("BatchNorm backward is only implemented for training-mode statistics")
-        co, ci = ctx.co, ctx.c_in
-        if BACKWARD_ENTRY_HOOK is not None and ctx.sinks is not None:
-            BACKWARD_ENTRY_HOOK(ctx.sinks)
-        st = _stream()
-        dev = x.device
-        n, gh, gw, ph, pw, ld = x.shape
-        mean_rstd, ab = stat[:2 * ld], stat[2 * ld:]
-        dout = dout.contiguous()
-        if ctx.act != ACT_NONE:
-            dy = torch.empty_like(dout)
-            a, b, c_ = _desc(out, co), _desc(dout, co), _desc(dy, co)
-            _lib.call("itg_act_bwd", C.byref(a), C.byref(b), C.byref(c_), ctx.act, float(ctx.slope), st)
-        else:
-            dy = dout
-        ddy = _desc(dy, co)
-        dxd = _desc(x, ci)
-        s_ = 2 if ups else 1
-        # ---- gradient w.r.t. u = up2x?(act(bn(x))) + the BatchNorm backward sums from the same epilogue
-        gu = torch.empty((n, gh, gw, ph * s_, pw * s_, ld), device=dev, dtype=torch.float32)
-        dgu = _desc(gu, ci)
-        sums = _zeros_f64(2 * ld, dev)
-        nin = _lib.InNorm(ab.data_ptr(), in_act, float(in_slope), ups, dxd, mean_rstd.data_ptr(), sums.data_ptr())
-        g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, None, nin)
-        if ctx.packed is not None:
-            wp = ctx.packed[1]
-        else:
-            wp = torch.empty(_lib.fn("itg_pack_dgrad_size")(ci, dy.shape[5], kh, kw, stride), device=dev, dtype=torch.float32)
-            _lib.call("itg_pack_dgrad", _ptr(w), None, _ptr(wp), co, ci, dy.shape[5], kh, kw, stride, st)
-        npix_out = dy.numel() // dy.shape[5]
-        nws = _lib.fn("itg_conv2d_dgrad_workspace")(C.byref(ddy), C.byref(dgu), C.byref(g))
-        ws = torch.empty(nws, device=dev, dtype=torch.float32) if nws else None
-        with _Prof(_nt_tag(ci), 1, 2.0 * npix_out * co * ci * kh * kw, 4 * (dy.numel() + gu.numel() + wp.numel())):
-            _lib.call("itg_conv2d_dgrad", C.byref(ddy), _ptr(wp), None, C.byref(dgu), C.byref(_null_desc()), ACT_NONE, 0.0,
-                      C.byref(g), _ptr(ws), nws, st)
-        # ---- weight / bias gradient (side stream), x transformed by the loader
-        gw_ = gb = None
-        need_w = ctx.needs_input_grad[3]
-        need_b = ctx.has_bias and ctx.needs_input_grad[4]
-        if need_w or need_b:
-            wsink, bsink = ctx.sinks if ctx.sinks is not None else (None, None)
-            side = None
-            if not ((need_w and wsink is None) or (need_b and bsink is None)):
-                side = wgrad_stream_for((wsink if wsink is not None else bsink).data_ptr())
-            if side is not None and _lib.CAPTURE_LOG is not None and not capture_rule(torch.cuda.current_stream(), "weight-gradient fork"):
-                side = None
-            if side is not None:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                WGRAD_KEEPALIVE.append((x, dy, stat))
-                side.wait_event(ev)
-                if side not in _wgrad_dirty:
-                    _wgrad_dirty.append(side)
-            with (torch.cuda.stream(side) if side is not None else _NullCtx()):
-                st2 = _stream()
-                nin_w = _lib.InNorm(ab.data_ptr(), in_act, float(in_slope), ups)
-                gwg = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, None, nin_w)
-                sinks_ok = not ((need_w and wsink is None) or (need_b and bsink is None))
-                deferred = (WGRAD_DEFER is not None and sinks_ok and
-                            _queue_wgrad(x, dxd, dy, ddy, gwg, w, wsink, bsink, need_w, need_b, None, st2))
-                nws = 0 if deferred else _lib.fn("itg_conv2d_wgrad_workspace")(C.byref(dxd), C.byref(ddy), C.byref(gwg))
-                ws2 = None if deferred else torch.empty(nws, device=dev, dtype=torch.float32)
-                direct_w = wsink is not None and need_w
-                direct_b = bsink is not None and need_b
-                if deferred:
-                    gw_ = gb = None
-                else:
-                    gw_ = wsink if direct_w else torch.empty_like(w)
-                    gb = bsink if direct_b else (torch.empty_like(w[:, 0, 0, 0]) if need_b else None)
-                    with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1, 2.0 * npix_out * co * ci * kh * kw,
-                               4 * (x.numel() + dy.numel() + w.numel())):
-                        _lib.call("itg_conv2d_wgrad", C.byref(dxd), C.byref(ddy), _ptr(gw_), _ptr(gb), C.byref(gwg),
-                                  (ACC_DW if direct_w else 0) | (ACC_DB if direct_b else 0), _ptr(ws2), nws, st2)
-                    if direct_w or not need_w:
-                        gw_ = None
-                    if direct_b:
-                        gb = None
-        # ---- BatchNorm backward: dx from (x, gu, sums)
-        if ctx.sync is not None and _active(ctx.sync):
-            local = sums.clone()
-            ctx.sync.all_reduce(sums)
-        else:
-            local = sums
-        gx = torch.empty_like(x)
-        dgx = _desc(gx, ci)
-        dg = db = None
-        acc = 0
-        if ctx.affine:
-            if ctx.bn_sinks is not None:
-                dg, db = ctx.bn_sinks
-                acc = 1
-            else:
-                dg = torch.empty(ci, device=dev, dtype=torch.float32)
-                db = torch.empty(ci, device=dev, dtype=torch.float32)
-        _lib.call("itg_bn_bwd_apply", C.byref(dxd), C.byref(dgu), _ptr(ab), _ptr(mean_rstd), _ptr(local), _ptr(sums),
-                  ctx.count, in_act, float(in_slope), C.byref(dgx), _ptr(dg), _ptr(db), acc, st)
-        if acc:
-            dg = db = None
-        gres = _residual_grad(dy, co, ctx.res_ups) if ctx.has_res and ctx.needs_input_grad[5] else None
-        return (gx, dg, db, gw_, gb, gres) + (None,) * 13
-
-
-def bn_conv(x, bn, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, residual=None,
-            out_grid=None, sinks=None, pad_h=-1, precision=None, packed=None, out_stats=False, in_act=ACT_LRELU, in_slope=0.0,
-            upsample=False):
-    """conv(up2x?(in_act(BatchNorm(x)))) with the normalisation folded into the conv kernels' loaders.  ``bn`` =
-    (gamma, beta, running_mean, running_var, num_batches_tracked, training, eps, momentum, sync, sinks)."""
-    gamma, beta, rm, rv, nbt, training, eps, momentum, sync, bn_sinks = bn
-    s_ = 2 if upsample else 1
-    og = out_grid if out_grid is not None else (x.gh, x.gw)
-    r = residual.t if residual is not None else None
-    prec = MFMA_PRECISION if precision is None else precision
-    stats = None
-    if out_stats and ld_for(w.shape[0]) <= 512 and w.shape[0] > 1:
-        stats = _zeros_f64(2 * ld_for(w.shape[0]), x.t.device)
-    t = _BNConv.apply(x.t, gamma, beta, w, bias, r, (rm, rv, nbt), x.c, (kh, kw, stride, pad, pad_mode, pad_h, prec),
-                      (bool(training), eps, momentum, in_act, float(in_slope), int(bool(upsample))), act, slope, og, sinks, bn_sinks,
-                      packed, x.stats if training else None, stats, sync)
-    return GT(t, w.shape[0], stats)
-
-
 # ------------------------------------------------------------------------------- SSM modulation
 class _SSM(torch.autograd.Function):
     """y = act((1+gamma)*xhat + beta), xhat = affine-free BN(x), [gamma,beta] = emb halves.

@@ -150,17 +150,6 @@ def _check_against_golden(fx, a, G, D, tr, losses):
                 assert rel_l2(got, v.double()) < 2e-3, (name, k, rel_l2(got, v.double()))
 
 
-@pytest.mark.parametrize("tag", ["bn_nl4_sn", "bn_nl4_g44", "bn_nl4_zeros", "bn_nl5_att"])
-def test_loader_side_batchnorm_option_matches_reference_golden(tag, monkeypatch):
-    """The opt-in form of the generator's normalisation (ITG_BN_LOADER=1, itg_in_norm): BatchNorm-apply + LeakyReLU + nearest
-    x2 upsample inside the conv kernels' tile loaders (forward and weight gradient), the BatchNorm backward sums in the
-    input-gradient epilogues.  Same goldens, same tolerances as the default path."""
-    from infinite_texture_gans_amd.models import layers as L
-    monkeypatch.setattr(L, "_ENV_BN_LOADER", True)
-    fx, a, G, D, tr, losses = _train(tag)
-    _check_against_golden(fx, a, G, D, tr, losses)
-
-
 @pytest.mark.parametrize("tag", ["bn_nl4_sn", "ssm_nl4", "bn_nl4_nosn"])
 def test_deferred_weight_gradient_reduce_option_matches_reference_golden(tag):
     """ITG_DEFER_REDUCE=1 (the default of bench.py --workload config3): per-layer slabs only in the backward pass, ONE
@@ -816,11 +805,8 @@ def test_bucketed_gradient_exchange_with_lookahead_equals_the_plain_exchange(tmp
             assert torch.equal(v, res["bucketed"][1]["D"][k]), k
 
 
-@pytest.mark.parametrize("loader_bn", [False, True], ids=["default", "loader_side_batchnorm"])
-def test_midsize_train_step_with_tile_and_thin_kernels_matches_oracle(loader_bn, monkeypatch):
-    """(``loader_side_batchnorm``: the same step with ITG_BN_LOADER=1's kernels - the halo-tile / vector-ALU / thin-output
-    kernels then carry the BatchNorm apply in their loaders and the backward sums in their epilogues.)
-    A model large enough (64x64 patches on a 3x3 grid = 192x192 fakes, 96x96 reals) that the special kernels of
+def test_midsize_train_step_with_tile_and_thin_kernels_matches_oracle():
+    """A model large enough (64x64 patches on a 3x3 grid = 192x192 fakes, 96x96 reals) that the special kernels of
     the full-size step are all on the path - halo-tile forward / input- / weight-gradient kernels for the narrow last
     block, taps-as-rows kernels for D's logit and first layers, split-K, stream overlap, packed panels, gradient
     sinks - held against the CPU oracle's train step on the same state and inputs."""
@@ -830,8 +816,6 @@ def test_midsize_train_step_with_tile_and_thin_kernels_matches_oracle(loader_bn,
     from infinite_texture_gans_amd.engine import Trainer
     from infinite_texture_gans_amd.models.generators import ResidualPatchGenerator
     from infinite_texture_gans_amd.models.discriminators import PatchDiscriminator
-    from infinite_texture_gans_amd.models import layers as L
-    monkeypatch.setattr(L, "_ENV_BN_LOADER", bool(loader_bn))
     torch.manual_seed(21)
     G = ResidualPatchGenerator(z_dim=16, G_ch=8, base_res=4, n_layers_G=5, attention=False, img_ch=3, leak=0.02,
                                type_norm="BN", padding_mode="local")
