@@ -95,6 +95,11 @@ int64_t itg_pack_wino3_size(int rows, int k_ld);   /* 36 * ... */
 /* fwd panel U[xi][co_pad][ci_ld'] = G g G^T of g = w[co][ci]; dgrad panel U'[xi][ci_pad][co_ld'] of the flipped filter */
 int itg_pack_wino_fwd(const float* w_oihw, const float* scale, float* out, int co, int ci, int ci_ld, void* stream);
 int itg_pack_wino_dgrad(const float* w_oihw, const float* scale, float* out, int co, int ci, int co_ld, void* stream);
+/* F(4 x 4, 2 x 2) panel of a 4 x 4 STRIDE-2 pad-1 layer (the discriminator's 64 -> 128 / 128 -> 256 layers, reference
+ * models/discriminators.py:190-195) for itg_conv2d_fwd with ITG_GEOM_WINO: U[25][co_pad][4 * ci_ld], the four parity classes
+ * of the filter concatenated along K.  Forward only: the layer's itg_conv2d_dgrad / _wgrad take the ordinary panels / no flag. */
+int64_t itg_pack_wino_s2_size(int co, int ci_ld);
+int itg_pack_wino_s2_fwd(const float* w, const float* scale, float* out, int co, int ci, int ci_ld, void* stream);
 int itg_pack_wino3_fwd(const float* w_oihw, const float* scale, float* out, int co, int ci, int ci_ld, void* stream);
 int itg_pack_wino3_dgrad(const float* w_oihw, const float* scale, float* out, int co, int ci, int co_ld, void* stream);
 #define ITG_ZERO_FRAMES_MAX 32

@@ -3,6 +3,7 @@
 #include "conv_common.h"
 #include "winograd_f44.h"
 #include "winograd_f43.h"
+#include "winograd_f42.h"
 
 using namespace itgk;
 
@@ -186,6 +187,36 @@ __device__ __forceinline__ void wino_pack4(const float* __restrict__ w, float* _
   }
 }
 
+// F(4 x 4, 2 x 2) panel of a 4 x 4 STRIDE-2 convolution (conv_wino.hip wino_conv_s2): the four parity classes (a, b) of the
+// filter, g_ab(jy, jx) = w(2 jy + a, 2 jx + b), concatenated along K: U[xi = al * 5 + be][co][k = cls * ld + c] =
+// sum_jy,jx G[al][jy] G[be][jx] g_ab[jy][jx]
+__device__ __forceinline__ float wino_s2_elem(const float* __restrict__ w, int co, int ci, int ld, unsigned e) {
+  const unsigned Kpad = (unsigned)round_up_d(4 * ld, BK), rows_pad = (unsigned)round_up_d(co, 16);
+  const int k = (int)(e % Kpad);
+  const unsigned r = e / Kpad;
+  const int row = (int)(r % rows_pad), xi = (int)(r / rows_pad);
+  const int cls = k / ld, c = k - cls * ld;
+  if (row >= co || cls >= 4 || c >= ci || xi >= 25) return 0.f;
+  const int a = cls >> 1, b = cls & 1, al = xi / 5, be = xi - al * 5;
+  const float* g = w + ((size_t)row * ci + c) * 16;
+  float v = 0.f;
+#pragma unroll
+  for (int jx = 0; jx < 2; ++jx) {
+    float t = 0.f;
+#pragma unroll
+    for (int jy = 0; jy < 2; ++jy) t = fmaf(WINO2_G[al][jy], g[(2 * jy + a) * 4 + 2 * jx + b], t);
+    v = fmaf(WINO2_G[be][jx], t, v);
+  }
+  return v;
+}
+
+__global__ void pack_wino_s2_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out, int co, int ci,
+                                    int ld, long long total) {
+  const float sc = scale ? *scale : 1.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    out[i] = sc * wino_s2_elem(w, co, ci, ld, (unsigned)i);
+}
+
 template <int R>
 __global__ void pack_wino_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out, int co,
                                  int ci, int ld, int dgrad, long long total) {
@@ -252,6 +283,9 @@ __global__ void pack_multi_kernel(const long long* __restrict__ table, int n, lo
       const unsigned unit = (run / 36u) * 256u + (L & 255u);
       if (run % 36u == 0 && unit < units) wino_pack4<3>(w, out, co, ci, ld, kind == 7, unit);
       continue;
+    } else if (kind == 8) {                   // F(4 x 4, 2 x 2) panel of a stride-2 4 x 4 layer (forward)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = wino_s2_elem(w, co, ci, ld, e + j);
     } else if (kind == 0) {
       const unsigned Kpad = (unsigned)round_up_d(kh * kw * ld, BK);
       const int k = (int)(e % Kpad), o = (int)(e / Kpad);
@@ -601,6 +635,18 @@ static int pack_wino(const float* w, const float* scale, float* out, int co, int
   return ITG_OK;
 }
 
+int64_t itg_pack_wino_s2_size(int co, int ci_ld) { return (int64_t)25 * round_up(co, 16) * round_up(4 * ci_ld, BK); }
+
+int itg_pack_wino_s2_fwd(const float* w, const float* scale, float* out, int co, int ci, int ci_ld, void* stream) {
+  if (!w || !out || co <= 0 || ci <= 0 || (ci_ld & 3) || ci_ld < ci) return ITG_ERR_ARG;
+  const int64_t total = itg_pack_wino_s2_size(co, ci_ld);
+  if (total >= ((int64_t)1 << 32)) return ITG_ERR_ARG;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(pack_wino_s2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, scale, out, co, ci, ci_ld, (long long)total);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
 int itg_pack_wino3_fwd(const float* w, const float* scale, float* out, int co, int ci, int ci_ld, void* stream) {
   return pack_wino(w, scale, out, co, ci, ci_ld, 0, 3, stream);
 }
@@ -635,11 +681,17 @@ static inline bool wino_geom(const itg_conv_geom* g) {
     return false;
   return (g->kh == 4 && g->pad_mode == ITG_PAD_ZERO) || (g->kh == 3 && (g->pad_mode == ITG_PAD_ZERO || g->pad_mode == ITG_PAD_REPLICATE));
 }
+// ... and the FORWARD-only stride-2 form: 4 x 4, stride 2, pad 1, zero padding (F(4 x 4, 2 x 2) on the parity classes)
+static inline bool wino_s2_geom(const itg_conv_geom* g) {
+  return (g->flags & ITG_GEOM_WINO) && g->kh == 4 && g->kw == 4 && g->stride == 2 && g->pad == 1 && pad_v_raw(g) == 1 && !g->up2 &&
+         g->pad_mode == ITG_PAD_ZERO && prec_of(g) == ITG_PREC_F32;
+}
 // the input gradient of a replicate-padded layer is evaluated on the padded extent and folded (conv_wino.hip)
 static inline int wino_fold(const itg_conv_geom* g) { return g->pad_mode == ITG_PAD_REPLICATE ? 1 : 0; }
 
 int64_t itg_conv2d_fwd_workspace(const itg_tensor* in, const itg_tensor* out, const itg_conv_geom* g) {
   if (!in || !out || !g) return 0;
+  if (wino_s2_geom(g)) return wino_s2_workspace_floats(in, out);
   if (g->flags & ITG_GEOM_WINO) return wino_geom(g) ? wino_workspace_floats(in, out, g->kh, 0) : 0;
   if (g->up2) return plan_nt(grid_pixels(out), round_up(out->c, 16), round_up(4 * in->ld, BK), 4, prec_of(g)).ws_floats;
   if (thin_out_conv(in, out, g)) {
@@ -679,6 +731,12 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   if ((rc = check_tensor(in)) || (rc = check_tensor(out))) return rc;
   if (!w_packed || !g || g->kh <= 0 || g->kw <= 0 || g->stride <= 0 || g->pad < 0) return ITG_ERR_ARG;
   if (g->reserved_ptr) return ITG_ERR_ARG;
+  if (wino_s2_geom(g)) {
+    if (residual && residual->ptr) return ITG_ERR_ARG;
+    if ((rc = wino_conv_s2(in, w_packed, bias, out_scale, out, act, slope, prec_of(g), workspace, workspace_floats, (hipStream_t)stream)))
+      return rc;
+    return g->out_stats ? itg_bn_stats(out, g->out_stats, stream) : ITG_OK;
+  }
   if (g->flags & ITG_GEOM_WINO) {
     if (!wino_geom(g)) return ITG_ERR_ARG;
     const itg_tensor* r = (residual && residual->ptr) ? residual : nullptr;
@@ -969,15 +1027,17 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
 
 // the weight gradient of an ITG_GEOM_WINO layer also goes through the transformed domain (conv_wino.hip) when both tensors
 // are plain fp32 images with 16-aligned pitches; ITG_WINOGRAD_WGRAD=0 keeps the direct contraction (A/B switch)
+// (the stride-2 form - wino_s2_geom - takes R = 2 in the plan: its four parity classes are 2 x 2 convolutions)
+static inline int wino_wg_R(const itg_conv_geom* g) { return wino_s2_geom(g) ? 2 : g->kh; }
 static bool wino_wgrad_ok(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g) {
   static const int on = env_int("ITG_WINOGRAD_WGRAD", 1);
-  return on && wino_geom(g) && prec_of(g) == ITG_PREC_F32 && !(x->ld & 15) && !(dy->ld & 15) && x->n == dy->n &&
-         plan_wino_wgrad(x, dy, g->kh).tn.ngroups == 0;
+  return on && (wino_geom(g) || wino_s2_geom(g)) && prec_of(g) == ITG_PREC_F32 && !(x->ld & 15) && !(dy->ld & 15) && x->n == dy->n &&
+         plan_wino_wgrad(x, dy, wino_wg_R(g)).tn.ngroups == 0;
 }
 
 int64_t itg_conv2d_wgrad_workspace(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g) {
   if (!x || !dy || !g) return 0;
-  if (wino_wgrad_ok(x, dy, g)) return plan_wino_wgrad(x, dy, g->kh).ws_floats;
+  if (wino_wgrad_ok(x, dy, g)) return plan_wino_wgrad(x, dy, wino_wg_R(g)).ws_floats;
   if (thin_out_conv(x, dy, g)) {
     int64_t Min = grid_pixels(x);
     TnPlan t = plan_tn(Min, 16, x->ld, prec_of(g));
@@ -1089,7 +1149,7 @@ int itg_conv2d_wgrad(const itg_tensor* x, const itg_tensor* dy, float* dw, float
     return ITG_OK;
   }
   if (wino_wgrad_ok(x, dy, g)) {
-    const WinoWgPlan w = plan_wino_wgrad(x, dy, g->kh);
+    const WinoWgPlan w = plan_wino_wgrad(x, dy, wino_wg_R(g));
     if (workspace_floats < w.ws_floats) return ITG_ERR_WORKSPACE;
     if ((rc = wino_wgrad_slabs(x, dy, g->pad, g->pad_mode, prec_of(g), w, workspace, db != nullptr, s, g->wino_v))) return rc;
     return launch_wgrad_reduce(workspace + w.slab_off, 1, workspace + w.db_off, w.Rr, dw, db, dy->c, x->c, x->ld, g->kh, g->kw, w.co_rows,
@@ -1113,7 +1173,7 @@ int itg_conv2d_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, const itg_
   if (thin_out_conv(x, dy, g)) return ITG_ERR_ARG;      // taps-as-rows path: not deferrable
   if (g->up2) return ITG_ERR_ARG;                                       // folded-upsample layers reduce through their own kernel
   if (wino_wgrad_ok(x, dy, g)) {
-    const WinoWgPlan w = plan_wino_wgrad(x, dy, g->kh);
+    const WinoWgPlan w = plan_wino_wgrad(x, dy, wino_wg_R(g));
     if (workspace_floats < w.ws_floats) return ITG_ERR_WORKSPACE;
     if ((rc = wino_wgrad_slabs(x, dy, g->pad, g->pad_mode, prec_of(g), w, workspace, true, (hipStream_t)stream, g->wino_v))) return rc;
     job->slab = workspace + w.slab_off; job->dbslab = workspace + w.db_off;

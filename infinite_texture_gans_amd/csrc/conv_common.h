@@ -168,6 +168,9 @@ int64_t wino_workspace_floats(const itg_tensor* in, const itg_tensor* out, int R
 int wino_conv(const itg_tensor* in, const float* u_panel, const float* bias, const float* out_scale, const itg_tensor* res, int res_ups,
               int res_mode, float res_slope, const itg_tensor* out, int R, int pad, int pad_mode, int fold, int act, float slope,
               int prec, float* workspace, int64_t workspace_floats, hipStream_t s, bool input_gradient = false);
+int64_t wino_s2_workspace_floats(const itg_tensor* in, const itg_tensor* out);
+int wino_conv_s2(const itg_tensor* in, const float* u_panel, const float* bias, const float* out_scale, const itg_tensor* out, int act,
+                 float slope, int prec, float* workspace, int64_t workspace_floats, hipStream_t s);
 // conv_nt.hip
 NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = ITG_PREC_F32);
 int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s);

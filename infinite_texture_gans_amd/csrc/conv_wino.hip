@@ -21,6 +21,7 @@
 #include "conv_common.h"
 #include "winograd_f44.h"
 #include "winograd_f43.h"
+#include "winograd_f42.h"
 
 namespace itgk {
 
@@ -40,6 +41,13 @@ template <> struct WM<3> {
   static __device__ constexpr float at(int k, int i) { return WINO3_AT[k][i]; }
   static __device__ constexpr float g(int i, int j) { return WINO3_G[i][j]; }
   static __device__ constexpr float bt(int i, int j) { return WINO3_BT[i][j]; }
+};
+
+template <> struct WM<2> {
+  static constexpr int NP = 5;
+  static __device__ constexpr float at(int k, int i) { return WINO2_AT[k][i]; }
+  static __device__ constexpr float g(int i, int j) { return WINO2_G[i][j]; }
+  static __device__ constexpr float bt(int i, int j) { return WINO2_BT[i][j]; }
 };
 
 // one thread = (tile, channel pair): NP x NP loads of 8 bytes, V = B^T d B, NP^2 coalesced 8-byte stores
@@ -88,6 +96,59 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const GridT x, int pad, in
 #pragma unroll
       for (int i = 0; i < NP; ++i)
         if (WM<R>::bt(a, i) != 0.f) v += WM<R>::bt(a, i) * tmp[i][b];
+      *reinterpret_cast<f32x2*>(vb + (size_t)(a * NP + b) * plane) = v;
+    }
+}
+
+// 4 x 4 STRIDE-2 convolutions (pad 1, zero padding; the discriminator's 64 -> 128 and 128 -> 256 layers, reference
+// models/discriminators.py:190-195): with ky = 2 jy + a, kx = 2 jx + b the layer is the SUM over the four parities (a, b) of a
+// 2 x 2 stride-1 correlation of the parity-decimated image x_ab(s, r) = x(2 s + a - 1, 2 r + b - 1) with g_ab(jy, jx) =
+// w(2 jy + a, 2 jx + b) - so F(4 x 4, 2 x 2) applies: 25 multiplications per 4 x 4 output tile and parity class instead of 64,
+// i.e. 25 GEMMs [tiles x 4 Cin] x [4 Cin x Cout] (the classes are concatenated along K: M = sum_ab U_ab .* V_ab) - 6.25 Cin
+// multiplications per output where the direct form has 16 Cin.  One thread = (tile, class, channel pair): 5 x 5 loads at pixel
+// stride 2, V[xi][tile][cls * ld + c] = B^T d B.
+__global__ __launch_bounds__(256) void wino_in_s2_kernel(const GridT x, int Ty, int Tx, float* __restrict__ V) {
+  constexpr int NP = 5;
+  const int ld = x.ld, cpairs = ld >> 1;
+  const int64_t tiles = (int64_t)x.n * Ty * Tx;
+  const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gt >= tiles * 4 * cpairs) return;
+  const int cp = (int)(gt % cpairs);
+  const int cls = (int)((gt / cpairs) & 3);
+  const int64_t tile = gt / (4 * cpairs);
+  const int tx = (int)(tile % Tx), ty = (int)((tile / Tx) % Ty), img = (int)(tile / ((int64_t)Ty * Tx));
+  const int y0 = 8 * ty + (cls >> 1) - 1, x0 = 8 * tx + (cls & 1) - 1;
+  f32x2 tmp[NP][NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    f32x2 d[NP];
+    const int iy = y0 + 2 * i;
+    const bool oky = (unsigned)iy < (unsigned)x.H;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int ix = x0 + 2 * j;
+      const bool ok = oky && (unsigned)ix < (unsigned)x.W;
+      d[j] = ok ? *reinterpret_cast<const f32x2*>(x.p + grid_off(x, img, ok ? iy : 0, ok ? ix : 0) + 2 * cp) : f32x2{0.f, 0.f};
+    }
+#pragma unroll
+    for (int b = 0; b < NP; ++b) {
+      f32x2 a = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NP; ++j)
+        if (WM<2>::bt(b, j) != 0.f) a += WM<2>::bt(b, j) * d[j];
+      tmp[i][b] = a;
+    }
+  }
+  const size_t plane = (size_t)tiles * 4 * ld;
+  float* const vb = V + (size_t)tile * 4 * ld + cls * ld + 2 * cp;
+#pragma unroll
+  for (int a = 0; a < NP; ++a)
+#pragma unroll
+    for (int b = 0; b < NP; ++b) {
+      f32x2 v = {0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+        if (WM<2>::bt(a, i) != 0.f) v += WM<2>::bt(a, i) * tmp[i][b];
       *reinterpret_cast<f32x2*>(vb + (size_t)(a * NP + b) * plane) = v;
     }
 }
@@ -224,6 +285,7 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const GridT dy, int Ty, in
 // dy; dbslab[r][c] = sum of the r-th run of tiles, in a fixed order (the generic reduce stage adds the Rr rows)
 static_assert(WINO_AT[0][1] == 1.f && WINO_AT[1][1] == 1.f && WINO_AT[2][1] == 1.f && WINO_AT[3][1] == 1.f, "point 1 is column 1");
 static_assert(WINO3_AT[0][1] == 1.f && WINO3_AT[1][1] == 1.f && WINO3_AT[2][1] == 1.f && WINO3_AT[3][1] == 1.f, "point 1 is column 1");
+static_assert(WINO2_AT[0][1] == 1.f && WINO2_AT[1][1] == 1.f && WINO2_AT[2][1] == 1.f && WINO2_AT[3][1] == 1.f, "point 1 is column 1");
 __global__ __launch_bounds__(256) void wino_db_kernel(const float* __restrict__ dM11, int64_t tiles, int ld, int co_rows, int Rr,
                                                        float* __restrict__ dbslab) {
   const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
@@ -280,6 +342,49 @@ __global__ __launch_bounds__(256) void wino_wg_out_kernel(const float* __restric
       for (int a = 0; a < NP; ++a)
         if (WM<R>::g(a, i) != 0.f) v += WM<R>::g(a, i) * tmp[a][j];
       dst[(size_t)(i * R + j) * ci_ld] = v;
+    }
+}
+
+// ... of the stride-2 form: one thread = (co, parity class, ci): dU[z][xi][co][cls * ci_ld + ci] summed over the splits,
+// dg_ab = G^T dU G (2 x 2), written at the class's taps (2 jy + a, 2 jx + b) of the generic 4 x 4 slab
+__global__ __launch_bounds__(256) void wino_wg_out_s2_kernel(const float* __restrict__ dU, int splits, int co_rows, int Kp, int ci_ld,
+                                                              float* __restrict__ slab) {
+  constexpr int NP = 5;
+  const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gt >= (int64_t)co_rows * 4 * ci_ld) return;
+  const int ci = (int)(gt % ci_ld), cls = (int)((gt / ci_ld) & 3), co = (int)(gt / (4 * ci_ld));
+  const int a = cls >> 1, b = cls & 1;
+  const size_t plane = (size_t)co_rows * Kp;
+  const float* src = dU + (size_t)co * Kp + cls * ci_ld + ci;
+  float tmp[NP][2];                       // tmp[al][jx] = sum_be dU[al][be] G[be][jx]
+#pragma unroll
+  for (int al = 0; al < NP; ++al) {
+    float u[NP];
+#pragma unroll
+    for (int be = 0; be < NP; ++be) {
+      float v = 0.f;
+      for (int z = 0; z < splits; ++z) v += src[((size_t)z * NP * NP + al * NP + be) * plane];
+      u[be] = v;
+    }
+#pragma unroll
+    for (int jx = 0; jx < 2; ++jx) {
+      float v = 0.f;
+#pragma unroll
+      for (int be = 0; be < NP; ++be)
+        if (WM<2>::g(be, jx) != 0.f) v += WM<2>::g(be, jx) * u[be];
+      tmp[al][jx] = v;
+    }
+  }
+  float* dst = slab + (size_t)co * (16 * ci_ld) + ci;
+#pragma unroll
+  for (int jy = 0; jy < 2; ++jy)
+#pragma unroll
+    for (int jx = 0; jx < 2; ++jx) {
+      float v = 0.f;
+#pragma unroll
+      for (int al = 0; al < NP; ++al)
+        if (WM<2>::g(al, jy) != 0.f) v += WM<2>::g(al, jy) * tmp[al][jx];
+      dst[(size_t)((2 * jy + a) * 4 + 2 * jx + b) * ci_ld] = v;
     }
 }
 
@@ -363,20 +468,92 @@ int wino_conv(const itg_tensor* in, const float* u_panel, const float* bias, con
   return ITG_OK;
 }
 
+// workspace of the stride-2 form: V[25][tiles][4 * in.ld] | M[25][tiles][out.ld]
+int64_t wino_s2_workspace_floats(const itg_tensor* in, const itg_tensor* out) {
+  int Ty, Tx;
+  wino_tiles(out->gh * out->ph, out->gw * out->pw, Ty, Tx);
+  const int64_t tiles = (int64_t)in->n * Ty * Tx;
+  return 25 * tiles * (4 * (int64_t)in->ld + out->ld);
+}
+
+// in -> out: 4 x 4 stride-2 pad-1 convolution with zero padding through F(4 x 4, 2 x 2) on the four parity classes (forward
+// only: the layer's input and weight gradients stay on the direct kernels - in the transformed domain they would move 4 x the
+// bytes of dx per class, which costs what the multiplications save).  u_panel: itg_pack_wino_s2_fwd.
+int wino_conv_s2(const itg_tensor* in, const float* u_panel, const float* bias, const float* out_scale, const itg_tensor* out, int act,
+                 float slope, int prec, float* workspace, int64_t workspace_floats, hipStream_t s) {
+  const int H = in->gh * in->ph, W = in->gw * in->pw, Ho = out->gh * out->ph, Wo = out->gw * out->pw;
+  if (in->n != out->n || Ho != (H + 2 - 4) / 2 + 1 || Wo != (W + 2 - 4) / 2 + 1 || (in->ld & 3) || (out->ld & 3)) return ITG_ERR_ARG;
+  int Ty, Tx;
+  wino_tiles(Ho, Wo, Ty, Tx);
+  constexpr int NC = 25;
+  const int64_t tiles = (int64_t)in->n * Ty * Tx;
+  const int kld = 4 * in->ld;
+  const int64_t vf = NC * tiles * kld, mf = NC * tiles * out->ld;
+  if (!workspace || workspace_floats < vf + mf) return ITG_ERR_WORKSPACE;
+  if (tiles * std::max(kld, (int)out->ld) * 4 >= 0xFFFF0000LL) return ITG_ERR_ARG;
+  float* V = workspace;
+  float* Mm = workspace + vf;
+  {
+    const int64_t th = tiles * 4 * (in->ld >> 1);
+    hipLaunchKernelGGL(wino_in_s2_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, make_grid(in), Ty, Tx, V);
+    ITG_CHECK_LAUNCH();
+  }
+  {
+    ConvP p;
+    memset(&p, 0, sizeof(p));
+    itg_tensor vin = {V, in->n, 1, 1, Ty, Tx, kld, kld};
+    itg_tensor vout = {Mm, in->n, 1, 1, Ty, Tx, out->c, out->ld};
+    p.in = make_grid(&vin); p.out = make_grid(&vout); p.res = null_grid();
+    p.w = u_panel; p.bias = nullptr; p.scale = nullptr;
+    p.ntaps = 1; p.kw = 1; p.cin_ld = kld; p.Kpad = round_up(kld, BK);
+    p.MT = Ty; p.MU = Tx; p.M = (int)tiles;
+    p.isy = p.isx = 1; p.osy = p.osx = 1;
+    p.pad_mode = ITG_PAD_ZERO; p.act = ITG_ACT_NONE;
+    p.co_rows = round_up(out->c, 16);
+    p.prec = prec;
+    p.ncls = 1;
+    p.ucls = NC;
+    // blocked fp64 accumulation as for F(4 x 4, 4 x 4) (NT_W64, ITG_WINO_ACC64): these are FORWARD GEMMs in front of a LeakyReLU -
+    // their rounding decides sign flips that move every upstream gradient by ~1e-3.  Plain fp32 chains of 64 - 128
+    // MFMA steps gave 1.1 - 2.5e-6 per layer and G's full-size gradients 2.1e-3 / 2.9e-3 from the fp64 truth (direct: 1.3 / 1.8)
+    p.u_dgrad = 0;
+    p.u_in = (unsigned)(tiles * kld); p.u_out = (unsigned)(tiles * out->ld); p.u_w = (unsigned)((size_t)p.co_rows * p.Kpad);
+    int rc = dispatch_nt(p, nullptr, 0, s);
+    if (rc) return rc;
+  }
+  {
+    const int64_t th = tiles * (out->ld >> 1);
+    hipLaunchKernelGGL(wino_out_kernel<2>, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, (const float*)Mm, make_grid(out), Ty, Tx, 0, bias,
+                       out_scale, null_grid(), 0, 0, 0.f, act, slope);
+    ITG_CHECK_LAUNCH();
+  }
+  return ITG_OK;
+}
+
 // ---- weight gradient (R x R stride-1 correlation with padding `pad`, zero or replicate frame)
 // workspace: V[NP^2][tiles][x.ld] | dM[NP^2][tiles][dy.ld] | dU[splits][NP^2][co_rows][Kp] | slab[co_rows][R^2 * x.ld] | db[Rr][co_rows]
 WinoWgPlan plan_wino_wgrad(const itg_tensor* x, const itg_tensor* dy, int R) {
+  // R = 2: the 4 x 4 STRIDE-2 layer as four parity classes of 2 x 2 convolutions (wino_conv_s2): V carries the classes side by
+  // side (4 * x.ld values per tile), dU likewise, and the slab is the 4 x 4 filter's
   WinoWgPlan w;
   const int Ho = dy->gh * dy->ph, Wo = dy->gw * dy->pw;
   const int NC = (4 + R - 1) * (4 + R - 1);
+  const int kld = R == 2 ? 4 * x->ld : x->ld;
   w.R = R;
   wino_tiles(Ho, Wo, w.Ty, w.Tx);
   w.tiles = (int64_t)x->n * w.Ty * w.Tx;
-  w.tn = plan_tn(w.tiles, dy->ld, x->ld, ITG_PREC_F32, NC);
+  w.tn = plan_tn(w.tiles, dy->ld, kld, ITG_PREC_F32, NC);
   // pixel-range splits of the NP^2 contractions: 49 classes x 8 tiles fill the chip on their own, and every split is one
   // more slab for the output transform to read (256 -> 512 layer: 274 -> 258 us on the generated batch, 120 -> 107 on the real one)
   {
-    const int sp = 1;
+    // (the stride-2 form on D's first two layers: 25 classes x 1-2 x 2-4 tiles = 50-200 workgroups - split the tiles so that
+    // ~512 workgroups run; the output transform sums the splits)
+    int sp = 1;
+    if (R == 2) {
+      const int64_t wg = (int64_t)NC * ((kld + w.tn.bcol - 1) / w.tn.bcol) * ((w.tn.co_rows + w.tn.bco - 1) / w.tn.bco);
+      sp = (int)std::min<int64_t>(8, std::max<int64_t>(1, (512 + wg - 1) / wg));
+      if (sp > w.tn.nchunks) sp = w.tn.nchunks > 0 ? w.tn.nchunks : 1;
+    }
     w.tn.chunks_per_split = (w.tn.nchunks + sp - 1) / sp;
     w.tn.splits = (w.tn.nchunks + w.tn.chunks_per_split - 1) / w.tn.chunks_per_split;
     w.tn.slab_floats = (int64_t)w.tn.splits * NC * w.tn.co_rows * w.tn.Kpad;
@@ -384,10 +561,10 @@ WinoWgPlan plan_wino_wgrad(const itg_tensor* x, const itg_tensor* dy, int R) {
     w.tn.ws_floats = w.tn.slab_floats;
   }
   w.co_rows = w.tn.co_rows;
-  w.Kpad = R * R * x->ld;
+  w.Kpad = (R == 2 ? 16 : R * R) * x->ld;
   w.Rr = (int)std::min<int64_t>(16, std::max<int64_t>(1, w.tiles / 32));
   w.v_off = 0;
-  w.m_off = w.v_off + NC * w.tiles * x->ld;
+  w.m_off = w.v_off + NC * w.tiles * kld;
   w.u_off = w.m_off + NC * w.tiles * dy->ld;
   w.slab_off = w.u_off + w.tn.slab_floats;
   w.db_off = w.slab_off + (int64_t)w.co_rows * w.Kpad;
@@ -399,23 +576,29 @@ int wino_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, int pad, int pad
                      bool want_db, hipStream_t s, const float* v_fwd) {
   const int H = x->gh * x->ph, W = x->gw * x->pw, Ho = dy->gh * dy->ph, Wo = dy->gw * dy->pw;
   const int R = w.R, NP = 4 + R - 1, NC = NP * NP;
-  if (x->n != dy->n || (R != 3 && R != 4)) return ITG_ERR_ARG;
-  if (Ho != H + 2 * pad - (R - 1) || Wo != W + 2 * pad - (R - 1) || (x->ld & 15) || (dy->ld & 15) || prec != ITG_PREC_F32) return ITG_ERR_ARG;
-  if (w.tiles * std::max(x->ld, dy->ld) * 4 >= 0xFFFF0000LL || w.tn.ngroups > 0) return ITG_ERR_ARG;
+  const int kld = R == 2 ? 4 * x->ld : x->ld;
+  if (x->n != dy->n || (R != 2 && R != 3 && R != 4)) return ITG_ERR_ARG;
+  if (R == 2 ? (pad != 1 || pad_mode != ITG_PAD_ZERO || Ho != (H + 2 - 4) / 2 + 1 || Wo != (W + 2 - 4) / 2 + 1)
+             : (Ho != H + 2 * pad - (R - 1) || Wo != W + 2 * pad - (R - 1)))
+    return ITG_ERR_ARG;
+  if ((x->ld & 15) || (dy->ld & 15) || prec != ITG_PREC_F32) return ITG_ERR_ARG;
+  if (w.tiles * std::max(kld, (int)dy->ld) * 4 >= 0xFFFF0000LL || w.tn.ngroups > 0) return ITG_ERR_ARG;
   const float* V = v_fwd ? v_fwd : workspace + w.v_off;       // v_fwd: the forward's transformed input (itg_conv_geom.wino_v)
   float* dM = workspace + w.m_off;
   float* dU = workspace + w.u_off;
   if (!v_fwd) {
-    const int64_t th = w.tiles * (x->ld >> 1);
+    const int64_t th = w.tiles * (kld >> 1);
     const dim3 grid((unsigned)((th + 255) / 256));
-    if (R == 4) hipLaunchKernelGGL(wino_in_kernel<4>, grid, dim3(256), 0, s, make_grid(x), pad, pad_mode, w.Ty, w.Tx, workspace + w.v_off);
+    if (R == 2) hipLaunchKernelGGL(wino_in_s2_kernel, grid, dim3(256), 0, s, make_grid(x), w.Ty, w.Tx, workspace + w.v_off);
+    else if (R == 4) hipLaunchKernelGGL(wino_in_kernel<4>, grid, dim3(256), 0, s, make_grid(x), pad, pad_mode, w.Ty, w.Tx, workspace + w.v_off);
     else hipLaunchKernelGGL(wino_in_kernel<3>, grid, dim3(256), 0, s, make_grid(x), pad, pad_mode, w.Ty, w.Tx, workspace + w.v_off);
     ITG_CHECK_LAUNCH();
   }
   {
     const int64_t th = w.tiles * (dy->ld >> 1);
     const dim3 grid((unsigned)((th + 255) / 256));
-    if (R == 4) hipLaunchKernelGGL(wino_dy_kernel<4>, grid, dim3(256), 0, s, make_grid(dy), w.Ty, w.Tx, dM);
+    if (R == 2) hipLaunchKernelGGL(wino_dy_kernel<2>, grid, dim3(256), 0, s, make_grid(dy), w.Ty, w.Tx, dM);
+    else if (R == 4) hipLaunchKernelGGL(wino_dy_kernel<4>, grid, dim3(256), 0, s, make_grid(dy), w.Ty, w.Tx, dM);
     else hipLaunchKernelGGL(wino_dy_kernel<3>, grid, dim3(256), 0, s, make_grid(dy), w.Ty, w.Tx, dM);
     ITG_CHECK_LAUNCH();
   }
@@ -429,26 +612,29 @@ int wino_wgrad_slabs(const itg_tensor* x, const itg_tensor* dy, int pad, int pad
     // `tiles` pixels), one uniform class per transformed point
     WgP p;
     memset(&p, 0, sizeof(p));
-    itg_tensor vx = {const_cast<float*>(V), 1, 1, 1, 1, (int)w.tiles, x->c, x->ld};
+    itg_tensor vx = {const_cast<float*>(V), 1, 1, 1, 1, (int)w.tiles, R == 2 ? kld : x->c, kld};
     itg_tensor vdy = {dM, 1, 1, 1, 1, (int)w.tiles, dy->c, dy->ld};
     p.x = make_grid(&vx); p.dy = make_grid(&vdy);
     p.slab = dU; p.dbslab = nullptr;
-    p.ntaps = 1; p.kw = 1; p.cin_ld = x->ld; p.Ktot = x->ld; p.Kpad = w.tn.Kpad;
+    p.ntaps = 1; p.kw = 1; p.cin_ld = kld; p.Ktot = kld; p.Kpad = w.tn.Kpad;
     p.MT = 1; p.MU = (int)w.tiles; p.M = (int)w.tiles;
     p.stride = 1; p.pad = 0; p.pad_h = 0; p.pad_mode = ITG_PAD_ZERO;
     p.co_rows = w.tn.co_rows;
     p.chunks_per_split = w.tn.chunks_per_split; p.nchunks = w.tn.nchunks;
-    p.x_bytes = (unsigned)(w.tiles * x->ld * 4); p.dy_bytes = (unsigned)(w.tiles * dy->ld * 4);
-    p.ucls = NC; p.u_x = (unsigned)(w.tiles * x->ld); p.u_dy = (unsigned)(w.tiles * dy->ld);
+    p.x_bytes = (unsigned)(w.tiles * kld * 4); p.dy_bytes = (unsigned)(w.tiles * dy->ld * 4);
+    p.ucls = NC; p.u_x = (unsigned)(w.tiles * kld); p.u_dy = (unsigned)(w.tiles * dy->ld);
     TileWgPlan none;
     memset(&none, 0, sizeof(none));
     int rc = run_wgrad_slabs(p, w.tn, none, prec, s);
     if (rc) return rc;
   }
   {
-    const int64_t th = (int64_t)w.co_rows * x->ld;
+    const int64_t th = (int64_t)w.co_rows * kld;
     const dim3 grid((unsigned)((th + 255) / 256));
-    if (R == 4)
+    if (R == 2)
+      hipLaunchKernelGGL(wino_wg_out_s2_kernel, grid, dim3(256), 0, s, (const float*)dU, w.tn.splits, w.co_rows, w.tn.Kpad, x->ld,
+                         workspace + w.slab_off);
+    else if (R == 4)
       hipLaunchKernelGGL(wino_wg_out_kernel<4>, grid, dim3(256), 0, s, (const float*)dU, w.tn.splits, w.co_rows, w.tn.Kpad, x->ld,
                          workspace + w.slab_off);
     else

@@ -94,18 +94,25 @@ class _ConvParams(nn.Module):
         return (self.k == 3 and ops.WINOGRAD_G and not self.up2 and self.ch_in >= 96 and self.ch_out >= 96
                 and ops.ld_for(self.ch_out) % 16 == 0)
 
+    @property
+    def wino_s2(self):
+        """Wide 4 x 4 stride-2 layer whose FORWARD runs through F(4 x 4, 2 x 2) on its four parity classes (ops.wino_s2_applicable;
+        the discriminator's 64 -> 128 and 128 -> 256 layers): 6.25 multiplications per output and input channel instead of 16."""
+        return (ops.WINOGRAD and ops.WINOGRAD_S2 and self.wino_ok and self.k == 4 and self.stride == 2 and self.padding == 1
+                and self.ch_in >= ops.WINO_S2_MIN_CI and self.ch_out >= 64 and ops.MFMA_PRECISION == ops.PREC_F32)
+
     def pack_jobs(self):
         """Allocate this layer's persistent panels and return its two ops.pack_multi jobs."""
         w = self.weight_orig if self.SN else self.weight
         co, ci, k, st = w.shape[0], w.shape[1], self.k, self.stride
-        kind = "wino" if self.wino else ("up2" if self.up2 else "plain")
-        nf, nd = ops.pack_sizes(co, ci, k, k, st, kind == "up2", kind == "wino")
+        kind = "wino" if self.wino else ("wino_s2" if self.wino_s2 else ("up2" if self.up2 else "plain"))
+        nf, nd = ops.pack_sizes(co, ci, k, k, st, kind == "up2", 2 if kind == "wino_s2" else kind == "wino")
         if (self._packed is None or self._packed[0].device != w.device or self._packed_kind != kind
                 or self._packed[0].numel() != nf):
             self._packed = (torch.empty(nf, device=w.device, dtype=torch.float32),
                             torch.empty(nd, device=w.device, dtype=torch.float32))
         self._packed_kind = kind
-        kf, kd = {"plain": (0, 1), "up2": (2, 3), "wino": (6, 7) if k == 3 else (4, 5)}[kind]
+        kf, kd = {"plain": (0, 1), "up2": (2, 3), "wino": (6, 7) if k == 3 else (4, 5), "wino_s2": (8, 1)}[kind]
         return [(w, self._packed[0], co, ci, ops.ld_for(ci), k, k, 1, kf),
                 (w, self._packed[1], co, ci, ops.ld_for(co), k, k, st, kd)]
 
@@ -132,7 +139,10 @@ class _ConvParams(nn.Module):
         p_ = self.padding if pad is None else pad
         wino = self.wino and ops.wino_applicable(x, self.k, self.k, self.stride, p_, pad_h, pad_mode, ops.MFMA_PRECISION, up2,
                                                  out_stats, out, self.ch_out)
-        kind = "wino" if wino else ("up2" if up2 else "plain")
+        if not wino and self.wino_s2 and ops.wino_s2_applicable(x, self.k, self.k, self.stride, p_, pad_h, pad_mode, ops.MFMA_PRECISION,
+                                                                up2, residual, out, self.ch_out):
+            wino = 2
+        kind = "wino_s2" if wino == 2 else ("wino" if wino else ("up2" if up2 else "plain"))
         packed = self._packed if (self._packed is None or self._packed_kind == kind) else None    # else: packed per call
         return ops.conv(x, w, self.bias, self.k, self.k, self.stride, p_,
                         pad_mode, act, slope, residual, sn, out_grid, self._sinks(w), pad_h, packed=packed,

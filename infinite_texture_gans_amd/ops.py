@@ -279,6 +279,9 @@ class _Conv(torch.autograd.Function):
         inv_sigma = sn[0] if sn is not None else None
         if packed is not None:      # panels packed once per optimizer step (engine.PackSet): 1/sigma rides in the epilogue
             wp, out_scale = packed[0], inv_sigma
+        elif wino == 2:             # 4 x 4 stride 2: F(4 x 4, 2 x 2) on the four parity classes, forward only
+            wp, out_scale = torch.empty(_lib.fn("itg_pack_wino_s2_size")(co, ld), device=x.device, dtype=torch.float32), None
+            _lib.call("itg_pack_wino_s2_fwd", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, ld, st)
         elif wino:
             sfx = "wino3" if kh == 3 else "wino"
             wp, out_scale = torch.empty(_lib.fn("itg_pack_%s_size" % sfx)(co, ld), device=x.device, dtype=torch.float32), None
@@ -305,7 +308,7 @@ class _Conv(torch.autograd.Function):
         if nws is None:
             nws = _WS_SIZE[key] = _lib.fn("itg_conv2d_fwd_workspace")(C.byref(dx_), C.byref(do_), C.byref(g))
         ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
-        taps = 4 if up2 else ((kh + 3) ** 2 / 16.0 if wino else kh * kw)          # multiply-adds per output element and input channel
+        taps = 4 if up2 else (6.25 if wino == 2 else ((kh + 3) ** 2 / 16.0 if wino else kh * kw))      # multiply-adds per output element and input channel
         with _Prof(_nt_tag(co), 1, 2.0 * n * Ho * Wo * co * ci * taps, 4 * (x.numel() + out.numel() + wp.numel())):
             _lib.call("itg_conv2d_fwd", C.byref(dx_), _ptr(wp), _ptr(bias), _ptr(out_scale), C.byref(dr_), C.byref(do_),
                       C.byref(g), act, float(slope), _ptr(ws), nws, st)
@@ -323,7 +326,7 @@ class _Conv(torch.autograd.Function):
         # same x takes it from there instead of transforming x again (itg_conv_geom.wino_v) - kept only when w takes a gradient
         # (only where the weight gradient can consume it - fp32 operands, Winograd weight gradient on; the workspace
         # is V followed by the GEMM result M, one allocation behind one C-ABI pointer: M's ~40 MB per pass stay alive with V)
-        ctx.wino_ws = ws if (wino and WINO_KEEP_V and WINOGRAD_WGRAD and prec == PREC_F32 and w.requires_grad) else None       # (grad mode reads off inside forward())
+        ctx.wino_ws = ws if (wino and (wino == 1 or _wino_s2_wgrad(x.shape, ci)) and WINO_KEEP_V and WINOGRAD_WGRAD and prec == PREC_F32 and w.requires_grad) else None       # (grad mode reads off inside forward())
         ctx.save_for_backward(x, w, out if act != ACT_NONE else None)
         return out
 
@@ -331,6 +334,8 @@ class _Conv(torch.autograd.Function):
     def backward(ctx, dout):
         x, w, out = ctx.saved_tensors
         kh, kw, stride, pad, pad_mode, pad_h, prec, up2, wino = ctx.geom
+        wino_s2 = wino == 2                 # the stride-2 form: forward and weight gradient in the transformed domain, the input
+        wino = 1 if wino == 1 else 0        # gradient on the direct kernel (per class it would move 4 x dx's bytes)
         taps = 4 if up2 else kh * kw
         co, ci = ctx.co, ctx.c_in
         if BACKWARD_ENTRY_HOOK is not None and ctx.sinks is not None:
@@ -395,7 +400,10 @@ class _Conv(torch.autograd.Function):
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if need_w or need_b:
-            if ctx.wino_ws is not None:       # a geometry of its own for the weight gradient: + the forward's V
+            if wino_s2 and _wino_s2_wgrad(x.shape, ci):
+                g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, None, None, up2, _lib.GEOM_WINO,
+                       ctx.wino_ws.data_ptr() if ctx.wino_ws is not None else None)
+            elif ctx.wino_ws is not None and not wino_s2:       # a geometry of its own for the weight gradient: + the forward's V
                 g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, None, None, up2, _lib.GEOM_WINO, ctx.wino_ws.data_ptr())
             wsink, bsink = ctx.sinks if ctx.sinks is not None else (None, None)
             # Everything below only writes into the flat gradient buffers when sinks cover the requested
@@ -455,7 +463,7 @@ class _Conv(torch.autograd.Function):
                     npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
                     wino_wg = bool(g.flags & _lib.GEOM_WINO) and WINOGRAD_WGRAD
                     with _Prof(_nt_tag(co).replace("nt", "tn(+reduce)"), 1,
-                               2.0 * npix_out * co * ci * ((kh + 3) ** 2 / 16.0 if wino_wg else taps),
+                               2.0 * npix_out * co * ci * ((6.25 if stride == 2 else (kh + 3) ** 2 / 16.0) if wino_wg else taps),
                                4 * (x.numel() + dy.numel() + w.numel())):
                         # separate accumulate flags: a spectrally normalised layer sinks its bias gradient but takes dW into a
                         # temporary (no zero-fill launch for it)
@@ -506,6 +514,39 @@ def wino_applicable(x, kh, kw, stride, pad, pad_h, pad_mode, prec, up2=False, ou
     return kh == 3 and WINOGRAD_G and pad_mode in (PAD_ZERO, PAD_REPLICATE)
 
 
+WINO_S2_MIN_CI = int(os.environ.get("ITG_WINO_S2_MIN_CI", "64"))      # narrower layers stay direct (64: both of D's stride-2 layers)
+WINO_S2_MIN_TILES = int(os.environ.get("ITG_WINO_S2_MIN_TILES", "1024"))
+WINO_S2_WGRAD_MIN_CI = int(os.environ.get("ITG_WINO_S2_WGRAD_MIN_CI", "128"))
+WINO_S2_WGRAD = os.environ.get("ITG_WINO_S2_WGRAD", "1") == "1"      # ... and its weight gradient (25 contractions over the tiles, the forward's V re-used)
+WINOGRAD_S2 = os.environ.get("ITG_WINOGRAD_S2", "1") == "1"      # F(4 x 4, 2 x 2) forward for 4 x 4 stride-2 layers (conv_wino.hip wino_conv_s2)
+
+
+def wino_s2_applicable(x, kh, kw, stride, pad, pad_h, pad_mode, prec, up2=False, residual=None, out=None, co=None):
+    """Whether conv(..., wino=2) takes the forward-only stride-2 Winograd form: 4 x 4, stride 2, pad 1, zero padding, fp32, no
+    residual (the discriminator's 64 -> 128 / 128 -> 256 layers, reference models/discriminators.py:190-195)."""
+    if not (WINOGRAD and WINOGRAD_S2 and kh == 4 and kw == 4 and stride == 2 and pad == 1 and pad_h in (-1, 1) and pad_mode == PAD_ZERO
+            and prec == PREC_F32 and not up2 and residual is None and out is None and x.t.shape[5] % 4 == 0):
+        return False
+    # 25 GEMMs over the 4 x 4 output tiles: below ~1 000 tiles (the real batch behind the 128 -> 256 layer: 288) they under-fill
+    # the chip and the direct kernel wins (94 vs 80 us)
+    return wino_s2_tiles(x) >= WINO_S2_MIN_TILES
+
+
+def wino_s2_tiles(x):
+    n, gh, gw, ph, pw, _ = x.t.shape
+    ho, wo = (gh * ph) // 2, (gw * pw) // 2
+    return n * ((ho + 3) // 4) * ((wo + 3) // 4)
+
+
+def _wino_s2_wgrad(x_shape, ci):
+    """The stride-2 form's weight gradient in the transformed domain: where the transforms are cheap next to the contraction -
+    >= 128 input channels on >= 1 000 tiles (D's 128 -> 256 layer on the generated batch: 196 -> 143 us; its 64 -> 128 layer
+    191 vs 194 us, the real batches 72 / 106 vs 70 / 72 us: direct)."""
+    n, gh, gw, ph, pw, _ = x_shape
+    tiles = n * (((gh * ph) // 2 + 3) // 4) * (((gw * pw) // 2 + 3) // 4)
+    return WINOGRAD_WGRAD and WINO_S2_WGRAD and ci >= WINO_S2_WGRAD_MIN_CI and tiles >= WINO_S2_MIN_TILES
+
+
 def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, residual=None,
          sn=None, out_grid=None, sinks=None, pad_h=-1, precision=None, packed=None, in_act=None, defer_act_bwd=False,
          out_stats=False, out=None, up2=False, wino=False):
@@ -524,8 +565,11 @@ def conv(x, w, bias=None, kh=3, kw=3, stride=1, pad=0, pad_mode=PAD_ZERO, act=AC
         stats = _zeros_f64(2 * ld_for(w.shape[0]), x.t.device)
     # wino: Winograd F(4 x 4, 4 x 4) for the forward and the input gradient (4 x 4, stride 1, pad 1, zero padding, plain images,
     # fp32; itg_conv_geom.flags & ITG_GEOM_WINO); ``packed`` panels must then be the itg_pack_wino_* ones
-    wino = bool(wino) and wino_applicable(x, kh, kw, stride, pad, pad_h, pad_mode, prec, up2, stats is not None, out, w.shape[0])
-    t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode, pad_h, prec, 1 if up2 else 0, 1 if wino else 0), act, slope, og, sinks, packed,
+    if wino == 2:
+        wino = 2 if wino_s2_applicable(x, kh, kw, stride, pad, pad_h, pad_mode, prec, up2, residual, out, w.shape[0]) else 0
+    else:
+        wino = 1 if (bool(wino) and wino_applicable(x, kh, kw, stride, pad, pad_h, pad_mode, prec, up2, stats is not None, out, w.shape[0])) else 0
+    t = _Conv.apply(x.t, w, bias, r, sn, x.c, (kh, kw, stride, pad, pad_mode, pad_h, prec, 1 if up2 else 0, wino), act, slope, og, sinks, packed,
                     (in_act, bool(defer_act_bwd)), stats, out)
     return GT(t, w.shape[0], stats)
 
@@ -615,7 +659,7 @@ def _queue_wgrad(x, dxd, dy, ddy, gwg, w, wsink, bsink, need_w, need_b, sn, st, 
     co, ci, kh, kw = w.shape
     wino_wg = bool(gwg.flags & _lib.GEOM_WINO) and WINOGRAD_WGRAD
     with _Prof(_nt_tag(co).replace("nt", "tn"), 1,
-               2.0 * (dy.numel() // dy.shape[5]) * co * ci * ((kh + 3) ** 2 / 16.0 if wino_wg else kh * kw),
+               2.0 * (dy.numel() // dy.shape[5]) * co * ci * ((6.25 if gwg.stride == 2 else (kh + 3) ** 2 / 16.0) if wino_wg else kh * kw),
                4 * (x.numel() + dy.numel() + w.numel())):
         if _lib.CAPTURE_LOG is not None:          # (this entry point is called through fn(): its error code is inspected below)
             _lib.CAPTURE_LOG.add(getattr(st, "value", st) or 0)
@@ -1240,6 +1284,8 @@ def pack_multi(tables):
 
 def pack_sizes(co, ci, kh, kw, stride, up2=False, wino=False):
     """(floats of the forward panel, floats of the dgrad panel) for a conv between patch-grid tensors."""
+    if wino == 2:
+        return (_lib.fn("itg_pack_wino_s2_size")(co, ld_for(ci)), _lib.fn("itg_pack_dgrad_size")(ci, ld_for(co), kh, kw, stride))
     if wino:
         f = _lib.fn("itg_pack_wino3_size" if kh == 3 else "itg_pack_wino_size")
         return (f(co, ld_for(ci)), f(ci, ld_for(co)))

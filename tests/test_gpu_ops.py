@@ -330,6 +330,58 @@ def test_capture_rule_bookkeeping():
     torch.cuda.synchronize()
 
 
+WINO_S2_CASES = [
+    # name, n, size, cin, cout
+    ("s2_64_128_d1", 2, 96, 64, 128),              # the discriminator's 64 -> 128 layer (48 x 48 outputs: whole tiles)
+    ("s2_128_256_d2_odd", 1, 46, 128, 256),        # 23 x 23 outputs: the last tile row / column is cropped, the frame is zero padding
+    ("s2_26_72_narrow", 3, 22, 26, 72),            # channel pitches 28 / 72: K = 4 x 28 is padded to the stage size
+]
+
+
+@pytest.mark.parametrize("case", WINO_S2_CASES, ids=[c[0] for c in WINO_S2_CASES])
+def test_conv_winograd_f42_stride2_forward(case, monkeypatch):
+    """ops.conv(wino=2): a 4 x 4 stride-2 pad-1 conv (reference models/discriminators.py:190-195) as the sum over its four
+    parity classes of F(4 x 4, 2 x 2) convolutions of the parity-decimated input - 25 GEMMs with the classes concatenated along
+    K - with bias + LeakyReLU in the output transform; the weight gradient as 25 contractions over the tiles of A dY A^T and the
+    forward's V (taken from its workspace), brought back per class by G^T . G into the 4 x 4 filter; the input gradient from the
+    direct kernel.  Output 5e-6 (F(4 x 4, 2 x 2) amplifies rounding ~3 x: measured 1-2.5e-6), input gradient at the direct
+    kernels' 5e-6, weight gradient 1e-5."""
+    ops = _ops()
+    monkeypatch.setattr(ops, "WINOGRAD", True)
+    monkeypatch.setattr(ops, "WINOGRAD_S2", True)
+    monkeypatch.setattr(ops, "WINO_S2_MIN_TILES", 1)          # the size rules of the step are not what is tested here
+    monkeypatch.setattr(ops, "WINO_S2_WGRAD_MIN_CI", 1)
+    name, n, size, cin, cout = case
+    g = _gen(zlib.crc32(name.encode()) % 1000)
+    x = torch.randn(n, cin, size, size, generator=g)
+    w = torch.randn(cout, cin, 4, 4, generator=g) / (cin * 16) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pre = F.conv2d(xr, wr, br, stride=2, padding=1)
+    yr = F.leaky_relu(pre, 0.2).detach()
+    xg, wg, bg = (t.to(cuda).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv(ops.to_grid(xg, 1, 1, merged=True), wg, bg, 4, 4, 2, 1, ops.PAD_ZERO, ops.ACT_LRELU, 0.2, wino=2)
+    assert ops._lib.fn("itg_last_conv_kernel")().decode().startswith("conv_nt_kernel")
+    yg = ops.to_nchw(y, merged=True)
+    e = rel_l2(yg.detach().cpu(), yr)
+    print("F(4x4,2x2) stride-2 forward rel-L2 vs F.conv2d:", e)
+    assert e < 5e-6, e
+    y0 = ops.to_nchw(ops.conv(ops.to_grid(xg, 1, 1, merged=True), wg, bg, 4, 4, 2, 1, ops.PAD_ZERO, ops.ACT_LRELU, 0.2), merged=True)
+    assert 1e-8 < rel_l2(yg.detach().cpu(), y0.detach().cpu()) < 5e-6          # another algorithm, the same result
+    dy = torch.randn(yr.shape, generator=g)
+    dyl = dy * torch.where(yg.detach().cpu() > 0, 1.0, 0.2)
+    dxr, dwr, dbr = torch.autograd.grad(pre, (xr, wr, br), dyl)
+    dxg, dwg, dbg = torch.autograd.grad(yg, (xg, wg, bg), dy.to(cuda))
+    print("  input gradient", rel_l2(dxg.cpu(), dxr), "weight gradient", rel_l2(dwg.cpu(), dwr))
+    assert rel_l2(dxg.cpu(), dxr) < 5e-6 and rel_l2(dwg.cpu(), dwr) < 1e-5
+    assert float((dbg.cpu() - dbr).abs().max()) <= 2e-6 * float(dyl.abs().sum((0, 2, 3)).max())
+    # the direct weight-gradient kernel on the same operands: another algorithm, the same result
+    monkeypatch.setattr(ops, "WINO_S2_WGRAD", False)
+    yg2 = ops.to_nchw(ops.conv(ops.to_grid(xg, 1, 1, merged=True), wg, bg, 4, 4, 2, 1, ops.PAD_ZERO, ops.ACT_LRELU, 0.2, wino=2), merged=True)
+    (dw0,) = torch.autograd.grad(yg2, (wg,), dy.to(cuda))
+    assert rel_l2(dwg.cpu(), dw0.cpu()) < 1e-5
+
+
 def test_winograd_weight_gradient_with_the_forwards_transformed_input_is_bit_exact(monkeypatch):
     """the Winograd weight gradient that takes the forward's V from the retained workspace (itg_conv_geom.wino_v,
     ops.WINO_KEEP_V) runs the same transform kernel on the same x as the one that transforms x again: weight and bias
@@ -1097,19 +1149,23 @@ def test_pack_multi_panels_equal_the_single_panel_entry_points_bit_exact():
     st = None
     layers = [  # (co, ci, k, stride, kind)
         (52, 26, 3, 1, "plain"), (128, 64, 4, 2, "plain"), (13, 26, 3, 1, "up2"), (104, 208, 3, 1, "up2"),
-        (96, 64, 4, 1, "wino"), (72, 80, 4, 1, "wino"), (1, 512, 4, 1, "plain"), (112, 96, 3, 1, "wino"), (40, 208, 3, 1, "wino")]
+        (96, 64, 4, 1, "wino"), (72, 80, 4, 1, "wino"), (1, 512, 4, 1, "plain"), (112, 96, 3, 1, "wino"), (40, 208, 3, 1, "wino"),
+        (128, 64, 4, 2, "wino_s2"), (72, 26, 4, 2, "wino_s2")]
     jobs, want = [], []
     for co, ci, k, s, kind in layers:
         w = torch.randn(co, ci, k, k, generator=g).to(cuda)
-        nf, nd = ops.pack_sizes(co, ci, k, k, s, kind == "up2", kind == "wino")
+        nf, nd = ops.pack_sizes(co, ci, k, k, s, kind == "up2", 2 if kind == "wino_s2" else kind == "wino")
         pf = torch.full((nf,), float("nan"), device=cuda)
         pd = torch.full((nd,), float("nan"), device=cuda)
-        kf, kd = {"plain": (0, 1), "up2": (2, 3), "wino": (6, 7) if k == 3 else (4, 5)}[kind]
+        kf, kd = {"plain": (0, 1), "up2": (2, 3), "wino": (6, 7) if k == 3 else (4, 5), "wino_s2": (8, 1)}[kind]
         ldi, ldo = ops.ld_for(ci), ops.ld_for(co)
         jobs += [(w, pf, co, ci, ldi, k, k, 1, kf), (w, pd, co, ci, ldo, k, k, s, kd)]
         sf, sd = torch.empty(nf, device=cuda), torch.empty(nd, device=cuda)
         P = lambda t: t.data_ptr()                                                       # noqa: E731
-        if kind == "wino":
+        if kind == "wino_s2":
+            _lib.call("itg_pack_wino_s2_fwd", P(w), None, P(sf), co, ci, ldi, st)
+            _lib.call("itg_pack_dgrad", P(w), None, P(sd), co, ci, ldo, k, k, s, st)
+        elif kind == "wino":
             sfx = "wino3" if k == 3 else "wino"
             _lib.call("itg_pack_%s_fwd" % sfx, P(w), None, P(sf), co, ci, ldi, st)
             _lib.call("itg_pack_%s_dgrad" % sfx, P(w), None, P(sd), co, ci, ldo, st)

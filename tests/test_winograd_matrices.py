@@ -31,10 +31,11 @@ def _header(fname, prefix):
 
 
 CASES = [(4, [Fr(0), Fr(1), Fr(-1), Fr(2), Fr(-2), Fr(1, 2)], "winograd_f44.h", "WINO"),
-         (3, [Fr(0), Fr(1), Fr(-1), Fr(2), Fr(-2)], "winograd_f43.h", "WINO3")]
+         (3, [Fr(0), Fr(1), Fr(-1), Fr(2), Fr(-2)], "winograd_f43.h", "WINO3"),
+         (2, [Fr(0), Fr(1), Fr(-1), Fr(2)], "winograd_f42.h", "WINO2")]
 
 
-@pytest.mark.parametrize("R,pts,fname,prefix", CASES, ids=["F(4x4,4x4)", "F(4x4,3x3)"])
+@pytest.mark.parametrize("R,pts,fname,prefix", CASES, ids=["F(4x4,4x4)", "F(4x4,3x3)", "F(4x4,2x2)"])
 def test_compiled_matrices_are_the_generators_and_exact(R, pts, fname, prefix):
     at, g, bt = _gen().matrices(R, pts)
     h = _header(fname, prefix)
