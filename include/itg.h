@@ -100,6 +100,10 @@ int itg_pack_wino_dgrad(const float* w_oihw, const float* scale, float* out, int
  * of the filter concatenated along K.  Forward only: the layer's itg_conv2d_dgrad / _wgrad take the ordinary panels / no flag. */
 int64_t itg_pack_wino_s2_size(int co, int ci_ld);
 int itg_pack_wino_s2_fwd(const float* w, const float* scale, float* out, int co, int ci, int ci_ld, void* stream);
+/* ... and the transposed panel UT[25][4 * ci_ld (padded to 16)][co_ld] for itg_conv2d_dgrad with ITG_GEOM_WINO on that layer: the
+ * input gradient as the adjoint of the forward pipeline (dM = A dY A^T, 25 GEMMs, gathered B dV B^T)                        */
+int64_t itg_pack_wino_s2_dgrad_size(int ci_ld, int co_ld);
+int itg_pack_wino_s2_dgrad(const float* w, const float* scale, float* out, int co, int ci, int ci_ld, int co_ld, void* stream);
 int itg_pack_wino3_fwd(const float* w_oihw, const float* scale, float* out, int co, int ci, int ci_ld, void* stream);
 int itg_pack_wino3_dgrad(const float* w_oihw, const float* scale, float* out, int co, int ci, int co_ld, void* stream);
 #define ITG_ZERO_FRAMES_MAX 32

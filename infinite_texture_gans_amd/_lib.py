@@ -74,6 +74,8 @@ SIGNATURES = {
     "itg_pack_wino_size": (_l, [_i, _i]),
     "itg_pack_wino_s2_size": (_l, [_i, _i]),
     "itg_pack_wino_s2_fwd": (_i, [_P, _P, _P, _i, _i, _i, _P]),
+    "itg_pack_wino_s2_dgrad_size": (_l, [_i, _i]),
+    "itg_pack_wino_s2_dgrad": (_i, [_P, _P, _P, _i, _i, _i, _i, _P]),
     "itg_pack_wino3_size": (_l, [_i, _i]),
     "itg_pack_wino_fwd": (_i, [_P, _P, _P, _i, _i, _i, _P]),
     "itg_pack_wino3_fwd": (_i, [_P, _P, _P, _i, _i, _i, _P]),

@@ -210,6 +210,34 @@ __device__ __forceinline__ float wino_s2_elem(const float* __restrict__ w, int c
   return v;
 }
 
+// ... and its transpose for the input gradient (wino_conv_s2_dgrad): UT[xi][row = cls * ci_ld + c][k = co] = U[xi][co][cls * ci_ld + c]
+__device__ __forceinline__ float wino_s2_dgrad_elem(const float* __restrict__ w, int co, int ci, int ci_ld, int co_ld, unsigned e) {
+  const unsigned Kpad = (unsigned)round_up_d(co_ld, BK), rows_pad = (unsigned)round_up_d(4 * ci_ld, 16);
+  const int k = (int)(e % Kpad);
+  const unsigned r = e / Kpad;
+  const int row = (int)(r % rows_pad), xi = (int)(r / rows_pad);
+  const int cls = row / ci_ld, c = row - cls * ci_ld;
+  if (k >= co || cls >= 4 || c >= ci || xi >= 25) return 0.f;
+  const int a = cls >> 1, b = cls & 1, al = xi / 5, be = xi - al * 5;
+  const float* g = w + ((size_t)k * ci + c) * 16;
+  float v = 0.f;
+#pragma unroll
+  for (int jx = 0; jx < 2; ++jx) {
+    float t = 0.f;
+#pragma unroll
+    for (int jy = 0; jy < 2; ++jy) t = fmaf(WINO2_G[al][jy], g[(2 * jy + a) * 4 + 2 * jx + b], t);
+    v = fmaf(WINO2_G[be][jx], t, v);
+  }
+  return v;
+}
+
+__global__ void pack_wino_s2_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out, int co,
+                                          int ci, int ci_ld, int co_ld, long long total) {
+  const float sc = scale ? *scale : 1.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    out[i] = sc * wino_s2_dgrad_elem(w, co, ci, ci_ld, co_ld, (unsigned)i);
+}
+
 __global__ void pack_wino_s2_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out, int co, int ci,
                                     int ld, long long total) {
   const float sc = scale ? *scale : 1.f;
@@ -647,6 +675,19 @@ int itg_pack_wino_s2_fwd(const float* w, const float* scale, float* out, int co,
   return ITG_OK;
 }
 
+int64_t itg_pack_wino_s2_dgrad_size(int ci_ld, int co_ld) { return (int64_t)25 * round_up(4 * ci_ld, 16) * round_up(co_ld, BK); }
+
+int itg_pack_wino_s2_dgrad(const float* w, const float* scale, float* out, int co, int ci, int ci_ld, int co_ld, void* stream) {
+  if (!w || !out || co <= 0 || ci <= 0 || (ci_ld & 3) || ci_ld < ci || (co_ld & 3) || co_ld < co) return ITG_ERR_ARG;
+  const int64_t total = itg_pack_wino_s2_dgrad_size(ci_ld, co_ld);
+  if (total >= ((int64_t)1 << 32)) return ITG_ERR_ARG;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(pack_wino_s2_dgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, scale, out, co, ci, ci_ld, co_ld,
+                     (long long)total);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
 int itg_pack_wino3_fwd(const float* w, const float* scale, float* out, int co, int ci, int ci_ld, void* stream) {
   return pack_wino(w, scale, out, co, ci, ci_ld, 0, 3, stream);
 }
@@ -703,6 +744,7 @@ int64_t itg_conv2d_fwd_workspace(const itg_tensor* in, const itg_tensor* out, co
 
 int64_t itg_conv2d_dgrad_workspace(const itg_tensor* dy, const itg_tensor* dx, const itg_conv_geom* g) {
   if (!dy || !dx || !g) return 0;
+  if (wino_s2_geom(g)) return wino_s2_dgrad_workspace_floats(dy, dx);
   if (g->flags & ITG_GEOM_WINO) return wino_geom(g) ? wino_workspace_floats(dy, dx, g->kh, wino_fold(g)) : 0;
   if (thin_in_conv(dy, dx, g)) {
     const int rows = 64;
@@ -870,6 +912,13 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
   if (!w_packed_dgrad || !g) return ITG_ERR_ARG;
   if (dy->n != dx->n) return ITG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  if (wino_s2_geom(g)) {
+    // the 4 x 4 stride-2 layer's input gradient as the ADJOINT of its F(4 x 4, 2 x 2) forward (conv_wino.hip): panel from
+    // itg_pack_wino_s2_dgrad
+    const itg_tensor* r = (act_out && act_out->ptr && act != ITG_ACT_NONE) ? act_out : nullptr;
+    if (r && ((rc = check_tensor(r)) || !same_shape(r, dx))) return rc ? rc : ITG_ERR_ARG;
+    return wino_conv_s2_dgrad(dy, w_packed_dgrad, out_scale, dx, r, r ? act : 0, slope, prec_of(g), workspace, workspace_floats, s);
+  }
   if (g->flags & ITG_GEOM_WINO) {
     // the input gradient of an R x R stride-1 pad-1 conv is the pad-(R - 2) correlation of dy with the flipped, transposed
     // filter; replicate padding: evaluated on the padded extent (pad R - 1), the frame folded onto dx's zeroed border

@@ -171,6 +171,9 @@ int wino_conv(const itg_tensor* in, const float* u_panel, const float* bias, con
 int64_t wino_s2_workspace_floats(const itg_tensor* in, const itg_tensor* out);
 int wino_conv_s2(const itg_tensor* in, const float* u_panel, const float* bias, const float* out_scale, const itg_tensor* out, int act,
                  float slope, int prec, float* workspace, int64_t workspace_floats, hipStream_t s);
+int64_t wino_s2_dgrad_workspace_floats(const itg_tensor* dy, const itg_tensor* dx);
+int wino_conv_s2_dgrad(const itg_tensor* dy, const float* ut_panel, const float* out_scale, const itg_tensor* dx, const itg_tensor* act_out,
+                       int act, float slope, int prec, float* workspace, int64_t workspace_floats, hipStream_t s);
 // conv_nt.hip
 NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = ITG_PREC_F32);
 int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s);

@@ -153,6 +153,127 @@ __global__ __launch_bounds__(256) void wino_in_s2_kernel(const GridT x, int Ty, 
     }
 }
 
+// The ADJOINT of wino_in_s2_kernel: dx from dV[xi][tile][cls * ld + c] (the gradient w.r.t. V).  V = B^T d B per tile and class,
+// so the gradient of the class's decimated pixel (s, r) is the sum over the tiles that cover it of (B dV B^T)[s - 4 ty][r - 4 tx]
+// - tiles are 5 x 5 at stride 4, so a pixel on a tile's first row / column also lies on the LAST row / column of the tile above /
+// to the left.  One thread = (4 x 4 block of the class image, class, channel pair): its own tile's 25 values, row 4 of the tile
+// above, column 4 of the tile to the left, the corner of the diagonal one (L2 hits: the neighbouring threads' tiles) - a gather,
+// so every dx pixel is written once with its complete sum (1/sigma and the producing layer's activation derivative applied).
+__global__ __launch_bounds__(256) void wino_in_s2_adjoint_kernel(const float* __restrict__ dV, const GridT dx, int Ty, int Tx,
+                                                                 const float* __restrict__ scale, const GridT res, int res_mode,
+                                                                 float res_slope) {
+  constexpr int NP = 5;
+  const int ld = dx.ld, cpairs = ld >> 1;
+  const int64_t tiles = (int64_t)dx.n * Ty * Tx;
+  // the block grid has one more row / column of blocks than tiles: the last row / column of the last tiles lands there
+  const int By = Ty + 1, Bx = Tx + 1;
+  const int64_t blocks = (int64_t)dx.n * By * Bx;
+  const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gt >= blocks * 4 * cpairs) return;
+  const int cp = (int)(gt % cpairs);
+  const int cls = (int)((gt / cpairs) & 3);
+  const int64_t blk = gt / (4 * cpairs);
+  const int bx = (int)(blk % Bx), by = (int)((blk / Bx) % By), img = (int)(blk / ((int64_t)By * Bx));
+  const size_t plane = (size_t)tiles * 4 * ld;
+  f32x2 d[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[i][j] = f32x2{0.f, 0.f};
+  // contribution of tile (ty, tx) to local rows i0 .. and columns j0 .. of this block: rows `ri` / columns `rj` of B dV B^T
+  auto add_tile = [&](int ty, int tx, bool last_row, bool last_col) {
+    if ((unsigned)ty >= (unsigned)Ty || (unsigned)tx >= (unsigned)Tx) return;
+    const int64_t tile = ((int64_t)img * Ty + ty) * Tx + tx;
+    const float* vb = dV + (size_t)tile * 4 * ld + cls * ld + 2 * cp;
+    // t[al][j] = sum_be dV[al][be] BT[be][j] for the needed columns j, then rows
+    f32x2 t[NP][4];
+    f32x2 tc[NP];                            // column 4 (last_col)
+#pragma unroll
+    for (int al = 0; al < NP; ++al) {
+      f32x2 v[NP];
+#pragma unroll
+      for (int be = 0; be < NP; ++be) v[be] = *reinterpret_cast<const f32x2*>(vb + (size_t)(al * NP + be) * plane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x2 a = {0.f, 0.f};
+#pragma unroll
+        for (int be = 0; be < NP; ++be)
+          if (WM<2>::bt(be, j) != 0.f) a += WM<2>::bt(be, j) * v[be];
+        t[al][j] = a;
+      }
+      f32x2 a4 = {0.f, 0.f};
+#pragma unroll
+      for (int be = 0; be < NP; ++be)
+        if (WM<2>::bt(be, 4) != 0.f) a4 += WM<2>::bt(be, 4) * v[be];
+      tc[al] = a4;
+    }
+    if (!last_row && !last_col) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x2 a = {0.f, 0.f};
+#pragma unroll
+          for (int al = 0; al < NP; ++al)
+            if (WM<2>::bt(al, i) != 0.f) a += WM<2>::bt(al, i) * t[al][j];
+          d[i][j] += a;
+        }
+    } else if (last_row && !last_col) {      // the tile above: its row 4 lands on this block's row 0
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x2 a = {0.f, 0.f};
+#pragma unroll
+        for (int al = 0; al < NP; ++al)
+          if (WM<2>::bt(al, 4) != 0.f) a += WM<2>::bt(al, 4) * t[al][j];
+        d[0][j] += a;
+      }
+    } else if (!last_row && last_col) {      // the tile to the left: its column 4 lands on this block's column 0
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x2 a = {0.f, 0.f};
+#pragma unroll
+        for (int al = 0; al < NP; ++al)
+          if (WM<2>::bt(al, i) != 0.f) a += WM<2>::bt(al, i) * tc[al];
+        d[i][0] += a;
+      }
+    } else {
+      f32x2 a = {0.f, 0.f};
+#pragma unroll
+      for (int al = 0; al < NP; ++al)
+        if (WM<2>::bt(al, 4) != 0.f) a += WM<2>::bt(al, 4) * tc[al];
+      d[0][0] += a;
+    }
+  };
+  add_tile(by, bx, false, false);
+  add_tile(by - 1, bx, true, false);
+  add_tile(by, bx - 1, false, true);
+  add_tile(by - 1, bx - 1, true, true);
+  const float osc = scale ? *scale : 1.f;
+  const int a_ = cls >> 1, b_ = cls & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int Y = 2 * (4 * by + i) + a_ - 1;
+    if ((unsigned)Y >= (unsigned)dx.H) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int X = 2 * (4 * bx + j) + b_ - 1;
+      if ((unsigned)X >= (unsigned)dx.W) continue;
+      f32x2 v = d[i][j] * osc;
+      const int off = grid_off(dx, img, Y, X) + 2 * cp;
+      if (res.p) {
+        const f32x2 r = *reinterpret_cast<const f32x2*>(res.p + grid_off(res, img, Y, X) + 2 * cp);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          v[e] *= res_mode == ITG_ACT_LRELU ? (r[e] > 0.f ? 1.f : res_slope) : (res_mode == ITG_ACT_TANH ? 1.f - r[e] * r[e] : 1.f);
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        if (2 * cp + e >= dx.c) v[e] = 0.f;
+      *reinterpret_cast<f32x2*>(dx.p + off) = v;
+    }
+  }
+}
+
 // one thread = (tile, output-channel pair): NP^2 loads, Y = A^T m A (4 x 4), epilogue, <= 16 stores
 // res_mode 0: y += res (read at (oy >> res_ups, ox >> res_ups));  ITG_ACT_*: y *= act'(res) (res = the activation's OUTPUT, as
 // itg_conv2d_dgrad's act_out).  fold = 1: the tiles cover the (H + 2) x (W + 2) gradient of a replicate-padded tensor; element
@@ -525,6 +646,66 @@ int wino_conv_s2(const itg_tensor* in, const float* u_panel, const float* bias, 
     const int64_t th = tiles * (out->ld >> 1);
     hipLaunchKernelGGL(wino_out_kernel<2>, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, (const float*)Mm, make_grid(out), Ty, Tx, 0, bias,
                        out_scale, null_grid(), 0, 0, 0.f, act, slope);
+    ITG_CHECK_LAUNCH();
+  }
+  return ITG_OK;
+}
+
+// workspace of the stride-2 input gradient: dM[25][tiles][dy.ld] | dV[25][tiles][4 * dx.ld]
+int64_t wino_s2_dgrad_workspace_floats(const itg_tensor* dy, const itg_tensor* dx) {
+  int Ty, Tx;
+  wino_tiles(dy->gh * dy->ph, dy->gw * dy->pw, Ty, Tx);
+  const int64_t tiles = (int64_t)dy->n * Ty * Tx;
+  return 25 * tiles * ((int64_t)dy->ld + 4 * dx->ld);
+}
+
+// dy -> dx of the 4 x 4 stride-2 pad-1 layer, as the adjoint of wino_conv_s2: dM = A dY A^T, dV[xi] = dM[xi] . U[xi] (25 GEMMs
+// [tiles x Cout] x [Cout x 4 Cin], panel itg_pack_wino_s2_dgrad), dx = the gathered B dV B^T of the parity classes.
+int wino_conv_s2_dgrad(const itg_tensor* dy, const float* ut_panel, const float* out_scale, const itg_tensor* dx, const itg_tensor* act_out,
+                       int act, float slope, int prec, float* workspace, int64_t workspace_floats, hipStream_t s) {
+  const int H = dx->gh * dx->ph, W = dx->gw * dx->pw, Ho = dy->gh * dy->ph, Wo = dy->gw * dy->pw;
+  if (dx->n != dy->n || Ho != (H + 2 - 4) / 2 + 1 || Wo != (W + 2 - 4) / 2 + 1 || (dx->ld & 3) || (dy->ld & 15)) return ITG_ERR_ARG;
+  int Ty, Tx;
+  wino_tiles(Ho, Wo, Ty, Tx);
+  // every dx pixel must lie inside the tiles' 5 x 5 windows of its class: 2 (4 Ty + 4) + 1 - 1 >= H - 1
+  if (8 * Ty + 8 < H || 8 * Tx + 8 < W) return ITG_ERR_ARG;
+  constexpr int NC = 25;
+  const int64_t tiles = (int64_t)dy->n * Ty * Tx;
+  const int kld = 4 * dx->ld;
+  const int64_t mf = NC * tiles * dy->ld, vf = NC * tiles * kld;
+  if (!workspace || workspace_floats < mf + vf) return ITG_ERR_WORKSPACE;
+  if (tiles * std::max(kld, (int)dy->ld) * 4 >= 0xFFFF0000LL) return ITG_ERR_ARG;
+  float* dM = workspace;
+  float* dV = workspace + mf;
+  {
+    const int64_t th = tiles * (dy->ld >> 1);
+    hipLaunchKernelGGL(wino_dy_kernel<2>, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, make_grid(dy), Ty, Tx, dM);
+    ITG_CHECK_LAUNCH();
+  }
+  {
+    ConvP p;
+    memset(&p, 0, sizeof(p));
+    itg_tensor vin = {dM, dy->n, 1, 1, Ty, Tx, dy->c, dy->ld};
+    itg_tensor vout = {dV, dy->n, 1, 1, Ty, Tx, kld, kld};
+    p.in = make_grid(&vin); p.out = make_grid(&vout); p.res = null_grid();
+    p.w = ut_panel; p.bias = nullptr; p.scale = nullptr;
+    p.ntaps = 1; p.kw = 1; p.cin_ld = dy->ld; p.Kpad = round_up(dy->ld, BK);
+    p.MT = Ty; p.MU = Tx; p.M = (int)tiles;
+    p.isy = p.isx = 1; p.osy = p.osx = 1;
+    p.pad_mode = ITG_PAD_ZERO; p.act = ITG_ACT_NONE;
+    p.co_rows = round_up(kld, 16);
+    p.prec = prec;
+    p.ncls = 1;
+    p.ucls = NC;
+    p.u_dgrad = 1;
+    p.u_in = (unsigned)(tiles * dy->ld); p.u_out = (unsigned)(tiles * kld); p.u_w = (unsigned)((size_t)p.co_rows * p.Kpad);
+    int rc = dispatch_nt(p, nullptr, 0, s);
+    if (rc) return rc;
+  }
+  {
+    const int64_t th = (int64_t)dx->n * (Ty + 1) * (Tx + 1) * 4 * (dx->ld >> 1);
+    hipLaunchKernelGGL(wino_in_s2_adjoint_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, (const float*)dV, make_grid(dx), Ty, Tx,
+                       out_scale, act_out ? make_grid(act_out) : null_grid(), act, slope);
     ITG_CHECK_LAUNCH();
   }
   return ITG_OK;

@@ -348,12 +348,18 @@ class _Conv(torch.autograd.Function):
             _lib.call("itg_act_bwd", C.byref(a), C.byref(b), C.byref(c_), ctx.act, float(ctx.slope), st)
         else:
             dy = dout
-        g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, None, None, up2, _lib.GEOM_WINO if wino else 0)
+        s2_dgrad = wino_s2 and dy.shape[5] % 16 == 0 and _wino_s2_dgrad(x.shape, ci)        # the input gradient as the adjoint of the stride-2 Winograd forward
+        g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, None, None, up2, _lib.GEOM_WINO if (wino or s2_dgrad) else 0)
         ddy = _desc(dy, co)
         inv_sigma = ctx.sn[0] if ctx.sn is not None else None
         gx = gw_ = gb = None
         if ctx.needs_input_grad[0]:
-            if ctx.packed is not None:
+            if s2_dgrad:                    # its transposed panel is packed per call (the layer's persistent input-gradient panel is the
+                                            # direct kernel's: the real batch of the same layer takes that one)
+                wp, out_scale = torch.empty(_lib.fn("itg_pack_wino_s2_dgrad_size")(x.shape[5], dy.shape[5]), device=x.device,
+                                            dtype=torch.float32), None
+                _lib.call("itg_pack_wino_s2_dgrad", _ptr(w), _ptr(inv_sigma), _ptr(wp), co, ci, x.shape[5], dy.shape[5], st)
+            elif ctx.packed is not None:
                 wp, out_scale = ctx.packed[1], inv_sigma
             elif wino:
                 sfx = "wino3" if kh == 3 else "wino"
@@ -385,12 +391,12 @@ class _Conv(torch.autograd.Function):
                 gx = torch.empty_like(x)
             ddx = _desc(gx, ci)
             npix_out = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * dy.shape[4]
-            key = ("d", tuple(dy.shape), tuple(gx.shape), ctx.geom, ci, co)
+            key = ("d", tuple(dy.shape), tuple(gx.shape), ctx.geom, ci, co, s2_dgrad)
             nws = _WS_SIZE.get(key)
             if nws is None:
                 nws = _WS_SIZE[key] = _lib.fn("itg_conv2d_dgrad_workspace")(C.byref(ddy), C.byref(ddx), C.byref(g))
             ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
-            with _Prof(_nt_tag(ci), 1, 2.0 * npix_out * co * ci * ((kh + 3) ** 2 / 16.0 if wino else taps),
+            with _Prof(_nt_tag(ci), 1, 2.0 * npix_out * co * ci * (6.25 if s2_dgrad else ((kh + 3) ** 2 / 16.0 if wino else taps)),
                        4 * (dy.numel() + gx.numel() + wp.numel())):
                 ia = ctx.in_act
                 dact = _desc(x, ci) if ia is not None else _null_desc()
@@ -400,9 +406,10 @@ class _Conv(torch.autograd.Function):
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if need_w or need_b:
-            if wino_s2 and _wino_s2_wgrad(x.shape, ci):
-                g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, None, None, up2, _lib.GEOM_WINO,
-                       ctx.wino_ws.data_ptr() if ctx.wino_ws is not None else None)
+            if wino_s2:                       # (its own geometry: the input gradient's flag does not carry over)
+                wg_w = _wino_s2_wgrad(x.shape, ci)
+                g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, None, None, up2, _lib.GEOM_WINO if wg_w else 0,
+                       ctx.wino_ws.data_ptr() if (wg_w and ctx.wino_ws is not None) else None)
             elif ctx.wino_ws is not None and not wino_s2:       # a geometry of its own for the weight gradient: + the forward's V
                 g = _G(kh, kw, stride, pad, pad_mode, pad_h, prec, None, None, up2, _lib.GEOM_WINO, ctx.wino_ws.data_ptr())
             wsink, bsink = ctx.sinks if ctx.sinks is not None else (None, None)
@@ -517,6 +524,8 @@ def wino_applicable(x, kh, kw, stride, pad, pad_h, pad_mode, prec, up2=False, ou
 WINO_S2_MIN_CI = int(os.environ.get("ITG_WINO_S2_MIN_CI", "64"))      # narrower layers stay direct (64: both of D's stride-2 layers)
 WINO_S2_MIN_TILES = int(os.environ.get("ITG_WINO_S2_MIN_TILES", "1024"))
 WINO_S2_WGRAD_MIN_CI = int(os.environ.get("ITG_WINO_S2_WGRAD_MIN_CI", "128"))
+WINO_S2_DGRAD = os.environ.get("ITG_WINO_S2_DGRAD", "1") == "1"
+WINO_S2_DGRAD_MIN_CI = int(os.environ.get("ITG_WINO_S2_DGRAD_MIN_CI", "128"))      # (64 -> 128 layer: 164 vs 171 us incl. its per-call panel: even)
 WINO_S2_WGRAD = os.environ.get("ITG_WINO_S2_WGRAD", "1") == "1"      # ... and its weight gradient (25 contractions over the tiles, the forward's V re-used)
 WINOGRAD_S2 = os.environ.get("ITG_WINOGRAD_S2", "1") == "1"      # F(4 x 4, 2 x 2) forward for 4 x 4 stride-2 layers (conv_wino.hip wino_conv_s2)
 
@@ -536,6 +545,13 @@ def wino_s2_tiles(x):
     n, gh, gw, ph, pw, _ = x.t.shape
     ho, wo = (gh * ph) // 2, (gw * pw) // 2
     return n * ((ho + 3) // 4) * ((wo + 3) // 4)
+
+
+def _wino_s2_dgrad(x_shape, ci):
+    """The stride-2 form's input gradient through the adjoint pipeline (conv_wino.hip wino_conv_s2_dgrad)."""
+    n, gh, gw, ph, pw, _ = x_shape
+    tiles = n * (((gh * ph) // 2 + 3) // 4) * (((gw * pw) // 2 + 3) // 4)
+    return WINO_S2_DGRAD and ci >= WINO_S2_DGRAD_MIN_CI and tiles >= WINO_S2_MIN_TILES
 
 
 def _wino_s2_wgrad(x_shape, ci):
