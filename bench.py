@@ -275,6 +275,12 @@ def _algorithms_note():
     if ops.WINOGRAD and ops.MFMA_PRECISION == ops.PREC_F32:
         parts.append("Winograd F(4x4,4x4) for the discriminator's 256->512 layer: forward, input gradient%s (49 of 256 multiplications)"
                      % (", weight gradient" if ops.WINOGRAD_WGRAD else ""))
+        if ops.WINOGRAD_S2:
+            parts.append("Winograd F(4x4,2x2) over the four parity classes of the discriminator's stride-2 64->128 and 128->256 layers "
+                         "(25 of 64 multiplications): forward from %d tiles per pass%s%s"
+                         % (ops.WINO_S2_MIN_TILES,
+                            ", weight gradient from %d input channels" % ops.WINO_S2_WGRAD_MIN_CI if ops.WINO_S2_WGRAD and ops.WINOGRAD_WGRAD else "",
+                            ", input gradient (adjoint pipeline) from %d input channels" % ops.WINO_S2_DGRAD_MIN_CI if ops.WINO_S2_DGRAD else ""))
         if ops.WINOGRAD_G:
             parts.append("Winograd F(4x4,3x3) for the generator's 416- and 208-channel 3x3 layers (36 of 144)")
     if up2_fold_enabled():

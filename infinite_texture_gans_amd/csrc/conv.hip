@@ -570,7 +570,7 @@ inline int up2_check(const itg_conv_geom* g, const itg_tensor* lo, const itg_ten
   return ITG_OK;
 }
 inline void clear_xf(ConvP& p) {
-  p.ucls = 0; p.u_in = p.u_w = p.u_out = 0; p.u_dgrad = 0;
+  p.ucls = 0; p.u_in = p.u_w = p.u_out = 0; p.u_acc = 0;
 }
 
 

@@ -48,7 +48,8 @@ struct ConvP {
   // p.out.p + c * u_out (floats); no split-K.  The class is the SLOWEST index of the tile id (classes share nothing).
   int ucls;
   unsigned u_in, u_w, u_out;
-  int u_dgrad;         // the uniform-class launch is an input gradient (blocked fp64 accumulation only with ITG_WINO_ACC64=2)
+  int u_acc;           // accumulation the uniform-class launch asks for: 0 one fp32 chain, 1 blocks of 16 summed in a second
+                       // fp32 accumulator (NT_W32), 2 blocks summed in fp64 (NT_W64); ITG_WINO_ACC64 overrides (conv_nt.hip)
   // stride-2 input-gradient: the 4 output-parity classes run as ONE grid (blockIdx.y = class)
   int ncls;
   int cMT[4], cMU[4], cM[4], cioy[4], ciox[4], cooy[4], coox[4];
@@ -181,6 +182,7 @@ int launch_zero_border(const GridT& g, hipStream_t s);
 int launch_zero_frames(const itg_tensor* t, int n, hipStream_t s);
 // conv_nt_w64.hip
 int launch_nt_w64(int bco, int bpix, const ConvP& p, int k, hipStream_t s);
+int launch_nt_w32(int bco, int bpix, const ConvP& p, int k, hipStream_t s);
 // conv_wgrad.hip
 TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g);
 TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec = ITG_PREC_F32, int ncls = 1);

@@ -318,13 +318,17 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
   if (plan_debug)
     fprintf(stderr, "[nt] M=%d x%d co_rows=%d Kpad=%d -> bco=%d bpix=%d ksplit=%d kchunks=%d\n", p.M, ncls_, p.co_rows, p.Kpad,
             pl.bco, pl.bpix, pl.ksplit, pl.kchunks);
-  // uniform-class launches (the Winograd GEMMs) with fp32 operands accumulate blockwise in fp64 (NT_W64, conv_nt_w64.hip):
-  // ITG_WINO_ACC64 = 1 (default) the FORWARD GEMMs - their rounding decides which LeakyReLU inputs change sign, and every flip
-  // moves all upstream gradients by ~1e-3 - 2 = the input-gradient GEMMs as well (their 6.6e-6 against 1.6e-6
-  // enters the gradients linearly: invisible next to the flips; 23 us per launch saved), 0 = off
+  // uniform-class launches (the Winograd GEMMs) with fp32 operands accumulate in blocks of 16 (conv_nt_w64.hip), the block sums
+  // in fp64 (NT_W64) or in a second fp32 accumulator (NT_W32), as the launch asks (ConvP.u_acc): the FORWARD GEMMs do - their
+  // rounding decides which LeakyReLU inputs change sign, and every flip moves all upstream gradients by ~1e-3 -
+  // F(4 x 4, 4 x 4) in fp64, F(4 x 4, 2 x 2) (a milder output transform) in fp32; the input-gradient GEMMs do not (their 6.6e-6
+  // against 1.6e-6 enters the gradients linearly: invisible next to the flips; 23 us per launch saved).
+  // ITG_WINO_ACC64: 1 (default) as asked, 0 = one chain everywhere, 2 = fp64 everywhere, 3 / 4 = fp64 / fp32 block sums for every launch that asks
   static const int w64 = env_int("ITG_WINO_ACC64", 1);
-  const bool acc64 = p.ucls && k == 16 && (w64 >= 2 || (w64 == 1 && !p.u_dgrad));
-  int rc = acc64 ? launch_nt_w64(pl.bco, pl.bpix, p, k, s) : launch_nt_shape<NT_PLAIN>(pl.bco, pl.bpix, p, k, s);
+  int accm = (p.ucls && k == 16) ? p.u_acc : 0;
+  if (p.ucls && k == 16) accm = w64 == 0 ? 0 : w64 == 2 ? 2 : (w64 == 3 && accm) ? 2 : (w64 == 4 && accm) ? 1 : accm;
+  int rc = accm == 2 ? launch_nt_w64(pl.bco, pl.bpix, p, k, s) : accm == 1 ? launch_nt_w32(pl.bco, pl.bpix, p, k, s)
+                                                                          : launch_nt_shape<NT_PLAIN>(pl.bco, pl.bpix, p, k, s);
   if (rc) return rc;
   if (!second_stage) return (want_stats && !p.stats) ? stats_after(p, want_stats, s) : ITG_OK;
   {

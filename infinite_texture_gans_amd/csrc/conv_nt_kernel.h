@@ -5,7 +5,7 @@
 
 namespace itgk {
 
-enum { NT_PLAIN = 0, NT_W64 = 3 };
+enum { NT_PLAIN = 0, NT_W32 = 2, NT_W64 = 3 };
 
 // NT_W64 (fp32 operands): blocked accumulation for the Winograd GEMMs.  v_mfma_f32_16x16x4_f32 adds its products to the
 // accumulator one after the other, so a K loop of length L is ONE chain of L fp32 roundings: error ~ eps * sqrt(L / 2) of the
@@ -15,6 +15,9 @@ enum { NT_PLAIN = 0, NT_W64 = 3 };
 // rounding is 8 x smaller).  Here every K stage (16 values = 4 MFMAs) starts from a zero accumulator and the stage sums are
 // added in fp64 on the vector ALU (v_cvt_f64_f32 + v_add_f64 per element and stage, in the shadow of the next stage's MFMAs):
 // the chain is 16 long whatever L is.
+// NT_W32: the same blocks, summed in a SECOND fp32 accumulator (v_pk_add_f32, one register per element instead of two): the
+// chain is 4 MFMA steps + L / 16 additions instead of L / 4 steps - error ~ sqrt((4 + L / 16) / (L / 4)) of the plain chain's
+// (0.56 at L = 256, 0.53 at L = 512).  For the F(4 x 4, 2 x 2) GEMMs, whose output transform amplifies less.
 #ifndef ITG_W64_BLOCK
 #define ITG_W64_BLOCK 16
 #endif
@@ -29,6 +32,7 @@ enum { NT_PLAIN = 0, NT_W64 = 3 };
 // medium fp32 tiles, 4 (128) for the medium bf16 tiles (their stage holds twice the prefetch registers).
 constexpr int nt_min_blocks(int bco, int bpix, int wco, int wpix, int tbk, int mode = 0) {
   if (mode == 3) return (wco / 16) * (wpix / 16) <= 4 ? 3 : 2;       // NT_W64: fp64 accumulators (2 registers per element)
+  if (mode == 2) return (wco / 16) * (wpix / 16) <= 4 ? 4 : ((wco / 16) * (wpix / 16) <= 8 ? 3 : 2);       // NT_W32: a second fp32 set
   return ((wco / 16) * (wpix / 16) <= 8 && (bco + bpix) <= 192) ? 4 : 3;
 }
 
@@ -207,14 +211,16 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK, MODE)
   for (int i = 0; i < FI; ++i)
 #pragma unroll
     for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr bool W64 = MODE == NT_W64;
-  static_assert(!W64 || !BF, "blocked fp64 accumulation is an fp32-operand mode");
-  f64x4 acc64[W64 ? FI : 1][W64 ? FJ : 1];
+  constexpr bool W64 = MODE == NT_W64 || MODE == NT_W32;      // blocked accumulation; the block sums in fp64 or fp32
+  static_assert(!W64 || !BF, "blocked accumulation is an fp32-operand mode");
+  using wide4 = std::conditional_t<MODE == NT_W64, f64x4, f32x4>;
+  using wide1 = std::conditional_t<MODE == NT_W64, double, float>;
+  wide4 acc64[W64 ? FI : 1][W64 ? FJ : 1];
   if constexpr (W64) {
 #pragma unroll
     for (int i = 0; i < FI; ++i)
 #pragma unroll
-      for (int j = 0; j < FJ; ++j) acc64[i][j] = f64x4{0., 0., 0., 0.};
+      for (int j = 0; j < FJ; ++j) acc64[i][j] = wide4{0, 0, 0, 0};
   }
 
   const int frow = lane & 15, fk = ((lane >> 4) ^ (((lane >> 3) & 1) << 1)) * 4;   // swizzled slot of K group lane >> 4 in row frow
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(256, nt_min_blocks(BCO, BPIX, WCO, WPIX, TBK, MODE)
 #pragma unroll
               for (int jj = 0; jj < JP; ++jj)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc64[i][j0 + jj][e] += (double)t[jj][e];
+                for (int e = 0; e < 4; ++e) acc64[i][j0 + jj][e] += (wide1)t[jj][e];
             }
       } else {
 #pragma unroll
@@ -474,8 +480,8 @@ inline int w64_bpix(int bco, int bpix) {
   if (bco == 64) return bpix > 128 ? 128 : bpix;
   return bpix;
 }
+template <int MODE>
 inline int launch_nt_shape_w64(int bco, int bpix, const ConvP& p, int k, hipStream_t s) {
-  constexpr int MODE = NT_W64;
   bpix = w64_bpix(bco, bpix);
   if (bco == 16)
     return bpix == 256 ? launch_nt<16, 256, 16, 64, MODE>(p, k, s) : bpix == 128 ? launch_nt<16, 128, 16, 32, MODE>(p, k, s)

@@ -7,7 +7,13 @@ namespace itgk {
 
 int launch_nt_w64(int bco, int bpix, const ConvP& p, int k, hipStream_t s) {
   if (k != 16) return ITG_ERR_ARG;
-  return launch_nt_shape_w64(bco, bpix, p, k, s);
+  return launch_nt_shape_w64<NT_W64>(bco, bpix, p, k, s);
+}
+
+// ... and with the block sums in a second fp32 accumulator (NT_W32): the F(4 x 4, 2 x 2) forward GEMMs of D's stride-2 layers
+int launch_nt_w32(int bco, int bpix, const ConvP& p, int k, hipStream_t s) {
+  if (k != 16) return ITG_ERR_ARG;
+  return launch_nt_shape_w64<NT_W32>(bco, bpix, p, k, s);
 }
 
 }  // namespace itgk

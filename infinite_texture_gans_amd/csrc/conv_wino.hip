@@ -569,7 +569,7 @@ int wino_conv(const itg_tensor* in, const float* u_panel, const float* bias, con
     p.prec = prec;
     p.ncls = 1;
     p.ucls = NC;
-    p.u_dgrad = input_gradient ? 1 : 0;
+    p.u_acc = input_gradient ? 0 : 2;
     p.u_in = (unsigned)(tiles * in->ld); p.u_out = (unsigned)(tiles * out->ld); p.u_w = (unsigned)((size_t)p.co_rows * p.Kpad);
     int rc = dispatch_nt(p, nullptr, 0, s);
     if (rc) return rc;
@@ -634,10 +634,11 @@ int wino_conv_s2(const itg_tensor* in, const float* u_panel, const float* bias, 
     p.prec = prec;
     p.ncls = 1;
     p.ucls = NC;
-    // blocked fp64 accumulation as for F(4 x 4, 4 x 4) (NT_W64, ITG_WINO_ACC64): these are FORWARD GEMMs in front of a LeakyReLU -
-    // their rounding decides sign flips that move every upstream gradient by ~1e-3.  Plain fp32 chains of 64 - 128
-    // MFMA steps gave 1.1 - 2.5e-6 per layer and G's full-size gradients 2.1e-3 / 2.9e-3 from the fp64 truth (direct: 1.3 / 1.8)
-    p.u_dgrad = 0;
+    // blocked accumulation as for F(4 x 4, 4 x 4) (ITG_WINO_ACC64): these are FORWARD GEMMs in front of a LeakyReLU - their
+    // rounding decides sign flips that move every upstream gradient by ~1e-3.  Plain fp32 chains of 64 - 128 MFMA
+    // steps gave 1.1 - 2.5e-6 per layer and G's full-size gradients 2.1e-3 / 2.9e-3 from the fp64 truth (direct: 1.3 / 1.8);
+    // blocks of 16 summed in a second fp32 accumulator (NT_W32) halve that at the plain kernel's occupancy
+    p.u_acc = 1;
     p.u_in = (unsigned)(tiles * kld); p.u_out = (unsigned)(tiles * out->ld); p.u_w = (unsigned)((size_t)p.co_rows * p.Kpad);
     int rc = dispatch_nt(p, nullptr, 0, s);
     if (rc) return rc;
@@ -697,7 +698,7 @@ int wino_conv_s2_dgrad(const itg_tensor* dy, const float* ut_panel, const float*
     p.prec = prec;
     p.ncls = 1;
     p.ucls = NC;
-    p.u_dgrad = 1;
+    p.u_acc = 0;
     p.u_in = (unsigned)(tiles * dy->ld); p.u_out = (unsigned)(tiles * kld); p.u_w = (unsigned)((size_t)p.co_rows * p.Kpad);
     int rc = dispatch_nt(p, nullptr, 0, s);
     if (rc) return rc;

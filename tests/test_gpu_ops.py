@@ -345,8 +345,9 @@ def test_conv_winograd_f42_stride2_forward(case, monkeypatch):
     K - with bias + LeakyReLU in the output transform; the weight gradient as 25 contractions over the tiles of A dY A^T and the
     forward's V (taken from its workspace), brought back per class by G^T . G into the 4 x 4 filter; the input gradient as the
     ADJOINT of the forward pipeline (A dY A^T, 25 GEMMs with the transposed panel, the gathered B dV B^T of the overlapping
-    tiles), incl. the producing layer's activation derivative.  Output 5e-6 (blocked fp64 accumulation: measured 6e-7), input
-    gradient 1e-5, weight gradient 1e-5; each also against the direct kernel on the same operands."""
+    tiles), incl. the producing layer's activation derivative.  Output 2e-6, the direct kernels' fp32 bound (accumulation in
+    blocks of 16 summed in a second fp32 accumulator, conv_nt_kernel.h NT_W32: measured 6 - 9e-7; block sums in fp64: 6 - 7e-7; one
+    fp32 chain: 1.1 - 2.5e-6), input gradient 1e-5, weight gradient 1e-5; each also against the direct kernel on the same operands."""
     ops = _ops()
     monkeypatch.setattr(ops, "WINOGRAD", True)
     monkeypatch.setattr(ops, "WINOGRAD_S2", True)
@@ -367,7 +368,7 @@ def test_conv_winograd_f42_stride2_forward(case, monkeypatch):
     yg = ops.to_nchw(y, merged=True)
     e = rel_l2(yg.detach().cpu(), yr)
     print("F(4x4,2x2) stride-2 forward rel-L2 vs F.conv2d:", e)
-    assert e < 5e-6, e
+    assert e < (2e-6 if os.environ.get("ITG_WINO_ACC64", "1") != "0" else 5e-6), e
     y0 = ops.to_nchw(ops.conv(ops.to_grid(xg, 1, 1, merged=True), wg, bg, 4, 4, 2, 1, ops.PAD_ZERO, ops.ACT_LRELU, 0.2), merged=True)
     assert 1e-8 < rel_l2(yg.detach().cpu(), y0.detach().cpu()) < 5e-6          # another algorithm, the same result
     dy = torch.randn(yr.shape, generator=g)
