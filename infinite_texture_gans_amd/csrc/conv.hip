@@ -314,6 +314,9 @@ __global__ void pack_multi_kernel(const long long* __restrict__ table, int n, lo
     } else if (kind == 8) {                   // F(4 x 4, 2 x 2) panel of a stride-2 4 x 4 layer (forward)
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = wino_s2_elem(w, co, ci, ld, e + j);
+    } else if (kind == 9) {                   // ... and its transposed panel (the adjoint input gradient); row: ld = co_ld, kh = ci_ld
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = wino_s2_dgrad_elem(w, co, ci, kh, ld, e + j);
     } else if (kind == 0) {
       const unsigned Kpad = (unsigned)round_up_d(kh * kw * ld, BK);
       const int k = (int)(e % Kpad), o = (int)(e / Kpad);

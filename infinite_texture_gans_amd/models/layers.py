@@ -102,19 +102,28 @@ class _ConvParams(nn.Module):
                 and self.ch_in >= ops.WINO_S2_MIN_CI and self.ch_out >= 64 and ops.MFMA_PRECISION == ops.PREC_F32)
 
     def pack_jobs(self):
-        """Allocate this layer's persistent panels and return its two ops.pack_multi jobs."""
+        """Allocate this layer's persistent panels and return its ops.pack_multi jobs (two, three for a stride-2 Winograd layer)."""
         w = self.weight_orig if self.SN else self.weight
         co, ci, k, st = w.shape[0], w.shape[1], self.k, self.stride
         kind = "wino" if self.wino else ("wino_s2" if self.wino_s2 else ("up2" if self.up2 else "plain"))
         nf, nd = ops.pack_sizes(co, ci, k, k, st, kind == "up2", 2 if kind == "wino_s2" else kind == "wino")
+        # the stride-2 Winograd layers whose input gradient may take the adjoint pipeline (ops._wino_s2_dgrad) keep a third
+        # panel: the forward panel transposed (packed per call it was 30 us on the input-gradient chain, twice per step)
+        nt = (ops._lib.fn("itg_pack_wino_s2_dgrad_size")(ops.ld_for(ci), ops.ld_for(co))
+              if kind == "wino_s2" and ops.WINO_S2_DGRAD and ci >= ops.WINO_S2_DGRAD_MIN_CI else 0)
         if (self._packed is None or self._packed[0].device != w.device or self._packed_kind != kind
-                or self._packed[0].numel() != nf):
+                or self._packed[0].numel() != nf or (self._packed[2].numel() if len(self._packed) > 2 else 0) != nt):
             self._packed = (torch.empty(nf, device=w.device, dtype=torch.float32),
                             torch.empty(nd, device=w.device, dtype=torch.float32))
+            if nt:
+                self._packed += (torch.empty(nt, device=w.device, dtype=torch.float32),)
         self._packed_kind = kind
         kf, kd = {"plain": (0, 1), "up2": (2, 3), "wino": (6, 7) if k == 3 else (4, 5), "wino_s2": (8, 1)}[kind]
-        return [(w, self._packed[0], co, ci, ops.ld_for(ci), k, k, 1, kf),
+        jobs = [(w, self._packed[0], co, ci, ops.ld_for(ci), k, k, 1, kf),
                 (w, self._packed[1], co, ci, ops.ld_for(co), k, k, st, kd)]
+        if nt:
+            jobs.append((w, self._packed[2], co, ci, ops.ld_for(co), ops.ld_for(ci), k, st, 9))      # (kh slot: ci_ld)
+        return jobs
 
     def weight_and_sn(self):
         """(weight tensor, sn tuple or None); runs the power iteration in training mode.  u / v are not

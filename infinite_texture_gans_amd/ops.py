@@ -354,7 +354,9 @@ class _Conv(torch.autograd.Function):
         inv_sigma = ctx.sn[0] if ctx.sn is not None else None
         gx = gw_ = gb = None
         if ctx.needs_input_grad[0]:
-            if s2_dgrad:                    # its transposed panel is packed per call (the layer's persistent input-gradient panel is the
+            if s2_dgrad and ctx.packed is not None and len(ctx.packed) > 2:
+                wp, out_scale = ctx.packed[2], inv_sigma      # the layer's third persistent panel (layers._ConvParams.pack_jobs)
+            elif s2_dgrad:                  # its transposed panel packed per call (the layer's persistent input-gradient panel is the
                                             # direct kernel's: the real batch of the same layer takes that one)
                 wp, out_scale = torch.empty(_lib.fn("itg_pack_wino_s2_dgrad_size")(x.shape[5], dy.shape[5]), device=x.device,
                                             dtype=torch.float32), None

@@ -1155,7 +1155,7 @@ def test_pack_multi_panels_equal_the_single_panel_entry_points_bit_exact():
         (52, 26, 3, 1, "plain"), (128, 64, 4, 2, "plain"), (13, 26, 3, 1, "up2"), (104, 208, 3, 1, "up2"),
         (96, 64, 4, 1, "wino"), (72, 80, 4, 1, "wino"), (1, 512, 4, 1, "plain"), (112, 96, 3, 1, "wino"), (40, 208, 3, 1, "wino"),
         (128, 64, 4, 2, "wino_s2"), (72, 26, 4, 2, "wino_s2")]
-    jobs, want = [], []
+    jobs, want, extra = [], [], []
     for co, ci, k, s, kind in layers:
         w = torch.randn(co, ci, k, k, generator=g).to(cuda)
         nf, nd = ops.pack_sizes(co, ci, k, k, s, kind == "up2", 2 if kind == "wino_s2" else kind == "wino")
@@ -1169,6 +1169,11 @@ def test_pack_multi_panels_equal_the_single_panel_entry_points_bit_exact():
         if kind == "wino_s2":
             _lib.call("itg_pack_wino_s2_fwd", P(w), None, P(sf), co, ci, ldi, st)
             _lib.call("itg_pack_dgrad", P(w), None, P(sd), co, ci, ldo, k, k, s, st)
+            # ... and the third panel of such a layer: the forward panel transposed, for the adjoint input gradient (kind 9)
+            nt = _lib.fn("itg_pack_wino_s2_dgrad_size")(ldi, ldo)
+            pt, stt = torch.full((nt,), float("nan"), device=cuda), torch.empty(nt, device=cuda)
+            _lib.call("itg_pack_wino_s2_dgrad", P(w), None, P(stt), co, ci, ldi, ldo, st)
+            extra.append(((w, pt, co, ci, ldo, ldi, k, s, 9), stt))
         elif kind == "wino":
             sfx = "wino3" if k == 3 else "wino"
             _lib.call("itg_pack_%s_fwd" % sfx, P(w), None, P(sf), co, ci, ldi, st)
@@ -1180,6 +1185,9 @@ def test_pack_multi_panels_equal_the_single_panel_entry_points_bit_exact():
             _lib.call("itg_pack_fwd", P(w), None, P(sf), co, ci, ldi, k, k, st)
             _lib.call("itg_pack_dgrad", P(w), None, P(sd), co, ci, ldo, k, k, s, st)
         want += [sf, sd]
+    for job, ref in extra:
+        jobs.append(job)
+        want.append(ref)
     ops.pack_multi(ops.pack_tables(jobs, cuda))
     torch.cuda.synchronize()
     for (job, ref) in zip(jobs, want):
