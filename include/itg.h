@@ -361,6 +361,12 @@ int itg_maxpool2_bwd(const itg_tensor* x, const itg_tensor* y, const itg_tensor*
 int itg_bce_logits_fwd(const float* logits, int64_t count, float target, float* loss_out, void* stream);
 int itg_bce_logits_bwd(const float* logits, int64_t count, float target, const float* upstream,
                        float* dlogits, void* stream);
+/* The same heads on the logit map in the patch-grid layout the discriminator's last conv writes (c == 1): the mean loss and
+ * d loss / d logit (upstream 1, same layout; padding channels zeroed) in ONE launch.  kind 0 = BCE against `target`,
+ * 1..3 = hinge mode 0..2.  workspace_zeroed: itg_logit_loss_grid_workspace() doubles that are ZERO at launch (left dirty). */
+int64_t itg_logit_loss_grid_workspace(void);
+int itg_logit_loss_grid(const itg_tensor* logits, int kind, float target, float* loss_out, itg_tensor* dlogits,
+                        void* workspace_zeroed, void* stream);
 int itg_hinge_fwd(const float* logits, int64_t count, int mode, float* loss_out, void* stream);
 int itg_hinge_bwd(const float* logits, int64_t count, int mode, const float* upstream, float* dlogits,
                   void* stream);

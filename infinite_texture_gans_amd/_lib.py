@@ -126,6 +126,8 @@ SIGNATURES = {
     "itg_maxpool2_bwd": (_i, [_TP, _TP, _TP, _TP, _P]),
     "itg_bce_logits_fwd": (_i, [_P, _l, _f, _P, _P]),
     "itg_bce_logits_bwd": (_i, [_P, _l, _f, _P, _P, _P]),
+    "itg_logit_loss_grid_workspace": (_l, []),
+    "itg_logit_loss_grid": (_i, [_TP, _i, _f, _P, _TP, _P, _P]),
     "itg_hinge_fwd": (_i, [_P, _l, _i, _P, _P]),
     "itg_hinge_bwd": (_i, [_P, _l, _i, _P, _P, _P]),
     "itg_spectral_norm_power_iter": (_i, [_P, _P, _P, _i, _i, _i, _f, _P, _P, _P, _P]),

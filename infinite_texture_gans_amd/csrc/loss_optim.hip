@@ -4,6 +4,7 @@
 //   hinge           : build-side extra, absent from the reference (utils.py:85 is never read)
 //   spectral norm   : torch.nn.utils.spectral_norm as wrapped at reference models/layers.py:190-194
 //   Adam / EMA      : reference train.py:57-58,153,169,176-180
+#include <algorithm>
 #include "itg_common.h"
 
 namespace {
@@ -60,6 +61,50 @@ __device__ __forceinline__ HingeC hinge_consts(int mode) {
   c.b = mode == 1 ? 1.f : -1.f;
   c.lo = mode == 2 ? -INFINITY : 0.f;
   return c;
+}
+
+// The loss head on the discriminator's logit map AS THE LAST CONV LEFT IT (patch-grid layout, one channel in an ld-wide
+// pixel): the mean loss and d loss / d logit in the same layout, one launch (the NCHW round trip of the generic heads above -
+// grid_to_nchw, the single-workgroup forward sum, the backward, nchw_to_grid - was four latency-bound launches, ~32 us of
+// every D pass's critical path).  kind 0: BCE-with-logits against t; 1..3: the hinge modes 0..2.
+// Blocks leave fp64 partial sums; the last one to finish adds them in block order (deterministic) - `counter` must be zero
+// at launch (a slice of the step's zeroed arena).
+constexpr int LOSS_GRID_MAX_BLOCKS = 64;
+__global__ __launch_bounds__(256) void logit_loss_grid_kernel(const float* __restrict__ x, long long npix, int ld, int kind, float t,
+                                                              float* __restrict__ dl, double* __restrict__ partial,
+                                                              unsigned* __restrict__ counter, float* __restrict__ out) {
+  const float inv_n = 1.f / (float)npix;
+  const HingeC c = hinge_consts(kind > 0 ? kind - 1 : 0);
+  double s = 0.0;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+    const float v = x[i * ld];
+    float f, d;
+    if (kind == 0) {
+      f = bce_elem(v, t);
+      d = 1.f / (1.f + expf(-v)) - t;
+    } else {
+      const float a = fmaf(c.b, v, c.a);
+      f = fmaxf(a, c.lo);
+      d = a > c.lo ? c.b : 0.f;
+    }
+    s += (double)f;
+    dl[i * ld] = d * inv_n;
+    for (int k = 1; k < ld; ++k) dl[i * ld + k] = 0.f;
+  }
+  s = block_sum_d(s);
+  __shared__ bool last;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&partial[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    last = atomicAdd(counter, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    __threadfence();
+    double tot = 0.0;
+    for (unsigned b = 0; b < gridDim.x; ++b) tot += __hip_atomic_load(&partial[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *out = (float)(tot / (double)npix);
+  }
 }
 
 __global__ __launch_bounds__(1024) void hinge_fwd_kernel(const float* __restrict__ x, int64_t n, int mode,
@@ -329,6 +374,25 @@ int itg_bce_logits_bwd(const float* logits, int64_t count, float target, const f
   if (!logits || !dlogits || count <= 0) return ITG_ERR_ARG;
   hipLaunchKernelGGL(bce_bwd_kernel, dim3(nblocks(count)), dim3(256), 0, (hipStream_t)stream, logits, count, target,
                      upstream, dlogits);
+  ITG_CHECK_LAUNCH();
+  return ITG_OK;
+}
+
+int64_t itg_logit_loss_grid_workspace(void) { return 8 + LOSS_GRID_MAX_BLOCKS; }      // doubles, zeroed
+
+int itg_logit_loss_grid(const itg_tensor* logits, int kind, float target, float* loss_out, itg_tensor* dlogits, void* workspace_zeroed,
+                        void* stream) {
+  if (!logits || !logits->ptr || !dlogits || !dlogits->ptr || !loss_out || !workspace_zeroed) return ITG_ERR_ARG;
+  if (logits->c != 1 || kind < 0 || kind > 3 || logits->ld < 1) return ITG_ERR_ARG;
+  if (dlogits->n != logits->n || dlogits->gh != logits->gh || dlogits->gw != logits->gw || dlogits->ph != logits->ph ||
+      dlogits->pw != logits->pw || dlogits->ld != logits->ld || dlogits->c != 1)
+    return ITG_ERR_ARG;
+  const long long npix = (long long)logits->n * logits->gh * logits->gw * logits->ph * logits->pw;
+  if (npix <= 0) return ITG_ERR_ARG;
+  const int blocks = (int)std::min<long long>(LOSS_GRID_MAX_BLOCKS, (npix + 255) / 256);
+  double* ws = (double*)workspace_zeroed;
+  hipLaunchKernelGGL(logit_loss_grid_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)logits->ptr, npix,
+                     (int)logits->ld, kind, target, (float*)dlogits->ptr, ws + 8, (unsigned*)ws, loss_out);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
 }

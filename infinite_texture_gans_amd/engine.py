@@ -243,6 +243,8 @@ class Trainer:
         self.label_t = 0.9 if args.smooth else 1.0
         self._one = torch.ones((), device=device)               # the seed of every backward pass (no ones_like fill per pass)
         self.hinge = getattr(args, "loss", "standard") == "hinge"
+        # the loss heads read D's logit map in the grid layout its last conv wrote: loss + derivative in one launch (ops.logit_loss)
+        self.fused_loss = os.environ.get("ITG_FUSED_LOSS", "1") == "1"
         self.packG, self.packD = PackSet(netG), PackSet(netD)
         # dx buffers of the generator's replicate-padded convs, kept across steps (ops.begin_frames); ITG_FRAMES=0: per-layer zeroing
         self._frames = {} if os.environ.get("ITG_FRAMES", "1") == "1" else None
@@ -362,11 +364,15 @@ class Trainer:
 
     # ---- loss heads
     def _d_loss(self, logit, real):
+        if isinstance(logit, ops.GT):        # the logit map as D's last conv left it: loss + derivative in one launch
+            return ops.logit_loss(logit, ("d_real" if real else "d_fake") if self.hinge else "bce", self.label_t if real else 0.0)
         if self.hinge:
             return ops.hinge(logit, "d_real" if real else "d_fake")
         return ops.bce_with_logits(logit, self.label_t if real else 0.0)
 
     def _g_loss(self, logit):
+        if isinstance(logit, ops.GT):
+            return ops.logit_loss(logit, "g" if self.hinge else "bce", self.label_t)
         return ops.hinge(logit, "g") if self.hinge else ops.bce_with_logits(logit, self.label_t)
 
     def _allreduce(self, flat):
@@ -398,17 +404,23 @@ class Trainer:
             self.marks.append((name, ev))
 
     def _d_logits(self, fake):
-        """D on the generator's output: a patch grid (consumed in place, no merge copy) or whole NCHW images."""
-        logit = ops.to_nchw(self.netD.forward_grid(fake)) if isinstance(fake, ops.GT) else self.netD(fake)
+        """D on the generator's output: a patch grid (consumed in place, no merge copy) or whole NCHW images.  The logit map
+        stays in the grid layout (ops.GT) for the fused loss head (ITG_FUSED_LOSS=0: NCHW logits and the generic heads)."""
+        grid = hasattr(self.netD, "forward_grid")
+        if isinstance(fake, ops.GT):
+            lg = self.netD.forward_grid(fake)
+        elif grid and self.fused_loss:
+            lg = self.netD.forward_grid(ops.to_grid(fake, 1, 1, merged=True))
+        else:
+            lg = self.netD(fake)
+        if isinstance(lg, ops.GT) and not (self.fused_loss and lg.c == 1):
+            lg = ops.to_nchw(lg)
         if self.record is not None:
-            self.record.append(logit.detach())
-        return logit
+            self.record.append((ops.to_nchw(lg) if isinstance(lg, ops.GT) else lg).detach())
+        return lg
 
     def _d_real_logits(self, real_x):
-        logit = self.netD(real_x)
-        if self.record is not None:
-            self.record.append(logit.detach())
-        return logit
+        return self._d_logits(real_x)
 
     def step(self, real_x, z, maps=None, next_real=None):
         """real_x: (B,3,crop,crop) on the device; z/maps: latents (see utils.sample_latents_train), or LISTS of
@@ -425,6 +437,7 @@ class Trainer:
         ops.ARENA = self.arena
         ops.WGRAD_STREAM = self.wstream
         ops.WGRAD_DEFER = self._defer if self.defer_reduce else None
+        ops.UNIT_GRAD = self._one
         sn_keep, ops.SN_FUSED_REDUCE = ops.SN_FUSED_REDUCE, self.sn_fused
         try:
             zs = list(z) if isinstance(z, (list, tuple)) else [z]
@@ -441,6 +454,7 @@ class Trainer:
             ops.ARENA = None
             ops.WGRAD_STREAM = None
             ops.WGRAD_DEFER = None
+            ops.UNIT_GRAD = None
             ops.SN_FUSED_REDUCE = sn_keep
             ops.BACKWARD_ENTRY_HOOK = None
             if self.wstream is not None and not torch.cuda.is_current_stream_capturing():

@@ -1495,6 +1495,45 @@ def hinge(logits, mode):
     return _Hinge.apply(logits, {"d_real": 0, "d_fake": 1, "g": 2}[mode])
 
 
+UNIT_GRAD = None       # engine.Trainer: the device tensor 1.0 it seeds every backward pass with (recognised by address)
+
+
+class _LogitLossGrid(torch.autograd.Function):
+    """The loss head on the discriminator's logit map in patch-grid layout (c == 1): mean BCE-with-logits / hinge and its
+    derivative in ONE launch (itg_logit_loss_grid) - reference train.py:131-132,148-149,164-165 on a (n, 1, h, w) map; the mean
+    does not care about the layout.  The generic heads (bce_with_logits / hinge on NCHW logits) cost grid_to_nchw + a
+    single-workgroup sum + the backward + nchw_to_grid: four latency-bound launches on every D pass's critical path."""
+
+    @staticmethod
+    def forward(ctx, t, c, kind, target):
+        _req_cuda(t, "logits")
+        if c != 1:
+            raise _lib.ItgError("logit_loss: a one-channel logit map expected, got %d channels" % c)
+        t = t.contiguous()
+        out = torch.empty((), device=t.device, dtype=torch.float32)
+        dl = torch.empty_like(t)
+        ws = _zeros_f64(int(_lib.fn("itg_logit_loss_grid_workspace")()), t.device)
+        a, b = _desc(t, 1), _desc(dl, 1)
+        _lib.call("itg_logit_loss_grid", C.byref(a), int(kind), float(target), _ptr(out), C.byref(b), _ptr(ws), _stream())
+        ctx.save_for_backward(dl)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        if UNIT_GRAD is not None and g.data_ptr() == UNIT_GRAD.data_ptr():
+            return dl, None, None, None            # seeded with 1.0: the stored derivative is the gradient
+        return dl * g, None, None, None
+
+
+_LOSS_KINDS = {"bce": 0, "d_real": 1, "d_fake": 2, "g": 3}
+
+
+def logit_loss(logits, kind, target=0.0):
+    """logits: GT with one channel; kind: 'bce' (against the constant ``target``) or a hinge mode 'd_real' | 'd_fake' | 'g'."""
+    return _LogitLossGrid.apply(logits.t, logits.c, _LOSS_KINDS[kind], target)
+
+
 # ------------------------------------------------------------------------------- flat helpers
 def axpby(x, y, a, b, a_dev=None, out=None):
     """out = a*(a_dev)*x + b*y over flat fp32 buffers."""

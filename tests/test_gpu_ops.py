@@ -704,6 +704,45 @@ def test_bce_and_hinge():
         assert rel_l2(dg.cpu(), dr) < 1e-6
 
 
+def test_fused_loss_head_on_grid_logits_equals_the_generic_heads():
+    """ops.logit_loss (itg_logit_loss_grid): the loss heads of reference train.py:131-132,148-149,164-165 evaluated on the logit
+    map in the patch-grid layout D's last conv writes (one channel in a 4-wide pixel), loss and derivative in one launch -
+    against the oracle's heads on the same logits in NCHW: loss 1e-6, gradient 1e-6 rel-L2, for the 17 672 logits of D(fake)
+    (more than one block: the last-block sum), a single-block map, a non-unit upstream gradient and the engine's recognised
+    unit seed; the padding channels of the gradient are zero."""
+    ops = _ops()
+    from oracle import step
+    g = _gen(41)
+    for shape in ((8, 1, 47, 47), (2, 1, 5, 7)):
+        x = torch.randn(shape, generator=g) * 3
+        heads = [("bce", t, (lambda xr, t=t: step.bce_logits(xr, t))) for t in (0.0, 0.9, 1.0)]
+        heads += [("d_real", 0.0, lambda xr: F.relu(1 - xr).mean()), ("d_fake", 0.0, lambda xr: F.relu(1 + xr).mean()),
+                  ("g", 0.0, lambda xr: -xr.mean())]
+        for kind, t, ref_fn in heads:
+            xr = x.clone().requires_grad_(True)
+            lr = ref_fn(xr)
+            (dr,) = torch.autograd.grad(lr, xr)
+            xg = x.to(cuda).requires_grad_(True)
+            gt = ops.to_grid(xg, 1, 1, merged=True)
+            assert gt.c == 1 and gt.t.shape[-1] == 4
+            for seed in ("unit", 0.37):
+                lg = ops.logit_loss(gt, kind, t)
+                assert abs(float(lg) - float(lr)) < 1e-6 * max(1.0, abs(float(lr))), (kind, t, float(lg), float(lr))
+                if seed == "unit":
+                    one = torch.ones((), device=cuda)
+                    ops.UNIT_GRAD = one
+                    try:
+                        (dgt,) = torch.autograd.grad(lg, gt.t, one, retain_graph=True)
+                    finally:
+                        ops.UNIT_GRAD = None
+                    assert float(dgt[..., 1:].abs().max()) == 0.0
+                    (dg,) = torch.autograd.grad(lg, xg, one)
+                    assert rel_l2(dg.cpu(), dr) < 1e-6, (kind, t)
+                else:
+                    (dg,) = torch.autograd.grad(lg, xg, torch.tensor(seed, device=cuda))
+                    assert rel_l2(dg.cpu(), seed * dr) < 1e-6, (kind, t)
+
+
 # ------------------------------------------------------------------------------- spectral norm
 def test_spectral_norm_iteration_and_backward():
     ops = _ops()
