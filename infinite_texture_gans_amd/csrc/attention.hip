@@ -267,8 +267,8 @@ __global__ void attention_bwd_reduce_kernel(const float* __restrict__ slab, floa
 
 // shapes the tiled kernels cover (everything the generator produces with base_res <= 4)
 inline bool att_tiled_ok(int J, int ld8, int ld2) {
-  static const char* off = getenv("ITG_ATT_TILED");
-  if (off && off[0] == '0') return false;
+  static const char* km = getenv("ITG_KERNEL_MASK");      // bit 7 (conv_common.h: kernel_on)
+  if (km && !((strtol(km, nullptr, 0) >> 7) & 1)) return false;
   return J <= 64 && ld2 <= 128 && ld8 <= 32;
 }
 

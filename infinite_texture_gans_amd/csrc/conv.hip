@@ -538,20 +538,20 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(GridT in, GridT out, con
 }
 
 inline bool cin1_conv(const itg_tensor* in, const itg_tensor* out, const itg_conv_geom* g) {
-  static const int enable = env_int("ITG_CIN1_CONV", 1);
+  const int enable = kernel_on(KM_CIN1);
   return enable && in->c == 1 && in->ld == 4 && g->kh == 3 && g->kw == 3 && g->stride == 1 && g->pad == 0 && pad_v_raw(g) == 0 &&
          out->ld <= 128 && out->c >= 16 && g->precision != ITG_PREC_BF16 && !g->out_stats;
 }
 
 inline bool thin_in_conv(const itg_tensor* dy, const itg_tensor* dx, const itg_conv_geom* g) {
-  static const int enable = env_int("ITG_THIN_CONV", 1);
+  const int enable = kernel_on(KM_THIN_CONV);
   const int ph = g->pad_h >= 0 ? g->pad_h : g->pad;
   return enable && dx->c <= 4 && dx->ld == 4 && g->kh == 4 && g->kw == 4 && g->stride == 2 && g->pad == 1 && ph == 1 &&
          g->pad_mode == ITG_PAD_ZERO && (dy->ld % 16) == 0;
 }
 
 inline bool thin_out_conv(const itg_tensor* in, const itg_tensor* out, const itg_conv_geom* g) {
-  static const int enable = env_int("ITG_THIN_CONV", 1);
+  const int enable = kernel_on(KM_THIN_CONV);
   const int ph = g->pad_h >= 0 ? g->pad_h : g->pad;
   return enable && out->c == 1 && g->kh * g->kw == 16 && g->stride == 1 && g->pad_mode == ITG_PAD_ZERO &&
          (in->ld % 16) == 0 && ph < g->kh && g->pad < g->kw && 2 * ph <= g->kh - 1 && 2 * g->pad <= g->kw - 1;
@@ -1162,7 +1162,7 @@ static int wgrad_setup(const itg_tensor* x, const itg_tensor* dy, const itg_conv
     if (xb >= 0xFFFF0000LL || yb >= 0xFFFF0000LL) return ITG_ERR_ARG;
     p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
   }
-  static const int plan_debug = env_int("ITG_PLAN_DEBUG", 0);
+  static const int plan_debug = env_int("ITG_DEBUG", 0) & 1;
   if (plan_debug)
     fprintf(stderr, "[tn] M=%lld co_rows=%d Kpad=%d -> bcol=%d bco=%d splits=%d ngroups=%d tile=%d\n", (long long)M, t.co_rows,
             t.Kpad, t.bcol, t.bco, t.splits, t.ngroups, tw.ok);

@@ -16,6 +16,16 @@ constexpr int LDK = 20;   // LDS row pitch (floats): BK + 4 keeps rows 16-B alig
 // name of the GEMM kernel instantiation launched by this thread's last conv call, exactly as a profiler prints it
 extern thread_local char g_last_launch[96];
 
+// ITG_KERNEL_MASK: the specialised kernels, one bit each (default all on; a cleared bit sends the layer to the generic kernel -
+// how tools compare paths): 0 conv_s2k4, 1 conv_cin1, 2 conv_valu, 3 wgrad_thin, 4 conv_tile, 5 wgrad_tile, 6 thin (taps-as-rows)
+// convs, 7 tiled attention, 8 flat weight-gradient producer, 9 conv_strip, 10 conv_up2_tile, 11 wgrad_up2_tile
+enum { KM_S2K4 = 0, KM_CIN1, KM_VALU, KM_WGRAD_THIN, KM_CONV_TILE, KM_WGRAD_TILE, KM_THIN_CONV, KM_ATT_TILED, KM_TN_FLAT, KM_STRIP,
+       KM_UP2_TILE, KM_UP2_WTILE };
+inline int env_int(const char* name, int dflt);
+inline bool kernel_on(int bit) {
+  static const int mask = env_int("ITG_KERNEL_MASK", 0xFFF);
+  return (mask >> bit) & 1;
+}
 inline int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;

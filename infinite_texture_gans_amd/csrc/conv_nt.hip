@@ -314,7 +314,7 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
     p.in_bytes = (unsigned)ib; p.w_bytes = (unsigned)wb;
   }
   const int k = pl.tbk;
-  static const int plan_debug = env_int("ITG_PLAN_DEBUG", 0);
+  static const int plan_debug = env_int("ITG_DEBUG", 0) & 1;
   if (plan_debug)
     fprintf(stderr, "[nt] M=%d x%d co_rows=%d Kpad=%d -> bco=%d bpix=%d ksplit=%d kchunks=%d\n", p.M, ncls_, p.co_rows, p.Kpad,
             pl.bco, pl.bpix, pl.ksplit, pl.kchunks);

@@ -37,8 +37,6 @@ struct StripP {
                     // row-sharded band whose input carries its halo rows (pad_h = 0), -1 for that band's input gradient
   int H, Hin, W;    // output rows, input rows, width of the merged image
   int res_half;     // residual has half the patch extent (read through a nearest x2 upsample)
-  unsigned long long* ts;   // ITG_STRIP_DEBUG & 64: cycle stamps of two workgroups' waves (printed by the host)
-  int dbg;          // timing experiments (ITG_STRIP_DEBUG; results wrong): 1 no stores, 2 no MFMAs, 4 no loads after the first rows
 };
 
 // pixel index of the first pixel of merged row Y of image n (column 0 of patch column 0)
@@ -90,12 +88,6 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
   // version spent 134 VALU + 86 SALU instructions per row on those)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nl = lane & 15, g = lane >> 4;
-  int tsn = 0;
-  const bool tson = sp.ts && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2);
-  unsigned long long* const tsp = sp.ts + ((blockIdx.x == 0 ? 0 : 4) + wave) * 40;
-#define STAMP() do { if (tson && tsn < 38) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) tsp[tsn] = t_; ++tsn; } } while (0)
-  STAMP();
-  if (tson && lane == 0) tsp[39] = __builtin_amdgcn_s_memrealtime();
   {
     // filter bank -> LDS: every 16-byte k group of the packed panel (k = tap * cin_ld + ci, four channels of one tap: cin_ld is
     // a multiple of 4) is one b128 load and one b128 LDS store; all of a thread's loads are in flight before its first store
@@ -120,7 +112,6 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
   }
   if (tid < 32) biasl[tid] = (p.bias && tid < p.out.c) ? p.bias[tid] : 0.f;
   __syncthreads();
-  STAMP();
   // (the nine A fragments of the 16 -> 16 layer as 36 permanent registers - no LDS read inside the MFMA bursts - was tried:
   // 25 - 46 spilled registers inside the 168-register budget, 64 -> 72 us; the switch stays for a larger budget)
   constexpr bool AREG = false;
@@ -178,7 +169,6 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
       bool ok = Yv <= y1;
       if (sp.rep_v) Yc = min(max(Yc, 0), Hin - 1); else ok = ok && (unsigned)Yc < (unsigned)Hin;
       if (!ok) return;                                    // wave-uniform: a row outside a zero-padded image is never used
-      if ((sp.dbg & 4) && Yv > y0 + 1) return;
       const unsigned rb = (unsigned)strip_rowpix(p.in, lpw, n, Yc) * ild4;
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
@@ -254,11 +244,6 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
           f32x4 v = acc[i][f] * osc + bv;
-          if (sp.dbg & 16) {
-            if (!(sp.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rout, vo[i][f], ob, 0);
-            acc[i][f] = zero4;
-            continue;
-          }
           // wave-uniform mode tests around whole vectors (per-element act_apply / act_deriv calls compiled into a scalar
           // branch chain per ELEMENT: ~1 200 instructions of epilogue per row against 72 MFMAs)
           if (has_res) {
@@ -276,7 +261,12 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
           }
-          if (!(sp.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rout, vo[i][f], ob, 0);
+          // The row offset goes into the VECTOR offset here, not the scalar operand as for the loads: a buffer_store_dwordx4 whose
+          // data registers a VALU instruction overwrites in the next cycle needs a wait state, and LLVM's hazard recognizer only
+          // inserts it for stores WITHOUT an SGPR offset (the GFX9 rule).  On gfx950 the SGPR-offset form is hit as well: with the
+          // accumulator zeroed right behind the store (`buffer_store_dwordx4 v[20:23], ..., s78 offen; v_mov_b32 v23, 0`) the
+          // generator's 128^2-patch layers stored zeros in ~6 % of their pixels once every wave ran several units.
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rout, vo[i][f] + ob, 0, 0);
           acc[i][f] = zero4;
         }
       }
@@ -295,12 +285,8 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
           for (int f = 0; f < 2; ++f) rv[i][f] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, vr[i][f], rb, 0));
       }
       const bool rowok = sp.rep_v || (unsigned)(Yv + sp.rsh) < (unsigned)Hin;
-      if (rowok && !(sp.dbg & 2)) {
+      if (rowok) {
         f32x4 bl[2][KC], br[2][KC];
-        if (sp.dbg & 8) {
-#pragma unroll
-          for (int c = 0; c < KC; ++c) { bl[0][c] = s0[c]; bl[1][c] = s1[c]; br[0][c] = s0[c]; br[1][c] = s1[c]; }
-        } else
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
           bl[0][c] = dpp4<DPP_ROW_SHR1>(se[c], s0[c]);                                   // lane 0: the pixel left of the strip
@@ -335,21 +321,14 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
     load_row(y0 - 1, c0[0], c1[0], ed[0]);
     load_row(y0, c0[1], c1[1], ed[1]);
     load_row(y0 + 1, c0[2], c1[2], ed[2]);
-    STAMP();
     for (int Yv = y0 - 1; Yv <= y1; Yv += 3) {
       step(Yv, c0[0], c1[0], ed[0], accA, accC, accB);          // targets: rows Yv + 1 (A), Yv (C), Yv - 1 (B)
-      STAMP();
       if (Yv + 1 > y1) break;
       step(Yv + 1, c0[1], c1[1], ed[1], accB, accA, accC);
-      STAMP();
       if (Yv + 2 > y1) break;
       step(Yv + 2, c0[2], c1[2], ed[2], accC, accB, accA);
-      STAMP();
     }
   }
-
-  STAMP();
-  if (tson && lane == 0) tsp[38] = __builtin_amdgcn_s_memrealtime();
 }
 
 static inline int ilog2_exact(int v) {
@@ -361,7 +340,7 @@ static inline int ilog2_exact(int v) {
 
 // eligibility + launch; returns 1 when it handled the call
 int try_conv_strip(const ConvP& p, hipStream_t s, int* rc) {
-  static const int enable = env_int("ITG_CONV_STRIP", 1);
+  const int enable = kernel_on(KM_STRIP);
   if (!enable || p.ncls > 1 || p.ucls || p.ntaps != 9 || p.kw != 3 || p.isy != 1 || p.isx != 1 || p.osy != 1 || p.osx != 1) return 0;
   if (p.prec != ITG_PREC_F32 || p.cin_ld > 32 || p.cin_ld < 8 || p.co_rows > 32) return 0;      // (4-float pixels: a chunk would be 3/4 padding - the halo-tile kernel packs four taps into one)
   const GridT& gi = p.in;
@@ -425,15 +404,7 @@ int try_conv_strip(const ConvP& p, hipStream_t s, int* rc) {
     const double cost = (double)rounds * (L + 0.35 * 2 + 1.0);      // rows of MFMA work per slot + halo loads + prologue
     if (cost < best) { best = cost; bestL = L; }
   }
-  { static const int forceL = env_int("ITG_STRIP_L", 0); if (forceL > 0) bestL = forceL; }
   sp.L = bestL;
-  { static const int dbg = env_int("ITG_STRIP_DEBUG", 0); sp.dbg = dbg; }
-  sp.ts = nullptr;
-  static unsigned long long* tsbuf = nullptr;
-  if (sp.dbg & 64) {
-    if (!tsbuf) { if (hipMalloc(&tsbuf, 8 * 40 * 8) != hipSuccess) tsbuf = nullptr; }
-    if (tsbuf) { (void)hipMemsetAsync(tsbuf, 0, 8 * 40 * 8, s); sp.ts = tsbuf; }
-  }
   sp.nseg = (go.H + sp.L - 1) / sp.L;
   const int64_t units = (int64_t)gi.n * sp.nseg * sp.nstrips;
   if (units > 0x7fffffff) return 0;
@@ -442,7 +413,7 @@ int try_conv_strip(const ConvP& p, hipStream_t s, int* rc) {
   // every CU gets the SAME number of workgroups: the kernel is MFMA-bound with all waves resident from the start, so a CU that
   // was handed four workgroups while its neighbour got two finishes a third later than the even deal (the dispatcher fills by
   // resources, not evenly: 2.5 resident waves per SIMD measured where 3 were launched).  LDS is what caps a CU at `occ`.
-  static const int even = env_int("ITG_STRIP_EVEN", 1);
+  constexpr int even = 1;
   if (even) { const size_t cap = (size_t)(160 * 1024) / (occ + 1) + 512; if (lds < cap) lds = cap; }
   int64_t blocks = (units + 3) / 4;
   const int64_t maxb = 256LL * occ;
@@ -468,20 +439,6 @@ int try_conv_strip(const ConvP& p, hipStream_t s, int* rc) {
   void* args[] = {(void*)&q, (void*)&sp};
   (void)hipLaunchKernel(kern, dim3((unsigned)blocks), dim3(256), args, lds, s);
   *rc = hipGetLastError() == hipSuccess ? ITG_OK : ITG_ERR_LAUNCH;
-  if (sp.ts) {            // diagnostic build path only: print the stamps of this launch (cycles since the first stamp of wave 0)
-    static int printed = 0;
-    (void)hipStreamSynchronize(s);
-    if (printed++ < 3) {
-      unsigned long long h[8 * 40];
-      (void)hipMemcpy(h, sp.ts, sizeof(h), hipMemcpyDeviceToHost);
-      for (int w = 0; w < 8; ++w) {
-        fprintf(stderr, "[strip ts] wg %s wave %d:", w < 4 ? "0" : "mid", w & 3);
-        for (int i = 0; i < 38 && h[w * 40 + i]; ++i) fprintf(stderr, " %lld", (long long)(h[w * 40 + i] - h[(w & 4) * 40]));
-        fprintf(stderr, " | realtime ticks (100 MHz) %lld", (long long)(h[w * 40 + 38] - h[w * 40 + 39]));
-        fprintf(stderr, "\n");
-      }
-    }
-  }
   return 1;
 }
 

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 5) void conv_valu_kernel(const ConvP p, int ti
 
 // eligibility + launch of the vector-ALU kernel; returns 1 when it handled the call
 int try_conv_valu(const ConvP& p, hipStream_t s, int* rc) {
-  static const int enable = env_int("ITG_CONV_VALU", 1);
+  const int enable = kernel_on(KM_VALU);
   if (!enable || p.ncls > 1 || p.ntaps != 9 || p.kw != 3 || p.isy != 1 || p.isx != 1 || p.osy != 1 || p.osx != 1) return 0;
   if (p.prec != ITG_PREC_F32 || p.stats || p.co_rows != 16) return 0;
   const int ci4 = p.cin_ld >> 2, co4 = p.out.ld >> 2;
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256, 2) void conv_up2_tile_kernel(const ConvP p, in
 
 // eligibility + launch; p is the 4-class ConvP of itg_conv2d_fwd's up2 branch (class geometry in the c* arrays)
 int try_conv_up2_tile(const ConvP& p, hipStream_t s, int* rc) {
-  static const int enable = env_int("ITG_UP2_TILE", 1);
+  const int enable = kernel_on(KM_UP2_TILE);
   if (!enable || p.ncls != 4 || p.ntaps != 4 || p.kw != 2 || p.cioy[0] != -1 || p.ciox[0] != -1 || p.out_mode != 0) return 0;
   if (p.prec != ITG_PREC_F32 || p.cin_ld > 32 || p.co_rows > 32 || p.res.p) return 0;
   if ((int64_t)p.MT * p.MU < 48 * 48) return 0;
@@ -633,7 +633,7 @@ int try_conv_up2_tile(const ConvP& p, hipStream_t s, int* rc) {
 }
 
 int try_conv_s2k4(const ConvP& p, hipStream_t s, int* rc) {
-  static const int enable = env_int("ITG_CONV_S2K4", 1);
+  const int enable = kernel_on(KM_S2K4);
   if (!enable || p.ncls > 1 || p.ntaps != 16 || p.kw != 4 || p.isy != 2 || p.isx != 2 || p.ioy != -1 || p.iox != -1) return 0;
   if (p.osy != 1 || p.osx != 1 || p.ooy != 0 || p.oox != 0 || p.out_mode != 0 || p.pad_mode != ITG_PAD_ZERO) return 0;
   if (p.prec != ITG_PREC_F32 || p.cin_ld != 4 || p.stats || p.res.p) return 0;
@@ -661,7 +661,7 @@ int try_conv_s2k4(const ConvP& p, hipStream_t s, int* rc) {
 
 // eligibility + launch of the halo-tile kernel; returns 1 when it handled the call
 int try_conv_tile(ConvP& p, hipStream_t s, int* rc) {
-  static const int enable = env_int("ITG_CONV_TILE", 1);
+  const int enable = kernel_on(KM_CONV_TILE);
   if (!enable || p.ncls > 1 || p.ntaps != 9 || p.kw != 3 || p.isy != 1 || p.isx != 1 || p.osy != 1 || p.osx != 1)
     return 0;
   if (p.prec != ITG_PREC_F32 || p.cin_ld > 32 || p.co_rows > 32) return 0;
@@ -679,7 +679,7 @@ int try_conv_tile(ConvP& p, hipStream_t s, int* rc) {
   const int64_t ntiles = (int64_t)p.in.n * tiles_x * tiles_y;
   const size_t lds = ((size_t)nch * 16 * FI * 20 + ((nch * 4 + 3) & ~3) + 32 + 128 + 128 + (size_t)TT_PIX * cpt) * sizeof(float);
   const int nld = (TT_PIX * (p.cin_ld >> 2) + 255) / 256;
-  static const int lds_cap = env_int("ITG_TILE_LDS_KB", 80) * 1024;       // 26 -> 26 channels (b5c2) needs 76 KB: two workgroups per CU
+  constexpr int lds_cap = 80 * 1024;       // 26 -> 26 channels (b5c2) needs 76 KB: two workgroups per CU
   if (ntiles > 0x7fffffff || lds > (size_t)lds_cap || nld > 11) return 0;
   const int stm = p.stats ? TS_STATS : TS_NONE;
   const bool small = nld <= 6;

@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_up2_tile_kernel(const WgP p, int
 TileWgPlan plan_wgrad_up2_tile(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g) {
   TileWgPlan t;
   t.ok = 0; t.thin = 0; t.gpp = 16; t.coef_off = 0;
-  static const int enable = env_int("ITG_UP2_WTILE", 1);
+  const int enable = kernel_on(KM_UP2_WTILE);
   const int ph = g->pad_h >= 0 ? g->pad_h : g->pad;
   if (!enable || !g->up2 || ph != 1 || g->precision == ITG_PREC_BF16 || x->ld > 32 || dy->ld > 16 || (dy->ld & 3)) return t;
   const int H = x->gh * x->ph, W = x->gw * x->pw;          // source domain
@@ -924,7 +924,7 @@ int launch_wgrad_up2_tile(const WgP& p, const TileWgPlan& t, hipStream_t s) {
 TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_conv_geom* g) {
   TileWgPlan t;
   t.ok = 0;
-  static const int enable = env_int("ITG_WGRAD_TILE", 1);
+  const int enable = kernel_on(KM_WGRAD_TILE);
   const int ph = g->pad_h >= 0 ? g->pad_h : g->pad;
   if (!enable || g->up2 || g->kh != 3 || g->kw != 3 || g->stride != 1 || g->pad != 1 || ph != 1) return t;
   if (g->precision == ITG_PREC_BF16 || x->ld > 32 || dy->ld > 16 || (dy->ld != 4 && dy->ld != 8 && dy->ld != 16)) return t;
@@ -937,7 +937,7 @@ TileWgPlan plan_wgrad_tile(const itg_tensor* x, const itg_tensor* dy, const itg_
   t.nld = t.nld <= 6 ? 6 : 11;
   if ((TT_PIX * (x->ld >> 2) + 255) / 256 > 11) return t;
   t.cpt = (x->ld % 8 == 4) ? x->ld : x->ld + 4;
-  static const int thin_en = env_int("ITG_WGRAD_THIN", 1);
+  const int thin_en = kernel_on(KM_WGRAD_THIN);
   t.thin = thin_en && dy->ld == 4 && x->ld <= 16;         // <= 36 (tap, c4) groups: three passes of 12 or 16
   t.gpp = 16;
   if (t.thin) { t.cpt = 16; t.gpp = x->ld == 16 ? 12 : 16; }   // 16 channels: three taps per pass, bank-conflict free at pitch 16
@@ -1119,7 +1119,7 @@ int launch_tn(WgP p, int splits, int prec, hipStream_t s) {
   // ones with two stages in flight (measured on D's 256->512 layer vs its 64->128 / 128->256 layers)
   const int depth = p.chunks_per_split >= 128 ? 1 : 2;
   const int kp = prec == ITG_PREC_BF16 ? 32 : BKP;
-  static const int flat_env = env_int("ITG_TN_FLAT", 1);
+  const int flat_env = kernel_on(KM_TN_FLAT);
   const bool flat = flat_env && prec != ITG_PREC_BF16 && !p.up2 && p.x.gh == 1 && p.x.gw == 1 && p.dy.gh == 1 &&
                     p.dy.gw == 1 && p.pad_mode != ITG_PAD_REPLICATE && otp <= 16 && p.MU >= kp;
   snprintf(g_last_launch, sizeof(g_last_launch), "conv_tn_kernel<%d, %d, %d, %d, %s, %d, %s>", BCOL, BCO, WCOL, WCO,

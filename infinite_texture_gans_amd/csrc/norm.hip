@@ -19,7 +19,6 @@ namespace {
 constexpr int MAX_LD = 2048;
 
 inline int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
-inline int env_i(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 // number of 256-thread workgroups: multiple of q4/gcd(256,q4), about `total/(256*per_thread)`
 inline int sweep_blocks(int64_t total_f4, int q4, int per_thread, int cap) {
@@ -31,7 +30,7 @@ inline int sweep_blocks(int64_t total_f4, int q4, int per_thread, int cap) {
   return (int)b;
 }
 
-// Reductions: at most ITG_BN_RED_BLOCKS (128) workgroups, of 1024 threads once the tensor gives each of them >= `per_thread`
+// Reductions: at most 128 workgroups, of 1024 threads once the tensor gives each of them >= `per_thread`
 // float4 per thread, of 256 threads below that.  Every workgroup ends with one fp64 atomic per channel onto the SAME 2 * ld
 // doubles, and those serialise at ~13 ns per workgroup (measured on the 75 MB tensor, rocprofv3: bn_stats 15.4 / 18.2 / 22.4 /
 // 23.8 us with 128 / 256 / 512 / 1024 workgroups against 14.8 / 15.7 / 15.6 / 17.0 us with the atomics compiled out;
@@ -45,7 +44,7 @@ inline int sweep_blocks_nt(int64_t total_f4, int q4, int per_thread, int cap, in
   return (int)((want + g0 - 1) / g0 * g0);
 }
 inline RedPlan plan_reduce(int64_t total_f4, int q4, int per_thread) {
-  static const int cap = env_i("ITG_BN_RED_BLOCKS", 128);
+  constexpr int cap = 128;
   RedPlan r;
   r.nt = total_f4 >= (int64_t)cap * 1024 * per_thread ? 1024 : 256;
   r.blocks = sweep_blocks_nt(total_f4, q4, per_thread, cap, r.nt);

@@ -244,10 +244,10 @@ class Trainer:
         self._one = torch.ones((), device=device)               # the seed of every backward pass (no ones_like fill per pass)
         self.hinge = getattr(args, "loss", "standard") == "hinge"
         # the loss heads read D's logit map in the grid layout its last conv wrote: loss + derivative in one launch (ops.logit_loss)
-        self.fused_loss = os.environ.get("ITG_FUSED_LOSS", "1") == "1"
+        self.fused_loss = True
         self.packG, self.packD = PackSet(netG), PackSet(netD)
-        # dx buffers of the generator's replicate-padded convs, kept across steps (ops.begin_frames); ITG_FRAMES=0: per-layer zeroing
-        self._frames = {} if os.environ.get("ITG_FRAMES", "1") == "1" else None
+        # dx buffers of the generator's replicate-padded convs, kept across steps (ops.begin_frames)
+        self._frames = {}
         self.repack()
         self.arena = ops.ZeroArena(device)
         # stream overlap (D(real) beside the generator forward, weight gradients beside the input-gradient chain).
@@ -405,7 +405,7 @@ class Trainer:
 
     def _d_logits(self, fake):
         """D on the generator's output: a patch grid (consumed in place, no merge copy) or whole NCHW images.  The logit map
-        stays in the grid layout (ops.GT) for the fused loss head (ITG_FUSED_LOSS=0: NCHW logits and the generic heads)."""
+        stays in the grid layout (ops.GT) for the fused loss head (`Trainer.fused_loss = False`: NCHW logits and the generic heads)."""
         grid = hasattr(self.netD, "forward_grid")
         if isinstance(fake, ops.GT):
             lg = self.netD.forward_grid(fake)
@@ -583,7 +583,7 @@ class Trainer:
         if self.wstream is not None:
             ops.flush_deferred(per_stream=True)      # each weight-gradient stream reduces its own layers, then is joined
             ops.wgrad_streams_join()
-            ops.flush_deferred()                     # (ITG_DEFER_STREAMS=0: the single reduce behind the join)
+            ops.flush_deferred()                     # (ops.DEFER_PER_STREAM = False: the single reduce behind the join)
             ops.WGRAD_KEEPALIVE.clear()
         else:
             ops.flush_deferred()

@@ -24,11 +24,11 @@ def _pad_mode(outer_padding):
 
 
 # read once at import (an os.environ lookup per layer call is measurable in the 6.8 ms a step takes to issue)
-_ENV_RES_UPS = os.environ.get("ITG_RES_UPS", "1") == "1"
-_ENV_BN_FUSE = os.environ.get("ITG_BN_FUSE", "1") == "1"
+_ENV_RES_UPS = True
+_ENV_BN_FUSE = True
 _ENV_UP2_FOLD = os.environ.get("ITG_UP2_FOLD", "1") == "1"
 _ENV_HALO_INTERIOR = os.environ.get("ITG_HALO_INTERIOR", "0") == "1"      # band training: interior rows first, border rows after the exchange
-_ENV_BN_FORK = os.environ.get("ITG_BN_FORK", "1") == "1"      # the shortcut's gradient is added inside bn1's backward kernel
+_ENV_BN_FORK = True      # the shortcut's gradient is added inside bn1's backward kernel
 
 
 def up2_fold_enabled():
@@ -39,7 +39,7 @@ def up2_fold_enabled():
 
 
 def res_upsample_enabled():
-    """ITG_RES_UPS=0: materialise the upsampled shortcut again (A/B)."""
+    """_ENV_RES_UPS = False: materialise the upsampled shortcut again (A/B)."""
     return _ENV_RES_UPS
 
 

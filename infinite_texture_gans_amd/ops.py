@@ -508,7 +508,7 @@ WINOGRAD = os.environ.get("ITG_WINOGRAD", "1") == "1"
 # three to five dependent launches of 8-20 us where the direct path has one or two - these layers are launch-latency-bound.  Opt-in.
 WINOGRAD_G = os.environ.get("ITG_WINOGRAD_G", "0") == "1"
 WINOGRAD_WGRAD = os.environ.get("ITG_WINOGRAD_WGRAD", "1") == "1"     # read by the library itself; here for the flop accounting
-WINO_KEEP_V = os.environ.get("ITG_WINO_KEEP_V", "1") == "1"           # the weight gradient re-uses the forward's transformed input
+WINO_KEEP_V = True           # the weight gradient re-uses the forward's transformed input
 
 
 def wino_applicable(x, kh, kw, stride, pad, pad_h, pad_mode, prec, up2=False, out_stats=False, out=None, co=None):
@@ -523,12 +523,12 @@ def wino_applicable(x, kh, kw, stride, pad, pad_h, pad_mode, prec, up2=False, ou
     return kh == 3 and WINOGRAD_G and pad_mode in (PAD_ZERO, PAD_REPLICATE)
 
 
-WINO_S2_MIN_CI = int(os.environ.get("ITG_WINO_S2_MIN_CI", "64"))      # narrower layers stay direct (64: both of D's stride-2 layers)
-WINO_S2_MIN_TILES = int(os.environ.get("ITG_WINO_S2_MIN_TILES", "1024"))
-WINO_S2_WGRAD_MIN_CI = int(os.environ.get("ITG_WINO_S2_WGRAD_MIN_CI", "128"))
-WINO_S2_DGRAD = os.environ.get("ITG_WINO_S2_DGRAD", "1") == "1"
-WINO_S2_DGRAD_MIN_CI = int(os.environ.get("ITG_WINO_S2_DGRAD_MIN_CI", "128"))      # (64 -> 128 layer: 164 vs 171 us incl. its per-call panel: even)
-WINO_S2_WGRAD = os.environ.get("ITG_WINO_S2_WGRAD", "1") == "1"      # ... and its weight gradient (25 contractions over the tiles, the forward's V re-used)
+WINO_S2_MIN_CI = 64      # narrower layers stay direct (64: both of D's stride-2 layers)
+WINO_S2_MIN_TILES = 1024      # (module constants: tests and tools set them; no environment variables since round 5)
+WINO_S2_WGRAD_MIN_CI = 128
+WINO_S2_DGRAD = True
+WINO_S2_DGRAD_MIN_CI = 128      # (64 -> 128 layer: 164 vs 171 us incl. its per-call panel: even)
+WINO_S2_WGRAD = True      # ... and its weight gradient (25 contractions over the tiles, the forward's V re-used)
 WINOGRAD_S2 = os.environ.get("ITG_WINOGRAD_S2", "1") == "1"      # F(4 x 4, 2 x 2) forward for 4 x 4 stride-2 layers (conv_wino.hip wino_conv_s2)
 
 
@@ -721,7 +721,7 @@ def _finish_jobs(jobs, st):
         _lib.call("itg_spectral_norm_bwd_multi", (_lib.SnJob * len(chunk))(*chunk), len(chunk), st)
 
 
-DEFER_PER_STREAM = os.environ.get("ITG_DEFER_STREAMS", "1") == "1"
+DEFER_PER_STREAM = True
 
 
 def flush_deferred(per_stream=False):
@@ -765,7 +765,7 @@ def wgrad_stream_for(sink_key):
     return w
 
 
-_STREAM_DEBUG = os.environ.get("ITG_STREAM_DEBUG", "0") == "1"
+_STREAM_DEBUG = bool(int(os.environ.get("ITG_DEBUG", "0"), 0) & 2)
 
 
 def concurrent_streams(device, want, spin_us=150, candidates=12):
@@ -828,7 +828,7 @@ def concurrent_streams(device, want, spin_us=150, candidates=12):
         # correct but partly serialised - say so once instead of silently benchmarking another schedule
         import sys
         print("[itg] stream placement: only %d of %d side streams run concurrently with the main stream "
-              "(ITG_STREAM_DEBUG=1 prints the probe timings)" % (found, min(want, 3)), file=sys.stderr, flush=True)
+              "(ITG_DEBUG=2 prints the probe timings)" % (found, min(want, 3)), file=sys.stderr, flush=True)
     else:
         _PLACED[ckey] = list(chosen)
     return chosen

@@ -45,7 +45,7 @@ EXTRA = [
     ("X fold b4c1 (52->104 s2, 96^2)", 8, (1, 1), 96, 52, 104, 4, 2, 1, "zero"),
     ("X fold b5c1 (26->52 s2, 192^2)", 8, (1, 1), 192, 26, 52, 4, 2, 1, "zero"),
     ("X fold b6c1 (13->26 s2, 384^2)", 8, (1, 1), 384, 13, 26, 4, 2, 1, "zero"),
-    ("X tile b5c2 26->26 P64", 8, (3, 3), 64, 26, 26, 3, 1, 1, "rep"),       # halo-tile kernel with 76 KB of LDS (ITG_TILE_LDS_KB)
+    ("X tile b5c2 26->26 P64", 8, (3, 3), 64, 26, 26, 3, 1, 1, "rep"),       # halo-tile kernel with 76 KB of LDS (the kernels' 80 KB cap)
     ("X tile b4c2 52->52 P32", 8, (3, 3), 32, 52, 52, 3, 1, 1, "rep"),
     # the folded-upsample layers themselves (mode "rep-up2": ops.conv(up2=True) on the half-size input; P = source patch)
     ("X up2 b6c1 26->13 P64", 8, (3, 3), 64, 26, 13, 3, 1, 1, "rep-up2"),
