@@ -313,6 +313,7 @@ class _Conv(torch.autograd.Function):
             _lib.call("itg_conv2d_fwd", C.byref(dx_), _ptr(wp), _ptr(bias), _ptr(out_scale), C.byref(dr_), C.byref(do_),
                       C.byref(g), act, float(slope), _ptr(ws), nws, st)
         ctx.geom, ctx.act, ctx.slope, ctx.c_in, ctx.co = geom, act, slope, c_in, co
+        _sink_act(out, co, act, "conv")
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.res_ups = residual is not None and residual.shape[3] * 2 == out.shape[3]     # read through a nearest x2 upsample
         ctx.sn = sn
@@ -911,6 +912,16 @@ class ZeroArena:
 
 ARENA = None      # set by engine.Trainer for the duration of a step
 
+# Test hook (tests/test_gpu_fullsize.py): a list that receives (output tensor, channels, op, halo_rows) of every LeakyReLU / ReLU this module
+# applies - BatchNorm + activation, the conv epilogues, the pointwise op - in host issue order.  The signs of these tensors are
+# the branches the step took; the test puts the fp64 oracle on the same branches (oracle.nets.ACT_REPLAY).
+ACT_SINK = None
+
+
+def _sink_act(y, c, act, op, halo_rows=False):
+    if ACT_SINK is not None and act == ACT_LRELU:
+        ACT_SINK.append((y, c, op, halo_rows))      # halo_rows: band layout, rows 0 and -1 are the neighbours' (not this op's output)
+
 
 def _zeros_f64(n, device):
     t = ARENA.take(n) if ARENA is not None and ARENA.buf.device == device else None
@@ -962,6 +973,7 @@ class _BNAct(torch.autograd.Function):
         ctx.meta = (c, act, slope, count, sync, training, gamma is not None)
         ctx.sinks = sinks
         ctx.save_for_backward(x, stat)
+        _sink_act(y, c, act, "bn", pad_rows)
         if fork:
             # second output: x itself (an alias).  Whatever consumes it (the block's residual shortcut) hands its gradient to
             # THIS backward, which adds it inside itg_bn_bwd_apply_add - instead of autograd summing the two gradients of x
@@ -1120,6 +1132,7 @@ class _Act(torch.autograd.Function):
         _lib.call("itg_act_fwd", C.byref(a), C.byref(b), act, float(slope), _stream())
         ctx.meta = (c, act, slope)
         ctx.save_for_backward(y)
+        _sink_act(y, c, act, "act")
         return y
 
     @staticmethod

@@ -72,7 +72,27 @@ def sn_weight(sd, prefix, training):
     return w / sigma
 
 
+# Test hook (tests/test_gpu_fullsize.py): a list of boolean masks, consumed in call order by every piecewise-linear activation
+# of g_forward / d_forward.  The activation then takes its branch from the mask instead of from the sign of its own input -
+# x where the mask is set, leak * x elsewhere - so that an fp64 run can be put on the SAME side of every LeakyReLU / ReLU as
+# another implementation's run of the same step: what is left between the two gradients is rounding, not the ~1e-3 per
+# flipped activation of SURVEY F10.  A mask of half the extent is read through a nearest x2 upsample (the product normalises
+# and activates in front of the upsample, which commutes).  None = the reference behaviour.
+ACT_REPLAY = None
+ACT_RECORD = None       # a list: receives the mask (x > 0) of every such activation, in call order
+
+
 def _act(x, leak):
+    if ACT_RECORD is not None:
+        ACT_RECORD.append(x.detach() > 0)
+    if ACT_REPLAY is not None:
+        m = ACT_REPLAY.pop(0)
+        if m.shape != x.shape:
+            if m.shape[:2] == x.shape[:2] and m.shape[2] * 2 == x.shape[2] and m.shape[3] * 2 == x.shape[3]:
+                m = m.repeat_interleave(2, 2).repeat_interleave(2, 3)
+            else:
+                raise ValueError("activation mask %s does not fit the activation input %s" % (tuple(m.shape), tuple(x.shape)))
+        return torch.where(m, x, x * leak)
     return F.leaky_relu(x, leak) if leak > 0 else F.relu(x)
 
 
@@ -207,5 +227,5 @@ def d_forward(sd, cfg, x, training=True):
         name = "model.%d" % (2 * i)
         h = F.conv2d(h, sn_weight(sd, name, training), sd[name + ".bias"], stride=s, padding=1)
         if i < len(strides) - 1:
-            h = F.leaky_relu(h, 0.2)
+            h = _act(h, 0.2)
     return h

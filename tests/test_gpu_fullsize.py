@@ -118,10 +118,32 @@ def _rel(a, b):
 _ORACLE_RUNS = {}
 
 
-def _fullsize_step(flags, nl_G, attention, crop, prec, fp64_truth=False, grid=3, band=False):
+def _act_masks(sink, band_grid=None):
+    """ops.ACT_SINK entries -> boolean masks in the oracle's layout: (images * patches, channels, h, w).  ``band_grid``: the
+    generator ran on image-layout bands (engine.BandTrainer: a 1 x 1 grid holding the merged rows) - its BatchNorm activations
+    are cut back into the (gh, gw) patches the oracle's generator works on."""
+    masks = []
+    for y, c, op, halo_rows in sink:
+        y = y.detach()
+        if halo_rows:
+            y = y[:, :, :, 1:-1]
+        n, gh, gw, ph, pw, _ = y.shape
+        m = (y[..., :c] > 0).permute(0, 1, 2, 5, 3, 4)          # n, gh, gw, c, ph, pw
+        if band_grid is not None and op == "bn":
+            bh, bw = band_grid
+            assert gh == 1 and gw == 1 and ph % bh == 0 and pw % bw == 0, y.shape
+            m = m.reshape(n, c, bh, ph // bh, bw, pw // bw).permute(0, 2, 4, 1, 3, 5)
+            gh, gw, ph, pw = bh, bw, ph // bh, pw // bw
+        masks.append(m.reshape(n * gh * gw, c, ph, pw).cpu())
+    return masks
+
+
+def _fullsize_step(flags, nl_G, attention, crop, prec, fp64_truth=False, grid=3, band=False, same_branches=False):
     """One train iteration at a BASELINE configuration on identical seeded state / real_x / z: HIP Trainer vs the
-    CPU oracle's train_step.  Returns the comparison numbers."""
+    CPU oracle's train_step.  Returns the comparison numbers.  ``same_branches``: additionally run the oracle in fp64 with
+    every LeakyReLU forced onto the side the HIP step took (ops.ACT_SINK -> oracle.nets.ACT_REPLAY): `gradG_same`, `gradD_same`."""
     from oracle import step as ostep
+    from oracle import nets as onets
     from oracle.nets import GCfg, DCfg
     from infinite_texture_gans_amd import ops, utils as U
     from infinite_texture_gans_amd.engine import Trainer, BandTrainer
@@ -130,6 +152,8 @@ def _fullsize_step(flags, nl_G, attention, crop, prec, fp64_truth=False, grid=3,
     args.beta1 = float(args.beta1)
     torch.manual_seed(1234)
     netG, netD = U.prepare_models(args, "cpu")
+    init_g = {k: v.clone() for k, v in netG.state_dict().items()}
+    init_d = {k: v.clone() for k, v in netD.state_dict().items()}
     gsd = ostep.as_leaf_params({k: v.clone() for k, v in netG.state_dict().items()})
     dsd = ostep.as_leaf_params({k: v.clone() for k, v in netD.state_dict().items()})
     gcfg = GCfg(z_dim=128, G_ch=52, base_res=4, n_layers_G=nl_G, attention=attention, leak=0.02, type_norm="BN",
@@ -162,13 +186,16 @@ def _fullsize_step(flags, nl_G, attention, crop, prec, fp64_truth=False, grid=3,
         tr = BandTrainer(netG, netD, args, cuda, BandComm(0, 1, None)) if band else Trainer(netG, netD, args, cuda)
         tr.record = []
         ops.ARENA, ops.WGRAD_STREAM = tr.arena, tr.wstream
+        ops.ACT_SINK = [] if same_branches else None
         tr.arena.reset()
         try:
             d_real, d_fake, fake = tr.d_step(real.to(cuda), z.to(cuda), None)
             gradD = {k: p.grad.clone() for k, p in netD.named_parameters()}
             g_loss = tr.g_step(fake)
+            torch.cuda.synchronize()
+            masks = _act_masks(ops.ACT_SINK, (grid, grid) if band else None) if same_branches else None
         finally:
-            ops.ARENA = ops.WGRAD_STREAM = None
+            ops.ARENA = ops.WGRAD_STREAM = ops.ACT_SINK = None
         torch.cuda.synchronize()
     out = {"losses": ([float(d_real), float(d_fake), float(g_loss)], [r["d_loss_real"], r["d_loss_fake"], r["g_loss"]]),
            "fake": _rel(fake if torch.is_tensor(fake) else ops.to_nchw(fake, merged=True), r["fake"]),
@@ -185,6 +212,23 @@ def _fullsize_step(flags, nl_G, attention, crop, prec, fp64_truth=False, grid=3,
     out["gradG"] = {k: p.grad.clone() for k, p in netG.named_parameters()}
     out["gradG_ref"] = {k: gsd[k].grad for k in ostep.trainable(gsd)}
     out["gradG_truth"] = truth
+    if same_branches:
+        # the fp64 oracle on the HIP step's side of every LeakyReLU: D(real) forward, G forward, D(fake) forward, the G step's D
+        # forward - the order both implementations issue them in
+        g64 = ostep.as_leaf_params({k: (v.double() if v.is_floating_point() else v.clone()) for k, v in init_g.items()})
+        d64 = ostep.as_leaf_params({k: (v.double() if v.is_floating_point() else v.clone()) for k, v in init_d.items()})
+        o64D = ostep.Adam([d64[k] for k in ostep.trainable(d64)])
+        o64G = ostep.Adam([g64[k] for k in ostep.trainable(g64)])
+        out["n_masks"] = len(masks)
+        onets.ACT_REPLAY = masks
+        try:
+            r64 = ostep.train_step(g64, d64, gcfg, dcfg, o64G, o64D, real.double(), z.double(), None, smooth=True)
+            left = len(onets.ACT_REPLAY)
+        finally:
+            onets.ACT_REPLAY = None
+        assert left == 0, "%d recorded activations were not consumed by the oracle" % left
+        out["gradG_same"] = {k: g64[k].grad for k in ostep.trainable(g64)}
+        out["gradD_same"] = r64["gradD"]
     return out
 
 
@@ -193,25 +237,41 @@ def test_config2_full_size_train_step_matches_cpu_oracle_within_1e3(winograd, mo
     """BASELINE config 2, literally: `same 241.jpg config, 1xMI355X, fp32, HIP conv/local-padding kernels, parity vs
     CPU within 1e-3` - one whole G+D iteration at bench.py's FLAGS (G_ch 52, 128^2 patches on a 3x3 grid, 384^2 fakes,
     192^2 reals, batch 8).  Forward tensors (fake images, the three logit maps, the three losses), BatchNorm running
-    statistics and spectral-norm vectors at <= 1e-3 relative (measured ~1e-5); G's first-step gradients per tensor,
-    with the fraction inside 1e-3 reported (a single LeakyReLU sign flip among millions of activations
-    costs ~1e-3 on every upstream gradient, in the oracle against itself as well)."""
+    statistics and spectral-norm vectors at <= 1e-3 relative (measured ~1e-5); G's and D's first-step gradients per tensor
+    at <= 2e-5 against the oracle's fp64 run on the HIP step's own side of every LeakyReLU (a single sign flip
+    among millions of activations costs ~1e-3 on every upstream gradient, in the oracle against itself as well - so the
+    comparison is made flip-free instead of bounded loosely)."""
     import bench
     from infinite_texture_gans_amd import ops as _ops_mod
     # both algorithms of the discriminator's 256 -> 512 layer: the direct implicit GEMM and (the default) Winograd
     # F(4 x 4, 4 x 4) with blocked fp64 accumulation (1.4e-6 against the direct form's 1.1e-6 rel-L2 vs fp64, tools/wino_accuracy.py)
     monkeypatch.setattr(_ops_mod, "WINOGRAD", bool(winograd))
-    o = _fullsize_step(bench.FLAGS, 6, False, 192, "f32", fp64_truth=True)
+    o = _fullsize_step(bench.FLAGS, 6, False, 192, "f32", fp64_truth=True, same_branches=True)
     got, want = o["losses"]
     print("config2 full-size (%s): losses" % ("winograd" if winograd else "direct"), got, want, "fake %.2e logits %s bn %.2e sn %.2e" % (o["fake"], o["logits"], o["bn"], o["sn"]))
     assert all(abs(a - b) <= 1e-3 * abs(b) for a, b in zip(got, want)), (got, want)
     assert o["fake"] < 1e-3, o["fake"]
     assert all(e < 1e-3 for e in o["logits"]), o["logits"]
     assert o["bn"] < 1e-3 and o["nbt"] and o["sn"] < 1e-3, (o["bn"], o["sn"])
-    # Gradients.  Yardstick: the oracle's own fp64 run of the same step.  Each LeakyReLU input whose sign differs
-    # between two arithmetic orders moves every upstream gradient by ~1e-3 rel-L2 (F10), for the fp32 oracle as
-    # much as for the HIP path - so the HIP gradients must be as close to the fp64 truth as the fp32 CPU oracle is
-    # (within 2x + 1e-4), and within 1e-2 of the fp32 oracle in any case (a wrong kernel is O(1) off).
+    # Gradients.  THE BAR (round 5; VERDICT r4 item 4a): the oracle's fp64 run of the same step with every LeakyReLU forced onto
+    # the side the HIP step took (ops.ACT_SINK records the 25 activation outputs of D(real), G, D(fake) and the G step's D
+    # pass; oracle.nets.ACT_REPLAY replays their signs).  What is left between the two sets of gradients is the rounding of the
+    # HIP kernels - no LeakyReLU flips, nothing that moves with oneDNN's threading or the kernels' summation orders.  Every
+    # tensor of G and of D within 2e-5 (measured, direct and Winograd alike: G median 1.9e-6 / max 2.9e-6, D 1.0e-6 / 2.5e-6).
+    same = sorted(_rel(o["gradG"][k], t) for k, t in o["gradG_same"].items() if float(t.abs().max()) >= 1e-9)
+    same_d = sorted(_rel(o["gradD"][k], t) for k, t in o["gradD_same"].items())
+    print("config2 full-size (%s): %d activations replayed; gradients vs the fp64 oracle ON THE SAME BRANCHES: G median %.2e max %.2e, "
+          "D median %.2e max %.2e" % ("winograd" if winograd else "direct", o["n_masks"], same[len(same) // 2], same[-1],
+                                      same_d[len(same_d) // 2], same_d[-1]))
+    assert len(same) >= 40 and len(same_d) == len(o["gradD"])
+    assert same[-1] < 2e-5 and same_d[-1] < 2e-5, (same[-1], same_d[-1])
+    # For the record, the comparison rounds 2-4 asserted: against the fp64 run on ITS OWN branches.  Each LeakyReLU input whose
+    # sign differs between two arithmetic orders moves every upstream gradient by ~1e-3 rel-L2 (F10), so any two fp32
+    # implementations - the HIP path, the fp32 CPU oracle, the HIP path with another kernel for one layer - sit 0.7-2.1e-3
+    # (median) / 1.0-3.1e-3 (max) from that truth and from each other, and WHICH end of the range a run lands on is chaotic:
+    # measured over this round's variant suites HIP 0.70-2.11e-3 / 0.96-2.92e-3, the fp32 CPU oracle 0.8-1.4e-3 / 1.1-3.1e-3
+    # (the HIP numbers at the top of the range came from switching the strip kernels of G's last block OFF, not from any
+    # Winograd setting).  Printed, and held to a sanity bound only: a wrong kernel is O(1) off.
     rows = []
     for k, ref in o["gradG_ref"].items():
         t = o["gradG_truth"][k]
@@ -219,23 +279,12 @@ def test_config2_full_size_train_step_matches_cpu_oracle_within_1e3(winograd, mo
             continue
         rows.append((k, _rel(o["gradG"][k], t), _rel(ref, t), _rel(o["gradG"][k], ref)))
     inside = sum(r[3] < 1e-3 for r in rows) / len(rows)
-    print("config2 full-size: G gradients, %d tensors: rel-L2 vs fp64 truth: HIP median %.2e max %.2e | fp32 CPU oracle "
-          "median %.2e max %.2e | HIP vs fp32 oracle: %.0f%% within 1e-3, max %.2e" % (
+    print("config2 full-size: G gradients, %d tensors: rel-L2 vs the fp64 run on its own branches: HIP median %.2e max %.2e | fp32 CPU "
+          "oracle median %.2e max %.2e | HIP vs fp32 oracle: %.0f%% within 1e-3, max %.2e" % (
               len(rows), sorted(r[1] for r in rows)[len(rows) // 2], max(r[1] for r in rows),
               sorted(r[2] for r in rows)[len(rows) // 2], max(r[2] for r in rows), 100 * inside, max(r[3] for r in rows)))
-    # ONE bar for both algorithms: <= 2x the fp32 oracle's own distance to the truth + 1e-4 per tensor (direct kernels: measured
-    # 0.6x).  Round 3's Winograd GEMMs accumulated K in one fp32 chain, which the output transform amplified to 4.1e-6 per
-    # layer (direct 1.1e-6 on the same data): ~4x the LeakyReLU flips behind the layer, G's gradients 2.0e-3 / 2.9e-3 from
-    # the truth and a wider bar here.  Round 4: blocked fp64 accumulation (conv_nt_kernel.h NT_W64) brings the layer to
-    # 1.4e-6 and the wider bar is gone.
     for k, e_hip, e_cpu, e_rel in rows:
-        assert e_hip <= 2 * e_cpu + 1e-4, (k, e_hip, e_cpu)
-        assert e_rel < 1e-2, (k, e_rel)
-    # ... and a bar that does not move with the oracle's run: the HIP gradients against the fp64 truth directly.  Every fp32
-    # implementation sits a handful of LeakyReLU sign flips (~1e-3 each, F10) from the truth, and WHICH flips depends on its
-    # summation orders: measured r4 direct median 0.65e-3 / max 0.86e-3, Winograd 1.03e-3 / 1.36e-3; r5 (strip kernels in the
-    # generator's last blocks: another order) direct 1.30e-3 / 1.81e-3; the fp32 CPU oracle itself 0.8-1.4e-3 / 1.1-3.1e-3.
-    assert sorted(r[1] for r in rows)[len(rows) // 2] <= 2e-3 and max(r[1] for r in rows) <= 4e-3
+        assert e_hip < 1e-2 and e_rel < 1e-2, (k, e_hip, e_rel)
     # D's first-step gradients (real + fake passes accumulated, as Adam(D) consumed them) against the oracle's: D has
     # one LeakyReLU per layer on far fewer, larger activations than G's backward chain, measured ~1e-5; bar 1e-3
     errs = {k: _rel(o["gradD"][k], ref) for k, ref in o["gradD_ref"].items()}
@@ -267,7 +316,7 @@ def test_config4_full_size_band_train_step_matches_cpu_oracle_within_1e3():
     vectors and D's first-step gradients at <= 1e-3 relative."""
     import bench
     flags = bench.FLAGS + ["--num_patches_height", "4", "--num_patches_width", "4"]
-    o = _fullsize_step(flags, 6, False, 192, "f32", grid=4, band=True)
+    o = _fullsize_step(flags, 6, False, 192, "f32", grid=4, band=True, same_branches=True)
     got, want = o["losses"]
     print("config4 full-size: losses", got, want, "fake %.2e logits %s bn %.2e sn %.2e" % (o["fake"], o["logits"], o["bn"], o["sn"]))
     assert all(abs(a - b) <= 1e-3 * abs(b) for a, b in zip(got, want)), (got, want)
@@ -277,6 +326,12 @@ def test_config4_full_size_band_train_step_matches_cpu_oracle_within_1e3():
     errs = {k: _rel(o["gradD"][k], ref) for k, ref in o["gradD_ref"].items()}
     print("config4 full-size: D gradients max rel-L2 %.2e" % max(errs.values()))
     assert max(errs.values()) < 1e-3, errs
+    # G's and D's gradients against the fp64 oracle on the SAME side of every LeakyReLU (see the config-2 test): rounding only
+    same = sorted(_rel(o["gradG"][k], t) for k, t in o["gradG_same"].items() if float(t.abs().max()) >= 1e-9)
+    same_d = sorted(_rel(o["gradD"][k], t) for k, t in o["gradD_same"].items())
+    print("config4 full-size: %d activations replayed; gradients vs the fp64 oracle on the same branches: G median %.2e max %.2e, "
+          "D median %.2e max %.2e" % (o["n_masks"], same[len(same) // 2], same[-1], same_d[len(same_d) // 2], same_d[-1]))
+    assert same[-1] < 2e-5 and same_d[-1] < 2e-5, (same[-1], same_d[-1])
 
 
 # ------------------------------------------------------------------------------- config 5: SSM inference tiling at size

@@ -25,6 +25,14 @@ def _gen(seed):
     return torch.Generator().manual_seed(seed)
 
 
+def _expect_kernel(ops, names):
+    """The last conv launch ran one of the named kernels - unless ITG_KERNEL_MASK sends the specialised kernels' layers to the
+    generic ones (tools/variant_suites.sh): the numbers of the test then hold for those."""
+    got = ops._lib.fn("itg_last_conv_kernel")().decode()
+    if int(os.environ.get("ITG_KERNEL_MASK", "0xFFF"), 0) & 0xFFF == 0xFFF:
+        assert got.startswith(names), got
+
+
 # ------------------------------------------------------------------------------- LocalPadder (bit exact)
 def test_local_pad_matches_reference_golden_bit_exact():
     ops = _ops()
@@ -164,7 +172,9 @@ STRIP_CASES = [
     ("b6c2_fwd_13_13_half_res_stats", 2, (3, 3), 64, 13, 13, "replicate", "half", "none", True),     # the generator's conv2: + shortcut through the upsample, BatchNorm sums
     ("b5c2_fwd_26_26_same_res_lrelu", 1, (2, 3), 32, 26, 26, "replicate", "same", "lrelu", True),
     ("zero_frame_13_26_tanh", 1, (3, 2), 32, 13, 26, "constant", None, "tanh", False),
-    ("many_units_per_wave_16_16", 5, (4, 4), 128, 16, 16, "replicate", None, "lrelu", True),         # 512^2 x 5: persistent waves take several units
+    # 512^2 x 5: persistent waves take several units (the case that caught the gfx950 store hazard: buffer_store_dwordx4 with an
+    # SGPR offset + a VALU write of its data registers in the next cycle stored zeros in ~6 % of the pixels, conv_strip.hip finish())
+    ("many_units_per_wave_16_16", 5, (4, 4), 128, 16, 16, "replicate", None, "lrelu", True),
 ]
 
 
@@ -196,7 +206,7 @@ def test_conv_strip_kernel_epilogues_and_fold(case):
     pm = ops.PAD_REPLICATE if mode == "replicate" else ops.PAD_ZERO
     a = {"none": ops.ACT_NONE, "lrelu": ops.ACT_LRELU, "tanh": ops.ACT_TANH}[act]
     y = ops.conv(gx, w.to(cuda), b.to(cuda), 3, 3, 1, 1, pm, a, 0.2, residual=gr, out_stats=stats)
-    assert ops._lib.fn("itg_last_conv_kernel")().decode().startswith("conv_strip_kernel")
+    _expect_kernel(ops, "conv_strip_kernel")
     yg = ops.to_nchw(y, merged=True)
     assert rel_l2(yg.detach().cpu(), yr.detach()) < 2e-6, rel_l2(yg.detach().cpu(), yr.detach())
     if y.t.shape[-1] > cout:
@@ -211,7 +221,7 @@ def test_conv_strip_kernel_epilogues_and_fold(case):
     dpre = dy * (torch.where(yc > 0, 1.0, 0.2) if act == "lrelu" else (1 - yc * yc) if act == "tanh" else 1.0)
     (dxr,) = torch.autograd.grad(pre, xr, dpre)
     (dxg,) = torch.autograd.grad(yg, xg, dy.to(cuda))
-    assert ops._lib.fn("itg_last_conv_kernel")().decode().startswith("conv_strip_kernel")
+    _expect_kernel(ops, "conv_strip_kernel")
     assert rel_l2(dxg.cpu(), dxr) < 5e-6, rel_l2(dxg.cpu(), dxr)
 
 
@@ -288,7 +298,7 @@ def test_input_gradient_only_call_on_the_halo_tile_path_eager_and_captured(ci, c
     dy[..., :co] = torch.randn(*y.t.shape[:-1], co, generator=g)
     dyg = dy.to(cuda)
     (dx,) = torch.autograd.grad(y.t, xg, dyg)
-    assert ops._lib.fn("itg_last_conv_kernel")().decode().startswith(("conv_strip_kernel", "conv_tile_kernel"))
+    _expect_kernel(ops, ("conv_strip_kernel", "conv_tile_kernel"))
     del y
     xm = ops.to_nchw(ops.GT(xg.detach(), ci), merged=True).cpu().double().requires_grad_(True)
     yr = F.conv2d(F.pad(xm, (1, 1, 1, 1), mode="replicate"), w.double())
@@ -306,7 +316,10 @@ def test_input_gradient_only_call_on_the_halo_tile_path_eager_and_captured(ci, c
     dxc.zero_()
     graph.replay()
     torch.cuda.synchronize()
-    assert torch.equal(dxc, dx)
+    if int(os.environ.get("ITG_KERNEL_MASK", "0xFFF"), 0) & 0xFFF == 0xFFF:
+        assert torch.equal(dxc, dx)
+    else:       # the generic kernels fold a replicate-padded layer's frame with fp32 atomics: the order of two runs may differ
+        assert rel_l2(dxc.cpu(), dx.cpu()) < 1e-6
 
 
 def test_capture_rule_bookkeeping():
@@ -848,7 +861,7 @@ def test_band_conv_on_the_strip_kernels(mode, cin, cout, H, W, res):
     y = ops.conv(ops.to_grid(xg, 1, 1, merged=True), wg, b.float().to(cuda), stride=1, pad=1,
                  pad_mode=ops.PAD_REPLICATE if mode == "replicate" else ops.PAD_ZERO, pad_h=0, residual=rg)
     want = "conv_strip_kernel" if W & (W - 1) == 0 else "conv_tile_kernel"
-    assert ops._lib.fn("itg_last_conv_kernel")().decode().startswith(want)
+    _expect_kernel(ops, want)
     out = ops.to_nchw(y, merged=True)
     assert rel_l2(out.detach().cpu(), ref.detach()) < 2e-6
     dxg, dwg = torch.autograd.grad(out, (xg, wg), gy.float().to(cuda))

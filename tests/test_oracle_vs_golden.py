@@ -211,6 +211,42 @@ def test_streamed_inference_matches_reference(tag):
         assert rel_l2(one, fx["image"]) < 2e-6   # streamed == one-shot grid
 
 
+def test_activation_replay_hook_reproduces_the_unhooked_step():
+    """oracle.nets.ACT_RECORD / ACT_REPLAY (the hook behind the flip-free gradient comparison of tests/test_gpu_fullsize.py): a
+    step whose LeakyReLUs take their branch from the masks recorded in a plain run of the same step is that run, bit for bit
+    (losses and every gradient of G and D); the masks are consumed in order, all of them; a flipped mask changes the result."""
+    fx = load("train_bn_nl4_sn")
+    a = parse_flags(fx["argv"])
+    gcfg, dcfg = cfgs(a)
+    real_x, z = torch.from_numpy(fx["real_x0"]), torch.from_numpy(fx["z0"])
+
+    def run(replay=None, record=None):
+        gsd = step.as_leaf_params(state(fx, "G0/"))
+        dsd = step.as_leaf_params(state(fx, "D0/"))
+        optD = step.Adam([dsd[k] for k in step.trainable(dsd)])
+        optG = step.Adam([gsd[k] for k in step.trainable(gsd)])
+        nets.ACT_REPLAY, nets.ACT_RECORD = replay, record
+        try:
+            r = step.train_step(gsd, dsd, gcfg, dcfg, optG, optD, real_x, z, None, smooth=True)
+        finally:
+            left = None if replay is None else len(replay)
+            nets.ACT_REPLAY = nets.ACT_RECORD = None
+        return r, {k: gsd[k].grad.clone() for k in step.trainable(gsd)}, left
+
+    masks = []
+    r0, g0, _ = run(record=masks)
+    n_d = len(nets.d_strides(dcfg.n_layers_D)) - 1
+    assert len(masks) == 3 * n_d + 2 * gcfg.n_layers_G + 1          # three D passes, two per block + the final BatchNorm
+    r1, g1, left = run(replay=[m.clone() for m in masks])
+    assert left == 0
+    assert (r0["d_loss_real"], r0["d_loss_fake"], r0["g_loss"]) == (r1["d_loss_real"], r1["d_loss_fake"], r1["g_loss"])
+    assert all(torch.equal(g0[k], g1[k]) for k in g0) and all(torch.equal(r0["gradD"][k], r1["gradD"][k]) for k in r0["gradD"])
+    flipped = [m.clone() for m in masks]
+    flipped[n_d + 1] = ~flipped[n_d + 1]                                 # an activation inside G's first block
+    r2, g2, _ = run(replay=flipped)
+    assert any(not torch.equal(g0[k], g2[k]) for k in g0)
+
+
 def test_hinge_is_unpinned_but_sane():
     r, f = torch.tensor([[0.5, 2.0]]), torch.tensor([[-2.0, 0.5]])
     dr, df = step.hinge_d(r, f)
