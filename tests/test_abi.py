@@ -74,6 +74,22 @@ def test_rejected_calls_return_error_codes_not_crashes(lib):
     ok = lib.Tensor(ctypes.c_void_p(64), 1, 1, 1, 4, 4, 3, 4)           # a well-formed descriptor (never dereferenced: the
     assert so.itg_conv2d_dgrad(ctypes.byref(ok), None, None, ctypes.byref(ok), None, 0, f0, None, None, 0, None) < 0   # panel is null)
     assert so.itg_conv2d_wgrad(ctypes.byref(ok), ctypes.byref(ok), None, None, None, 0, None, 0, None) < 0               # geometry is null
+    # round 5's entry points: the band halo rows (a band is one 1 x 1-grid image with >= 3 rows; buffer mode needs the buffer),
+    # the fused loss head (one-channel logits, a zeroed workspace), the stride-2 Winograd panels
+    assert so.itg_band_halo_fill(None, None, None, 1, 1, None) < 0
+    assert so.itg_band_halo_fill(ctypes.byref(ok), None, None, 0, 1, None) < 0          # rows from a buffer, no buffer
+    assert so.itg_band_halo_fill(ctypes.byref(ok), None, None, 3, 1, None) < 0          # unknown mode
+    assert so.itg_band_halo_grad(ctypes.byref(ok), None, None, 1, 0, None) < 0
+    assert so.itg_band_rows_get(ctypes.byref(ok), 0, 9, None, None, None) < 0
+    assert so.itg_band_interior_copy(ctypes.byref(ok), ctypes.byref(ok), 1, None) < 0   # the band must be two rows shorter
+    assert so.itg_logit_loss_grid(None, 0, f0, None, None, None, None) < 0
+    assert so.itg_logit_loss_grid(ctypes.byref(ok), 0, f0, ctypes.c_void_p(64), ctypes.byref(ok), ctypes.c_void_p(64), None) < 0   # 3 channels
+    one = lib.Tensor(ctypes.c_void_p(64), 1, 1, 1, 4, 4, 1, 4)
+    assert so.itg_logit_loss_grid(ctypes.byref(one), 7, f0, ctypes.c_void_p(64), ctypes.byref(one), ctypes.c_void_p(64), None) < 0  # unknown kind
+    assert so.itg_logit_loss_grid_workspace() >= 9
+    assert so.itg_pack_wino_s2_fwd(None, None, None, 128, 64, 64, None) < 0
+    assert so.itg_pack_wino_s2_dgrad(None, None, None, 128, 64, 64, 128, None) < 0
+    assert so.itg_pack_wino_s2_size(256, 128) == 25 * 256 * 512 and so.itg_pack_wino_s2_dgrad_size(128, 256) == 25 * 512 * 256
     bad_ld = lib.Tensor(ctypes.c_void_p(64), 1, 1, 1, 4, 4, 3, 3)      # ld not a multiple of 4
     assert so.itg_act_fwd(ctypes.byref(bad_ld), ctypes.byref(bad_ld), 1, ctypes.c_float(0.2), None) == -2
 
