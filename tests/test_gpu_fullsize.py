@@ -294,18 +294,28 @@ def test_config2_full_size_train_step_matches_cpu_oracle_within_1e3(winograd, mo
         assert e < 1e-3, (k, e)
 
 
-def test_config3_full_size_bf16_train_step_tracks_cpu_oracle():
+@pytest.mark.parametrize("prec", ["bf16", "f32"])
+def test_config3_full_size_bf16_train_step_tracks_cpu_oracle(prec):
     """BASELINE config 3's shapes (nl_G 5, attention, 128^2 crops, 64^2 patches) on the bf16-operand MFMA path against
-    the fp32 oracle at bf16's tolerance (2e-2 forward)."""
+    the fp32 oracle at bf16's tolerance (2e-2 forward) - and the same step with fp32 operands (the attention
+    generator at size) at 1e-3.  Gradients of G and D against the oracle's fp64 run on the SAME side of every LeakyReLU (see the
+    config-2 test): fp32 operands 2e-5 per tensor, bf16 operands 5e-2 (operand rounding, ~3e-3 per conv, is all that is left)."""
     import bench
     flags = [f for f in bench.FLAGS3 if f != "--bf16"]
-    o = _fullsize_step(flags, 5, True, 128, "bf16")
+    o = _fullsize_step(flags, 5, True, 128, prec, same_branches=True)
     got, want = o["losses"]
-    print("config3 full-size bf16: losses", got, want, "fake %.2e logits %s bn %.2e" % (o["fake"], o["logits"], o["bn"]))
-    assert all(abs(a - b) <= 3e-2 * abs(b) + 1e-3 for a, b in zip(got, want)), (got, want)
-    assert o["fake"] < 2e-2, o["fake"]
-    assert all(e < 2e-2 for e in o["logits"]), o["logits"]
-    assert o["bn"] < 2e-2 and o["nbt"]
+    tol = 2e-2 if prec == "bf16" else 1e-3
+    print("config3 full-size %s: losses" % prec, got, want, "fake %.2e logits %s bn %.2e" % (o["fake"], o["logits"], o["bn"]))
+    assert all(abs(a - b) <= 1.5 * tol * abs(b) + (1e-3 if prec == "bf16" else 0.0) for a, b in zip(got, want)), (got, want)
+    assert o["fake"] < tol, o["fake"]
+    assert all(e < tol for e in o["logits"]), o["logits"]
+    assert o["bn"] < tol and o["nbt"]
+    same = sorted(_rel(o["gradG"][k], t) for k, t in o["gradG_same"].items() if float(t.abs().max()) >= 1e-9)
+    same_d = sorted(_rel(o["gradD"][k], t) for k, t in o["gradD_same"].items())
+    print("config3 full-size %s: %d activations replayed; gradients vs the fp64 oracle on the same branches: G median %.2e max %.2e, "
+          "D median %.2e max %.2e" % (prec, o["n_masks"], same[len(same) // 2], same[-1], same_d[len(same_d) // 2], same_d[-1]))
+    bar = 5e-2 if prec == "bf16" else 2e-5
+    assert same[-1] < bar and same_d[-1] < bar, (same[-1], same_d[-1])
 
 
 def test_config4_full_size_band_train_step_matches_cpu_oracle_within_1e3():
