@@ -1,5 +1,5 @@
 // conv_nt_kernel: the implicit-GEMM forward / input-gradient kernel template and its launcher, shared by conv_nt.hip
-// (plain instantiations) and conv_nt_fused.hip (loader-transform / BatchNorm-backward-sums instantiations).
+// (plain instantiations) and conv_nt_w64.hip (blocked-accumulation instantiations for the Winograd GEMMs).
 #pragma once
 #include "conv_common.h"
 

@@ -71,6 +71,9 @@ __device__ __forceinline__ f32x4 dppmov4(f32x4 src) {
   }
   return r;
 }
+// byte offset of a store that must be dropped: above every admissible tensor size (try_conv_strip: < 0xFFFF0000 bytes) and 16
+// bytes below the 32-bit wrap, so the hardware range check discards it whatever the row
+constexpr unsigned STRIP_DROP = 0xFFFFFFF0u;
 constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHR1 = 0x111, DPP_ROW_ROR1 = 0x121, DPP_ROW_ROR15 = 0x12F;
 
 // KC = 16-channel chunks of an input pixel (1: cin_ld <= 16, 2: cin_ld <= 32), FI = 16-row tiles of output channels
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         const int co = 16 * i + 4 * g;
-        vo[i][f] = co < p.out.ld ? (unsigned)(strip_colpix(p.out, lpw, X0) + 16 * f + nl) * old4 + (unsigned)co * 4u : out_bytes;
+        vo[i][f] = co < p.out.ld ? (unsigned)(strip_colpix(p.out, lpw, X0) + 16 * f + nl) * old4 + (unsigned)co * 4u : STRIP_DROP;
         vr[i][f] = res_bytes;
         if (has_res && co < p.res.ld) {
           const int rp = sp.res_half ? strip_colpix(p.res, lpw - 1, X0 >> 1) + ((16 * f + nl) >> 1) : strip_colpix(p.res, lpw, X0) + 16 * f + nl;
@@ -266,7 +269,10 @@ __global__ __launch_bounds__(256, (KC * FI == 1 ? 3 : 2)) void conv_strip_kernel
           // inserts it for stores WITHOUT an SGPR offset (the GFX9 rule).  On gfx950 the SGPR-offset form is hit as well: with the
           // accumulator zeroed right behind the store (`buffer_store_dwordx4 v[20:23], ..., s78 offen; v_mov_b32 v23, 0`) the
           // generator's 128^2-patch layers stored zeros in ~6 % of their pixels once every wave ran several units.
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rout, vo[i][f] + ob, 0, 0);
+          // A lane whose channel group lies past out.ld drops its store through the range check: its offset stays the sentinel
+          // (adding the row offset to it would wrap back INTO a tensor above 2 GiB and zero 16 bytes of another pixel).
+          const unsigned so = vo[i][f] == STRIP_DROP ? STRIP_DROP : vo[i][f] + ob;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rout, so, 0, 0);
           acc[i][f] = zero4;
         }
       }

@@ -306,7 +306,11 @@ class Trainer:
         names = ("bucketed gradient exchange (ITG_BUCKETS)", "head bucket share (ITG_BUCKET_HEAD)", "collective warm-up (ITG_WARM_COLLECTIVES)",
                  "sync-BN (--sync_bn / ITG_SYNC_BN)", "deferred weight-gradient reduce (--wgrad_reduce / ITG_DEFER_REDUCE)",
                  "fused spectral-norm reduce (ITG_SN_FUSED_REDUCE)", "stream overlap (ITG_OVERLAP)")
-        mine = [int(bool(buckets)), int(round(float(os.environ.get("ITG_BUCKET_HEAD", "0.2")) * 1e6)),
+        try:
+            head = int(round(float(os.environ.get("ITG_BUCKET_HEAD", "0.2")) * 1e6))
+        except ValueError:
+            head = -1          # a malformed value on this rank must still reach both all-reduces: the mismatch raises on every rank
+        mine = [int(bool(buckets)), head,
                 int(os.environ.get("ITG_WARM_COLLECTIVES", "1") == "1"), int(self.sync_bn), int(self.defer_reduce), int(self.sn_fused),
                 int(self.overlap)]
         dev = self.device if torch.device(self.device).type == "cuda" else "cpu"
@@ -315,6 +319,8 @@ class Trainer:
         self.sync.dist.all_reduce(lo, op=self.sync.dist.ReduceOp.MIN, group=self.sync.group)
         self.sync.dist.all_reduce(hi, op=self.sync.dist.ReduceOp.MAX, group=self.sync.group)
         bad = [n for n, a, b in zip(names, lo.tolist(), hi.tolist()) if a != b]
+        if not bad and head < 0:
+            bad = ["head bucket share (ITG_BUCKET_HEAD is not a number)"]
         if bad:
             raise RuntimeError("the ranks of this job disagree on %s: set it identically on every rank" % ", ".join(bad))
 

@@ -77,6 +77,7 @@ class _ConvParams(nn.Module):
     grad_sinks = False
     _preset_inv = None      # 1/sigma computed ahead by a model-level batched power iteration
     _packed = None          # (forward panel, dgrad panel) kept current by engine.PackSet, else packed per call
+    _packed_direct = None   # stride-2 Winograd layers: (direct forward panel, direct dgrad panel) for batches under the size rule
     _packed_kind = "plain"  # what the persistent panels are: "plain" | "up2" (itg_pack_up2_*) | "wino" (itg_pack_wino_*)
     up2 = False             # this conv sits behind a x2 upsample that its owner folds into it (ResBlockGenerator.conv1)
 
@@ -123,6 +124,16 @@ class _ConvParams(nn.Module):
                 (w, self._packed[1], co, ci, ops.ld_for(co), k, k, st, kd)]
         if nt:
             jobs.append((w, self._packed[2], co, ci, ops.ld_for(co), ops.ld_for(ci), k, st, 9))      # (kh slot: ci_ld)
+        self._packed_direct = None
+        if kind == "wino_s2":
+            # A stride-2 Winograd layer runs BOTH forms every step: the generated batch through F(4 x 4, 2 x 2), a batch under
+            # ops.WINO_S2_MIN_TILES (the real 192^2 crops behind D's 128 -> 256 layer: 288 tiles) through the direct kernels.
+            # The direct forward panel is persistent too, and the direct form's input gradient takes _packed[1] (kind 1 IS the
+            # direct input-gradient panel): two pack launches fewer on D(real)'s chain per step.
+            npf = ops.pack_sizes(co, ci, k, k, st)[0]
+            fwd = torch.empty(npf, device=w.device, dtype=torch.float32)
+            self._packed_direct = (fwd, self._packed[1])
+            jobs.append((w, fwd, co, ci, ops.ld_for(ci), k, k, 1, 0))
         return jobs
 
     def weight_and_sn(self):
@@ -153,6 +164,8 @@ class _ConvParams(nn.Module):
             wino = 2
         kind = "wino_s2" if wino == 2 else ("wino" if wino else ("up2" if up2 else "plain"))
         packed = self._packed if (self._packed is None or self._packed_kind == kind) else None    # else: packed per call
+        if packed is None and self._packed is not None and kind == "plain" and self._packed_kind == "wino_s2":
+            packed = self._packed_direct          # the direct form of a stride-2 Winograd layer (pack_jobs)
         return ops.conv(x, w, self.bias, self.k, self.k, self.stride, p_,
                         pad_mode, act, slope, residual, sn, out_grid, self._sinks(w), pad_h, packed=packed,
                         in_act=in_act, defer_act_bwd=defer_act_bwd, out_stats=out_stats, out=out, up2=up2, wino=wino)

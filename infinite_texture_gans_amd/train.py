@@ -164,18 +164,29 @@ def train(args):
             if fatal_capture:
                 raise
             tr.graph = None
+            if probe_deferred[0]:
+                # the probe switched the deferred reduce on for the replay it had picked: eager launches keep the per-layer
+                # reduces (the deferred form costs them ~2 %, launch_plan)
+                tr.set_defer_reduce(False)
+                probe_deferred[0] = False
             if rank == 0:
-                print("launch (auto): recording the step failed (%s: %s) - continuing with eager launches" % (type(e).__name__, e))
+                print("launch (auto): recording the step failed (%s: %s) - continuing with eager launches, weight-gradient reduce %s"
+                      % (type(e).__name__, e, "deferred" if tr.defer_reduce else "per layer"))
             return False
+
+    # --launch_mode auto: 1 untimed + 4 timed eager iterations, carried ACROSS epochs (a run with fewer than five batches per
+    # epoch still decides); the epoch-end host sync, checkpoint and print stay out of its clock
+    probe = {"n": 0, "issue": 0.0, "wall": 0.0, "start": None}
+    probe_deferred = [False]
 
     print("Starting Training Loop...")
     for epoch in range(args.epochs):
         d_run = torch.zeros((), device=device)
         g_run = torch.zeros((), device=device)
         n_d = n_g = 0
-        if use_graph == "probe":
-            # the probe's five iterations lie inside ONE epoch: the epoch-end host sync, checkpoint and print stay out of its clock
-            probe = {"n": 0, "issue": 0.0, "start": 0.0}
+        if use_graph == "probe" and probe["n"] >= 1:
+            torch.cuda.synchronize()
+            probe["start"] = time.perf_counter()          # the probe goes on in this epoch: restart its clock on an idle GPU
         for data_b in data:
             real_x = data_b[0]
             b = real_x.shape[0]
@@ -193,10 +204,11 @@ def train(args):
                 probe["n"] += 1
                 if probe["n"] == 5:
                     torch.cuda.synchronize()
-                    wall = time.perf_counter() - probe["start"]
+                    wall = probe["wall"] + time.perf_counter() - probe["start"]
                     use_graph = probe["issue"] > 0.9 * wall
                     if use_graph and defer_with_replay(args):
                         tr.set_defer_reduce(True)          # the schedule that pays under replay (launch_plan)
+                        probe_deferred[0] = True
                     if rank == 0:
                         print("launch (auto): the host issues an iteration in %.2f ms, the GPU finishes one every %.2f ms -> %s"
                               % (probe["issue"] / 4 * 1e3, wall / 4 * 1e3, "hipGraph replay" if use_graph else "eager"))
@@ -231,6 +243,9 @@ def train(args):
             g_run += g_loss * args.num_images
             n_d += b
             n_g += args.num_images
+        if use_graph == "probe" and probe["n"] >= 2:
+            torch.cuda.synchronize()                      # close the probe's clock before the epoch-end work
+            probe["wall"] += time.perf_counter() - probe["start"]
         if args.decay_lr:
             f = lr_factor(args.decay_lr, epoch + 1)
             tr.optD.lr, tr.optG.lr = args.lr_D * f, args.lr_G * f

@@ -236,6 +236,8 @@ def switches_worker(rank, world, port, out, differ):
     os.environ.pop("ITG_BUCKET_HEAD", None)
     if differ == "bucket_head_last_digit" and rank == 1:
         os.environ["ITG_BUCKET_HEAD"] = "0.21"       # a value whose hash differs by little (the float-variance test of r4 missed those)
+    if differ == "bucket_head_malformed" and rank == 1:
+        os.environ["ITG_BUCKET_HEAD"] = "0,2"        # float() raised on this rank BEFORE the all-reduces, the others hung
     if differ == "explicit_default" and rank == 1:
         os.environ["ITG_BUCKET_HEAD"] = "0.2"        # the default written out: NOT a disagreement (r4 raised a false mismatch)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -259,7 +261,8 @@ def switches_worker(rank, world, port, out, differ):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("differ", [None, "explicit_default", "buckets", "defer_reduce_argument", "bucket_head_last_digit"])
+@pytest.mark.parametrize("differ", [None, "explicit_default", "buckets", "defer_reduce_argument", "bucket_head_last_digit",
+                                    "bucket_head_malformed"])
 def test_ranks_that_disagree_on_a_collective_switch_fail_together_instead_of_hanging(tmp_path, differ):
     """the bucketed exchange, the deferred reduce (constructor argument / --wgrad_reduce as much as the
     environment), sync-BN ... decide WHICH collectives a rank issues; if they differ between ranks the sequences diverge and
@@ -269,7 +272,8 @@ def test_ranks_that_disagree_on_a_collective_switch_fail_together_instead_of_han
     mp.spawn(switches_worker, args=(2, free_port(), out, differ), nprocs=2, join=True)
     r0, r1 = torch.load(out + "0"), torch.load(out + "1")
     assert r0[1] == 2.0 and r1[1] == 2.0
-    word = {"buckets": "ITG_BUCKETS", "defer_reduce_argument": "--wgrad_reduce", "bucket_head_last_digit": "ITG_BUCKET_HEAD"}.get(differ)
+    word = {"buckets": "ITG_BUCKETS", "defer_reduce_argument": "--wgrad_reduce", "bucket_head_last_digit": "ITG_BUCKET_HEAD",
+            "bucket_head_malformed": "ITG_BUCKET_HEAD"}.get(differ)
     if word:
         assert word in r0[0] and word in r1[0], (r0, r1)
     else:
