@@ -231,6 +231,61 @@ __device__ __forceinline__ float wino_s2_dgrad_elem(const float* __restrict__ w,
   return v;
 }
 
+// Both F(4 x 4, 2 x 2) panels, one thread = FOUR consecutive k of one row and all 25 classes of them (round 6; as wino_pack4 does
+// for F(4 x 4, 4 x 4)): the element form above reads a filter's taps 25 times and stores 4 bytes at a time.  Bit-identical to
+// wino_s2_elem / wino_s2_dgrad_elem (same fma order: t over jy, v over jx).
+//   forward  (transposed = 0): row = co, k = cls * ld + c        - the four k are four input channels of one parity class
+//   adjoint  (transposed = 1): row = cls * ci_ld + c, k = co     - the four k are four filters
+// item < rows_pad * Kpad / 4.
+__device__ __forceinline__ void wino_s2_pack4(const float* __restrict__ w, float* __restrict__ out, int co, int ci, int ci_ld,
+                                              int co_ld, int transposed, unsigned item) {
+  const unsigned Kpad = (unsigned)round_up_d(transposed ? co_ld : 4 * ci_ld, BK);
+  const unsigned rows_pad = (unsigned)round_up_d(transposed ? 4 * ci_ld : co, 16);
+  const unsigned kq = Kpad >> 2;
+  const int row = (int)(item / kq), k0 = (int)(item - (unsigned)row * kq) * 4;
+  const int rc = transposed ? row : k0;                    // the index that carries (cls, c)
+  const int cls = rc / ci_ld, c0 = rc - cls * ci_ld;
+  const int a = cls >> 1, b = cls & 1;
+  float g[4][2][2];                                        // [q][jy][jx]
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int o = transposed ? k0 + q : row, c = transposed ? c0 : c0 + q;
+    const bool ok = cls < 4 && o < co && c < ci;
+    const float* src = w + ((size_t)(ok ? o : 0) * ci + (ok ? c : 0)) * 16;
+#pragma unroll
+    for (int jy = 0; jy < 2; ++jy)
+#pragma unroll
+      for (int jx = 0; jx < 2; ++jx) g[q][jy][jx] = ok ? src[(2 * jy + a) * 4 + 2 * jx + b] : 0.f;
+  }
+  const size_t plane = (size_t)rows_pad * Kpad;
+  float* o = out + (size_t)row * Kpad + k0;
+#pragma unroll
+  for (int al = 0; al < 5; ++al) {
+    float t[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int jx = 0; jx < 2; ++jx) {
+        float s = 0.f;
+#pragma unroll
+        for (int jy = 0; jy < 2; ++jy) s = fmaf(WINO2_G[al][jy], g[q][jy][jx], s);
+        t[q][jx] = s;
+      }
+#pragma unroll
+    for (int be = 0; be < 5; ++be) {
+      f32x4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float s = 0.f;
+#pragma unroll
+        for (int jx = 0; jx < 2; ++jx) s = fmaf(WINO2_G[be][jx], t[q][jx], s);
+        v[q] = s;
+      }
+      *reinterpret_cast<f32x4*>(o + (size_t)(al * 5 + be) * plane) = v;
+    }
+  }
+}
+
 __global__ void pack_wino_s2_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out, int co,
                                           int ci, int ci_ld, int co_ld, long long total) {
   const float sc = scale ? *scale : 1.f;
@@ -311,12 +366,16 @@ __global__ void pack_multi_kernel(const long long* __restrict__ table, int n, lo
       const unsigned unit = (run / 36u) * 256u + (L & 255u);
       if (run % 36u == 0 && unit < units) wino_pack4<3>(w, out, co, ci, ld, kind == 7, unit);
       continue;
-    } else if (kind == 8) {                   // F(4 x 4, 2 x 2) panel of a stride-2 4 x 4 layer (forward)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = wino_s2_elem(w, co, ci, ld, e + j);
-    } else if (kind == 9) {                   // ... and its transposed panel (the adjoint input gradient); row: ld = co_ld, kh = ci_ld
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = wino_s2_dgrad_elem(w, co, ci, kh, ld, e + j);
+    } else if (kind == 8 || kind == 9) {
+      // F(4 x 4, 2 x 2) panel of a stride-2 4 x 4 layer (8: forward, row ld = ci_ld) and its transposed panel (9: the adjoint
+      // input gradient; row: ld = co_ld, kh = ci_ld): runs of 256 items as for kinds 4 / 5, 25 classes per unit
+      const unsigned L = e >> 2, run = L >> 8;
+      const int ci_ld = kind == 9 ? kh : ld, co_ld = kind == 9 ? ld : 0;
+      const unsigned units = (kind == 9 ? (unsigned)(round_up_d(4 * ci_ld, 16) * round_up_d(co_ld, BK))
+                                        : (unsigned)(round_up_d(co, 16) * round_up_d(4 * ci_ld, BK))) >> 2;
+      const unsigned unit = (run / 25u) * 256u + (L & 255u);
+      if (run % 25u == 0 && unit < units) wino_s2_pack4(w, out, co, ci, ci_ld, co_ld, kind == 9, unit);
+      continue;
     } else if (kind == 0) {
       const unsigned Kpad = (unsigned)round_up_d(kh * kw * ld, BK);
       const int k = (int)(e % Kpad), o = (int)(e / Kpad);

@@ -246,6 +246,21 @@ NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls, int prec) {
       if (eff > best_eff * 1.02) { best_eff = eff; pl.bpix = bp; pl.ksplit = ks; }
     }
   }
+  // Round 6 (measured with tools/probes/r6_plans.sh): un-split 32 x 64 tiles over the full K for layers with
+  // more than 64 filter rows.  On the generator's 3 x 3 layers (K = 936 ... 3 744) they LOSE to the split plan - 95 vs 59 us on
+  // 416 -> 416 at 4 x 4 patches, even at 208 -> 208 - because one workgroup per CU runs its K loop latency-bound and 96 operand
+  // rows per 2 048 outputs ask the L2 for ~14 TB/s; where the K loop is SHORT (<= 512: the 1 x 1 shortcuts, which cannot split)
+  // the wide tile leaves 36 / 72 workgroups on 256 CUs and the narrow one wins: 25.8 -> 16.5 us and 18.6 -> 13.1 us forward,
+  // 15.3 -> 11.9 and 12.2 -> 10.0 us input gradient.
+  if (co_rows > 64 && Kpad <= 512 && ncls <= 4) {        // (ncls > 4: the Winograd GEMMs' uniform classes keep their plan)
+    const int64_t b112 = ((M + 63) / 64) * nco * ncls, b32 = ((M + 63) / 64) * ((co_rows + 31) / 32) * ncls;
+    if (b112 < 256 && b32 > b112) { pl.bco = 32; pl.bpix = 64; pl.ksplit = 1; }
+  }
+  {   // EXPERIMENT (round 6, removed once the plans are settled): ITG_X_NT="bco,bpix,ks" for layers with >= 100 filter rows
+    static const char* x = getenv("ITG_X_NT");
+    int a, b, c;
+    if (x && co_rows >= 100 && co_rows <= 420 && sscanf(x, "%d,%d,%d", &a, &b, &c) == 3) { pl.bco = a; pl.bpix = b; pl.ksplit = c; }
+  }
   pl.kchunks = (nk + pl.ksplit - 1) / pl.ksplit;
   pl.ksplit = (nk + pl.kchunks - 1) / pl.kchunks;
   pl.ws_floats = pl.ksplit > 1 ? (int64_t)pl.ksplit * M * co_rows * ncls : 0;

@@ -1159,6 +1159,13 @@ TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec, int ncls) {
   int max_splits = (t.nchunks + 7) / 8;             // at least 8 chunks per split
   int splits = want < max_splits ? want : max_splits;
   if (splits < 1) splits = 1;
+  {   // EXPERIMENT (round 6): ITG_X_TN="bcol,bco,splits" for layers with >= 100 filter rows
+    static const char* x = getenv("ITG_X_TN");
+    int a, b, c;
+    if (x && t.co_rows >= 100 && t.co_rows <= 420 && sscanf(x, "%d,%d,%d", &a, &b, &c) == 3) {
+      t.bcol = a; t.bco = b; splits = c < max_splits ? c : max_splits;
+    }
+  }
   t.chunks_per_split = (t.nchunks + splits - 1) / splits;
   t.splits = (t.nchunks + t.chunks_per_split - 1) / t.chunks_per_split;
   t.slab_floats = (int64_t)t.splits * ncls * t.co_rows * t.Kpad;

@@ -51,6 +51,14 @@ EXTRA = [
     ("X up2 b6c1 26->13 P64", 8, (3, 3), 64, 26, 13, 3, 1, 1, "rep-up2"),
     ("X up2 b5c1 52->26 P32", 8, (3, 3), 32, 52, 26, 3, 1, 1, "rep-up2"),
     ("X up2 b4c1 104->52 P16", 8, (3, 3), 16, 104, 52, 3, 1, 1, "rep-up2"),
+    # the generator's wide layers as the step runs them (round 6: un-split plan experiments; filter "XW")
+    ("XW b1c 416->416 P4", 8, (3, 3), 4, 416, 416, 3, 1, 1, "rep"),
+    ("XW b2c1 up2 416->208 P4", 8, (3, 3), 4, 416, 208, 3, 1, 1, "rep-up2"),
+    ("XW b2c2 208->208 P8", 8, (3, 3), 8, 208, 208, 3, 1, 1, "rep"),
+    ("XW b2sc 1x1 416->208 P4", 8, (3, 3), 4, 416, 208, 1, 1, 0, "zero"),
+    ("XW b3c1 up2 208->104 P8", 8, (3, 3), 8, 208, 104, 3, 1, 1, "rep-up2"),
+    ("XW b3c2 104->104 P16", 8, (3, 3), 16, 104, 104, 3, 1, 1, "rep"),
+    ("XW b3sc 1x1 208->104 P8", 8, (3, 3), 8, 208, 104, 1, 1, 0, "zero"),
 ]
 
 
@@ -92,7 +100,7 @@ def main():
         b = torch.zeros(co, device=dev)
         up2 = mode.endswith("-up2")
         pm = ops.PAD_REPLICATE if mode.startswith("rep") else ops.PAD_ZERO
-        og = (gh, gw) if k == 3 else (1, 1)
+        og = (gh, gw) if k in (1, 3) else (1, 1)
         gx = ops.GT(x.requires_grad_(True), ci)
         wq = w.requires_grad_(True)
         y = ops.conv(gx, wq, b, k, k, s, pad, pm, out_grid=og, up2=up2)
