@@ -3,8 +3,8 @@
 // total thread count is a multiple of ld/4, so a thread's channel group - and therefore its
 // alpha/beta/mean/rstd registers - is fixed for the whole sweep; every thread keeps four 16-byte loads in flight.
 // Per-channel sums are kept in fp64.  Round 4 (2.6 TB/s, 38 % LDS bank conflicts, 1.1 waves/SIMD):
-// the reductions run in 1024-thread workgroups, one or two per CU (a quarter of the global fp64 atomics of round 3's 256-thread
-// groups: every workgroup ends with one atomic per channel onto the SAME 2*ld doubles, which serialise in L2), thread partials
+// the reductions ended with one atomic per channel and workgroup onto the SAME 2*ld doubles, which serialise in L2 - few, wide
+// workgroups (round 4: 128 x 1 024 threads; round 6: 512 x 256, see plan_reduce - what counts is the step, not the kernel alone), thread partials
 // go wave butterfly (when ld/4 divides 64) -> plain LDS stores -> a fixed-order sum by the thread that owns the channel (no
 // ds_add_f64 scatter: 2 048 same-address LDS atomics per group at ld = 16 before), LDS is sized by ld instead of 32 KB flat;
 // the apply kernels derive the affine coefficients once per workgroup in LDS (before: two fp64 divisions and a square root
@@ -30,11 +30,15 @@ inline int sweep_blocks(int64_t total_f4, int q4, int per_thread, int cap) {
   return (int)b;
 }
 
-// Reductions: at most 128 workgroups, of 1024 threads once the tensor gives each of them >= `per_thread`
-// float4 per thread, of 256 threads below that.  Every workgroup ends with one fp64 atomic per channel onto the SAME 2 * ld
-// doubles, and those serialise at ~13 ns per workgroup (measured on the 75 MB tensor, rocprofv3: bn_stats 15.4 / 18.2 / 22.4 /
-// 23.8 us with 128 / 256 / 512 / 1024 workgroups against 14.8 / 15.7 / 15.6 / 17.0 us with the atomics compiled out;
-// tools/probes/bn_prof2.sh) - 128 x 1024 threads with four 16-byte loads in flight each already stream at 4.9 TB/s.
+// Reductions: at most 512 workgroups of 256 threads.  Every workgroup ends with one fp64 atomic per channel onto the SAME
+// 2 * ld doubles, and those serialise at ~13 ns per workgroup; ALONE on the chip, 128 workgroups of 1 024 threads were therefore
+// the fastest form (round 4, rocprofv3 on the 75 MB tensor: bn_stats 15.4 / 18.2 / 22.4 / 23.8 us with 128 / 256 / 512 / 1 024
+// workgroups against 14.8 - 17.0 us with the atomics compiled out).  Round 6: INSIDE the train step these kernels sit on the
+// latency-bound generator chain while weight-gradient kernels on the side streams keep three 168-register workgroups resident
+// on every CU - a 16-wave workgroup then waits until two of them have retired on one CU (kernel trace of the replayed step:
+// bn_bwd_reduce 81 - 118 us on the 128^2 layers where it takes 30 us alone, 35 - 52 us where it takes 10), a 4-wave workgroup
+// takes the first slot that frees.  256 threads everywhere, A/B on one box (tools/probes/multi_ab.sh, medians of 3 x 60 steps):
+// cap 128 / 256 / 512 / 1 024 / 2 048 workgroups = 0.999 / 1.002 / 1.010 / 1.000 / 0.994 of the 1 024-thread form; twice.
 struct RedPlan { int nt, blocks; size_t lds; };
 inline int sweep_blocks_nt(int64_t total_f4, int q4, int per_thread, int cap, int nt) {
   int g0 = q4 / gcd_i(nt, q4);
@@ -44,9 +48,9 @@ inline int sweep_blocks_nt(int64_t total_f4, int q4, int per_thread, int cap, in
   return (int)((want + g0 - 1) / g0 * g0);
 }
 inline RedPlan plan_reduce(int64_t total_f4, int q4, int per_thread) {
-  constexpr int cap = 128;
+  constexpr int cap = 512;
   RedPlan r;
-  r.nt = total_f4 >= (int64_t)cap * 1024 * per_thread ? 1024 : 256;
+  r.nt = 256;
   r.blocks = sweep_blocks_nt(total_f4, q4, per_thread, cap, r.nt);
   r.lds = (size_t)8 * r.nt * sizeof(double);
   return r;
@@ -456,11 +460,7 @@ int itg_bn_stats(const itg_tensor* x, double* sums, void* stream) {
   int64_t npix = grid_pixels(x);
   int q4 = x->ld >> 2;
   const RedPlan rp = plan_reduce(npix * q4, q4, 8);
-  if (rp.nt == 1024)
-    hipLaunchKernelGGL(bn_stats_kernel<1024>, dim3(rp.blocks), dim3(1024), rp.lds, (hipStream_t)stream, (const float*)x->ptr, npix,
-                       x->ld, sums);
-  else
-    hipLaunchKernelGGL(bn_stats_kernel<256>, dim3(rp.blocks), dim3(256), rp.lds, (hipStream_t)stream, (const float*)x->ptr, npix,
+  hipLaunchKernelGGL(bn_stats_kernel<256>, dim3(rp.blocks), dim3(256), rp.lds, (hipStream_t)stream, (const float*)x->ptr, npix,
                        x->ld, sums);
   ITG_CHECK_LAUNCH();
   return ITG_OK;
@@ -554,8 +554,7 @@ int itg_bn_bwd_reduce(const itg_tensor* x, const itg_tensor* dy, const float* ab
 #define ITG_BWD_RED(U, N)                                                                                              \
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<U, N>), dim3(rp.blocks), dim3(N), rp.lds, (hipStream_t)stream,               \
                      (const float*)x->ptr, (const float*)dy->ptr, ab, mean_rstd, npix, x->ld, x->ph, x->pw, act, slope, sums)
-  if (rp.nt == 1024) { if (ups == BN_PADROWS) ITG_BWD_RED(BN_PADROWS, 1024); else if (ups) ITG_BWD_RED(1, 1024); else ITG_BWD_RED(0, 1024); }
-  else { if (ups == BN_PADROWS) ITG_BWD_RED(BN_PADROWS, 256); else if (ups) ITG_BWD_RED(1, 256); else ITG_BWD_RED(0, 256); }
+  if (ups == BN_PADROWS) ITG_BWD_RED(BN_PADROWS, 256); else if (ups) ITG_BWD_RED(1, 256); else ITG_BWD_RED(0, 256);
 #undef ITG_BWD_RED
   ITG_CHECK_LAUNCH();
   return ITG_OK;

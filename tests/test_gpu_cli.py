@@ -272,3 +272,45 @@ def test_sample_cli_on_two_ranks_row_sharded_and_replica_mode(tmp_path):
     finally:
         del os.environ["ITG_SAMPLE_SEED"]
     assert np.abs(np.asarray(Image.open(d / "att_one.png")).astype(int) - r0).max() <= 1      # rank 0's replica = the seed-11 image
+
+
+def _bench_two_ranks(workload, extra=()):
+    """`python bench.py --gpus 2 --workload ...` as the driver starts it on a multi-GPU node, rehearsed on ONE GPU: the parent
+    spawns the two ranks itself (bench.relaunch -> torch.distributed.run, never an exec from a GPU process), both ranks use device
+    0 (ITG_FORCE_DEVICE) and the collectives run over gloo (RCCL refuses two ranks on one device)."""
+    import json
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ITG_DIST_BACKEND="gloo", ITG_FORCE_DEVICE="0", PYTHONPATH=ROOT)
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-membound", "--no-direct", "--workload", workload] + list(extra)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]            # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["config1", "config4", "config5"])
+def test_bench_two_rank_launch_prints_one_line_with_both_ranks(workload):
+    """the driver's first multi-GPU run of bench.py must not fail on plumbing.  Two ranks of every sharded
+    workload - config 1 (data parallel, gradient all-reduce), config 4 (patch rows of ONE batch, halo rows + band gather +
+    gradient all-reduce), config 5 (inference bands, halo rows + strip gather) - run to the JSON line: n_gpus 2, ranks 2, the
+    partitioning named, finite losses / a finite rate."""
+    import math
+    out = _bench_two_ranks(workload, ("--out", "768") if workload == "config5" else ())
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1
+    assert out["config"].get("ranks") == 2 and out["config"].get("backend") == "gloo", out["config"]
+    assert math.isfinite(out["value"]) and out["value"] > 0 and out["ms_per_step"] > 0
+    par = out["config"]["parallelism"]
+    if workload == "config1":
+        assert out["scaling"] == "weak" and par.startswith("dp2") and out["config"]["global_batch"] == 16
+    else:
+        assert out["scaling"] == "strong" and "patch rows over 2 rank" in par, par
+    if workload == "config5":
+        assert out["config"]["finite"] is True
+    else:
+        assert len(out["config"]["last_losses"]) == 3 and all(math.isfinite(v) for v in out["config"]["last_losses"])
