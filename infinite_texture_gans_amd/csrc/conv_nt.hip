@@ -256,11 +256,6 @@ NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls, int prec) {
     const int64_t b112 = ((M + 63) / 64) * nco * ncls, b32 = ((M + 63) / 64) * ((co_rows + 31) / 32) * ncls;
     if (b112 < 256 && b32 > b112) { pl.bco = 32; pl.bpix = 64; pl.ksplit = 1; }
   }
-  {   // EXPERIMENT (round 6, removed once the plans are settled): ITG_X_NT="bco,bpix,ks" for layers with >= 100 filter rows
-    static const char* x = getenv("ITG_X_NT");
-    int a, b, c;
-    if (x && co_rows >= 100 && co_rows <= 420 && sscanf(x, "%d,%d,%d", &a, &b, &c) == 3) { pl.bco = a; pl.bpix = b; pl.ksplit = c; }
-  }
   pl.kchunks = (nk + pl.ksplit - 1) / pl.ksplit;
   pl.ksplit = (nk + pl.kchunks - 1) / pl.kchunks;
   pl.ws_floats = pl.ksplit > 1 ? (int64_t)pl.ksplit * M * co_rows * ncls : 0;

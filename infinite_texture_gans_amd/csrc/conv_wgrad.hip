@@ -1154,19 +1154,11 @@ TnPlan plan_tn(int64_t M, int co_ld, int Ktot, int prec, int ncls) {
   t.nchunks = (int)((M + kp - 1) / kp);
   // workgroup target: ~3 per CU; with bf16 operands a split's MFMA work is a quarter as long and the slab round trip
   // weighs more: 2 per CU (config 3: 1996 -> 2026 crops/s; config 1 loses 1 % with it)
-  static const int x_blocks = env_int("ITG_X_TN_BLOCKS", 0);   // EXPERIMENT (round 6)
-  const int want_blocks = x_blocks ? x_blocks : prec == ITG_PREC_BF16 ? 512 : 768;        // (384 / 512 / 1024 with fp32 operands: -3.8 / -0.8 / -1.1 %)
+  const int want_blocks = prec == ITG_PREC_BF16 ? 512 : 768;        // (384 / 512 / 640 / 1024 / 1152 / 1536 with fp32 operands: -3.8 / +0.2 / 0.0 / -1.1 / -1.0 / -1.1 %)
   int want = (want_blocks / ncls + tiles - 1) / tiles;      // ncls grids of (tiles x splits) workgroups run as one launch
   int max_splits = (t.nchunks + 7) / 8;             // at least 8 chunks per split
   int splits = want < max_splits ? want : max_splits;
   if (splits < 1) splits = 1;
-  {   // EXPERIMENT (round 6): ITG_X_TN="bcol,bco,splits" for layers with >= 100 filter rows
-    static const char* x = getenv("ITG_X_TN");
-    int a, b, c;
-    if (x && t.co_rows >= 100 && t.co_rows <= 420 && sscanf(x, "%d,%d,%d", &a, &b, &c) == 3) {
-      t.bcol = a; t.bco = b; splits = c < max_splits ? c : max_splits;
-    }
-  }
   t.chunks_per_split = (t.nchunks + splits - 1) / splits;
   t.splits = (t.nchunks + t.chunks_per_split - 1) / t.chunks_per_split;
   t.slab_floats = (int64_t)t.splits * ncls * t.co_rows * t.Kpad;

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 6: un-split / small-tile plans for the generator's wide layers.  conv_bench "XW" under the
+# Round 6: un-split / small-tile plans for the generator's wide layers.  The two planner overrides it sets were
+# experiment knobs (removed once the numbers were in DESIGN section 3): kept as the record of what was swept.
 # experimental planner overrides ITG_X_NT="bco,bpix,ks" (forward / input gradient) and ITG_X_TN="bcol,bco,splits" (weight gradient).
 out=${1:-gpurun_out/r6_plans.log}
 : > $out
