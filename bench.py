@@ -155,7 +155,12 @@ def gpu_leg(a):
         ops.PROFILE = []
     if hasattr(tr, "set_overlap"):
         tr.set_overlap(False)      # kernels timed one at a time: concurrent streams would stretch each other's events
-    tr.step(reals[0], zs[-1])
+    from infinite_texture_gans_amd import _lib as _itg_lib
+    _itg_lib.BYTE_LOG = {"bytes": 0, "calls": 0}      # algorithmic HBM bytes of this iteration (every tensor a launch is handed, once)
+    try:
+        tr.step(reals[0], zs[-1])
+    finally:
+        byte_log, _itg_lib.BYTE_LOG = _itg_lib.BYTE_LOG, None
     torch.cuda.synchronize()
     if rank == 0:
         agg = {}
@@ -202,6 +207,10 @@ def gpu_leg(a):
                 # the same step priced at the REFERENCE algorithm's flop count (direct convolutions, materialised upsample): what a
                 # direct implementation would have to sustain to match this step time - an equivalence figure, not a utilisation
                 "step_reference_equivalent_tflops": round(nec_gf / (dt / a.steps) / 1e3, 1),
+                # the whole iteration against BOTH rooflines, and which one (if any) binds it: algorithmic HBM
+                # bytes = every tensor a launch is handed, counted once per launch (operands read once, results written once;
+                # Winograd / split-K / slab workspaces are the implementation's traffic, not counted), flat buffers by element count
+                "step_hbm": _step_hbm(byte_log, dt / a.steps, sum(x[1] for x in agg.values()) / (dt / a.steps) / 1e12 / peak_tf),
                 "algorithms": _algorithms_note(),
                 "direct_algorithm": direct,
                 "traffic_source": traffic_note,
@@ -211,6 +220,22 @@ def gpu_leg(a):
         dist.barrier()
     _PAR[0] = exchange_desc(tr)
     return rank, world, dt, args, losses, roof
+
+
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def _step_hbm(byte_log, step_s, mfma_frac):
+    """Algorithmic HBM bytes of one iteration / step time against 8 TB/s, beside the MFMA fraction of the same iteration, and the
+    bound they name: `mfma` / `hbm` when the larger fraction is at least 0.25, else `launch` - the step is a chain of short
+    dependent launches (average below) and neither the matrix pipe nor the memory system is what it waits for."""
+    b, calls = byte_log["bytes"], byte_log["calls"]
+    gbps = b / step_s / 1e9
+    fh = gbps / HBM_PEAK_GBPS
+    bound = "launch" if max(fh, mfma_frac) < 0.25 else ("hbm" if fh > mfma_frac else "mfma")
+    return {"algorithmic_bytes_per_step": int(b), "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(fh, 4), "mfma_frac_same_step": round(mfma_frac, 4), "bound": bound,
+            "abi_calls_per_step": calls, "avg_us_per_call": round(step_s / max(calls, 1) * 1e6, 2)}
 
 
 def direct_leg(a, args, dev, reals, zs, use_graph):
@@ -458,33 +483,91 @@ def membound_leg(dev):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters * 1e-3
 
-    def row(name, nbytes, t):
-        rows.append({"op": name, "mbytes": round(nbytes / 1e6, 1), "us": round(t * 1e6, 1), "gbps": round(nbytes / t / 1e9, 1),
-                     "frac_of_8tbps": round(nbytes / t / 8e12, 3)})
+    def row(name, nbytes, t, t_cold=None):
+        r = {"op": name, "mbytes": round(nbytes / 1e6, 1), "us": round(t * 1e6, 1), "gbps": round(nbytes / t / 1e9, 1),
+             "frac_of_8tbps": round(nbytes / t / 8e12, 3)}
+        if t_cold is not None:
+            # the same launches rotating over enough tensor sets that the replay's working set exceeds 600 MB - past the 256 MB
+            # Infinity Cache, so every byte comes from / goes to HBM (the figure above re-reads a 75-377 MB
+            # set that the cache partly holds)
+            r.update(us_hbm=round(t_cold * 1e6, 1), gbps_hbm=round(nbytes / t_cold / 1e9, 1), frac_of_8tbps_hbm=round(nbytes / t_cold / 8e12, 3))
+        rows.append(r)
+
+    def timeit_sets(make, nbytes_set, iters=10):
+        """timeit over K = ceil(600 MB / set) (+1) independent tensor sets, call i on set i % K."""
+        k = max(2, int(600e6 // max(nbytes_set, 1)) + 2)
+        fns = [make() for _ in range(min(k, iters))]
+        calls = iter(range(1 << 30))
+        return timeit(lambda: fns[next(calls) % len(fns)](), iters=iters)
 
     for c, p in ((26, 128), (104, 32)):
         g = ops.GT(torch.randn(8, 3, 3, p, p, ops.ld_for(c), device=dev), c)
-        row("LocalPadder halo gather C=%d P=%d" % (c, p), 4 * 72 * g.ld * (p * p + (p + 2) ** 2),
-            timeit(lambda: ops.local_pad_grid(g, ops.PAD_REPLICATE)))
+        nb = 4 * 72 * g.ld * (p * p + (p + 2) ** 2)
+
+        def mk_pad(c=c, p=p):
+            gi = ops.GT(torch.randn(8, 3, 3, p, p, ops.ld_for(c), device=dev), c)
+            return lambda: ops.local_pad_grid(gi, ops.PAD_REPLICATE)
+        row("LocalPadder halo gather C=%d P=%d" % (c, p), nb, timeit(lambda: ops.local_pad_grid(g, ops.PAD_REPLICATE)), timeit_sets(mk_pad, nb))
     c, p = 13, 128
     xg = ops.GT(torch.randn(8, 3, 3, p, p, ops.ld_for(c), device=dev), c)
     numel = xg.t.numel()
     gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
     rm, rv, nbt = torch.zeros(c, device=dev), torch.ones(c, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
+
+    def mk_bn_f():
+        xi = ops.GT(torch.randn(8, 3, 3, p, p, ops.ld_for(c), device=dev), c)
+        return lambda: ops.bn_act(xi, gamma, beta, rm, rv, nbt, True, 1e-5, 0.1, ops.ACT_LRELU, 0.02, False)
+
+    def mk_bn_fb():
+        xi = torch.randn(8, 3, 3, p, p, ops.ld_for(c), device=dev).requires_grad_(True)
+        gi, bi = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        di = torch.randn_like(xi)
+        return lambda: torch.autograd.grad(ops.bn_act(ops.GT(xi, c), gi, bi, rm, rv, nbt, True, 1e-5, 0.1, ops.ACT_LRELU, 0.02, False).t,
+                                           (xi, gi, bi), di)
     # backward: forward + backward recorded together (a backward alone would run on an autograd graph built outside the capture,
     # whose stale default-stream AccumulateGrad nodes break hipStreamEndCapture - DESIGN section 3), the forward's time subtracted
-    t_f = timeit(lambda: ops.bn_act(xg, gamma, beta, rm, rv, nbt, True, 1e-5, 0.1, ops.ACT_LRELU, 0.02, False))
-    row("BatchNorm train fwd + LeakyReLU C=13 P=128", 4 * numel * 3, t_f)
-    xr = xg.t.clone().requires_grad_(True)
-    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
-    dy = torch.randn_like(xg.t)
-    t_fb = timeit(lambda: torch.autograd.grad(ops.bn_act(ops.GT(xr, c), gr, br, rm, rv, nbt, True, 1e-5, 0.1, ops.ACT_LRELU, 0.02, False).t,
-                                              (xr, gr, br), dy))
-    row("BatchNorm train bwd C=13 P=128", 4 * numel * 5, t_fb - t_f)
-    row("LeakyReLU C=13 P=128", 8 * numel, timeit(lambda: ops.act(xg, ops.ACT_LRELU, 0.2)))
-    xs = ops.GT(torch.randn(8, 3, 3, 64, 64, 28, device=dev), 26)
-    row("nearest x2 upsample C=26 P=64", 4 * xs.t.numel() * 5, timeit(lambda: ops.upsample2x(xs)))
+    t_f = timeit(mk_bn_f())
+    t_f_cold = timeit_sets(mk_bn_f, 4 * numel * 2)
+    row("BatchNorm train fwd + LeakyReLU C=13 P=128", 4 * numel * 3, t_f, t_f_cold)
+    t_fb = timeit(mk_bn_fb())
+    t_fb_cold = timeit_sets(mk_bn_fb, 4 * numel * 4)
+    row("BatchNorm train bwd C=13 P=128", 4 * numel * 5, t_fb - t_f, t_fb_cold - t_f_cold)
+
+    def mk_act():
+        xi = ops.GT(torch.randn(8, 3, 3, p, p, ops.ld_for(c), device=dev), c)
+        return lambda: ops.act(xi, ops.ACT_LRELU, 0.2)
+    row("LeakyReLU C=13 P=128", 8 * numel, timeit(mk_act()), timeit_sets(mk_act, 8 * numel))
+
+    def mk_ups():
+        xi = ops.GT(torch.randn(8, 3, 3, 64, 64, 28, device=dev), 26)
+        return lambda: ops.upsample2x(xi)
+    nu = 4 * 8 * 9 * 64 * 64 * 28 * 5
+    row("nearest x2 upsample C=26 P=64", nu, timeit(mk_ups()), timeit_sets(mk_ups, nu))
+    # ... and the normalisation kernels' HBM-side rates INSIDE the train step, from the committed rocprofv3 passes of this build:
+    # (FETCH_SIZE + WRITE_SIZE per launch) / the kernel's average duration in the un-overlapped step
+    rows.extend(_rocprof_membound())
     return rows
+
+
+def _rocprof_membound():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic.json")))
+    if not files:
+        return []
+    try:
+        js = json.load(open(files[-1]))
+        meta = js.get("_meta", {})
+        if meta.get("kernel_source_sha16") != kernel_source_hash():
+            return [{"op": "rocprof rows withheld", "note": "profiles/%s was measured on other kernel sources" % os.path.basename(files[-1])}]
+        out = []
+        for k, v in js.items():
+            if k.startswith(("bn_", "local_pad", "act_", "upsample_")) and "hbm_gbps" in v and v.get("fetch_bytes", 0) + v.get("write_bytes", 0) > 20e6:
+                out.append({"op": "rocprof: " + k, "mbytes": round((v["fetch_bytes"] + v["write_bytes"]) / 1e6, 1), "us": v["avg_us"],
+                            "gbps_hbm": v["hbm_gbps"], "frac_of_8tbps_hbm": round(v["hbm_gbps"] / 8000.0, 3), "launches": v["launches"],
+                            "source": "profiles/%s: HBM counters / kernel time, averaged over the launches of one train step" % os.path.basename(files[-1])})
+        return out
+    except Exception as e:      # noqa: BLE001
+        return [{"op": "rocprof rows unreadable", "note": str(e)}]
 
 
 def relaunch(n):

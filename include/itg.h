@@ -49,6 +49,24 @@ typedef struct {
 enum { ITG_PAD_ZERO = 0, ITG_PAD_REPLICATE = 1 };
 enum { ITG_ACT_NONE = 0, ITG_ACT_LRELU = 1, ITG_ACT_TANH = 2 };
 
+/* Round 6: the generator's backward chain is latency-bound: conv input gradient (+ split-K second stage) -> itg_bn_bwd_reduce ->
+ * itg_bn_bwd_apply -> next input gradient (reference models/layers.py:301-322 run backwards).  When the input gradient of the conv
+ * that consumed y = act(BatchNorm(x)) runs with a split-K second stage, that stage already sweeps dx once: it then also
+ * accumulates the BatchNorm's backward sums  sums[c] += dy'  and  sums[ld + c] += dy' * xhat  with  dy' = dx * act'(a x + b),
+ * xhat = (x - mean) * rstd  - exactly what itg_bn_bwd_reduce would compute from (x, dx) in a launch of its own (a replicate-padded
+ * layer's frame gradients count with the border pixel they fold onto: the sums are linear in dx).  `taken` tells the caller
+ * whether it happened; if not (another kernel family ran the layer, ld > 512) the caller launches itg_bn_bwd_reduce as before. */
+typedef struct itg_bn_bwd_fuse {
+  const itg_tensor* x;       /* the BatchNorm's input: dx's shape */
+  const float* ab;           /* 2 * ld floats: y = act(a x + b), as itg_bn_finalize(_apply) left them */
+  const float* mean_rstd;    /* 2 * ld floats */
+  int32_t act;               /* ITG_ACT_* of the BatchNorm's fused activation */
+  float slope;
+  double* sums;              /* 2 * ld doubles, zeroed by the caller, accumulated into */
+  int32_t taken;             /* OUT, written on the host before the call returns: 1 = the sums are (being) accumulated on `stream` */
+  int32_t reserved;          /* 0 */
+} itg_bn_bwd_fuse;
+
 typedef struct {
   int32_t kh, kw, stride, pad;
   int32_t pad_mode; /* ITG_PAD_*: how reads outside the merged image resolve */
@@ -66,8 +84,9 @@ typedef struct {
                       * output pixel), ACCUMULATED into by the conv's epilogue - the BatchNorm statistics of the
                       * layer that consumes this output (nn.BatchNorm2d after every generator conv, reference
                       * models/layers.py:279-280,301-322) without a second pass over the tensor (out.ld <= 512) */
-  const void* reserved_ptr;   /* NULL (rounds 3-4: an input transform - BatchNorm-apply inside the conv's tile loader - that was
-                               * measured slower in every configuration and removed; the slot keeps the struct layout) */
+  struct itg_bn_bwd_fuse* bn_bwd; /* itg_conv2d_dgrad only, or NULL (every other entry point requires NULL): the BatchNorm whose OUTPUT
+                               * this conv read - see itg_bn_bwd_fuse below.  (Rounds 3-4 kept an input transform in this slot:
+                               * BatchNorm-apply inside the conv's tile loader, measured slower and removed.) */
   int32_t flags;     /* ITG_GEOM_*; zero-initialise the struct */
   int32_t reserved;  /* 0 */
   const float* wino_v; /* itg_conv2d_wgrad / itg_conv2d_wgrad_slabs of an ITG_GEOM_WINO layer only, or NULL: the transformed

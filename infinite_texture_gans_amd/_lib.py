@@ -21,15 +21,22 @@ class Tensor(C.Structure):
 PREC_F32, PREC_BF16 = 0, 1      # itg.h ITG_PREC_*
 
 
+class BnBwdFuse(C.Structure):
+    """itg_bn_bwd_fuse: the BatchNorm in front of a conv, handed to the conv's input gradient (itg.h)."""
+    _fields_ = [("x", C.POINTER(Tensor)), ("ab", C.c_void_p), ("mean_rstd", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float),
+                ("sums", C.c_void_p), ("taken", C.c_int32), ("reserved", C.c_int32)]
+
+
 class ConvGeom(C.Structure):
     _fields_ = [("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("pad_mode", C.c_int32), ("pad_h", C.c_int32), ("precision", C.c_int32), ("up2", C.c_int32),
-                ("out_stats", C.c_void_p), ("reserved_ptr", C.c_void_p), ("flags", C.c_int32), ("reserved", C.c_int32),
+                ("out_stats", C.c_void_p), ("bn_bwd", C.POINTER(BnBwdFuse)), ("flags", C.c_int32), ("reserved", C.c_int32),
                 ("wino_v", C.c_void_p)]
 
-    def __init__(self, kh, kw, stride, pad, pad_mode, pad_h=-1, precision=0, out_stats=None, _reserved=None, up2=0, flags=0,
+    def __init__(self, kh, kw, stride, pad, pad_mode, pad_h=-1, precision=0, out_stats=None, bn_bwd=None, up2=0, flags=0,
                  wino_v=None):
-        super().__init__(kh, kw, stride, pad, pad_mode, pad_h, precision, int(up2), out_stats, None, int(flags), 0, wino_v)
+        super().__init__(kh, kw, stride, pad, pad_mode, pad_h, precision, int(up2), out_stats,
+                         C.pointer(bn_bwd) if bn_bwd is not None else None, int(flags), 0, wino_v)
 
 
 GEOM_FRAME_ZEROED = 1
@@ -169,8 +176,38 @@ def load():
 CAPTURE_LOG = None      # a set while an engine records a hipGraph: raw handles of the streams that received a launch (ops.capture_rule)
 
 
+BYTE_LOG = None         # {"bytes": 0, "calls": 0} while bench.py counts the algorithmic HBM bytes of a step (roofline.step_hbm)
+
+# entry points whose operands are raw pointers: (index of the element count, bytes moved per element)
+_PTR_BYTES = {"itg_adam_ema_step": (5, 7 * 4), "itg_axpby": (6, 3 * 4), "itg_dot": (2, 2 * 4), "itg_pack_multi": (2, 4),
+              "itg_bce_logits_fwd": (1, 4), "itg_bce_logits_bwd": (1, 2 * 4), "itg_hinge_fwd": (1, 4), "itg_hinge_bwd": (1, 2 * 4)}
+
+
+def _algorithmic_bytes(name, args):
+    """Bytes a launch must move at least: every itg_tensor it is handed once (operands read once, results written once - a
+    Winograd / split-K / slab workspace is NOT counted: that traffic is the implementation's), flat buffers by their count."""
+    n = 0
+    for a in args:
+        t = getattr(a, "_obj", None)
+        if isinstance(t, Tensor) and t.ptr:
+            n += 4 * t.n * t.gh * t.gw * t.ph * t.pw * t.ld
+    pb = _PTR_BYTES.get(name)
+    if pb is not None:
+        n += int(args[pb[0]]) * pb[1]
+    if name in ("itg_conv2d_fwd", "itg_conv2d_dgrad", "itg_conv2d_wgrad", "itg_conv2d_wgrad_slabs"):
+        # + the filter (panel read / gradient written once): kh * kw * ci * co floats; the first and last tensors are the two sides
+        ts = [a._obj for a in args if isinstance(getattr(a, "_obj", None), Tensor) and a._obj.ptr]
+        g = next((a._obj for a in args if isinstance(getattr(a, "_obj", None), ConvGeom)), None)
+        if g is not None and len(ts) >= 2:
+            n += 4 * g.kh * g.kw * ts[0].ld * ts[1 if name != "itg_conv2d_fwd" else -1].ld
+    return n
+
+
 def call(name, *args):
     """Invoke an int-returning entry point and raise on a non-zero status."""
+    if BYTE_LOG is not None:
+        BYTE_LOG["calls"] += 1
+        BYTE_LOG["bytes"] += _algorithmic_bytes(name, args)
     if CAPTURE_LOG is not None and args:
         st = args[-1]          # every launching entry point takes its stream last
         CAPTURE_LOG.add(getattr(st, "value", st) or 0)

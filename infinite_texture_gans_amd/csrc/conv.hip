@@ -634,6 +634,18 @@ inline int up2_check(const itg_conv_geom* g, const itg_tensor* lo, const itg_ten
 inline void clear_xf(ConvP& p) {
   p.ucls = 0; p.u_in = p.u_w = p.u_out = 0; p.u_acc = 0;
 }
+// itg_bn_bwd_fuse of an input gradient: validate and hand to the launch (dispatch_nt decides whether its second stage takes the sums)
+inline int set_bnb(ConvP& p, const itg_conv_geom* g, const itg_tensor* dx) {
+  itg_bn_bwd_fuse* f = g->bn_bwd;
+  if (!f) return ITG_OK;
+  f->taken = 0;
+  int rc;
+  if (!f->x || (rc = check_tensor(f->x))) return ITG_ERR_ARG;
+  if (!same_shape(f->x, dx) || !f->ab || !f->mean_rstd || !f->sums || (((uintptr_t)f->sums) & 7)) return ITG_ERR_ARG;
+  p.bnb_x = (const float*)f->x->ptr; p.bnb_ab = f->ab; p.bnb_mr = f->mean_rstd; p.bnb_sums = f->sums;
+  p.bnb_act = f->act; p.bnb_slope = f->slope;
+  return ITG_OK;
+}
 
 
 }  // namespace
@@ -834,7 +846,7 @@ int itg_conv2d_fwd(const itg_tensor* in, const float* w_packed, const float* bia
   int rc;
   if ((rc = check_tensor(in)) || (rc = check_tensor(out))) return rc;
   if (!w_packed || !g || g->kh <= 0 || g->kw <= 0 || g->stride <= 0 || g->pad < 0) return ITG_ERR_ARG;
-  if (g->reserved_ptr) return ITG_ERR_ARG;
+  if (g->bn_bwd) return ITG_ERR_ARG;
   if (wino_s2_geom(g)) {
     if (residual && residual->ptr) return ITG_ERR_ARG;
     if ((rc = wino_conv_s2(in, w_packed, bias, out_scale, out, act, slope, prec_of(g), workspace, workspace_floats, (hipStream_t)stream)))
@@ -973,6 +985,7 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
   if ((rc = check_tensor(dy)) || (rc = check_tensor(dx))) return rc;
   if (!w_packed_dgrad || !g) return ITG_ERR_ARG;
   if (dy->n != dx->n) return ITG_ERR_ARG;
+  if (g->bn_bwd) g->bn_bwd->taken = 0;       // the kernel families below that do not take the sums leave it at 0
   hipStream_t s = (hipStream_t)stream;
   if (wino_s2_geom(g)) {
     // the 4 x 4 stride-2 layer's input gradient as the ADJOINT of its F(4 x 4, 2 x 2) forward (conv_wino.hip): panel from
@@ -1026,7 +1039,8 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
     const int64_t M = (int64_t)dx->n * p.MT * p.MU;
     if (M >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
     p.M = (int)M;
-    return dispatch_nt(p, workspace, workspace_floats, s);
+    if (!p.res.p && (rc = set_bnb(p, g, dx))) return rc;
+    return dispatch_nt(p, workspace, workspace_floats, s, g->bn_bwd ? &g->bn_bwd->taken : nullptr);
   }
   if (thin_in_conv(dy, dx, g)) {
     const int Ho = dy->gh * dy->ph, Wo = dy->gw * dy->pw, H = dx->gh * dx->ph, W = dx->gw * dx->pw;
@@ -1067,7 +1081,6 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
   p.prec = prec_of(g);
   p.in = make_grid(dy);
   p.out = make_grid(dx);
-  if (g->reserved_ptr) return ITG_ERR_ARG;
   p.res = null_grid();
   p.res_mode = 0; p.res_slope = 0.f; p.res_ups = 0;
   if (act_out && act_out->ptr && act != ITG_ACT_NONE) {
@@ -1104,7 +1117,8 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
     int64_t M = (int64_t)dx->n * p.MT * p.MU;
     if (M >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
     p.M = (int)M;
-    return dispatch_nt(p, workspace, workspace_floats, s);
+    if (!p.res.p && (rc = set_bnb(p, g, dx))) return rc;
+    return dispatch_nt(p, workspace, workspace_floats, s, g->bn_bwd ? &g->bn_bwd->taken : nullptr);
   }
   if (g->stride != 2 || g->pad != 1 || padh != 1 || (g->kh & 1) || (g->kw & 1) || g->pad_mode != ITG_PAD_ZERO)
     return ITG_ERR_ARG;
@@ -1198,7 +1212,7 @@ static int wgrad_setup(const itg_tensor* x, const itg_tensor* dy, const itg_conv
     t_out = t; prec_out = prec;
     return ITG_OK;
   }
-  if (g->reserved_ptr) return ITG_ERR_ARG;
+  if (g->bn_bwd) return ITG_ERR_ARG;
   int Ho = conv_out_dim(p.x.H, g->kh, g->stride, pad_v(g)), Wo = conv_out_dim(p.x.W, g->kw, g->stride, g->pad);
   if (Ho != p.dy.H || Wo != p.dy.W) return ITG_ERR_ARG;
   if (g->pad_mode == ITG_PAD_REPLICATE && g->stride != 1) return ITG_ERR_ARG;

@@ -65,6 +65,14 @@ struct ConvP {
   int cMT[4], cMU[4], cM[4], cioy[4], ciox[4], cooy[4], coox[4];
   unsigned cwoff[4];   // float offset of the class's packed sub-kernel
   unsigned cpoff[4];   // float offset of the class's split-K slabs
+  // input gradients only (itg_bn_bwd_fuse, round 6): the split-K second stage also accumulates the backward sums of the BatchNorm
+  // whose output the conv read - bnb_x = that BatchNorm's input (p.out's shape), sums into bnb_sums[2][out.ld]
+  const float* bnb_x = nullptr;
+  const float* bnb_ab = nullptr;
+  const float* bnb_mr = nullptr;
+  double* bnb_sums = nullptr;
+  int bnb_act = 0;
+  float bnb_slope = 0.f;
 };
 
 // derivative of an activation expressed through its OUTPUT o (as itg_act_bwd does)
@@ -187,7 +195,7 @@ int wino_conv_s2_dgrad(const itg_tensor* dy, const float* ut_panel, const float*
                        int act, float slope, int prec, float* workspace, int64_t workspace_floats, hipStream_t s);
 // conv_nt.hip
 NtPlan plan_nt(int64_t M_total, int co_rows, int Kpad, int ncls = 1, int prec = ITG_PREC_F32);
-int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s);
+int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s, int* bnb_taken = nullptr);
 int launch_zero_border(const GridT& g, hipStream_t s);
 int launch_zero_frames(const itg_tensor* t, int n, hipStream_t s);
 // conv_nt_w64.hip

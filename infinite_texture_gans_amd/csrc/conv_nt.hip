@@ -42,7 +42,7 @@ __global__ void zero_border_kernel(GridT g) {
 // read-only - a modified copy of the struct would live in scratch memory)
 // one output element group (4 channels of pixel m of class cls): slab sum in a fixed order, epilogue, store; returns the values
 __device__ __forceinline__ f32x4 splitk_finish(const ConvP& p, const float* __restrict__ partial, int M, int MT, int MU, int ooy, int oox,
-                                               int m, int co) {
+                                               int m, int co, int* out_off = nullptr) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   {
     const float* q = partial + (size_t)m * p.co_rows + co;
@@ -69,6 +69,7 @@ __device__ __forceinline__ f32x4 splitk_finish(const ConvP& p, const float* __re
     oy = ty; ox = tx;
   }
   const int off = grid_off(p.out, n, oy, ox);
+  if (out_off) *out_off = off;
   if (p.bias) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -111,6 +112,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvP p) {
 // LDS by plain stores and a fixed-order sum, and a channel receives one global fp64 atomic per PIXEL RANGE (tens) instead of one
 // per workgroup of a channel-agnostic sweep (round 3: ~58 workgroups of 8 sequential elements per thread with ds_add_f64
 // scatter, 20 us per launch on the generator's 4 x 4 ... 16 x 16 layers); one pixel group per thread keeps the slab loads wide.
+// BNB (round 6, itg_bn_bwd_fuse): the launch is an INPUT gradient and the sums are the backward sums of the BatchNorm whose
+// output the conv read: s1 += dy', s2 += dy' * xhat with dy' = v * act'(a x + b), xhat = (x - mean) * rstd, x read at the pixel the
+// value lands on (a replicated frame's gradient at the border pixel it folds onto - the sums are linear in dx) - the arithmetic of
+// bn_bwd_reduce_kernel (norm.hip), whose launch the caller then skips.
+template <bool BNB>
 __global__ __launch_bounds__(256) void splitk_epilogue_stats_kernel(const ConvP p, int ngroups, int nranges) {
   __shared__ double lst[8][256];
   const int q4 = p.out.ld >> 2;
@@ -124,10 +130,32 @@ __global__ __launch_bounds__(256) void splitk_epilogue_stats_kernel(const ConvP 
   const int m0 = rng * per, m1 = min(M, m0 + per);
   double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   if (c4 < q4) {
-    for (int m = m0 + prow; m < m1; m += 16) {
-      const f32x4 v = splitk_finish(p, partial, M, MT, MU, ooy, oox, m, c4 * 4);
+    if constexpr (BNB) {
+      const int ld = p.out.ld;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p.bnb_ab + c4 * 4), b = *reinterpret_cast<const f32x4*>(p.bnb_ab + ld + c4 * 4);
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(p.bnb_mr + c4 * 4), rs = *reinterpret_cast<const f32x4*>(p.bnb_mr + ld + c4 * 4);
+      for (int m = m0 + prow; m < m1; m += 16) {
+        int off;
+        const f32x4 v = splitk_finish(p, partial, M, MT, MU, ooy, oox, m, c4 * 4, &off);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(p.bnb_x + off + c4 * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const double d = v[e]; s1[e] += d; s2[e] += d * d; }
+        for (int e = 0; e < 4; ++e) {
+          const float pre = fmaf(xv[e], a[e], b[e]);
+          float d1 = 1.f;
+          if (p.bnb_act == ITG_ACT_LRELU) d1 = pre > 0.f ? 1.f : p.bnb_slope;
+          else if (p.bnb_act == ITG_ACT_TANH) { const float t = tanhf(pre); d1 = 1.f - t * t; }
+          const float ge = v[e] * d1;
+          const float xh = (xv[e] - mu[e]) * rs[e];
+          s1[e] += (double)ge;
+          s2[e] += (double)ge * (double)xh;
+        }
+      }
+    } else {
+      for (int m = m0 + prow; m < m1; m += 16) {
+        const f32x4 v = splitk_finish(p, partial, M, MT, MU, ooy, oox, m, c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const double d = v[e]; s1[e] += d; s2[e] += d * d; }
+      }
     }
   }
 #pragma unroll
@@ -140,7 +168,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_stats_kernel(const ConvP 
       double t = 0.0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) t += lst[which * 4 + e][r * 16 + l];
-      atomicAdd(&p.stats[which * p.out.ld + ch], t);
+      atomicAdd(&(BNB ? p.bnb_sums : p.stats)[which * p.out.ld + ch], t);
     }
   }
 }
@@ -268,7 +296,7 @@ int stats_after(const ConvP& p, double* stats, hipStream_t s) {
   return itg_bn_stats(&t, stats, s);
 }
 
-int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s) {
+int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t s, int* bnb_taken) {
   // ITG_STATS_PATHS: bit 0 halo-tile kernels, bit 1 implicit-GEMM epilogue, bit 2 split-K second stage take the consumer
   // BatchNorm's statistics themselves; a cleared bit runs the separate statistics launch over the finished output instead.
   // Default 5 since round 4: the implicit-GEMM epilogue's flush is one fp64 atomic per channel and WORKGROUP onto the same
@@ -315,6 +343,8 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
   p.ksplit = pl.ksplit; p.kchunks = pl.kchunks; p.partial = workspace;
   const bool second_stage = pl.ksplit > 1;      // (an in-launch combine - agent-scope release / ticket / acquire - measured slower: DESIGN section 3)
   const bool stats_in_stage2 = second_stage && p.stats && (stats_paths & 4) && p.out_mode == 0 && p.out.ld <= 512;
+  // ... or, for an input gradient, the backward sums of the BatchNorm in front of the conv (itg_bn_bwd_fuse; also with the frame fold)
+  const bool bnb_in_stage2 = second_stage && p.bnb_x && p.bnb_sums && !p.stats && p.out.ld <= 512 && p.act == ITG_ACT_NONE && !p.bias;
   if (second_stage || !(stats_paths & 2)) p.stats = nullptr;
   for (int c = 0; c < 4; ++c) p.cpoff[c] = (unsigned)((size_t)c * pl.ksplit * p.M * p.co_rows);
   {
@@ -348,7 +378,7 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
     int64_t total = (int64_t)mmax * (p.out.ld >> 2);
     int per = 8192 / ncls;
     int blocks = (int)((total + 255) / 256 < per ? (total + 255) / 256 : per);
-    if (blocks > 0 && stats_in_stage2) {
+    if (blocks > 0 && (stats_in_stage2 || bnb_in_stage2)) {
       // (channel group of 64, pixel range) workgroups: enough ranges for ~2 workgroups per CU, at least 16 pixels each
       const int q4 = p.out.ld >> 2;
       const int ngroups = (q4 + 15) / 16;
@@ -356,7 +386,12 @@ int dispatch_nt(ConvP p, float* workspace, int64_t workspace_floats, hipStream_t
       if (nranges > (mmax + 15) / 16) nranges = (mmax + 15) / 16;
       if (nranges < 1) nranges = 1;
       p.stats = want_stats;
-      hipLaunchKernelGGL(splitk_epilogue_stats_kernel, dim3(ngroups * nranges, ncls), dim3(256), 0, s, p, ngroups, nranges);
+      if (bnb_in_stage2) {
+        hipLaunchKernelGGL(splitk_epilogue_stats_kernel<true>, dim3(ngroups * nranges, ncls), dim3(256), 0, s, p, ngroups, nranges);
+        if (bnb_taken) *bnb_taken = 1;
+      } else {
+        hipLaunchKernelGGL(splitk_epilogue_stats_kernel<false>, dim3(ngroups * nranges, ncls), dim3(256), 0, s, p, ngroups, nranges);
+      }
       ITG_CHECK_LAUNCH();
     } else if (blocks > 0) {
       hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks, ncls), dim3(256), 0, s, p);

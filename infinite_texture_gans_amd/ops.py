@@ -7,6 +7,7 @@ channel count ``c`` (ld = c rounded up to 4, pad channels are zero) - see :class
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -399,6 +400,18 @@ class _Conv(torch.autograd.Function):
             if nws is None:
                 nws = _WS_SIZE[key] = _lib.fn("itg_conv2d_dgrad_workspace")(C.byref(ddy), C.byref(ddx), C.byref(g))
             ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
+            fuse = bn = None
+            if _BN_FUSE:
+                bn = _BN_FUSE.pop(x.data_ptr(), None)
+                bx, bstat, by = (bn[0](), bn[1](), bn[5]()) if bn is not None else (None, None, None)
+                if (by is not None and bx is not None and bstat is not None and ctx.in_act is None and not wino and not s2_dgrad
+                        and by.shape == x.shape and bn[4] == ci):
+                    bact, bslope = bn[2], bn[3]
+                    bsums = _zeros_f64(2 * x.shape[5], x.device)
+                    bxd = _desc(bx, ci)
+                    fuse = _lib.BnBwdFuse(C.pointer(bxd), bstat[2 * x.shape[5]:].data_ptr(), bstat.data_ptr(), int(bact), float(bslope),
+                                          bsums.data_ptr(), 0, 0)
+                    g.bn_bwd = C.pointer(fuse)
             with _Prof(_nt_tag(ci), 1, 2.0 * npix_out * co * ci * (6.25 if s2_dgrad else ((kh + 3) ** 2 / 16.0 if wino else taps)),
                        4 * (dy.numel() + gx.numel() + wp.numel())):
                 ia = ctx.in_act
@@ -406,6 +419,10 @@ class _Conv(torch.autograd.Function):
                 _lib.call("itg_conv2d_dgrad", C.byref(ddy), _ptr(wp), _ptr(out_scale), C.byref(ddx), C.byref(dact),
                           ia[0] if ia is not None else ACT_NONE, float(ia[1]) if ia is not None else 0.0, C.byref(g),
                           _ptr(ws), nws, st)
+            if fuse is not None:
+                g.bn_bwd = None
+                if fuse.taken:                 # the BatchNorm's backward (next on the chain) finds its sums here
+                    _BN_SUMS[gx.data_ptr()] = (bsums, gx, bx.data_ptr())
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if need_w or need_b:
@@ -814,7 +831,7 @@ def concurrent_streams(device, want, spin_us=150, candidates=12):
     for _ in range(candidates):
         if len(chosen) >= min(want, 3):
             break
-        cand = torch.cuda.Stream(device=device)
+        cand = torch.cuda.Stream(device=device)      # (stream priorities: the range here is (0, -1); high-priority side or main streams change nothing)
         together([cand])                                 # first use of a stream: its queue is set up now, not timed
         if together(chosen + [cand]):
             chosen.append(cand)
@@ -912,6 +929,16 @@ class ZeroArena:
 
 ARENA = None      # set by engine.Trainer for the duration of a step
 
+# Round 6 (itg.h itg_bn_bwd_fuse): the conv that consumed y = act(BatchNorm(x)) hands the BatchNorm to its input gradient; when
+# that launch has a split-K second stage (the generator's wide layers) the stage also accumulates the BatchNorm's backward sums and
+# the BatchNorm's backward skips its reduce launch - one dependent launch fewer per BatchNorm on the latency-bound backward chain.
+# ITG_STATS_PATHS bit 3 (default on).  _BN_FUSE: y.data_ptr() -> weak references to (x, stat, y) + (act, slope, c), registered
+# by _BNAct.forward and consumed by _Conv.backward (an entry whose y has died - its pointer may belong to another tensor by
+# then - dereferences to None and is ignored); _BN_SUMS: dx.data_ptr() -> (sums, dx, x.data_ptr()), left by _Conv.backward for the
+# _BNAct.backward that follows it; it holds dx, so that pointer cannot be re-used while the entry exists.
+BN_BWD_FUSE = (int(os.environ.get("ITG_STATS_PATHS", "13")) & 8) != 0
+_BN_FUSE, _BN_SUMS = {}, {}
+
 # Test hook (tests/test_gpu_fullsize.py): a list that receives (output tensor, channels, op, halo_rows) of every LeakyReLU / ReLU this module
 # applies - BatchNorm + activation, the conv epilogues, the pointwise op - in host issue order.  The signs of these tensors are
 # the branches the step took; the test puts the fp64 oracle on the same branches (oracle.nets.ACT_REPLAY).
@@ -973,6 +1000,10 @@ class _BNAct(torch.autograd.Function):
         ctx.meta = (c, act, slope, count, sync, training, gamma is not None)
         ctx.sinks = sinks
         ctx.save_for_backward(x, stat)
+        if BN_BWD_FUSE and training and not ups and not pad_rows and ctx.needs_input_grad[0]:
+            if len(_BN_FUSE) > 256:        # outputs that no conv's backward consumed: drop the stale (weak) entries
+                _BN_FUSE.clear()
+            _BN_FUSE[y.data_ptr()] = (weakref.ref(x), weakref.ref(stat), act, slope, c, weakref.ref(y))
         _sink_act(y, c, act, "bn", pad_rows)
         if fork:
             # second output: x itself (an alias).  Whatever consumes it (the block's residual shortcut) hands its gradient to
@@ -994,9 +1025,13 @@ class _BNAct(torch.autograd.Function):
         dy = dy.contiguous()
         st = _stream()
         dx_, ddy_ = _desc(x, c), _desc(dy, c)
-        sums = _zeros_f64(2 * ld, x.device)
-        _lib.call("itg_bn_bwd_reduce", C.byref(dx_), C.byref(ddy_), _ptr(ab), _ptr(mean_rstd), act, float(slope),
-                  _ptr(sums), st)
+        ent = _BN_SUMS.pop(dy.data_ptr(), None) if _BN_SUMS else None
+        if ent is not None and ent[1].shape == x.shape and ent[2] == x.data_ptr():
+            sums = ent[0]                   # accumulated by the split-K second stage of the input gradient that produced dy
+        else:
+            sums = _zeros_f64(2 * ld, x.device)
+            _lib.call("itg_bn_bwd_reduce", C.byref(dx_), C.byref(ddy_), _ptr(ab), _ptr(mean_rstd), act, float(slope),
+                      _ptr(sums), st)
         if sync is not None and _active(sync):
             # dgamma/dbeta are the LOCAL sums (the gradient all-reduce adds the ranks up later);
             # the dx formula needs the GLOBAL ones.

@@ -1264,3 +1264,62 @@ def test_public_current_stream_fallback_gives_the_same_result(monkeypatch):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     assert torch.equal(y0, y1) and torch.equal(y0, y2)
+
+
+@pytest.mark.parametrize("ci,co,p,up2,expect_fused", [
+    (416, 416, 4, False, True),      # generator block 1: split-K input gradient on the padded extent, frame folded with atomics
+    (416, 208, 4, True, True),       # block 2's first conv: folded upsample, its input gradient lands on the half-size tensor
+    (104, 104, 16, False, True),     # block 3's second conv
+    (26, 26, 32, False, False),      # a narrow layer: strip / halo-tile kernels, no second stage -> the separate reduce runs
+])
+def test_bn_backward_sums_taken_by_the_split_k_stage_of_the_consuming_convs_input_gradient(ci, co, p, up2, expect_fused, monkeypatch):
+    """itg_bn_bwd_fuse (round 6): conv(act(BatchNorm(x))) backward.  With the fusion the split-K second stage of the conv's input
+    gradient accumulates the BatchNorm's backward sums and itg_bn_bwd_reduce is NOT launched; the gradients of x, gamma, beta
+    equal those of the separate-reduce path (fp64 sums both ways: the summation order is all that differs) and torch's."""
+    ops = _ops()
+    from infinite_texture_gans_amd import _lib
+    g = _gen(1000 + ci + p)
+    n, gh, gw = 8, 3, 3
+    x = torch.randn(n * gh * gw, ci, p, p, generator=g) * 1.3 + 0.2
+    gamma, beta = 1 + 0.1 * torch.randn(ci, generator=g), 0.1 * torch.randn(ci, generator=g)
+    w = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).to(cuda)
+    q = p * 2 if up2 else p
+    dy = torch.randn(n, gh, gw, q, q, ops.ld_for(co), generator=g).to(cuda)
+    dy[..., co:] = 0
+
+    def run(fuse):
+        monkeypatch.setattr(ops, "BN_BWD_FUSE", fuse)
+        calls = []
+        real_call = _lib.call
+
+        def counting(name, *a):
+            calls.append(name)
+            return real_call(name, *a)
+        monkeypatch.setattr(_lib, "call", counting)
+        xg, gg, bg = (t.to(cuda).requires_grad_(True) for t in (x, gamma, beta))
+        xgrid = ops.GT(ops.to_grid(xg, gh, gw, merged=False).t * 1.0, ci)
+        y = ops.bn_act(xgrid, gg, bg, torch.zeros(ci, device=cuda), torch.ones(ci, device=cuda),
+                       torch.zeros((), dtype=torch.int64, device=cuda), True, 1e-5, 0.1, ops.ACT_LRELU, 0.02,
+                       consumer_upsamples=up2)
+        out = ops.conv(y, w, None, 3, 3, 1, 1, ops.PAD_REPLICATE, out_grid=(gh, gw), up2=up2)
+        grads = torch.autograd.grad(out.t, (xg, gg, bg), dy)
+        torch.cuda.synchronize()
+        monkeypatch.setattr(_lib, "call", real_call)
+        return [t.cpu() for t in grads], calls.count("itg_bn_bwd_reduce")
+
+    ops._BN_FUSE.clear(), ops._BN_SUMS.clear()             # (BatchNorm outputs of earlier tests that no conv consumed)
+    (dx0, dg0, db0), n0 = run(False)
+    (dx1, dg1, db1), n1 = run(True)
+    assert n0 == 1 and n1 == (0 if expect_fused else 1), (n0, n1)
+    assert not ops._BN_FUSE and not ops._BN_SUMS              # both registries are consumed
+    assert rel_l2(dx1, dx0) < 1e-6 and rel_l2(dg1, dg0) < 1e-6 and rel_l2(db1, db0) < 1e-6
+    # ... and torch on the CPU
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    yr = F.leaky_relu(F.batch_norm(xr, torch.zeros(ci), torch.ones(ci), gr, br, True, 0.1, 1e-5), 0.02)
+    m = yr.view(n, gh, gw, ci, p, p).permute(0, 3, 1, 4, 2, 5).reshape(n, ci, gh * p, gw * p)
+    if up2:
+        m = F.interpolate(m, scale_factor=2, mode="nearest")
+    o = F.conv2d(F.pad(m, (1, 1, 1, 1), mode="replicate"), w.cpu())
+    dyr = dy.cpu()[..., :co].permute(0, 5, 1, 3, 2, 4).reshape(n, co, gh * q, gw * q)
+    dxr, dgr, dbr = torch.autograd.grad(o, (xr, gr, br), dyr)
+    assert rel_l2(dx1, dxr) < 2e-5 and rel_l2(dg1, dgr) < 2e-5 and rel_l2(db1, dbr) < 2e-5

@@ -76,6 +76,7 @@ def main():
                 float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
         if a.fetch and a.write:
             fe, wr = pmc(a.fetch, "FETCH_SIZE"), pmc(a.write, "WRITE_SIZE")
+            avg_ns = {short(r["Name"]): float(r["AverageNs"]) for r in rows}       # the --stats pass: the kernel ALONE (un-overlapped step)
             traffic = {}
             f.write("\n## HBM traffic per launch (separate --pmc passes; FETCH_SIZE x2 gfx950 correction, KiB -> bytes)\n\n")
             f.write("| kernel | launches | avg fetch MB | avg write MB |\n|---|---|---|---|\n")
@@ -83,6 +84,9 @@ def main():
                 fb = fe[k][0] * 2 * 1024
                 wb = wr.get(k, (0, 0))[0] * 1024
                 traffic[k] = {"fetch_bytes": fb, "write_bytes": wb, "launches": fe[k][1]}
+                if k in avg_ns:          # HBM-side rate of the kernel: bytes the memory moved / its average duration
+                    traffic[k]["avg_us"] = round(avg_ns[k] / 1e3, 2)
+                    traffic[k]["hbm_gbps"] = round((fb + wb) / avg_ns[k], 1)
                 if fb * fe[k][1] > 50e6:
                     f.write("| `%s` | %d | %.1f | %.1f |\n" % (k[:70], fe[k][1], fb / 1e6, wb / 1e6))
             import subprocess, sys
