@@ -102,3 +102,44 @@ def test_product_has_no_cpu_fallback_and_does_not_import_oracle():
             "try:\n    ops.to_grid(torch.zeros(1,3,4,4), 1, 1, True)\n    raise SystemExit('CPU tensor was accepted')\n"
             "except _lib.ItgError: pass") % ROOT
     subprocess.check_call([sys.executable, "-c", code])
+
+
+def test_struct_layouts_match_the_header(lib, tmp_path):
+    """The ctypes mirrors of itg_tensor / itg_conv_geom / itg_bn_bwd_fuse (round 6) have the C structs' sizes and field offsets:
+    a C program that includes include/itg.h prints them (gcc is enough - the header is plain C)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not installed")
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "itg.h"\nint main(void) {\n'
+                   '  printf("%zu %zu %zu\\n", sizeof(itg_tensor), sizeof(itg_conv_geom), sizeof(itg_bn_bwd_fuse));\n'
+                   '  printf("%zu %zu %zu %zu\\n", offsetof(itg_conv_geom, out_stats), offsetof(itg_conv_geom, bn_bwd), '
+                   'offsetof(itg_conv_geom, flags), offsetof(itg_conv_geom, wino_v));\n'
+                   '  printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(itg_bn_bwd_fuse, x), offsetof(itg_bn_bwd_fuse, ab), '
+                   'offsetof(itg_bn_bwd_fuse, mean_rstd), offsetof(itg_bn_bwd_fuse, act), offsetof(itg_bn_bwd_fuse, sums), '
+                   'offsetof(itg_bn_bwd_fuse, taken));\n  return 0;\n}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split()
+    got = [int(v) for v in out]
+    G, F = lib.ConvGeom, lib.BnBwdFuse
+    want = [ctypes.sizeof(lib.Tensor), ctypes.sizeof(G), ctypes.sizeof(F),
+            G.out_stats.offset, G.bn_bwd.offset, G.flags.offset, G.wino_v.offset,
+            F.x.offset, F.ab.offset, F.mean_rstd.offset, F.act.offset, F.sums.offset, F.taken.offset]
+    assert got == want, (got, want)
+
+
+def test_bn_bwd_fuse_is_an_input_gradient_argument_only(lib):
+    """itg_conv_geom.bn_bwd (round 6): the forward and the weight gradient reject a geometry that carries it; the input gradient
+    validates it (a null BatchNorm input is an argument error, not a crash) and clears `taken` before anything else."""
+    so = lib.load()
+    f0 = ctypes.c_float(0.0)
+    ok = lib.Tensor(ctypes.c_void_p(64), 1, 1, 1, 4, 4, 3, 4)
+    fuse = lib.BnBwdFuse(None, None, None, 1, 0.02, None, 7, 0)
+    g = lib.ConvGeom(3, 3, 1, 1, 0, bn_bwd=fuse)
+    panel = ctypes.c_void_p(64)
+    assert so.itg_conv2d_fwd(ctypes.byref(ok), panel, None, None, None, ctypes.byref(ok), ctypes.byref(g), 0, f0, None, 0, None) < 0
+    assert so.itg_conv2d_wgrad(ctypes.byref(ok), ctypes.byref(ok), panel, None, ctypes.byref(g), 0, None, 0, None) < 0
+    assert so.itg_conv2d_dgrad(ctypes.byref(ok), panel, None, ctypes.byref(ok), None, 0, f0, ctypes.byref(g), None, 0, None) < 0
+    assert g.bn_bwd.contents.taken == 0
