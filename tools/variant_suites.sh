@@ -26,4 +26,5 @@ ITG_WINOGRAD_G=1 ITG_SN_FUSED_REDUCE=1
 ITG_HALO_INTERIOR=1 ITG_OVERLAP=0
 ITG_KERNEL_MASK=0xDFF
 ITG_KERNEL_MASK=0
+ITG_STATS_PATHS=5
 VARS
