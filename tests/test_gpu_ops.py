@@ -1323,3 +1323,38 @@ def test_bn_backward_sums_taken_by_the_split_k_stage_of_the_consuming_convs_inpu
     dyr = dy.cpu()[..., :co].permute(0, 5, 1, 3, 2, 4).reshape(n, co, gh * q, gw * q)
     dxr, dgr, dbr = torch.autograd.grad(o, (xr, gr, br), dyr)
     assert rel_l2(dx1, dxr) < 2e-5 and rel_l2(dg1, dgr) < 2e-5 and rel_l2(db1, dbr) < 2e-5
+
+
+def test_stride2_winograd_layer_gradients_rounding_against_fp64(monkeypatch):
+    """D's 128 -> 256 stride-2 layer (reference models/discriminators.py:190-195) through F(4 x 4, 2 x 2).
+    Its forward is held to the direct kernels' rounding per layer (test above); its input gradient (the adjoint pipeline) and
+    its weight gradient (25 contractions in the transformed domain) run on ONE fp32 accumulation chain per GEMM - their error
+    enters the gradients linearly and decides no LeakyReLU sign - and were only checked at 1e-5 against torch's fp32.  Here:
+    all three against F.conv2d / torch.nn.grad in fp64 on the operand distribution the layer sees, Winograd and direct side by
+    side on the same operands."""
+    ops = _ops()
+    monkeypatch.setattr(ops, "WINOGRAD", True)
+    monkeypatch.setattr(ops, "WINOGRAD_S2", True)
+    monkeypatch.setattr(ops, "WINO_S2_MIN_TILES", 1)
+    g = _gen(41)
+    x = F.leaky_relu(torch.randn(2, 128, 96, 96, generator=g), 0.2)
+    w = torch.randn(256, 128, 4, 4, generator=g) / (128 * 16) ** 0.5
+    dy = torch.randn(2, 256, 48, 48, generator=g)
+    xd, wd, dyd = x.double(), w.double(), dy.double()
+    ref = F.conv2d(xd, wd, None, stride=2, padding=1)
+    dx_ref = torch.nn.grad.conv2d_input(x.shape, wd, dyd, stride=2, padding=1)
+    dw_ref = torch.nn.grad.conv2d_weight(xd, w.shape, dyd, stride=2, padding=1)
+    err = {}
+    for wino in (0, 2):
+        xg, wg = x.to(cuda).requires_grad_(True), w.to(cuda).requires_grad_(True)
+        y = ops.to_nchw(ops.conv(ops.to_grid(xg, 1, 1, merged=True), wg, None, 4, 4, 2, 1, ops.PAD_ZERO, wino=wino), merged=True)
+        dx, dw = torch.autograd.grad(y, (xg, wg), dy.to(cuda))
+        r = lambda a, b: float((a.cpu().double() - b).norm() / b.norm())          # noqa: E731
+        err[wino] = (r(y.detach(), ref), r(dx, dx_ref), r(dw, dw_ref))
+    print("128->256 stride-2 layer rel-L2 vs fp64 (forward, input gradient, weight gradient): direct %.2e %.2e %.2e | F(4x4,2x2) %.2e %.2e %.2e"
+          % (err[0] + err[2]))
+    # measured (round 6): direct 2.9e-7 / 2.9e-7 / 2.6e-7; F(4 x 4, 2 x 2) forward 8.1e-7 (fp32 block sums), input gradient 1.9e-6
+    # and weight gradient 1.1e-6 (one fp32 chain each)
+    assert max(err[0]) < 1e-6, err
+    assert err[2][0] < (2e-6 if os.environ.get("ITG_WINO_ACC64", "1") != "0" else 5e-6), err
+    assert err[2][1] < 4e-6 and err[2][2] < 3e-6, err
