@@ -602,6 +602,109 @@ inline bool cin1_conv(const itg_tensor* in, const itg_tensor* out, const itg_con
          out->ld <= 128 && out->c >= 16 && g->precision != ITG_PREC_BF16 && !g->out_stats;
 }
 
+// Round 6: the same input gradient in ONE launch.  The three-launch form above writes Q (one 64-float row per dy pixel: 75 MB on the
+// generated 384^2 batch) and reads it back - 3 x the bytes of an operation that has to read dy once (75 MB) and write dx (19 MB): 80 us
+// where HBM needs ~20.  Here a workgroup owns an 8 x 16 tile of dy pixels plus a 1-pixel halo (180 pixels), computes their Q rows on the
+// MFMA pipe straight from global memory (B operand = dy pixels, 16-byte loads in the K-permuted fragment layout; A operand = the 64 x
+// co_ld panel, built in LDS once per workgroup from the packed input-gradient panel), parks Q in LDS (pitch 68: conflict-free for the
+// 16-lane groups of a ds_read_b128) and gathers the 16 x 32 dx pixels of its tile from it: dy is read once from HBM (the halo from L2),
+// Q never leaves the CU.  Out-of-image dy pixels load as zeros through the buffer range check.  fp32 operands whatever the launch's MFMA
+// precision (2.4 GF: not worth a second instantiation).
+constexpr int TD_TH = 8, TD_TW = 16, TD_HP = TD_TH + 2, TD_WP = TD_TW + 2, TD_PIX = TD_HP * TD_WP, TD_QP = 68;
+template <int NKB>      // dy.ld / 16
+__global__ __launch_bounds__(256) void thin_dgrad_fused_kernel(const GridT dy, const float* __restrict__ wd, const float* __restrict__ scale,
+                                                               const GridT dx, const GridT act_out, int act, float slope, int cin,
+                                                               int ci_pad, int tiles_x, int tiles_y, int ntiles, unsigned dy_bytes) {
+  extern __shared__ __attribute__((aligned(16))) float lds_td[];
+  constexpr int co_ld = 16 * NKB, WP = co_ld + 4;
+  float* Wl = lds_td;                    // [64][WP]: row (cls, tap, c), k = dy channel
+  float* Ql = lds_td + 64 * WP;          // [TD_PIX][TD_QP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < 64 * co_ld; e += 256) {
+    const int o = e % co_ld, r = e / co_ld;
+    const int c = r & 3, tap = (r >> 2) & 3, cls = r >> 4;
+    Wl[r * WP + o] = c < cin ? wd[((size_t)(cls * ci_pad + c) * 4 + tap) * co_ld + o] : 0.f;
+  }
+  const float sc = scale ? *scale : 1.f;
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dy.p, 0, dy_bytes, 0x00020000);
+  const int fr = lane & 15, g = lane >> 4;
+  // the tile's 3 x NKB operand loads of this lane (all in flight at once; the NEXT tile's are issued before this tile's gather)
+  f32x4 bq[3][NKB];
+  auto load_tile = [&](int tile) {
+    int b = tile;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int oy0 = ty * TD_TH - 1, ox0 = tx * TD_TW - 1;          // dy coordinates of the tile's local (0, 0)
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      const int slot = (wave * 3 + f) * 16 + fr;
+      const int ly = slot / TD_WP, lx = slot - ly * TD_WP;
+      const int oy = oy0 + ly, ox = ox0 + lx;
+      const bool ok = slot < TD_PIX && (unsigned)oy < (unsigned)dy.H && (unsigned)ox < (unsigned)dy.W;
+      const unsigned po = ok ? (unsigned)grid_off(dy, n, oy, ox) * 4u + (unsigned)g * 16u : dy_bytes;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+        bq[f][kb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, po + (unsigned)kb * 64u, 0, 0));
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile);
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    int b = tile;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    f32x4 acc[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int f = 0; f < 3; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      f32x4 a[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4*>(Wl + (16 * i + fr) * WP + kb * 16 + 4 * g);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int f = 0; f < 3; ++f) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s4], bq[f][kb][s4], acc[i][f], 0, 0, 0);
+    }
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      const int slot = (wave * 3 + f) * 16 + fr;
+      if (slot < TD_PIX) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Ql + slot * TD_QP + 16 * i + 4 * g) = acc[i][f];
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);      // in flight under the gather below
+    for (int e = tid; e < 4 * TD_TH * TD_TW; e += 256) {
+      const int lyy = e / (2 * TD_TW), lxx = e - lyy * (2 * TD_TW);
+      const int Y = 2 * ty * TD_TH + lyy, X = 2 * tx * TD_TW + lxx;
+      if (Y >= dx.H || X >= dx.W) continue;
+      const int ry = Y & 1, rx = X & 1, t = lyy >> 1, u = lxx >> 1;
+      const int by = (ry + 1 - ((ry + 1) & 1)) >> 1, bx = (rx + 1 - ((rx + 1) & 1)) >> 1;
+      const int cls = ry * 2 + rx;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jy = 0; jy < 2; ++jy)
+#pragma unroll
+        for (int jx = 0; jx < 2; ++jx)
+          v += *reinterpret_cast<const f32x4*>(Ql + ((t + by + jy) * TD_WP + (u + bx + jx)) * TD_QP + (cls * 4 + jy * 2 + jx) * 4);
+      v *= sc;
+      const int off = grid_off(dx, n, Y, X);
+      if (act_out.p) v *= act_deriv(*reinterpret_cast<const f32x4*>(act_out.p + grid_off(act_out, n, Y, X)), act, slope);
+      *reinterpret_cast<f32x4*>(dx.p + off) = v;
+    }
+    __syncthreads();                     // Ql is rewritten by the next tile
+  }
+}
+
 inline bool thin_in_conv(const itg_tensor* dy, const itg_tensor* dx, const itg_conv_geom* g) {
   const int enable = kernel_on(KM_THIN_CONV);
   const int ph = g->pad_h >= 0 ? g->pad_h : g->pad;
@@ -1046,6 +1149,42 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
     const int Ho = dy->gh * dy->ph, Wo = dy->gw * dy->pw, H = dx->gh * dx->ph, W = dx->gw * dx->pw;
     if (conv_out_dim(H, 4, 2, 1) != Ho || conv_out_dim(W, 4, 2, 1) != Wo) return ITG_ERR_ARG;
     const int rows = 64;     // 4 parity classes x 4 taps x 4 (padded) input channels
+    if ((dy->ld == 16 || dy->ld == 32 || dy->ld == 64 || dy->ld == 128) && grid_pixels(dy) * dy->ld * 4 < 0xFFFF0000LL) {
+      // one launch: Q stays in LDS (thin_dgrad_fused_kernel)
+      GridT ao = null_grid();
+      if (act_out && act_out->ptr && act != ITG_ACT_NONE) {
+        if ((rc = check_tensor(act_out))) return rc;
+        if (!same_shape(act_out, dx)) return ITG_ERR_ARG;
+        ao = make_grid(act_out);
+      }
+      const int tiles_x = ((W + 1) / 2 + TD_TW - 1) / TD_TW, tiles_y = ((H + 1) / 2 + TD_TH - 1) / TD_TH;
+      const int64_t nt = (int64_t)dx->n * tiles_x * tiles_y;
+      if (nt <= 0 || nt >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
+      const size_t lds = (size_t)(64 * (dy->ld + 4) + TD_PIX * TD_QP) * sizeof(float);
+      const int64_t rounds = (nt + 511) / 512;                   // two workgroups fit a CU (66 KB of LDS each): an even deal over 512
+      const int blocks = (int)((nt + rounds - 1) / rounds);
+      const unsigned dyb = (unsigned)(grid_pixels(dy) * dy->ld * 4);
+      const GridT gdy = make_grid(dy), gdx = make_grid(dx);
+      const int cpad = round_up(dx->c, 16);
+#define ITG_TDF(NKB)                                                                                                                     \
+  do {                                                                                                                                   \
+    if (lds > 64 * 1024) {                                                                                                               \
+      static bool attr_done = false;                                                                                                     \
+      if (!attr_done) {                                                                                                                  \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_dgrad_fused_kernel<NKB>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                96 * 1024) != hipSuccess) { (void)hipGetLastError(); return ITG_ERR_LAUNCH; }                              \
+        attr_done = true;                                                                                                                \
+      }                                                                                                                                  \
+    }                                                                                                                                    \
+    hipLaunchKernelGGL(thin_dgrad_fused_kernel<NKB>, dim3(blocks), dim3(256), lds, s, gdy, w_packed_dgrad, out_scale, gdx, ao, act, slope, \
+                       dx->c, cpad, tiles_x, tiles_y, (int)nt, dyb);                                                                     \
+  } while (0)
+      if (dy->ld == 16) ITG_TDF(1); else if (dy->ld == 32) ITG_TDF(2); else if (dy->ld == 64) ITG_TDF(4); else ITG_TDF(8);
+#undef ITG_TDF
+      ITG_CHECK_LAUNCH();
+      snprintf(g_last_launch, sizeof(g_last_launch), "thin_dgrad_fused_kernel");
+      return ITG_OK;
+    }
     const int64_t Mo = grid_pixels(dy), qf = Mo * rows, pf = (int64_t)rows * dy->ld;
     if (!workspace || workspace_floats < qf + pf || qf >= ((int64_t)1 << 31)) return ITG_ERR_WORKSPACE;
     float* Q = workspace;
