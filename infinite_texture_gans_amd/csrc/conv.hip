@@ -610,19 +610,19 @@ inline bool cin1_conv(const itg_tensor* in, const itg_tensor* out, const itg_con
 // 16-lane groups of a ds_read_b128) and gathers the 16 x 32 dx pixels of its tile from it: dy is read once from HBM (the halo from L2),
 // Q never leaves the CU.  Out-of-image dy pixels load as zeros through the buffer range check.  fp32 operands whatever the launch's MFMA
 // precision (2.4 GF: not worth a second instantiation).
-constexpr int TD_TH = 8, TD_TW = 16, TD_HP = TD_TH + 2, TD_WP = TD_TW + 2, TD_PIX = TD_HP * TD_WP, TD_QP = 68;
+constexpr int TD_TH = 8, TD_TW = 16, TD_HP = TD_TH + 2, TD_WP = TD_TW + 2, TD_PIX = TD_HP * TD_WP, TD_ROWS = 48, TD_QP = TD_ROWS + 4;
 template <int NKB>      // dy.ld / 16
 __global__ __launch_bounds__(256) void thin_dgrad_fused_kernel(const GridT dy, const float* __restrict__ wd, const float* __restrict__ scale,
                                                                const GridT dx, const GridT act_out, int act, float slope, int cin,
                                                                int ci_pad, int tiles_x, int tiles_y, int ntiles, unsigned dy_bytes) {
   extern __shared__ __attribute__((aligned(16))) float lds_td[];
   constexpr int co_ld = 16 * NKB, WP = co_ld + 4;
-  float* Wl = lds_td;                    // [64][WP]: row (cls, tap, c), k = dy channel
-  float* Ql = lds_td + 64 * WP;          // [TD_PIX][TD_QP]
+  float* Wl = lds_td;                    // [48][WP]: row (c, cls, tap) - one 16-row MFMA fragment per input channel - k = dy channel
+  float* Ql = lds_td + TD_ROWS * WP;     // [TD_PIX][TD_QP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int e = tid; e < 64 * co_ld; e += 256) {
+  for (int e = tid; e < TD_ROWS * co_ld; e += 256) {
     const int o = e % co_ld, r = e / co_ld;
-    const int c = r & 3, tap = (r >> 2) & 3, cls = r >> 4;
+    const int c = r >> 4, cls = (r >> 2) & 3, tap = r & 3;
     Wl[r * WP + o] = c < cin ? wd[((size_t)(cls * ci_pad + c) * 4 + tap) * co_ld + o] : 0.f;
   }
   const float sc = scale ? *scale : 1.f;
@@ -656,20 +656,20 @@ __global__ __launch_bounds__(256) void thin_dgrad_fused_kernel(const GridT dy, c
     const int tx = b % tiles_x; b /= tiles_x;
     const int ty = b % tiles_y;
     const int n = b / tiles_y;
-    f32x4 acc[4][3];
+    f32x4 acc[3][3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int f = 0; f < 3; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      f32x4 a[4];
+      f32x4 a[3];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4*>(Wl + (16 * i + fr) * WP + kb * 16 + 4 * g);
+      for (int i = 0; i < 3; ++i) a[i] = *reinterpret_cast<const f32x4*>(Wl + (16 * i + fr) * WP + kb * 16 + 4 * g);
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
           for (int f = 0; f < 3; ++f) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s4], bq[f][kb][s4], acc[i][f], 0, 0, 0);
     }
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256) void thin_dgrad_fused_kernel(const GridT dy, c
       const int slot = (wave * 3 + f) * 16 + fr;
       if (slot < TD_PIX) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Ql + slot * TD_QP + 16 * i + 4 * g) = acc[i][f];
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(Ql + slot * TD_QP + 16 * i + 4 * g) = acc[i][f];
       }
     }
     __syncthreads();
@@ -694,8 +694,10 @@ __global__ __launch_bounds__(256) void thin_dgrad_fused_kernel(const GridT dy, c
 #pragma unroll
       for (int jy = 0; jy < 2; ++jy)
 #pragma unroll
-        for (int jx = 0; jx < 2; ++jx)
-          v += *reinterpret_cast<const f32x4*>(Ql + ((t + by + jy) * TD_WP + (u + bx + jx)) * TD_QP + (cls * 4 + jy * 2 + jx) * 4);
+        for (int jx = 0; jx < 2; ++jx) {
+          const float* q = Ql + ((t + by + jy) * TD_WP + (u + bx + jx)) * TD_QP + cls * 4 + jy * 2 + jx;
+          v[0] += q[0]; v[1] += q[16]; v[2] += q[32];           // rows (c, cls, tap)
+        }
       v *= sc;
       const int off = grid_off(dx, n, Y, X);
       if (act_out.p) v *= act_deriv(*reinterpret_cast<const f32x4*>(act_out.p + grid_off(act_out, n, Y, X)), act, slope);
@@ -1149,7 +1151,7 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
     const int Ho = dy->gh * dy->ph, Wo = dy->gw * dy->pw, H = dx->gh * dx->ph, W = dx->gw * dx->pw;
     if (conv_out_dim(H, 4, 2, 1) != Ho || conv_out_dim(W, 4, 2, 1) != Wo) return ITG_ERR_ARG;
     const int rows = 64;     // 4 parity classes x 4 taps x 4 (padded) input channels
-    if ((dy->ld == 16 || dy->ld == 32 || dy->ld == 64 || dy->ld == 128) && grid_pixels(dy) * dy->ld * 4 < 0xFFFF0000LL) {
+    if (dx->c <= 3 && (dy->ld == 16 || dy->ld == 32 || dy->ld == 64 || dy->ld == 128) && grid_pixels(dy) * dy->ld * 4 < 0xFFFF0000LL) {
       // one launch: Q stays in LDS (thin_dgrad_fused_kernel)
       GridT ao = null_grid();
       if (act_out && act_out->ptr && act != ITG_ACT_NONE) {
@@ -1160,8 +1162,8 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
       const int tiles_x = ((W + 1) / 2 + TD_TW - 1) / TD_TW, tiles_y = ((H + 1) / 2 + TD_TH - 1) / TD_TH;
       const int64_t nt = (int64_t)dx->n * tiles_x * tiles_y;
       if (nt <= 0 || nt >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
-      const size_t lds = (size_t)(64 * (dy->ld + 4) + TD_PIX * TD_QP) * sizeof(float);
-      const int64_t rounds = (nt + 511) / 512;                   // two workgroups fit a CU (66 KB of LDS each): an even deal over 512
+      const size_t lds = (size_t)(TD_ROWS * (dy->ld + 4) + TD_PIX * TD_QP) * sizeof(float);
+      const int64_t rounds = (nt + 767) / 768;                   // three workgroups fit a CU (50 KB of LDS each at 64 channels): an even deal over 768
       const int blocks = (int)((nt + rounds - 1) / rounds);
       const unsigned dyb = (unsigned)(grid_pixels(dy) * dy->ld * 4);
       const GridT gdy = make_grid(dy), gdx = make_grid(dx);
