@@ -707,6 +707,85 @@ __global__ __launch_bounds__(256) void thin_dgrad_fused_kernel(const GridT dy, c
   }
 }
 
+// Round 6: input gradient of a SINGLE-output-channel 4 x 4 stride-1 pad-1 layer (D's logit layer, 512 -> 1).  dx[pix][c] = sum over the 16
+// taps of dy[pix + tap] w[c][tap] (x act'(x)): 16 multiply-adds per output element, 72 MB of x read + dx written on the generated batch - a
+// streaming operation that the implicit GEMM ran at 2.1 TB/s (K = 16 taps padded to 64, four K stages of prologue per 128 x 96 tile).  Here the
+// MFMA does the 16-deep contraction with the roles swapped to keep the stores wide: A = the filter (16 channels per fragment, K = taps, 40 KB
+// of LDS for 512 channels), B = a row of 16 pixels' tap windows gathered from a 7 x 19 window of dy in LDS; a wave owns 16 pixels x CH channels
+// and streams x in / dx out as 16-byte accesses with the next fragments' loads in flight.  A workgroup = 4 image rows x 16 pixels x CH (<= 128)
+// channels, so that the grid has >= 1 000 workgroups on the 47 x 47 maps.
+constexpr int LG_TW = 16, LG_TH = 4, LG_WW = LG_TW + 3, LG_WH = LG_TH + 3;
+__global__ __launch_bounds__(256) void logit_dgrad_kernel(const GridT dy, const float* __restrict__ panel, int Kpad, const float* __restrict__ scale,
+                                                          const GridT dx, const GridT act_out, int act, float slope, int CH, int tiles_x,
+                                                          int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) float lds_lg[];
+  float* Wl = lds_lg;                         // [CH][20]: taps of channel c0 + r
+  float* Dl = lds_lg + CH * 20;               // [LG_WH][LG_WW] window of dy (its one channel)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y;
+  const int n = b / tiles_y;
+  const int c0 = blockIdx.y * CH;
+  for (int e = tid; e < CH * 16; e += 256) {
+    const int r = e >> 4, t = e & 15;
+    Wl[r * 20 + t] = c0 + r < dx.c ? panel[(size_t)(c0 + r) * Kpad + t * 4] : 0.f;
+  }
+  const int y0 = ty * LG_TH, x0 = tx * LG_TW;
+  for (int e = tid; e < LG_WH * LG_WW; e += 256) {
+    const int wy = e / LG_WW, wx = e - wy * LG_WW;
+    const int iy = y0 + wy - 2, ix = x0 + wx - 2;
+    Dl[e] = ((unsigned)iy < (unsigned)dy.H && (unsigned)ix < (unsigned)dy.W) ? dy.p[grid_off(dy, n, iy, ix)] : 0.f;
+  }
+  __syncthreads();
+  const int fr = lane & 15, g = lane >> 4;
+  const int Y = y0 + wave, X = x0 + fr;
+  if (Y >= dx.H) return;                       // (wave-uniform)
+  // B fragment: pixel fr of row `wave`, K group g = tap row g: dy[Y - 2 + g][X - 2 + 0..3]
+  f32x4 bq;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bq[e] = Dl[(wave + g) * LG_WW + fr + e];
+  const float sc = scale ? *scale : 1.f;
+  const bool ok = X < dx.W;
+  const int off = ok ? grid_off(dx, n, Y, X) : 0;
+  const int nf = CH >> 4;
+  for (int i0 = 0; i0 < nf; i0 += 4) {         // four fragments (64 channels) at a time: their act_out loads in flight together
+    f32x4 r[4], acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int co = c0 + 16 * (i0 + k) + 4 * g;
+      r[k] = (act_out.p && ok && i0 + k < nf && co < dx.ld) ? *reinterpret_cast<const f32x4*>(act_out.p + grid_off(act_out, n, Y, X) + co)
+                                                            : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i0 + k < nf) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Wl + (16 * (i0 + k) + fr) * 20 + 4 * g);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], bq[s4], acc[k], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int co = c0 + 16 * (i0 + k) + 4 * g;
+      if (!ok || i0 + k >= nf || co >= dx.ld) continue;
+      f32x4 v = acc[k] * sc;
+      if (act_out.p) v *= act_deriv(r[k], act, slope);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (co + e >= dx.c) v[e] = 0.f;
+      *reinterpret_cast<f32x4*>(dx.p + off + co) = v;
+    }
+  }
+}
+
+inline bool logit_dgrad_ok(const itg_tensor* dy, const itg_tensor* dx, const itg_conv_geom* g) {
+  const int ph = g->pad_h >= 0 ? g->pad_h : g->pad;
+  return kernel_on(KM_THIN_CONV) && dy->c == 1 && dy->ld == 4 && g->kh == 4 && g->kw == 4 && g->stride == 1 && g->pad == 1 && ph == 1 &&
+         g->pad_mode == ITG_PAD_ZERO && !g->up2 && !(g->flags & ITG_GEOM_WINO) && (dx->ld % 16) == 0 && dy->gh == 1 && dy->gw == 1;
+}
+
 inline bool thin_in_conv(const itg_tensor* dy, const itg_tensor* dx, const itg_conv_geom* g) {
   const int enable = kernel_on(KM_THIN_CONV);
   const int ph = g->pad_h >= 0 ? g->pad_h : g->pad;
@@ -1146,6 +1225,26 @@ int itg_conv2d_dgrad(const itg_tensor* dy, const float* w_packed_dgrad, const fl
     p.M = (int)M;
     if (!p.res.p && (rc = set_bnb(p, g, dx))) return rc;
     return dispatch_nt(p, workspace, workspace_floats, s, g->bn_bwd ? &g->bn_bwd->taken : nullptr);
+  }
+  if (logit_dgrad_ok(dy, dx, g)) {
+    const int Ho = dy->ph, Wo = dy->pw, H = dx->gh * dx->ph, W = dx->gw * dx->pw;
+    if (conv_out_dim(H, 4, 1, 1) != Ho || conv_out_dim(W, 4, 1, 1) != Wo) return ITG_ERR_ARG;
+    GridT ao = null_grid();
+    if (act_out && act_out->ptr && act != ITG_ACT_NONE) {
+      if ((rc = check_tensor(act_out))) return rc;
+      if (!same_shape(act_out, dx)) return ITG_ERR_ARG;
+      ao = make_grid(act_out);
+    }
+    const int CH = dx->ld >= 128 ? 128 : dx->ld;
+    const int tiles_x = (W + LG_TW - 1) / LG_TW, tiles_y = (H + LG_TH - 1) / LG_TH;
+    const int64_t nb = (int64_t)dx->n * tiles_x * tiles_y;
+    if (nb <= 0 || nb >= ((int64_t)1 << 31)) return ITG_ERR_ARG;
+    const size_t lds = (size_t)(CH * 20 + LG_WH * LG_WW) * sizeof(float);
+    hipLaunchKernelGGL(logit_dgrad_kernel, dim3((unsigned)nb, (unsigned)((dx->ld + CH - 1) / CH)), dim3(256), lds, s, make_grid(dy),
+                       w_packed_dgrad, round_up(16 * dy->ld, BK), out_scale, make_grid(dx), ao, act, slope, CH, tiles_x, tiles_y);
+    ITG_CHECK_LAUNCH();
+    snprintf(g_last_launch, sizeof(g_last_launch), "logit_dgrad_kernel");
+    return ITG_OK;
   }
   if (thin_in_conv(dy, dx, g)) {
     const int Ho = dy->gh * dy->ph, Wo = dy->gw * dy->pw, H = dx->gh * dx->ph, W = dx->gw * dx->pw;
