@@ -93,6 +93,10 @@ CONV_CASES = [
     ("d4x4_s1_64_1_taps_as_rows_grid", 1, (2, 3), 6, 64, 1, 4, 1, 1, "zeros"),
     ("d4x4_s2_3_64_first_layer", 1, (1, 1), 36, 3, 64, 4, 2, 1, "zeros"),           # K = 16 taps x 4: 64x64 wgrad tile
     ("fake_grid_into_D_16ch", 2, (3, 3), 6, 3, 16, 4, 2, 1, "zeros"),                # taps-as-rows input gradient, odd size
+    ("d4x4_s2_3_32_fused_dgrad", 2, (1, 1), 26, 3, 32, 4, 2, 1, "zeros"),            # round 6: fused first-layer input gradient, 2 K blocks, partial tiles
+    ("d4x4_s2_3_128_fused_dgrad", 1, (1, 1), 44, 3, 128, 4, 2, 1, "zeros"),          # ... 8 K blocks (D_ch = 128), more than one tile per image
+    ("d4x4_s1_128_1_logit_dgrad", 2, (1, 1), 21, 128, 1, 4, 1, 1, "zeros"),          # round 6: streaming logit input gradient, one 128-channel chunk
+    ("d4x4_s1_256_1_logit_dgrad", 1, (1, 1), 35, 256, 1, 4, 1, 1, "zeros"),          # ... two chunks, three column tiles
     # narrow 3x3 layers on images >= 64x64: the persistent halo-tile kernels (forward / input gradient / weight gradient)
     ("tile3x3_rep_13_3", 2, (3, 3), 32, 13, 3, 3, 1, 1, "replicate"),
     ("tile3x3_rep_26_13", 1, (3, 3), 24, 26, 13, 3, 1, 1, "replicate"),              # 72x72: partial tiles, cin_ld 28
